@@ -1,0 +1,135 @@
+"""LIBSVM data-file reader / writer (the on-disk format on the input side of the hot path).
+
+Follows the reference's rules (citations relative to /root/reference):
+  * lines are split at ``\\r`` / ``\\n``, left-trimmed, and dropped when empty or starting with ``#``
+    (src/plssvm/detail/io/file_reader.cpp:179-205);
+  * number of features = largest index found on any line (include/plssvm/detail/io/libsvm_parsing.hpp:47-95);
+  * one-based, strictly increasing feature indices, dense zero fill, labels either on every line or on none
+    (libsvm_parsing.hpp:118-229); the error messages are the reference's.
+"""
+
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from .exceptions import FileNotFoundPlssvmError, InvalidFileFormatError
+
+__all__ = ["read_lines", "parse_libsvm_data", "write_libsvm_data"]
+
+
+def read_lines(filename, comment: str = "#") -> list[str]:
+    """file_reader::read_lines (file_reader.cpp:179-205)."""
+    if not os.path.isfile(filename):
+        raise FileNotFoundPlssvmError(f"Couldn't find file: '{filename}'!")
+    with open(filename, "rb") as f:
+        content = f.read().decode("utf-8", errors="replace")
+    lines = []
+    for raw in content.replace("\r", "\n").split("\n"):
+        sv = raw.lstrip(" \t\v\f")
+        if sv and not sv.startswith(comment):
+            lines.append(sv)
+    return lines
+
+
+def _to_float(token: str, what: str) -> float:
+    try:
+        return float(token)
+    except ValueError:
+        raise InvalidFileFormatError(f"Can't convert '{token}' to a value of type {what}!") from None
+
+
+def _to_index(token: str) -> int:
+    t = token.strip()
+    if not t or not t.isdigit():
+        raise InvalidFileFormatError(f"Can't convert '{token}' to a value of type unsigned long!")
+    return int(t)
+
+
+def parse_libsvm_data(filename, dtype=np.float64, skipped_lines: int = 0, label_type=float):
+    """Parse a LIBSVM file into ``(X[num_points, num_features], labels | None)`` (libsvm_parsing.hpp:118-229)."""
+    lines = read_lines(filename)[skipped_lines:]
+    if not lines:
+        raise InvalidFileFormatError("Can't parse file: no data points are given!")
+
+    # strip a trailing in-line comment exactly as the tokenizer would stop: the reference does not support in-line
+    # comments on data lines with features after them; "value # comment" parses because conversion trims the token
+    parsed = []
+    num_features = 0
+    has_label = False
+    has_no_label = False
+    for line in lines:
+        hash_pos = line.find("#")
+        if hash_pos != -1:
+            line = line[:hash_pos]
+        line = line.rstrip()
+        first_space = len(line)
+        for k, ch in enumerate(line):
+            if ch in " \n":
+                first_space = k
+                break
+        first_colon = line.find(":")
+        if first_colon == -1:
+            first_colon = len(line)
+        if first_colon >= first_space:
+            has_label = True
+            label_tok = line[:first_space]
+            rest = line[first_space:]
+        else:
+            has_no_label = True
+            label_tok = None
+            rest = line
+        feats = []
+        last_index = 0
+        for tok in rest.split():
+            if ":" not in tok:
+                raise InvalidFileFormatError(f"Can't convert '{tok}' to a value of type unsigned long!")
+            idx_tok, val_tok = tok.split(":", 1)
+            index = _to_index(idx_tok)
+            if index == 0:
+                raise InvalidFileFormatError("LIBSVM assumes a 1-based feature indexing scheme, but 0 was given!")
+            if last_index >= index:
+                raise InvalidFileFormatError(
+                    f"The features indices must be strictly increasing, but {index} is smaller or equal than {last_index}!")
+            last_index = index
+            if val_tok == "":
+                raise InvalidFileFormatError("Can't convert '' to a value of type real!")
+            feats.append((index - 1, _to_float(val_tok, "real")))
+        num_features = max(num_features, last_index)
+        parsed.append((label_tok, feats))
+
+    if num_features == 0:
+        raise InvalidFileFormatError("Can't parse file: no data points are given!")
+    if has_label and has_no_label:
+        raise InvalidFileFormatError("Inconsistent label specification found (some data points are labeled, others are not)!")
+
+    X = np.zeros((len(parsed), num_features), dtype=dtype)
+    for i, (_, feats) in enumerate(parsed):
+        for j, v in feats:
+            X[i, j] = v
+    labels = None
+    if has_label:
+        if label_type is str:
+            labels = [p[0] for p in parsed]
+        else:
+            labels = [label_type(_to_float(p[0], "label")) for p in parsed]
+    return X, labels
+
+
+def write_libsvm_data(filename, X, labels=None, comment: str | None = None) -> None:
+    """Write a (sparse: zeros omitted) LIBSVM file, one-based indices (libsvm_parsing.hpp:254-296; format ``{:.10e}``)."""
+    X = np.asarray(X)
+    with open(filename, "w") as f:
+        if comment is not None:
+            f.write(f"# {comment}\n")
+        for i in range(X.shape[0]):
+            parts = []
+            if labels is not None:
+                lab = labels[i]
+                parts.append(str(int(lab)) if isinstance(lab, (int, np.integer)) or float(lab).is_integer() else repr(float(lab)))
+            for j in range(X.shape[1]):
+                v = X[i, j]
+                if v != 0:
+                    parts.append(f"{j + 1}:{float(v):.10e}")
+            f.write(" ".join(parts) + "\n")
