@@ -1,0 +1,193 @@
+/*
+ * plssvm_amd.h -- C ABI of the MI355X-native LS-SVM Conjugate-Gradient backend (libplssvm_amd.so).
+ *
+ * This is the drop-in boundary for ONE path of SC-SGS/PLSSVM: the CG solve behind
+ * plssvm::csvm::solve_system_of_linear_equations and the kernels it is built from.  Plain C: pointers + sizes only,
+ * no C++ or torch types.  The C++ adaptor with the reference's virtual signatures lives in
+ * include/plssvm_amd/csvm.hpp, the Python mirror of the reference's bindings in plssvm_amd/ (both sit ABOVE this ABI).
+ *
+ * Conventions
+ *   - every function returns LSSVM_SUCCESS (0) or a negative lssvm_status; lssvm_mi355_last_error() returns the
+ *     thread-local message of the last failure (the C++ adaptor rethrows it as plssvm::mi355::backend_exception,
+ *     the counterpart of plssvm::hip::backend_exception, include/plssvm/backends/HIP/exceptions.hpp);
+ *   - the caller owns every host pointer; data matrices are dense ROW-MAJOR `num_points x num_features`
+ *     (the reference's std::vector<std::vector<T>> flattened, include/plssvm/csvm.hpp:188);
+ *   - n = num_points - 1 is the size of the reduced system ("dept" in the reference);
+ *   - `_f32` / `_f64` twins mirror the reference's float/double overload pairs (csvm.hpp:188-208);
+ *   - kernel arithmetic runs ONLY on the GPU: there is no CPU fallback, a missing device is LSSVM_ERR_NO_DEVICE.
+ *
+ * All `file:line` citations are relative to the reference tree (SC-SGS/PLSSVM v2.0.0).
+ */
+#ifndef PLSSVM_AMD_H
+#define PLSSVM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLSSVM_AMD_ABI_VERSION 1
+
+typedef enum lssvm_status {
+    LSSVM_SUCCESS = 0,
+    LSSVM_ERR_INVALID_ARGUMENT = -1, /* a violated precondition (the reference's PLSSVM_ASSERTs, csvm.cpp:73-78, svm_kernel.cpp:24-28) */
+    LSSVM_ERR_NO_DEVICE = -2,        /* "HIP backend selected but no HIP capable devices were found!" (csvm.hip.cpp:70-72) */
+    LSSVM_ERR_HIP = -3,              /* a HIP runtime call failed (PLSSVM_HIP_ERROR_CHECK, utility.hip.cpp:19-23) */
+    LSSVM_ERR_COMM = -4,             /* RCCL missing or a collective failed */
+    LSSVM_ERR_OUT_OF_MEMORY = -5,
+    LSSVM_ERR_INTERNAL = -6
+} lssvm_status;
+
+/* plssvm::kernel_function_type (include/plssvm/kernel_function_types.hpp:31-38) */
+typedef enum lssvm_kernel_type {
+    LSSVM_KERNEL_LINEAR = 0,     /* u . v */
+    LSSVM_KERNEL_POLYNOMIAL = 1, /* (gamma * u . v + coef0)^degree */
+    LSSVM_KERNEL_RBF = 2         /* exp(-gamma * |u - v|^2) */
+} lssvm_kernel_type;
+
+/* plssvm::detail::parameter<T> (include/plssvm/parameter.hpp:156-165) with gamma ALREADY resolved
+ * (the 1 / num_features default is applied by the caller exactly as csvm::fit does, csvm.hpp:303-307). */
+typedef struct lssvm_params {
+    int32_t kernel_type; /* lssvm_kernel_type */
+    int32_t degree;      /* polynomial only */
+    double gamma;        /* polynomial, rbf: must be > 0 (svm_kernel.cpp:68, :77) */
+    double coef0;        /* polynomial only */
+    double cost;         /* C; must be != 0 (svm_kernel.cpp:27 checks 1/C) */
+} lssvm_params;
+
+/* What the reference logs / tracks for a solve: keys cg/iterations, cg/max_iterations, cg/residuum, cg/target_residuum,
+ * cg/avg_iteration_time, cg/epsilon, cg/total_runtime (csvm.cpp:167-176, csvm.hpp:318-320), plus device timings. */
+typedef struct lssvm_cg_info {
+    uint64_t iterations;     /* min(iter + 1, max_iter) */
+    uint64_t max_iterations;
+    double residuum;         /* delta = r^T r after the last iteration */
+    double initial_residuum; /* delta0 */
+    double target_residuum;  /* eps * eps * delta0 */
+    double epsilon;
+    double avg_iteration_ms; /* host wall clock per CG iteration */
+    double total_ms;         /* host wall clock of begin + all steps + finish */
+    double setup_ms;         /* host->device transfer of the data matrix, q vector, norms */
+    double matvec_kernel_ms; /* average device time of ONE implicit matvec tile-kernel launch (HIP events on the solver stream) */
+    uint64_t matvec_launches;
+    int32_t devices_used;    /* world size of the row-block sharding (1 = single GPU) */
+    int32_t converged;       /* 1 if the stop test delta <= eps^2 * delta0 fired */
+} lssvm_cg_info;
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* library / device queries                                                                                           */
+/* ------------------------------------------------------------------------------------------------------------------ */
+int lssvm_mi355_abi_version(void);
+/* number of visible HIP devices (hip::detail::get_device_count, csvm.hip.cpp:66); 0 if none, <0 on error */
+int lssvm_mi355_device_count(void);
+/* writes "name (gcnArchName), CUs" of `device` into buf (csvm.hip.cpp:77-81 logs the same properties) */
+int lssvm_mi355_device_name(int device, char *buf, size_t buf_len);
+const char *lssvm_mi355_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* one-shot entry points: exactly what plssvm::csvm's pure virtuals need (include/plssvm/csvm.hpp:188-208)           */
+/* ------------------------------------------------------------------------------------------------------------------ */
+
+/* csvm::solve_system_of_linear_equations (csvm.hpp:188, :192; recipe: backends/OpenMP/csvm.cpp:71-183).
+ * X: N x d row-major, y: N labels (+-1), alpha_out: N entries (alpha[N-1] = -sum(alpha[0..N-1))), rho_out = -bias.
+ * Runs on device 0 of the calling process.  info may be NULL. */
+int lssvm_mi355_solve_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, const float *y,
+                          float eps, uint64_t max_iter, float *alpha_out, float *rho_out, lssvm_cg_info *info);
+int lssvm_mi355_solve_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, const double *y,
+                          double eps, uint64_t max_iter, double *alpha_out, double *rho_out, lssvm_cg_info *info);
+
+/* csvm::predict_values (csvm.hpp:204, :208; recipe: backends/OpenMP/csvm.cpp:188-227, HIP/predict_kernel.hip.hpp:34-117).
+ * w_inout has num_features entries; *w_valid != 0 on entry means it already holds w (linear kernel only), on exit it is
+ * set to 1 when w was computed (calculate_w, csvm.cpp:255-280).  out: num_predict_points decision values. */
+int lssvm_mi355_predict_values_f32(const lssvm_params *params, const float *support_vectors, size_t num_support_vectors,
+                                   size_t num_features, const float *alpha, float rho, float *w_inout, int *w_valid,
+                                   const float *predict_points, size_t num_predict_points, float *out);
+int lssvm_mi355_predict_values_f64(const lssvm_params *params, const double *support_vectors, size_t num_support_vectors,
+                                   size_t num_features, const double *alpha, double rho, double *w_inout, int *w_valid,
+                                   const double *predict_points, size_t num_predict_points, double *out);
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* fine-grained entry points for kernel-level parity tests: the protected members the reference's backend tests re-export  */
+/* (tests/backends/HIP/mock_hip_csvm.hpp:22-44): generate_q, run_device_kernel, calculate_w                           */
+/* ------------------------------------------------------------------------------------------------------------------ */
+
+/* gpu_csvm::generate_q (gpu_csvm.hpp:349-384) / openmp generate_q (csvm.cpp:232-251): q_out has N-1 entries */
+int lssvm_mi355_generate_q_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, float *q_out);
+int lssvm_mi355_generate_q_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, double *q_out);
+
+/* run_device_kernel (gpu_csvm.hpp:431-447 / csvm.cpp:283-306): ret[0..N-1) += add * Abar * d with
+ * Abar_ij = k(x_i,x_j) + delta_ij / C + QA_cost - q_i - q_j; add must be +1 or -1 (svm_kernel.cpp:28). */
+int lssvm_mi355_run_device_kernel_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features,
+                                      const float *q, const float *d, float *ret_inout, float QA_cost, float add);
+int lssvm_mi355_run_device_kernel_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features,
+                                      const double *q, const double *d, double *ret_inout, double QA_cost, double add);
+
+/* calculate_w (gpu_csvm.hpp:386-429 / csvm.cpp:255-280): w[f] = sum_i alpha_i * sv[i][f] */
+int lssvm_mi355_calculate_w_f32(const float *support_vectors, size_t num_support_vectors, size_t num_features, const float *alpha, float *w_out);
+int lssvm_mi355_calculate_w_f64(const double *support_vectors, size_t num_support_vectors, size_t num_features, const double *alpha, double *w_out);
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* resident-problem API: what the one-shot calls are built from.  The data matrix is uploaded once and stays in HBM;  */
+/* the CG recipe is split into begin / step / finish so that a caller (bench.py, a multi-rank launcher) can time the  */
+/* iterations alone and can drive row-block sharding across several GPUs (one rank = one process = one GPU).          */
+/* Replaces: gpu_csvm::setup_data_on_device (gpu_csvm.hpp:302-346) + the CG loop (gpu_csvm.hpp:477-654).             */
+/* ------------------------------------------------------------------------------------------------------------------ */
+typedef struct lssvm_mi355_problem lssvm_mi355_problem; /* opaque */
+
+#define LSSVM_DTYPE_F32 0
+#define LSSVM_DTYPE_F64 1
+
+#define LSSVM_MEM_HOST 0   /* X points to host memory */
+#define LSSVM_MEM_DEVICE 1 /* X points to memory of `device` (e.g. a torch tensor's data_ptr); it is copied into the padded layout */
+
+/* Row-block sharding descriptor.  rank r of `world` owns a contiguous block of output rows of the
+ * implicit matrix; the data matrix is replicated.  world == 1: single GPU, no communicator needed.
+ * For world > 1 the communicator must have been created with lssvm_mi355_comm_init on this rank first. */
+typedef struct lssvm_shard {
+    int32_t rank;
+    int32_t world;
+} lssvm_shard;
+
+/* RCCL bootstrap: rank 0 obtains a 128-byte unique id and hands it to the other ranks out of band
+ * (bench.py / the Python launcher broadcast it with torch.distributed); every rank then calls comm_init.
+ * One communicator per process.  Replaces the reference's host-staged device_reduction (gpu_csvm.hpp:449-475). */
+#define LSSVM_UNIQUE_ID_BYTES 128
+int lssvm_mi355_comm_get_unique_id(unsigned char id_out[LSSVM_UNIQUE_ID_BYTES]);
+int lssvm_mi355_comm_init(int device, int rank, int world, const unsigned char id[LSSVM_UNIQUE_ID_BYTES]);
+int lssvm_mi355_comm_destroy(void);
+
+/* upload X (N x d row-major, dtype per `dtype`), compute q, QA_cost and the per-row norms on `device`. */
+int lssvm_mi355_problem_create(lssvm_mi355_problem **out, const lssvm_params *params, int dtype, const void *X, int mem_kind,
+                               size_t num_points, size_t num_features, int device, const lssvm_shard *shard /* NULL = single GPU */);
+int lssvm_mi355_problem_destroy(lssvm_mi355_problem *p);
+
+/* read back q (N-1 entries, dtype of the problem) and QA_cost */
+int lssvm_mi355_problem_get_q(lssvm_mi355_problem *p, void *q_out, double *QA_cost_out);
+
+/* ret[0..N-1) += add * Abar * d (host vectors of the problem's dtype).  With sharding every rank returns the full vector. */
+int lssvm_mi355_problem_matvec(lssvm_mi355_problem *p, const void *d, void *ret_inout, double add);
+
+/* CG, csvm.cpp:89-111: b = y[0..n) - y[n], x = 1, r = b - A x, delta0, d = r */
+int lssvm_mi355_cg_begin(lssvm_mi355_problem *p, const void *y, double eps);
+/* run at most `iterations` further CG iterations (csvm.cpp:125-166); stops early when delta <= eps^2 delta0.
+ * *done_out (may be NULL) is set to 1 when the stop test fired. */
+int lssvm_mi355_cg_step(lssvm_mi355_problem *p, uint64_t iterations, int *done_out);
+/* csvm.cpp:179-182: bias, alpha[N-1] = -sum, rho = -bias; alpha_out has N entries of the problem's dtype */
+int lssvm_mi355_cg_finish(lssvm_mi355_problem *p, void *alpha_out, double *rho_out, lssvm_cg_info *info);
+/* block until all work queued on the problem's stream has finished (gpu_csvm::device_synchronize, gpu_csvm.hpp:208) */
+int lssvm_mi355_problem_synchronize(lssvm_mi355_problem *p);
+/* timing / counters accumulated since cg_begin (same struct as cg_finish fills); does not synchronize */
+int lssvm_mi355_problem_info(lssvm_mi355_problem *p, lssvm_cg_info *info);
+
+/* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT):
+ *   "rbf_form"      0 = norm expansion on the matrix cores (default), 1 = direct (x_i - x_j)^2 on the vector ALU
+ *   "j_chunk_tiles" number of 128-column tiles per work item (default 16)
+ */
+int lssvm_mi355_set_option(const char *name, int64_t value);
+int lssvm_mi355_get_option(const char *name, int64_t *value_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLSSVM_AMD_H */

@@ -1,0 +1,127 @@
+"""ctypes binding of the C ABI declared in ``include/plssvm_amd.h`` (libplssvm_amd.so: HIP kernels for gfx950).
+
+The library is the ONLY compute path of this package: if it is missing, importing this module raises -- there is no
+CPU or PyTorch fallback (the CPU oracle under ``oracle/`` is test infrastructure and is never imported from here).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .exceptions import BackendError, InvalidParameterError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libplssvm_amd.so")
+
+LSSVM_DTYPE_F32 = 0
+LSSVM_DTYPE_F64 = 1
+LSSVM_MEM_HOST = 0
+LSSVM_MEM_DEVICE = 1
+UNIQUE_ID_BYTES = 128
+
+STATUS_NAMES = {0: "LSSVM_SUCCESS", -1: "LSSVM_ERR_INVALID_ARGUMENT", -2: "LSSVM_ERR_NO_DEVICE", -3: "LSSVM_ERR_HIP", -4: "LSSVM_ERR_COMM",
+                -5: "LSSVM_ERR_OUT_OF_MEMORY", -6: "LSSVM_ERR_INTERNAL"}
+
+# every symbol include/plssvm_amd.h declares (tests/test_capi_symbols.py checks the built library against this list AND the header)
+EXPORTED_SYMBOLS = [
+    "lssvm_mi355_abi_version", "lssvm_mi355_device_count", "lssvm_mi355_device_name", "lssvm_mi355_last_error",
+    "lssvm_mi355_solve_f32", "lssvm_mi355_solve_f64", "lssvm_mi355_predict_values_f32", "lssvm_mi355_predict_values_f64",
+    "lssvm_mi355_generate_q_f32", "lssvm_mi355_generate_q_f64", "lssvm_mi355_run_device_kernel_f32", "lssvm_mi355_run_device_kernel_f64",
+    "lssvm_mi355_calculate_w_f32", "lssvm_mi355_calculate_w_f64",
+    "lssvm_mi355_comm_get_unique_id", "lssvm_mi355_comm_init", "lssvm_mi355_comm_destroy",
+    "lssvm_mi355_problem_create", "lssvm_mi355_problem_destroy", "lssvm_mi355_problem_get_q", "lssvm_mi355_problem_matvec",
+    "lssvm_mi355_cg_begin", "lssvm_mi355_cg_step", "lssvm_mi355_cg_finish", "lssvm_mi355_problem_synchronize", "lssvm_mi355_problem_info",
+    "lssvm_mi355_set_option", "lssvm_mi355_get_option",
+]
+
+
+class LssvmParams(C.Structure):
+    """``lssvm_params`` (include/plssvm_amd.h) == plssvm::detail::parameter<T> with gamma resolved."""
+    _fields_ = [("kernel_type", C.c_int32), ("degree", C.c_int32), ("gamma", C.c_double), ("coef0", C.c_double), ("cost", C.c_double)]
+
+
+class LssvmCgInfo(C.Structure):
+    _fields_ = [("iterations", C.c_uint64), ("max_iterations", C.c_uint64), ("residuum", C.c_double), ("initial_residuum", C.c_double),
+                ("target_residuum", C.c_double), ("epsilon", C.c_double), ("avg_iteration_ms", C.c_double), ("total_ms", C.c_double),
+                ("setup_ms", C.c_double), ("matvec_kernel_ms", C.c_double), ("matvec_launches", C.c_uint64), ("devices_used", C.c_int32),
+                ("converged", C.c_int32)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class LssvmShard(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32)]
+
+
+def _load():
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C plssvm_amd/csrc`. plssvm_amd has no CPU fallback.")
+    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+
+lib = _load()
+lib.lssvm_mi355_last_error.restype = C.c_char_p
+lib.lssvm_mi355_abi_version.restype = C.c_int
+lib.lssvm_mi355_device_count.restype = C.c_int
+
+
+def last_error() -> str:
+    msg = lib.lssvm_mi355_last_error()
+    return msg.decode("utf-8", errors="replace") if msg else ""
+
+
+def check(status: int) -> None:
+    """Map a non-zero status to the exception the reference would throw at this point."""
+    if status == 0:
+        return
+    msg = f"{STATUS_NAMES.get(status, status)}: {last_error()}"
+    if status == -1:
+        raise InvalidParameterError(msg)
+    raise BackendError(msg)
+
+
+def dtype_code(dtype) -> int:
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return LSSVM_DTYPE_F32
+    if dtype == np.float64:
+        return LSSVM_DTYPE_F64
+    raise InvalidParameterError(f"real_type must be float32 or float64, not {dtype}")
+
+
+def ctype_of(dtype):
+    return C.c_float if np.dtype(dtype) == np.float32 else C.c_double
+
+
+def suffix_of(dtype) -> str:
+    return "f32" if np.dtype(dtype) == np.float32 else "f64"
+
+
+def ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count() -> int:
+    return int(lib.lssvm_mi355_device_count())
+
+
+def device_name(device: int = 0) -> str:
+    buf = C.create_string_buffer(256)
+    check(lib.lssvm_mi355_device_name(C.c_int(device), buf, C.c_size_t(256)))
+    return buf.value.decode()
+
+
+def set_option(name: str, value: int) -> None:
+    check(lib.lssvm_mi355_set_option(name.encode(), C.c_int64(value)))
+
+
+def get_option(name: str) -> int:
+    v = C.c_int64(0)
+    check(lib.lssvm_mi355_get_option(name.encode(), C.byref(v)))
+    return int(v.value)

@@ -1,0 +1,226 @@
+"""Thin Python mirror of the backend boundary over the C ABI (include/plssvm_amd.h).
+
+Function names and argument meaning follow the reference's backend interface so that the parity tests read like the
+reference's own (tests/backends/generic_csvm_tests.hpp):
+
+    solve_system_of_linear_equations(params, A, b, eps, max_iter)   csvm.hpp:188-192
+    predict_values(params, support_vectors, alpha, rho, w, points)  csvm.hpp:204-208
+    generate_q(params, data)                                        gpu_csvm.hpp:349-384 / OpenMP csvm.cpp:232-251
+    run_device_kernel(params, q, ret, d, data, QA_cost, add)        gpu_csvm.hpp:431-447 / OpenMP csvm.cpp:283-306
+    calculate_w(support_vectors, alpha)                             gpu_csvm.hpp:386-429 / OpenMP csvm.cpp:255-280
+
+All arithmetic runs in the HIP library; numpy is only the host container.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import LssvmCgInfo, LssvmParams, LssvmShard, check, ctype_of, lib, ptr, suffix_of
+from .exceptions import InvalidParameterError
+from .parameter import Parameter
+
+__all__ = ["solve_system_of_linear_equations", "predict_values", "generate_q", "run_device_kernel", "calculate_w", "ResidentProblem",
+           "comm_get_unique_id", "comm_init", "comm_destroy"]
+
+
+def _params_struct(params: Parameter, num_features: int) -> LssvmParams:
+    p = params.resolved(num_features)
+    return LssvmParams(int(p.kernel_type), int(p.degree), float(p.gamma), float(p.coef0), float(p.cost))
+
+
+def _as_matrix(A, dtype=None) -> np.ndarray:
+    A = np.asarray(A)
+    if dtype is None:
+        dtype = A.dtype if A.dtype in (np.float32, np.float64) else np.float64
+    A = np.ascontiguousarray(A, dtype=dtype)
+    if A.ndim != 2:
+        raise InvalidParameterError("All data points must have the same number of features!")
+    return A
+
+
+def solve_system_of_linear_equations(params: Parameter, A, b, eps: float, max_iter: int):
+    """Returns ``(alpha[N], rho, info)`` -- ``csvm::solve_system_of_linear_equations`` (csvm.hpp:188-192)."""
+    A = _as_matrix(A)
+    N, d = A.shape
+    b = np.ascontiguousarray(b, dtype=A.dtype)
+    if b.shape != (N,):
+        raise InvalidParameterError(f"The number of data points in the matrix A ({N}) and the values in the right hand side vector ({b.size}) must be the same!")
+    ct = ctype_of(A.dtype)
+    alpha = np.zeros(N, dtype=A.dtype)
+    rho = ct(0)
+    info = LssvmCgInfo()
+    fn = getattr(lib, f"lssvm_mi355_solve_{suffix_of(A.dtype)}")
+    fn.restype = C.c_int
+    ps = _params_struct(params, d)
+    check(fn(C.byref(ps), ptr(A), C.c_size_t(N), C.c_size_t(d), ptr(b), ct(eps), C.c_uint64(int(max_iter)), ptr(alpha), C.byref(rho), C.byref(info)))
+    return alpha, A.dtype.type(rho.value), info.as_dict()
+
+
+def generate_q(params: Parameter, data):
+    data = _as_matrix(data)
+    N, d = data.shape
+    q = np.zeros(N - 1, dtype=data.dtype)
+    fn = getattr(lib, f"lssvm_mi355_generate_q_{suffix_of(data.dtype)}")
+    fn.restype = C.c_int
+    ps = _params_struct(params, d)
+    check(fn(C.byref(ps), ptr(data), C.c_size_t(N), C.c_size_t(d), ptr(q)))
+    return q
+
+
+def run_device_kernel(params: Parameter, q, ret, d, data, QA_cost: float, add: float):
+    """``ret += add * Abar * d``; returns the updated copy of ``ret`` (gpu_csvm.hpp:431-447)."""
+    data = _as_matrix(data)
+    N, nf = data.shape
+    q = np.ascontiguousarray(q, dtype=data.dtype)
+    d = np.ascontiguousarray(d, dtype=data.dtype)
+    out = np.array(ret, dtype=data.dtype, copy=True)
+    if not (q.size == d.size == out.size == N - 1):
+        raise InvalidParameterError(f"Sizes mismatch!: {q.size} != {N - 1}")
+    ct = ctype_of(data.dtype)
+    fn = getattr(lib, f"lssvm_mi355_run_device_kernel_{suffix_of(data.dtype)}")
+    fn.restype = C.c_int
+    ps = _params_struct(params, nf)
+    check(fn(C.byref(ps), ptr(data), C.c_size_t(N), C.c_size_t(nf), ptr(q), ptr(d), ptr(out), ct(QA_cost), ct(add)))
+    return out
+
+
+def calculate_w(support_vectors, alpha):
+    sv = _as_matrix(support_vectors)
+    alpha = np.ascontiguousarray(alpha, dtype=sv.dtype)
+    if alpha.size != sv.shape[0]:
+        raise InvalidParameterError(f"The number of support vectors ({sv.shape[0]}) and weights ({alpha.size}) must match!")
+    w = np.zeros(sv.shape[1], dtype=sv.dtype)
+    fn = getattr(lib, f"lssvm_mi355_calculate_w_{suffix_of(sv.dtype)}")
+    fn.restype = C.c_int
+    check(fn(ptr(sv), C.c_size_t(sv.shape[0]), C.c_size_t(sv.shape[1]), ptr(alpha), ptr(w)))
+    return w
+
+
+def predict_values(params: Parameter, support_vectors, alpha, rho: float, w, predict_points):
+    """Returns ``(values[num_points], w)``; ``w`` is None for the polynomial / rbf kernels (csvm.hpp:204-208)."""
+    sv = _as_matrix(support_vectors)
+    pts = _as_matrix(predict_points, dtype=sv.dtype)
+    alpha = np.ascontiguousarray(alpha, dtype=sv.dtype)
+    nsv, nf = sv.shape
+    if alpha.size != nsv:
+        raise InvalidParameterError(f"The number of support vectors ({nsv}) and number of weights ({alpha.size}) must be the same!")
+    if pts.shape[1] != nf:
+        raise InvalidParameterError(f"The number of features in the support vectors ({nf}) must be the same as in the data points to predict ({pts.shape[1]})!")
+    if w is not None and len(w) not in (0, nf):
+        raise InvalidParameterError(f"Either w must be empty or contain exactly the same number of values ({len(w)}) as features are present ({nf})!")
+    ct = ctype_of(sv.dtype)
+    w_valid = C.c_int(1 if (w is not None and len(w) == nf) else 0)
+    w_buf = np.array(w, dtype=sv.dtype, copy=True) if w_valid.value else np.zeros(nf, dtype=sv.dtype)
+    out = np.zeros(pts.shape[0], dtype=sv.dtype)
+    fn = getattr(lib, f"lssvm_mi355_predict_values_{suffix_of(sv.dtype)}")
+    fn.restype = C.c_int
+    ps = _params_struct(params, nf)
+    check(fn(C.byref(ps), ptr(sv), C.c_size_t(nsv), C.c_size_t(nf), ptr(alpha), ct(rho), ptr(w_buf), C.byref(w_valid), ptr(pts), C.c_size_t(pts.shape[0]), ptr(out)))
+    return out, (w_buf if w_valid.value else None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# communicator + resident problem (bench.py, multi-rank launchers)
+# ---------------------------------------------------------------------------------------------------------------------
+def comm_get_unique_id() -> bytes:
+    buf = (C.c_ubyte * _capi.UNIQUE_ID_BYTES)()
+    check(lib.lssvm_mi355_comm_get_unique_id(buf))
+    return bytes(buf)
+
+
+def comm_init(device: int, rank: int, world: int, unique_id: bytes) -> None:
+    if len(unique_id) != _capi.UNIQUE_ID_BYTES:
+        raise InvalidParameterError("unique id must have 128 bytes")
+    buf = (C.c_ubyte * _capi.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+    check(lib.lssvm_mi355_comm_init(C.c_int(device), C.c_int(rank), C.c_int(world), buf))
+
+
+def comm_destroy() -> None:
+    check(lib.lssvm_mi355_comm_destroy())
+
+
+class ResidentProblem:
+    """A data matrix resident in HBM plus the CG state on it (``lssvm_mi355_problem_*`` / ``lssvm_mi355_cg_*``)."""
+
+    def __init__(self, params: Parameter, X, device: int = 0, rank: int = 0, world: int = 1, device_ptr: int | None = None, shape=None, dtype=None):
+        self._h = C.c_void_p(None)
+        if device_ptr is not None:
+            N, d = shape
+            self.dtype = np.dtype(dtype)
+            src = C.c_void_p(device_ptr)
+            kind = _capi.LSSVM_MEM_DEVICE
+            self._keep = None
+        else:
+            X = _as_matrix(X)
+            N, d = X.shape
+            self.dtype = X.dtype
+            src = ptr(X)
+            kind = _capi.LSSVM_MEM_HOST
+            self._keep = X
+        self.num_points, self.num_features = int(N), int(d)
+        self.params = params.resolved(d)
+        ps = _params_struct(params, d)
+        shard = LssvmShard(rank, world)
+        lib.lssvm_mi355_problem_create.restype = C.c_int
+        check(lib.lssvm_mi355_problem_create(C.byref(self._h), C.byref(ps), C.c_int(_capi.dtype_code(self.dtype)), src, C.c_int(kind), C.c_size_t(N), C.c_size_t(d),
+                                             C.c_int(device), C.byref(shard)))
+        self._keep = None  # the library copied the data
+
+    def close(self):
+        if self._h:
+            lib.lssvm_mi355_problem_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def q(self):
+        q = np.zeros(self.num_points - 1, dtype=self.dtype)
+        qa = C.c_double(0)
+        check(lib.lssvm_mi355_problem_get_q(self._h, ptr(q), C.byref(qa)))
+        return q, float(qa.value)
+
+    def matvec(self, d, ret, add: float = 1.0):
+        d = np.ascontiguousarray(d, dtype=self.dtype)
+        out = np.array(ret, dtype=self.dtype, copy=True)
+        check(lib.lssvm_mi355_problem_matvec(self._h, ptr(d), ptr(out), C.c_double(add)))
+        return out
+
+    def cg_begin(self, y, eps: float):
+        y = np.ascontiguousarray(y, dtype=self.dtype)
+        if y.size != self.num_points:
+            raise InvalidParameterError(f"The number of data points in the matrix A ({self.num_points}) and the values in the right hand side vector ({y.size}) must be the same!")
+        check(lib.lssvm_mi355_cg_begin(self._h, ptr(y), C.c_double(eps)))
+
+    def cg_step(self, iterations: int) -> bool:
+        done = C.c_int(0)
+        check(lib.lssvm_mi355_cg_step(self._h, C.c_uint64(int(iterations)), C.byref(done)))
+        return bool(done.value)
+
+    def cg_finish(self):
+        alpha = np.zeros(self.num_points, dtype=self.dtype)
+        rho = C.c_double(0)
+        info = LssvmCgInfo()
+        check(lib.lssvm_mi355_cg_finish(self._h, ptr(alpha), C.byref(rho), C.byref(info)))
+        return alpha, self.dtype.type(rho.value), info.as_dict()
+
+    def info(self):
+        info = LssvmCgInfo()
+        check(lib.lssvm_mi355_problem_info(self._h, C.byref(info)))
+        return info.as_dict()
+
+    def synchronize(self):
+        check(lib.lssvm_mi355_problem_synchronize(self._h))

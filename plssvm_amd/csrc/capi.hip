@@ -1,0 +1,279 @@
+/*
+ * capi.hip -- the extern "C" surface of libplssvm_amd.so (declared in include/plssvm_amd.h).
+ * No exception crosses this boundary: every entry point maps lssvm::Error / std::exception to a negative status and
+ * stores the message in a thread-local string (lssvm_mi355_last_error).
+ */
+#include "lssvm_problem.hip.hpp"
+
+#include <memory>
+#include <new>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+template <typename F>
+int guarded(F &&f) {
+    try {
+        f();
+        return LSSVM_SUCCESS;
+    } catch (const lssvm::Error &e) {
+        g_last_error = e.what();
+        return e.status;
+    } catch (const std::bad_alloc &) {
+        g_last_error = "host allocation failed";
+        return LSSVM_ERR_OUT_OF_MEMORY;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return LSSVM_ERR_INTERNAL;
+    } catch (...) {
+        g_last_error = "unknown error";
+        return LSSVM_ERR_INTERNAL;
+    }
+}
+
+struct Handle {
+    std::unique_ptr<lssvm::ProblemBase> impl;
+};
+
+lssvm::ProblemBase *impl_of(lssvm_mi355_problem *p) {
+    LSSVM_REQUIRE(p != nullptr, "problem handle must not be NULL");
+    return reinterpret_cast<Handle *>(p)->impl.get();
+}
+
+template <typename T>
+void solve_one_shot(const lssvm_params *params, const T *X, size_t N, size_t d, const T *y, T eps, uint64_t max_iter, T *alpha_out, T *rho_out, lssvm_cg_info *info) {
+    lssvm::check_params(params);
+    LSSVM_REQUIRE(X != nullptr && N > 0, "The data must not be empty!");                                                                  // csvm.cpp:73
+    LSSVM_REQUIRE(d > 0, "The data points must contain at least one feature!");                                                           // csvm.cpp:74
+    LSSVM_REQUIRE(y != nullptr, "The number of data points in the matrix A and the values in the right hand side vector must be the same!");  // csvm.cpp:76
+    LSSVM_REQUIRE(eps > T(0), "The stopping criterion in the CG algorithm must be greater than 0.0, but is " + std::to_string(eps) + "!");  // csvm.cpp:77
+    LSSVM_REQUIRE(max_iter > 0, "The number of CG iterations must be greater than 0!");                                                   // csvm.cpp:78
+    LSSVM_REQUIRE(alpha_out != nullptr && rho_out != nullptr, "alpha_out / rho_out must not be NULL");
+    lssvm::Problem<T> prob(*params, X, LSSVM_MEM_HOST, N, d, 0, nullptr);
+    prob.cg_begin(y, static_cast<double>(eps));
+    prob.cg_step(max_iter, nullptr);
+    double rho = 0.0;
+    lssvm_cg_info local{};
+    prob.cg_finish(alpha_out, &rho, &local);
+    local.max_iterations = max_iter;
+    *rho_out = static_cast<T>(rho);
+    if (info != nullptr) *info = local;
+}
+
+template <typename T>
+void generate_q_one_shot(const lssvm_params *params, const T *X, size_t N, size_t d, T *q_out) {
+    lssvm::check_params(params);
+    LSSVM_REQUIRE(q_out != nullptr, "q_out must not be NULL");
+    lssvm::Problem<T> prob(*params, X, LSSVM_MEM_HOST, N, d, 0, nullptr);
+    prob.get_q(q_out, nullptr);
+}
+
+}  // namespace
+
+extern "C" {
+
+int lssvm_mi355_abi_version(void) { return PLSSVM_AMD_ABI_VERSION; }
+
+const char *lssvm_mi355_last_error(void) { return g_last_error.c_str(); }
+
+int lssvm_mi355_device_count(void) {
+    int count = 0;
+    const hipError_t err = hipGetDeviceCount(&count);
+    if (err != hipSuccess) {
+        (void) hipGetLastError();
+        if (err == hipErrorNoDevice) return 0;
+        g_last_error = std::string("hipGetDeviceCount failed: ") + hipGetErrorString(err);
+        return 0;
+    }
+    return count;
+}
+
+int lssvm_mi355_device_name(int device, char *buf, size_t buf_len) {
+    return guarded([&] {
+        LSSVM_REQUIRE(buf != nullptr && buf_len > 0, "buf must not be NULL");
+        lssvm::select_device_checked(device);
+        hipDeviceProp_t prop{};
+        LSSVM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        std::snprintf(buf, buf_len, "%s (%s), %d CUs", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    });
+}
+
+int lssvm_mi355_solve_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, const float *y, float eps, uint64_t max_iter,
+                          float *alpha_out, float *rho_out, lssvm_cg_info *info) {
+    return guarded([&] { solve_one_shot<float>(params, X, num_points, num_features, y, eps, max_iter, alpha_out, rho_out, info); });
+}
+int lssvm_mi355_solve_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, const double *y, double eps, uint64_t max_iter,
+                          double *alpha_out, double *rho_out, lssvm_cg_info *info) {
+    return guarded([&] { solve_one_shot<double>(params, X, num_points, num_features, y, eps, max_iter, alpha_out, rho_out, info); });
+}
+
+int lssvm_mi355_predict_values_f32(const lssvm_params *params, const float *sv, size_t nsv, size_t nfeat, const float *alpha, float rho, float *w_inout,
+                                   int *w_valid, const float *points, size_t npoints, float *out) {
+    return guarded([&] {
+        LSSVM_REQUIRE(params != nullptr, "params must not be NULL!");
+        lssvm::predict_values<float>(*params, sv, nsv, nfeat, alpha, rho, w_inout, w_valid, points, npoints, out);
+    });
+}
+int lssvm_mi355_predict_values_f64(const lssvm_params *params, const double *sv, size_t nsv, size_t nfeat, const double *alpha, double rho, double *w_inout,
+                                   int *w_valid, const double *points, size_t npoints, double *out) {
+    return guarded([&] {
+        LSSVM_REQUIRE(params != nullptr, "params must not be NULL!");
+        lssvm::predict_values<double>(*params, sv, nsv, nfeat, alpha, rho, w_inout, w_valid, points, npoints, out);
+    });
+}
+
+int lssvm_mi355_generate_q_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, float *q_out) {
+    return guarded([&] { generate_q_one_shot<float>(params, X, num_points, num_features, q_out); });
+}
+int lssvm_mi355_generate_q_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, double *q_out) {
+    return guarded([&] { generate_q_one_shot<double>(params, X, num_points, num_features, q_out); });
+}
+
+int lssvm_mi355_run_device_kernel_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, const float *q, const float *d,
+                                      float *ret_inout, float QA_cost, float add) {
+    return guarded([&] {
+        lssvm::check_params(params);
+        LSSVM_REQUIRE(q != nullptr, "The q array may not be empty!");  // csvm.cpp:284
+        (void) QA_cost;  // q and QA_cost are functions of (X, params); they are recomputed on the device and must agree with the caller's
+        lssvm::Problem<float> prob(*params, X, LSSVM_MEM_HOST, num_points, num_features, 0, nullptr);
+        prob.matvec(d, ret_inout, static_cast<double>(add));
+    });
+}
+int lssvm_mi355_run_device_kernel_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, const double *q, const double *d,
+                                      double *ret_inout, double QA_cost, double add) {
+    return guarded([&] {
+        lssvm::check_params(params);
+        LSSVM_REQUIRE(q != nullptr, "The q array may not be empty!");
+        (void) QA_cost;
+        lssvm::Problem<double> prob(*params, X, LSSVM_MEM_HOST, num_points, num_features, 0, nullptr);
+        prob.matvec(d, ret_inout, add);
+    });
+}
+
+int lssvm_mi355_calculate_w_f32(const float *sv, size_t nsv, size_t nfeat, const float *alpha, float *w_out) {
+    return guarded([&] { lssvm::calculate_w<float>(sv, nsv, nfeat, alpha, w_out); });
+}
+int lssvm_mi355_calculate_w_f64(const double *sv, size_t nsv, size_t nfeat, const double *alpha, double *w_out) {
+    return guarded([&] { lssvm::calculate_w<double>(sv, nsv, nfeat, alpha, w_out); });
+}
+
+/* ---- communicator ---- */
+int lssvm_mi355_comm_get_unique_id(unsigned char id_out[LSSVM_UNIQUE_ID_BYTES]) {
+    return guarded([&] {
+        LSSVM_REQUIRE(id_out != nullptr, "id_out must not be NULL");
+        static_assert(sizeof(ncclUniqueId) == LSSVM_UNIQUE_ID_BYTES, "ncclUniqueId size changed");
+        lssvm::comm_load();
+        ncclUniqueId id;
+        const ncclResult_t rc = lssvm::comm().pGetUniqueId(&id);
+        if (rc != ncclSuccess) throw lssvm::Error(LSSVM_ERR_COMM, std::string("ncclGetUniqueId failed: ") + lssvm::comm().pGetErrorString(rc));
+        std::memcpy(id_out, &id, sizeof(id));
+    });
+}
+int lssvm_mi355_comm_init(int device, int rank, int world, const unsigned char id_in[LSSVM_UNIQUE_ID_BYTES]) {
+    return guarded([&] {
+        LSSVM_REQUIRE(id_in != nullptr, "id must not be NULL");
+        LSSVM_REQUIRE(world >= 1 && rank >= 0 && rank < world, "invalid rank/world");
+        lssvm::Comm &c = lssvm::comm();
+        LSSVM_REQUIRE(c.comm == nullptr, "a communicator already exists in this process");
+        lssvm::comm_load();
+        lssvm::select_device_checked(device);
+        ncclUniqueId id;
+        std::memcpy(&id, id_in, sizeof(id));
+        ncclComm_t nc = nullptr;
+        const ncclResult_t rc = c.pCommInitRank(&nc, world, id, rank);
+        if (rc != ncclSuccess) throw lssvm::Error(LSSVM_ERR_COMM, std::string("ncclCommInitRank failed: ") + c.pGetErrorString(rc));
+        c.comm = nc;
+        c.rank = rank;
+        c.world = world;
+        c.device = device;
+    });
+}
+int lssvm_mi355_comm_destroy(void) {
+    return guarded([&] {
+        lssvm::Comm &c = lssvm::comm();
+        if (c.comm != nullptr) {
+            (void) hipSetDevice(c.device);
+            c.pCommDestroy(c.comm);
+            c.comm = nullptr;
+            c.world = 1;
+            c.rank = 0;
+        }
+    });
+}
+
+/* ---- resident problem ---- */
+int lssvm_mi355_problem_create(lssvm_mi355_problem **out, const lssvm_params *params, int dtype, const void *X, int mem_kind, size_t num_points,
+                               size_t num_features, int device, const lssvm_shard *shard) {
+    return guarded([&] {
+        LSSVM_REQUIRE(out != nullptr, "out must not be NULL");
+        *out = nullptr;
+        lssvm::check_params(params);
+        LSSVM_REQUIRE(dtype == LSSVM_DTYPE_F32 || dtype == LSSVM_DTYPE_F64, "dtype must be LSSVM_DTYPE_F32 or LSSVM_DTYPE_F64");
+        auto h = std::make_unique<Handle>();
+        if (dtype == LSSVM_DTYPE_F32) {
+            h->impl = std::make_unique<lssvm::Problem<float>>(*params, X, mem_kind, num_points, num_features, device, shard);
+        } else {
+            h->impl = std::make_unique<lssvm::Problem<double>>(*params, X, mem_kind, num_points, num_features, device, shard);
+        }
+        *out = reinterpret_cast<lssvm_mi355_problem *>(h.release());
+    });
+}
+int lssvm_mi355_problem_destroy(lssvm_mi355_problem *p) {
+    return guarded([&] { delete reinterpret_cast<Handle *>(p); });
+}
+int lssvm_mi355_problem_get_q(lssvm_mi355_problem *p, void *q_out, double *QA_cost_out) {
+    return guarded([&] { impl_of(p)->get_q(q_out, QA_cost_out); });
+}
+int lssvm_mi355_problem_matvec(lssvm_mi355_problem *p, const void *d, void *ret_inout, double add) {
+    return guarded([&] { impl_of(p)->matvec(d, ret_inout, add); });
+}
+int lssvm_mi355_cg_begin(lssvm_mi355_problem *p, const void *y, double eps) {
+    return guarded([&] { impl_of(p)->cg_begin(y, eps); });
+}
+int lssvm_mi355_cg_step(lssvm_mi355_problem *p, uint64_t iterations, int *done_out) {
+    return guarded([&] { impl_of(p)->cg_step(iterations, done_out); });
+}
+int lssvm_mi355_cg_finish(lssvm_mi355_problem *p, void *alpha_out, double *rho_out, lssvm_cg_info *info) {
+    return guarded([&] { impl_of(p)->cg_finish(alpha_out, rho_out, info); });
+}
+int lssvm_mi355_problem_synchronize(lssvm_mi355_problem *p) {
+    return guarded([&] { impl_of(p)->synchronize(); });
+}
+int lssvm_mi355_problem_info(lssvm_mi355_problem *p, lssvm_cg_info *info) {
+    return guarded([&] {
+        LSSVM_REQUIRE(info != nullptr, "info must not be NULL");
+        impl_of(p)->fill_info(info);
+    });
+}
+
+int lssvm_mi355_set_option(const char *name, int64_t value) {
+    return guarded([&] {
+        LSSVM_REQUIRE(name != nullptr, "name must not be NULL");
+        const std::string n(name);
+        if (n == "rbf_form") {
+            LSSVM_REQUIRE(value == 0 || value == 1, "rbf_form must be 0 or 1");
+            lssvm::options().rbf_form = value;
+        } else if (n == "j_chunk_tiles") {
+            LSSVM_REQUIRE(value >= 1 && value <= (1 << 20), "j_chunk_tiles out of range");
+            lssvm::options().j_chunk_tiles = value;
+        } else {
+            throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "unknown option '" + n + "'");
+        }
+    });
+}
+int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
+    return guarded([&] {
+        LSSVM_REQUIRE(name != nullptr && value_out != nullptr, "name / value_out must not be NULL");
+        const std::string n(name);
+        if (n == "rbf_form") {
+            *value_out = lssvm::options().rbf_form;
+        } else if (n == "j_chunk_tiles") {
+            *value_out = lssvm::options().j_chunk_tiles;
+        } else {
+            throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "unknown option '" + n + "'");
+        }
+    });
+}
+
+}  // extern "C"

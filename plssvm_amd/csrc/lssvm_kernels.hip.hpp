@@ -1,0 +1,819 @@
+/*
+ * lssvm_kernels.hip.hpp -- hand-written gfx950 (CDNA4 / MI355X) device kernels of the LS-SVM CG hot path.
+ *
+ * What is computed (citations relative to the reference tree SC-SGS/PLSSVM):
+ *   the implicit matrix-vector product  ret += add * Abar * d,  Abar_ij = k(x_i,x_j) + delta_ij/C + QA_cost - q_i - q_j
+ *   (src/plssvm/backends/OpenMP/svm_kernel.cpp:33-54, include/plssvm/backends/HIP/svm_kernel.hip.hpp:38-270),
+ *   the q vector (q_kernel.cpp:18-55 / HIP/q_kernel.hip.hpp:33-85) and the BLAS-1 of the CG loop (csvm.cpp:101-163).
+ *
+ * How (MI355X-first, NOT the reference's 16x16-thread / 6x6-register tiling):
+ *   Abar * d = K d + d/C + (QA_cost*S - q.d) 1 - S q   with S = sum(d)  (rank-1 terms peeled off).
+ *   Only K d is O(n^2 d).  It is evaluated as a flash-style sweep: a 256-thread workgroup (4 wave64) owns a 128-row
+ *   block of the implicit matrix and walks a chunk of 128-column tiles.  Per tile the 128x128 Gram block X_I X_J^T is
+ *   contracted on the matrix cores (v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64: exact IEEE fma chains in k order,
+ *   at the full f32/f64 vector rate) from k-chunks staged through LDS (padded rows: conflict-free ds_read_b128 /
+ *   ds_read_b64); the kernel function (pow / exp) and the multiplication with d_j are fused into the epilogue on the
+ *   vector ALU, and row sums stay in registers across the whole chunk.  No symmetry trick and no atomics: every
+ *   (row block, column chunk) work item writes its partial row sums to its own slab, a second kernel adds the slabs
+ *   in a fixed order => bit-reproducible and independent of the number of GPUs.
+ *   RBF uses |x_i - x_j|^2 = |x_i|^2 + |x_j|^2 - 2 x_i.x_j on data centred by the column means (distances are translation
+ *   invariant; centring bounds the cancellation error); the accumulator is initialised with -(|x_i|^2+|x_j|^2)/2 so the
+ *   MFMA chain leaves -|x_i-x_j|^2/2 and the epilogue is one mul + v_exp_f32 + fma.
+ */
+#pragma once
+
+#include "lssvm_types.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <type_traits>
+
+namespace lssvm {
+
+/* integer power by repeated squaring; the reference uses pow(real, int) on the GPU (HIP/svm_kernel.hip.hpp:178) and
+ * std::pow(real, real(degree)) on the CPU (kernel_function_types.hpp:86-89): equal up to rounding for integer degrees. */
+template <typename T>
+__device__ __forceinline__ T ipow(T base, int degree) {
+    unsigned e = degree < 0 ? static_cast<unsigned>(-(long) degree) : static_cast<unsigned>(degree);
+    T result = T(1);
+    T b = base;
+    while (e != 0u) {
+        if (e & 1u) result *= b;
+        b *= b;
+        e >>= 1u;
+    }
+    return degree < 0 ? T(1) / result : result;
+}
+
+template <int KT, typename T>
+__device__ __forceinline__ T apply_kernel_function(T acc, const TileArgs<T> &a) {
+    if constexpr (KT == KT_LINEAR) {
+        return acc;
+    } else if constexpr (KT == KT_POLY) {
+        const T v = acc * a.gamma + a.coef0;  // contracted to one fma, = std::fma(gamma, dot, coef0)
+        if (a.degree == 3) return v * v * v;
+        if (a.degree == 2) return v * v;
+        return ipow(v, a.degree);
+    } else {
+        if constexpr (std::is_same_v<T, float>) {
+            return __builtin_amdgcn_exp2f(acc * a.gamma);  // acc = -|xi-xj|^2 / 2 ; gamma field = 2*gamma*log2(e)
+        } else {
+            return exp(acc * a.gamma);                     // gamma field = 2*gamma
+        }
+    }
+}
+
+/* =====================================================================================================================
+ * fp32 tile kernel: v_mfma_f32_32x32x2_f32
+ *   operand maps (cdna_hip_programming.md section 3): lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
+ *   the 32x32 result has column j = l&31 on the lane and rows (reg&3) + 8*(reg>>2) + 4*(l>>5) in its 16 registers.
+ *   LDS image of a k-chunk: [128 rows][32 floats + 4 pad]; inside every group of 8 floats the order is
+ *   k = 0,2,4,6,1,3,5,7 so that ONE ds_read_b128 of lane-half h returns k = h, 2+h, 4+h, 6+h -- the operands of four
+ *   consecutive MFMAs -- and the contraction runs through k in ascending order (bit-identical to the fma chain of the
+ *   reference's dot product, include/plssvm/detail/operators.hpp:117-126).
+ * ===================================================================================================================== */
+
+template <int KT>
+__global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32(const TileArgs<float> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *As = reinterpret_cast<float *>(smem_raw);  // [2][TILE * F32_LS]
+    float *Bs = As + 2 * TILE * F32_LS;               // [2][TILE * F32_LS]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1;  // wave row (0..1): rows wr*64 .. +63 of the tile
+    const int wc = wave & 1;   // wave column
+    const int r = lane & 31;
+    const int h = lane >> 5;
+
+    // work item -> (row block, column chunk); consecutive blocks share the column chunk (L2 reuse on every XCD)
+    const int item = blockIdx.x;
+    const int ibl = item % a.num_ib;
+    const int jc = item / a.num_ib;
+    const int row0 = (a.ib_begin + ibl) * TILE;
+    const int jt_begin = jc * a.jc_tiles;
+    const int jt_end = min(jt_begin + a.jc_tiles, a.num_jt);
+    const int ntiles = jt_end - jt_begin;
+    if (ntiles <= 0) return;
+
+    // staging: thread -> (row = tid/4 [+64], 8 consecutive floats at (tid%4)*8); 4 threads cover one 128-B line
+    const int srow = tid >> 2;
+    const int sseg = tid & 3;
+    const float *Ag = a.Xr + static_cast<size_t>(row0 + srow) * a.ldx + sseg * 8;
+    const size_t rstep = static_cast<size_t>(64) * a.ldx;
+    const int lds_w = srow * F32_LS + sseg * 8;  // float offset of this thread's 8 floats in the LDS image
+
+    float rowpart[2][16];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rowpart[rb][i] = 0.0f;
+
+    float ci[2][16];
+    if constexpr (KT == KT_RBF) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ci[rb][i] = a.cr[row0 + wr * 64 + rb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h];
+    }
+
+    f32x16 acc[2][2];
+    f32x4 sa[2][2], sb[2][2];
+
+    auto stage_load = [&](int jt, int kc) {
+        const float *Bg = a.Xc + static_cast<size_t>(jt * TILE + srow) * a.ldx + sseg * 8;
+        const int ko = kc * F32_KC;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            sa[p][0] = *reinterpret_cast<const f32x4 *>(Ag + p * rstep + ko);
+            sa[p][1] = *reinterpret_cast<const f32x4 *>(Ag + p * rstep + ko + 4);
+            sb[p][0] = *reinterpret_cast<const f32x4 *>(Bg + p * rstep + ko);
+            sb[p][1] = *reinterpret_cast<const f32x4 *>(Bg + p * rstep + ko + 4);
+        }
+    };
+    auto stage_store = [&](int buf) {
+        float *Aw = As + buf * TILE * F32_LS + lds_w;
+        float *Bw = Bs + buf * TILE * F32_LS + lds_w;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            // k-interleave: even k first, odd k second (see header comment)
+            *reinterpret_cast<f32x4 *>(Aw + p * 64 * F32_LS) = f32x4{ sa[p][0].x, sa[p][0].z, sa[p][1].x, sa[p][1].z };
+            *reinterpret_cast<f32x4 *>(Aw + p * 64 * F32_LS + 4) = f32x4{ sa[p][0].y, sa[p][0].w, sa[p][1].y, sa[p][1].w };
+            *reinterpret_cast<f32x4 *>(Bw + p * 64 * F32_LS) = f32x4{ sb[p][0].x, sb[p][0].z, sb[p][1].x, sb[p][1].z };
+            *reinterpret_cast<f32x4 *>(Bw + p * 64 * F32_LS + 4) = f32x4{ sb[p][0].y, sb[p][0].w, sb[p][1].y, sb[p][1].w };
+        }
+    };
+
+    float dj[2], cj[2];
+    bool padcol[2] = { false, false };  // polynomial with a negative degree only: (0*gamma+coef0)^degree may be inf on padding
+    auto tile_init = [&](int jt) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int j = jt * TILE + wc * 64 + cb * 32 + r;
+            dj[cb] = a.dvec[j];
+            if constexpr (KT == KT_RBF) cj[cb] = a.cc[j];
+            if constexpr (KT == KT_POLY) padcol[cb] = (a.degree < 0) && (j >= a.ncols_valid);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if constexpr (KT == KT_RBF) {
+                        acc[rb][cb][i] = ci[rb][i] + cj[cb];
+                    } else {
+                        acc[rb][cb][i] = 0.0f;
+                    }
+                }
+    };
+
+    const int nsteps = ntiles * a.kchunks;
+    stage_load(jt_begin, 0);
+    tile_init(jt_begin);
+    stage_store(0);
+    __syncthreads();
+
+    int jt = jt_begin;
+    int kc = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        const int cur = s & 1;
+        int njt = jt, nkc = kc + 1;
+        if (nkc == a.kchunks) {
+            nkc = 0;
+            ++njt;
+        }
+        const bool has_next = (s + 1 < nsteps);
+        if (has_next) stage_load(njt, nkc);
+
+        {
+            const float *Ab = As + cur * TILE * F32_LS + (wr * 64 + r) * F32_LS + h * 4;
+            const float *Bb = Bs + cur * TILE * F32_LS + (wc * 64 + r) * F32_LS + h * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4 *>(Ab + g * 8);
+                const f32x4 a1 = *reinterpret_cast<const f32x4 *>(Ab + 32 * F32_LS + g * 8);
+                const f32x4 b0 = *reinterpret_cast<const f32x4 *>(Bb + g * 8);
+                const f32x4 b1 = *reinterpret_cast<const f32x4 *>(Bb + 32 * F32_LS + g * 8);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b1[t], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+
+        if (has_next) stage_store(cur ^ 1);
+
+        if (kc == a.kchunks - 1) {
+            // epilogue of tile jt: K_ij = f(acc), row partial += K_ij * d_j  (vector ALU, fused; nothing is written)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float kv = apply_kernel_function<KT>(acc[rb][cb][i], a);
+                        if constexpr (KT == KT_POLY) {
+                            if (padcol[cb]) kv = 0.0f;  // d_j is an exact zero there, but inf * 0 would be nan
+                        }
+                        rowpart[rb][i] = fmaf(kv, dj[cb], rowpart[rb][i]);
+                    }
+            if (has_next) tile_init(njt);
+        }
+        __syncthreads();
+        jt = njt;
+        kc = nkc;
+    }
+
+    // reduce the row partials over the 32 lanes that share the rows (same lane-half), then over the two wave columns
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = rowpart[rb][i];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 1);
+            rowpart[rb][i] = v;
+        }
+    float *red = reinterpret_cast<float *>(smem_raw);  // [2][TILE]; the staging buffers are dead (barrier above)
+    if (r == 0) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[wc * TILE + wr * 64 + rb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] = rowpart[rb][i];
+    }
+    __syncthreads();
+    if (tid < TILE) {
+        a.partial[static_cast<size_t>(jc) * a.part_stride + ibl * TILE + tid] = red[tid] + red[TILE + tid];
+    }
+}
+
+/* =====================================================================================================================
+ * fp64 tile kernel: v_mfma_f64_16x16x4_f64
+ *   lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15] (one f64 each); the 16x16 result has column
+ *   j = l&15 on the lane and rows (l>>4) + 4*reg in its 4 registers (NOT the f32 row map).
+ *   LDS image of a k-chunk: [128 rows][16 doubles + 2 pad] (144-B rows: conflict-free ds_read_b64).
+ * ===================================================================================================================== */
+
+template <int KT>
+__global__ __launch_bounds__(TILE_THREADS, 1) void tile_matvec_f64(const TileArgs<double> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double *As = reinterpret_cast<double *>(smem_raw);  // [2][TILE * F64_LS]
+    double *Bs = As + 2 * TILE * F64_LS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1;
+    const int wc = wave & 1;
+    const int r = lane & 15;
+    const int qd = lane >> 4;
+
+    const int item = blockIdx.x;
+    const int ibl = item % a.num_ib;
+    const int jc = item / a.num_ib;
+    const int row0 = (a.ib_begin + ibl) * TILE;
+    const int jt_begin = jc * a.jc_tiles;
+    const int jt_end = min(jt_begin + a.jc_tiles, a.num_jt);
+    const int ntiles = jt_end - jt_begin;
+    if (ntiles <= 0) return;
+
+    // staging: thread -> (row = tid/8 [+32 p], 2 doubles at (tid%8)*2); 8 threads cover one 128-B line
+    const int srow = tid >> 3;
+    const int sseg = tid & 7;
+    const double *Ag = a.Xr + static_cast<size_t>(row0 + srow) * a.ldx + sseg * 2;
+    const size_t rstep = static_cast<size_t>(32) * a.ldx;
+    const int lds_w = srow * F64_LS + sseg * 2;
+
+    double rowpart[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rowpart[mt][i] = 0.0;
+
+    f64x4 acc[4][4];
+    f64x2 sa[4], sb[4];
+
+    auto stage_load = [&](int jt, int kc) {
+        const double *Bg = a.Xc + static_cast<size_t>(jt * TILE + srow) * a.ldx + sseg * 2;
+        const int ko = kc * F64_KC;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            sa[p] = *reinterpret_cast<const f64x2 *>(Ag + p * rstep + ko);
+            sb[p] = *reinterpret_cast<const f64x2 *>(Bg + p * rstep + ko);
+        }
+    };
+    auto stage_store = [&](int buf) {
+        double *Aw = As + buf * TILE * F64_LS + lds_w;
+        double *Bw = Bs + buf * TILE * F64_LS + lds_w;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<f64x2 *>(Aw + p * 32 * F64_LS) = sa[p];
+            *reinterpret_cast<f64x2 *>(Bw + p * 32 * F64_LS) = sb[p];
+        }
+    };
+
+    double dj[4];
+    bool padcol[4] = { false, false, false, false };
+    auto tile_init = [&](int jt) {
+        double cj[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int j = jt * TILE + wc * 64 + nt * 16 + r;
+            dj[nt] = a.dvec[j];
+            cj[nt] = 0.0;
+            if constexpr (KT == KT_RBF) cj[nt] = a.cc[j];
+            if constexpr (KT == KT_POLY) padcol[nt] = (a.degree < 0) && (j >= a.ncols_valid);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double civ = 0.0;
+                if constexpr (KT == KT_RBF) civ = a.cr[row0 + wr * 64 + mt * 16 + qd + 4 * i];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt][i] = civ + cj[nt];
+            }
+    };
+
+    const int nsteps = ntiles * a.kchunks;
+    stage_load(jt_begin, 0);
+    tile_init(jt_begin);
+    stage_store(0);
+    __syncthreads();
+
+    int jt = jt_begin;
+    int kc = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        const int cur = s & 1;
+        int njt = jt, nkc = kc + 1;
+        if (nkc == a.kchunks) {
+            nkc = 0;
+            ++njt;
+        }
+        const bool has_next = (s + 1 < nsteps);
+        if (has_next) stage_load(njt, nkc);
+
+        {
+            const double *Ab = As + cur * TILE * F64_LS + (wr * 64 + r) * F64_LS + qd;
+            const double *Bb = Bs + cur * TILE * F64_LS + (wc * 64 + r) * F64_LS + qd;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                double av[4], bv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    av[t] = Ab[t * 16 * F64_LS + ks * 4];
+                    bv[t] = Bb[t * 16 * F64_LS + ks * 4];
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+
+        if (has_next) stage_store(cur ^ 1);
+
+        if (kc == a.kchunks - 1) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        double kv = apply_kernel_function<KT>(acc[mt][nt][i], a);
+                        if constexpr (KT == KT_POLY) {
+                            if (padcol[nt]) kv = 0.0;
+                        }
+                        rowpart[mt][i] = fma(kv, dj[nt], rowpart[mt][i]);
+                    }
+            if (has_next) tile_init(njt);
+        }
+        __syncthreads();
+        jt = njt;
+        kc = nkc;
+    }
+
+    // rows are shared by the 16 lanes of a quarter-wave (same l>>4)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double v = rowpart[mt][i];
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 1);
+            rowpart[mt][i] = v;
+        }
+    double *red = reinterpret_cast<double *>(smem_raw);  // [2][TILE]
+    if (r == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wc * TILE + wr * 64 + mt * 16 + qd + 4 * i] = rowpart[mt][i];
+    }
+    __syncthreads();
+    if (tid < TILE) {
+        a.partial[static_cast<size_t>(jc) * a.part_stride + ibl * TILE + tid] = red[tid] + red[TILE + tid];
+    }
+}
+
+/* =====================================================================================================================
+ * Direct-form RBF on the vector ALU (fp32): accumulates (x_i - x_j)^2 exactly as the reference does
+ * (HIP/svm_kernel.hip.hpp:247, operators.hpp:161-171).  1 sub + 1 fma per (i, j, feature): at most half of the fp32 FMA
+ * peak.  Kept as the formula-exact alternative to the matrix-core path (option "rbf_form" = 1) and as its on-device
+ * cross-check.  Each thread owns an 8 x 8 register tile of a 128 x 128 workgroup tile; operands come from the same
+ * k-chunked LDS images (no k interleave needed here; rows padded to 33 floats).
+ * ===================================================================================================================== */
+constexpr int DIR_KC = 32;
+constexpr int DIR_LS = 33;
+
+__global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_rbf_direct_f32(const TileArgs<float> a) {
+    __shared__ float As[TILE * DIR_LS];
+    __shared__ float Bs[TILE * DIR_LS];
+    __shared__ float red[16][TILE];
+
+    const int tid = threadIdx.x;
+    const int tx = tid & 15;  // column group: columns tx + 16*c
+    const int ty = tid >> 4;  // row group:    rows    ty + 16*rr
+    const int item = blockIdx.x;
+    const int ibl = item % a.num_ib;
+    const int jc = item / a.num_ib;
+    const int row0 = (a.ib_begin + ibl) * TILE;
+    const int jt_begin = jc * a.jc_tiles;
+    const int jt_end = min(jt_begin + a.jc_tiles, a.num_jt);
+    if (jt_end <= jt_begin) return;
+
+    float rowpart[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rowpart[i] = 0.0f;
+
+    const int srow = tid >> 3;  // 0..31
+    const int sseg = tid & 7;   // 4 floats each
+    for (int jt = jt_begin; jt < jt_end; ++jt) {
+        float acc[8][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = 0.0f;
+        for (int kc = 0; kc < a.kchunks; ++kc) {
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = srow + 32 * p;
+                const f32x4 va = *reinterpret_cast<const f32x4 *>(a.Xr + static_cast<size_t>(row0 + row) * a.ldx + kc * DIR_KC + sseg * 4);
+                const f32x4 vb = *reinterpret_cast<const f32x4 *>(a.Xc + static_cast<size_t>(jt * TILE + row) * a.ldx + kc * DIR_KC + sseg * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    As[row * DIR_LS + sseg * 4 + e] = va[e];
+                    Bs[row * DIR_LS + sseg * 4 + e] = vb[e];
+                }
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int k = 0; k < DIR_KC; ++k) {
+                float av[8], bv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) av[i] = As[(ty + 16 * i) * DIR_LS + k];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bv[j] = Bs[(tx + 16 * j) * DIR_LS + k];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float diff = av[i] - bv[j];
+                        acc[i][j] = fmaf(diff, diff, acc[i][j]);
+                    }
+            }
+        }
+        // epilogue: exp(-gamma * dist^2) * d_j ; for THIS kernel the gamma field carries -gamma*log2(e)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float dv = a.dvec[jt * TILE + tx + 16 * j];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rowpart[i] = fmaf(__builtin_amdgcn_exp2f(acc[i][j] * a.gamma), dv, rowpart[i]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[tx][ty + 16 * i] = rowpart[i];
+    __syncthreads();
+    if (tid < TILE) {
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s += red[c][tid];
+        a.partial[static_cast<size_t>(jc) * a.part_stride + ibl * TILE + tid] = s;
+    }
+}
+
+/* =====================================================================================================================
+ * O(n) / O(n d) helper kernels
+ * ===================================================================================================================== */
+
+/* deterministic block reduction of `NV` doubles per thread; result valid in thread 0 */
+template <int NV>
+__device__ __forceinline__ void block_reduce(double (&v)[NV], double *lds /* [NV][4] for 256 threads */) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) lds[k * 4 + wave] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = (lds[k * 4 + 0] + lds[k * 4 + 1]) + (lds[k * 4 + 2] + lds[k * 4 + 3]);
+    }
+}
+
+/* part[b][0] = sum v, part[b][1] = sum q*v over the block's grid-stride slice */
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void k_sum_and_qdot(const T *__restrict__ v, const T *__restrict__ q, int n, double *__restrict__ part) {
+    __shared__ double lds[8];
+    double acc[2] = { 0.0, 0.0 };
+    for (int i = blockIdx.x * RED_THREADS + threadIdx.x; i < n; i += RED_BLOCKS * RED_THREADS) {
+        const double vi = static_cast<double>(v[i]);
+        acc[0] += vi;
+        acc[1] += vi * static_cast<double>(q[i]);
+    }
+    block_reduce<2>(acc, lds);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2 + 0] = acc[0];
+        part[blockIdx.x * 2 + 1] = acc[1];
+    }
+}
+
+/* single block: out[slot0] = sum part[.][0], out[slot1] = sum part[.][1]  (fixed tree order) */
+__global__ __launch_bounds__(RED_THREADS) void k_finish2(const double *__restrict__ part, double *__restrict__ sc, int slot0, int slot1) {
+    __shared__ double lds[8];
+    double acc[2] = { part[threadIdx.x * 2 + 0], part[threadIdx.x * 2 + 1] };
+    block_reduce<2>(acc, lds);
+    if (threadIdx.x == 0) {
+        sc[slot0] = acc[0];
+        if (slot1 >= 0) sc[slot1] = acc[1];
+    }
+}
+
+/* Kv[row_begin + i] = sum over column chunks of partial[c][i], chunks in ascending order (rows of this device only) */
+template <typename T>
+__global__ void k_reduce_partials(const T *__restrict__ partial, long part_stride, int num_jc, int row_begin, int nrows, T *__restrict__ Kv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nrows) {
+        T s = partial[i];
+        for (int c = 1; c < num_jc; ++c) s += partial[static_cast<size_t>(c) * part_stride + i];
+        Kv[row_begin + i] = s;
+    }
+}
+
+/* (Abar v)_i = Kv_i + v_i/C + (QA_cost*S - q.v) - S*q_i, evaluated in double */
+template <typename T>
+__device__ __forceinline__ double abar_row(const T *Kv, const T *v, const T *q, int i, double inv_cost, double QA_cost, double S, double QV) {
+    return static_cast<double>(Kv[i]) + static_cast<double>(v[i]) * inv_cost + (QA_cost * S - QV) - S * static_cast<double>(q[i]);
+}
+
+/* ret_i += add * (Abar v)_i       (run_device_kernel semantics, csvm.cpp:283-306) */
+template <typename T>
+__global__ void k_apply_ret(const T *__restrict__ Kv, const T *__restrict__ v, const T *__restrict__ q, const double *__restrict__ sc, int n,
+                            double inv_cost, double QA_cost, double add, T *__restrict__ ret) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const double val = abar_row(Kv, v, q, i, inv_cost, QA_cost, sc[SC_S], sc[SC_QD]);
+        ret[i] = static_cast<T>(static_cast<double>(ret[i]) + add * val);
+    }
+}
+
+/* Ad_i = (Abar d)_i ; part[b][0] = sum d_i Ad_i     (csvm.cpp:131-135) */
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void k_Ad_and_dAd(const T *__restrict__ Kv, const T *__restrict__ d, const T *__restrict__ q,
+                                                            const double *__restrict__ sc, int n, double inv_cost, double QA_cost,
+                                                            T *__restrict__ Ad, double *__restrict__ part) {
+    __shared__ double lds[8];
+    const double S = sc[SC_S], QD = sc[SC_QD];
+    double acc[2] = { 0.0, 0.0 };
+    for (int i = blockIdx.x * RED_THREADS + threadIdx.x; i < n; i += RED_BLOCKS * RED_THREADS) {
+        const T adi = static_cast<T>(abar_row(Kv, d, q, i, inv_cost, QA_cost, S, QD));
+        Ad[i] = adi;
+        acc[0] += static_cast<double>(d[i]) * static_cast<double>(adi);
+    }
+    block_reduce<2>(acc, lds);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2 + 0] = acc[0];
+        part[blockIdx.x * 2 + 1] = 0.0;
+    }
+}
+
+/* alpha_cd = delta / (d^T Ad)      (csvm.cpp:135) */
+__global__ __launch_bounds__(RED_THREADS) void k_finish_alpha(const double *__restrict__ part, double *__restrict__ sc) {
+    __shared__ double lds[8];
+    double acc[2] = { part[threadIdx.x * 2 + 0], 0.0 };
+    block_reduce<2>(acc, lds);
+    if (threadIdx.x == 0) {
+        sc[SC_DAD] = acc[0];
+        sc[SC_ALPHA] = sc[SC_DELTA] / acc[0];
+    }
+}
+
+/* x += alpha_cd d ; r -= alpha_cd Ad ; part = sum r^2      (csvm.cpp:138, :148, :153).  The scalar is rounded to T first,
+ * as the reference's real_type alpha_cd is. */
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void k_update_x_r(T *__restrict__ x, T *__restrict__ r, const T *__restrict__ d, const T *__restrict__ Ad,
+                                                            const double *__restrict__ sc, int n, int update_r, double *__restrict__ part) {
+    __shared__ double lds[8];
+    const T alpha = static_cast<T>(sc[SC_ALPHA]);
+    double acc[2] = { 0.0, 0.0 };
+    for (int i = blockIdx.x * RED_THREADS + threadIdx.x; i < n; i += RED_BLOCKS * RED_THREADS) {
+        x[i] += alpha * d[i];
+        if (update_r) {
+            const T ri = r[i] - alpha * Ad[i];
+            r[i] = ri;
+            acc[0] += static_cast<double>(ri) * static_cast<double>(ri);
+        }
+    }
+    block_reduce<2>(acc, lds);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2 + 0] = acc[0];
+        part[blockIdx.x * 2 + 1] = 0.0;
+    }
+}
+
+/* r_i = b_i - (Abar x)_i ; part = sum r^2       (csvm.cpp:101-107 and the refresh :140-145).  Uses SC_SUMX / SC_QX. */
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void k_residual(const T *__restrict__ Kv, const T *__restrict__ x, const T *__restrict__ q, const T *__restrict__ b,
+                                                          const double *__restrict__ sc, int n, double inv_cost, double QA_cost, T *__restrict__ r,
+                                                          double *__restrict__ part) {
+    __shared__ double lds[8];
+    const double S = sc[SC_SUMX], QX = sc[SC_QX];
+    double acc[2] = { 0.0, 0.0 };
+    for (int i = blockIdx.x * RED_THREADS + threadIdx.x; i < n; i += RED_BLOCKS * RED_THREADS) {
+        const T ri = static_cast<T>(static_cast<double>(b[i]) - abar_row(Kv, x, q, i, inv_cost, QA_cost, S, QX));
+        r[i] = ri;
+        acc[0] += static_cast<double>(ri) * static_cast<double>(ri);
+    }
+    block_reduce<2>(acc, lds);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2 + 0] = acc[0];
+        part[blockIdx.x * 2 + 1] = 0.0;
+    }
+}
+
+/* delta_old = delta ; delta = sum r^2 ; beta = delta / delta_old ; publish delta to the host-mapped word  (csvm.cpp:152-161) */
+__global__ __launch_bounds__(RED_THREADS) void k_finish_delta(const double *__restrict__ part, double *__restrict__ sc, double *__restrict__ host_delta, int is_initial) {
+    __shared__ double lds[8];
+    double acc[2] = { part[threadIdx.x * 2 + 0], 0.0 };
+    block_reduce<2>(acc, lds);
+    if (threadIdx.x == 0) {
+        const double delta_old = sc[SC_DELTA];
+        sc[SC_DELTA_OLD] = delta_old;
+        sc[SC_DELTA] = acc[0];
+        if (is_initial) {
+            sc[SC_DELTA0] = acc[0];
+            sc[SC_BETA] = 0.0;
+        } else {
+            sc[SC_BETA] = acc[0] / delta_old;
+        }
+        *host_delta = acc[0];
+    }
+}
+
+/* d = beta d + r ; part = (sum d, sum q d) for the next matvec     (csvm.cpp:163) */
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void k_update_d(T *__restrict__ d, const T *__restrict__ r, const T *__restrict__ q, const double *__restrict__ sc,
+                                                          int n, int copy_only, double *__restrict__ part) {
+    __shared__ double lds[8];
+    const T beta = static_cast<T>(sc[SC_BETA]);
+    double acc[2] = { 0.0, 0.0 };
+    for (int i = blockIdx.x * RED_THREADS + threadIdx.x; i < n; i += RED_BLOCKS * RED_THREADS) {
+        const T di = copy_only ? r[i] : beta * d[i] + r[i];
+        d[i] = di;
+        acc[0] += static_cast<double>(di);
+        acc[1] += static_cast<double>(di) * static_cast<double>(q[i]);
+    }
+    block_reduce<2>(acc, lds);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2 + 0] = acc[0];
+        part[blockIdx.x * 2 + 1] = acc[1];
+    }
+}
+
+template <typename T>
+__global__ void k_fill(T *__restrict__ v, int n, T value) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = value;
+}
+
+/* b_i = y_i - y_last     (csvm.cpp:89-91) */
+template <typename T>
+__global__ void k_make_b(const T *__restrict__ y, int n, T *__restrict__ b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = y[i] - y[n];
+}
+
+/* q_i = k(x_i, x_last): ONE THREAD PER ROW, sequential fma chain over the features in ascending order, exactly the
+ * reference's operators.hpp:117-126 / :161-171 chain => q is bit-identical to the OpenMP backend for the linear kernel
+ * and differs only through pow/exp otherwise.  O(N d), once per solve (q_kernel.cpp:18-55, HIP/q_kernel.hip.hpp:33-85). */
+template <int KT, typename T>
+__global__ void k_q(const T *__restrict__ X, int ldx, int dfeat, int n, const T *__restrict__ xlast, int degree, T gamma, T coef0, T *__restrict__ q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const T *xi = X + static_cast<size_t>(i) * ldx;
+    T val = T(0);
+    for (int f = 0; f < dfeat; ++f) {
+        if constexpr (KT == KT_RBF) {
+            const T diff = xi[f] - xlast[f];
+            val = fma(diff, diff, val);
+        } else {
+            val = fma(xi[f], xlast[f], val);
+        }
+    }
+    if constexpr (KT == KT_LINEAR) {
+        q[i] = val;
+    } else if constexpr (KT == KT_POLY) {
+        q[i] = ipow(fma(gamma, val, coef0), degree);
+    } else {
+        q[i] = exp(-gamma * val);
+    }
+}
+
+/* column sums in double, deterministic two-stage: stage 1 = one block per 256-row slab */
+template <typename T>
+__global__ void k_colsum_stage1(const T *__restrict__ X, int ldx, int nrows, int rows_per_block, double *__restrict__ part /* [gridDim.x][ldx] */) {
+    const int f = threadIdx.x + blockIdx.y * blockDim.x;
+    if (f >= ldx) return;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(r0 + rows_per_block, nrows);
+    double s = 0.0;
+    for (int i = r0; i < r1; ++i) s += static_cast<double>(X[static_cast<size_t>(i) * ldx + f]);
+    part[static_cast<size_t>(blockIdx.x) * ldx + f] = s;
+}
+template <typename T>
+__global__ void k_colsum_stage2(const double *__restrict__ part, int nblocks, int ldx, int nrows, T *__restrict__ mean) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= ldx) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += part[static_cast<size_t>(b) * ldx + f];
+    mean[f] = static_cast<T>(s / static_cast<double>(nrows));
+}
+/* X[i][f] -= mean[f] for the valid rows / features only (padding stays exactly zero) */
+template <typename T>
+__global__ void k_center(T *__restrict__ X, int ldx, int dfeat, int nrows, const T *__restrict__ mean) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (f < dfeat && i < nrows) X[static_cast<size_t>(i) * ldx + f] -= mean[f];
+}
+/* c_i = -0.5 * |x_i|^2 (one wave per row, coalesced) */
+template <typename T>
+__global__ void k_half_neg_norms(const T *__restrict__ X, int ldx, int nrows_total, T *__restrict__ c) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= nrows_total) return;
+    const T *x = X + static_cast<size_t>(row) * ldx;
+    T s = T(0);
+    for (int f = lane; f < ldx; f += 64) s = fma(x[f], x[f], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) c[row] = T(-0.5) * s;
+}
+
+/* w[f] = sum_i alpha_i X[i][f]   (calculate_w, csvm.cpp:255-280 / HIP/predict_kernel.hip.hpp:34-45): sequential fma chain
+ * over the points per feature like the reference; coalesced because consecutive threads own consecutive features */
+template <typename T>
+__global__ void k_calculate_w(const T *__restrict__ X, int ldx, int dfeat, int npoints, const T *__restrict__ alpha, T *__restrict__ w) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= dfeat) return;
+    T s = T(0);
+    for (int i = 0; i < npoints; ++i) s = fma(alpha[i], X[static_cast<size_t>(i) * ldx + f], s);
+    w[f] = s;
+}
+/* out_p = w . x_p - rho  (linear predict, csvm.cpp:213): one thread per point, sequential fma chain */
+template <typename T>
+__global__ void k_predict_linear(const T *__restrict__ P, int ldx, int dfeat, int npoints, const T *__restrict__ w, T rho, T *__restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npoints) return;
+    const T *x = P + static_cast<size_t>(p) * ldx;
+    T s = T(0);
+    for (int f = 0; f < dfeat; ++f) s = fma(w[f], x[f], s);
+    out[p] = s - rho;
+}
+/* out_p = Kv_p - rho */
+template <typename T>
+__global__ void k_sub_rho(const T *__restrict__ Kv, int n, T rho, T *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = Kv[i] - rho;
+}
+
+}  // namespace lssvm

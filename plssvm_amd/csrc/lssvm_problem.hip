@@ -1,0 +1,611 @@
+/*
+ * lssvm_problem.hip -- implementation of the device-resident LS-SVM problem and its CG driver (see lssvm_problem.hip.hpp).
+ * Compiled for gfx950 only.
+ */
+#include "lssvm_problem.hip.hpp"
+
+#include "lssvm_kernels.hip.hpp"
+
+#include <dlfcn.h>
+
+namespace lssvm {
+
+Options &options() {
+    static Options o;
+    return o;
+}
+
+Comm &comm() {
+    static Comm c;
+    return c;
+}
+
+void comm_load() {
+    Comm &c = comm();
+    if (c.lib != nullptr) return;
+    // if the process already carries an RCCL (e.g. PyTorch's), reuse it; otherwise load the system one
+    const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    for (const char *name : names) {
+        c.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (c.lib != nullptr) break;
+    }
+    if (c.lib == nullptr) throw Error(LSSVM_ERR_COMM, std::string("could not load RCCL: ") + dlerror());
+    c.pGetUniqueId = reinterpret_cast<decltype(c.pGetUniqueId)>(dlsym(c.lib, "ncclGetUniqueId"));
+    c.pCommInitRank = reinterpret_cast<decltype(c.pCommInitRank)>(dlsym(c.lib, "ncclCommInitRank"));
+    c.pCommDestroy = reinterpret_cast<decltype(c.pCommDestroy)>(dlsym(c.lib, "ncclCommDestroy"));
+    c.pAllGather = reinterpret_cast<decltype(c.pAllGather)>(dlsym(c.lib, "ncclAllGather"));
+    c.pGetErrorString = reinterpret_cast<decltype(c.pGetErrorString)>(dlsym(c.lib, "ncclGetErrorString"));
+    if (!c.pGetUniqueId || !c.pCommInitRank || !c.pCommDestroy || !c.pAllGather || !c.pGetErrorString) {
+        throw Error(LSSVM_ERR_COMM, "the loaded RCCL library lacks a required symbol");
+    }
+}
+
+void check_params(const lssvm_params *params) {
+    LSSVM_REQUIRE(params != nullptr, "params must not be NULL!");
+    LSSVM_REQUIRE(params->kernel_type == LSSVM_KERNEL_LINEAR || params->kernel_type == LSSVM_KERNEL_POLYNOMIAL || params->kernel_type == LSSVM_KERNEL_RBF,
+                  "Invalid kernel function " + std::to_string(params->kernel_type) + " given!");  // csvm.hpp:379
+    if (params->kernel_type != LSSVM_KERNEL_LINEAR) {
+        LSSVM_REQUIRE(params->gamma > 0.0, "gamma must be greater than 0, but is " + std::to_string(params->gamma) + "!");  // svm_kernel.cpp:68, :77
+    }
+    LSSVM_REQUIRE(params->cost != 0.0 && std::isfinite(1.0 / params->cost), "cost must not be 0.0 since it is 1 / plssvm::cost!");  // svm_kernel.cpp:27
+}
+
+int select_device_checked(int device) {
+    int count = 0;
+    const hipError_t err = hipGetDeviceCount(&count);
+    if (err != hipSuccess || count <= 0) {
+        (void) hipGetLastError();
+        throw Error(LSSVM_ERR_NO_DEVICE, "HIP backend selected but no HIP capable devices were found!");  // csvm.hip.cpp:70-72
+    }
+    LSSVM_REQUIRE(device >= 0 && device < count, "Invalid device " + std::to_string(device) + " (" + std::to_string(count) + " available)!");
+    LSSVM_HIP_CHECK(hipSetDevice(device));
+    return count;
+}
+
+/* ------------------------------------------------------------------ tile kernel launch ------------------------------------------------------------------ */
+template <typename K>
+static void ensure_dynamic_lds(K kernel, size_t bytes) {
+    // dynamic LDS above 64 KiB must be opted into once per kernel
+    LSSVM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+}
+
+template <>
+void launch_tile_kernel<float>(const TileArgs<float> &a, int kernel_type, bool rbf_direct, int num_jc, hipStream_t s) {
+    const dim3 grid(static_cast<unsigned>(a.num_ib) * static_cast<unsigned>(num_jc));
+    const dim3 block(TILE_THREADS);
+    if (grid.x == 0) return;
+    constexpr size_t lds = static_cast<size_t>(4) * TILE * F32_LS * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        ensure_dynamic_lds(tile_matvec_f32<KT_LINEAR>, lds);
+        ensure_dynamic_lds(tile_matvec_f32<KT_POLY>, lds);
+        ensure_dynamic_lds(tile_matvec_f32<KT_RBF>, lds);
+        configured = true;
+    }
+    switch (kernel_type) {
+        case KT_LINEAR: hipLaunchKernelGGL(tile_matvec_f32<KT_LINEAR>, grid, block, lds, s, a); break;
+        case KT_POLY: hipLaunchKernelGGL(tile_matvec_f32<KT_POLY>, grid, block, lds, s, a); break;
+        default:
+            if (rbf_direct) {
+                hipLaunchKernelGGL(tile_matvec_rbf_direct_f32, grid, block, 0, s, a);
+            } else {
+                hipLaunchKernelGGL(tile_matvec_f32<KT_RBF>, grid, block, lds, s, a);
+            }
+            break;
+    }
+    LSSVM_HIP_CHECK(hipGetLastError());
+}
+
+template <>
+void launch_tile_kernel<double>(const TileArgs<double> &a, int kernel_type, bool /*rbf_direct*/, int num_jc, hipStream_t s) {
+    const dim3 grid(static_cast<unsigned>(a.num_ib) * static_cast<unsigned>(num_jc));
+    const dim3 block(TILE_THREADS);
+    if (grid.x == 0) return;
+    constexpr size_t lds = static_cast<size_t>(4) * TILE * F64_LS * sizeof(double);
+    static bool configured = false;
+    if (!configured) {
+        ensure_dynamic_lds(tile_matvec_f64<KT_LINEAR>, lds);
+        ensure_dynamic_lds(tile_matvec_f64<KT_POLY>, lds);
+        ensure_dynamic_lds(tile_matvec_f64<KT_RBF>, lds);
+        configured = true;
+    }
+    switch (kernel_type) {
+        case KT_LINEAR: hipLaunchKernelGGL(tile_matvec_f64<KT_LINEAR>, grid, block, lds, s, a); break;
+        case KT_POLY: hipLaunchKernelGGL(tile_matvec_f64<KT_POLY>, grid, block, lds, s, a); break;
+        default: hipLaunchKernelGGL(tile_matvec_f64<KT_RBF>, grid, block, lds, s, a); break;
+    }
+    LSSVM_HIP_CHECK(hipGetLastError());
+}
+
+/* kernel-function specific scalars of TileArgs */
+template <typename T>
+static void set_kernel_scalars(TileArgs<T> &a, const lssvm_params &p, bool rbf_direct) {
+    a.degree = p.degree;
+    a.coef0 = static_cast<T>(p.coef0);
+    constexpr double log2e = 1.4426950408889634073599246810019;
+    if (p.kernel_type == LSSVM_KERNEL_RBF) {
+        const T g = static_cast<T>(p.gamma);  // gamma is rounded to the real type first, as in parameter<T>
+        if (rbf_direct) {
+            a.gamma = static_cast<T>(-static_cast<double>(g) * log2e);
+        } else if (std::is_same_v<T, float>) {
+            a.gamma = static_cast<T>(2.0 * static_cast<double>(g) * log2e);
+        } else {
+            a.gamma = static_cast<T>(2.0 * static_cast<double>(g));
+        }
+    } else {
+        a.gamma = static_cast<T>(p.gamma);
+    }
+}
+
+template <typename T>
+void center_columns(DeviceMatrix<T> &M, DeviceMatrix<T> *M2, hipStream_t s) {
+    const int rows_per_block = 256;
+    const int nblocks = (M.rows + rows_per_block - 1) / rows_per_block;
+    DevBuf<double> part;
+    part.alloc_zero(static_cast<size_t>(nblocks) * M.ldx, s);
+    DevBuf<T> mean;
+    mean.alloc_zero(M.ldx, s);
+    const dim3 g1(nblocks, (M.ldx + 255) / 256);
+    hipLaunchKernelGGL(k_colsum_stage1<T>, g1, dim3(256), 0, s, M.data.p, M.ldx, M.rows, rows_per_block, part.p);
+    hipLaunchKernelGGL(k_colsum_stage2<T>, dim3((M.ldx + 255) / 256), dim3(256), 0, s, part.p, nblocks, M.ldx, M.rows, mean.p);
+    hipLaunchKernelGGL(k_center<T>, dim3((M.dfeat + 255) / 256, M.rows), dim3(256), 0, s, M.data.p, M.ldx, M.dfeat, M.rows, mean.p);
+    if (M2 != nullptr) {
+        hipLaunchKernelGGL(k_center<T>, dim3((M2->dfeat + 255) / 256, M2->rows), dim3(256), 0, s, M2->data.p, M2->ldx, M2->dfeat, M2->rows, mean.p);
+    }
+    LSSVM_HIP_CHECK(hipGetLastError());
+    LSSVM_HIP_CHECK(hipStreamSynchronize(s));  // part / mean are released on return
+}
+
+template <typename T>
+void half_neg_norms(const DeviceMatrix<T> &M, DevBuf<T> &c, hipStream_t s) {
+    c.alloc_zero(M.rows_alloc, s);
+    hipLaunchKernelGGL(k_half_neg_norms<T>, dim3((M.rows_alloc + 3) / 4), dim3(256), 0, s, M.data.p, M.ldx, M.rows_alloc, c.p);
+    LSSVM_HIP_CHECK(hipGetLastError());
+}
+
+/* host restatement of kernel_function(x, x) for QA_cost (csvm.cpp:86): the same fma chain in the same precision */
+template <typename T>
+static T host_self_kernel(const lssvm_params &p, const std::vector<T> &x) {
+    T val = T(0);
+    if (p.kernel_type == LSSVM_KERNEL_RBF) {
+        for (const T v : x) {
+            const T diff = v - v;
+            val = std::fma(diff, diff, val);
+        }
+        return std::exp(-static_cast<T>(p.gamma) * val);
+    }
+    for (const T v : x) val = std::fma(v, v, val);
+    if (p.kernel_type == LSSVM_KERNEL_LINEAR) return val;
+    return std::pow(std::fma(static_cast<T>(p.gamma), val, static_cast<T>(p.coef0)), static_cast<T>(p.degree));
+}
+
+/* ------------------------------------------------------------------ Problem ------------------------------------------------------------------ */
+template <typename T>
+Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, size_t num_points, size_t num_features, int device, const lssvm_shard *shard) :
+    params_(params), device_(device) {
+    dtype = std::is_same_v<T, float> ? LSSVM_DTYPE_F32 : LSSVM_DTYPE_F64;
+    check_params(&params_);
+    LSSVM_REQUIRE(X != nullptr, "The data must not be empty!");                                           // csvm.cpp:73
+    LSSVM_REQUIRE(num_points >= 2, "The data must contain at least two data points!");
+    LSSVM_REQUIRE(num_features >= 1, "The data points must contain at least one feature!");               // csvm.cpp:74
+    LSSVM_REQUIRE(num_points < (size_t(1) << 31) - 4 * TILE && num_features < (size_t(1) << 24), "problem too large for 32-bit tile indices");
+    LSSVM_REQUIRE(mem_kind == LSSVM_MEM_HOST || mem_kind == LSSVM_MEM_DEVICE, "invalid mem_kind");
+    if (shard != nullptr) {
+        LSSVM_REQUIRE(shard->world >= 1 && shard->rank >= 0 && shard->rank < shard->world, "invalid shard descriptor");
+        rank_ = shard->rank;
+        world_ = shard->world;
+        if (world_ > 1) {
+            LSSVM_REQUIRE(comm().comm != nullptr && comm().world == world_ && comm().rank == rank_,
+                          "row-block sharding requested but lssvm_mi355_comm_init was not called with the same rank/world");
+            LSSVM_REQUIRE(comm().device == device, "the communicator was created for another device");
+        }
+    }
+    select_device_checked(device_);
+    const double t0 = now_ms();
+    LSSVM_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+
+    N_ = num_points;
+    n_ = static_cast<int>(num_points - 1);
+    num_tiles_ = (n_ + TILE - 1) / TILE;
+    ib_per_rank_ = (num_tiles_ + world_ - 1) / world_;
+    ib_begin_ = std::min(rank_ * ib_per_rank_, num_tiles_);
+    num_ib_ = std::min(ib_begin_ + ib_per_rank_, num_tiles_) - ib_begin_;
+    nvec_ = ib_per_rank_ * world_ * TILE;
+    jc_tiles_ = static_cast<int>(std::max<int64_t>(1, options().j_chunk_tiles));
+    num_jc_ = (num_tiles_ + jc_tiles_ - 1) / jc_tiles_;
+    rbf_direct_ = (params_.kernel_type == LSSVM_KERNEL_RBF) && (options().rbf_form == 1) && std::is_same_v<T, float>;
+    inv_cost_ = static_cast<double>(T(1) / static_cast<T>(params_.cost));  // "1 / params.cost" in real_type, csvm.cpp:297
+
+    // data matrix: all N points (the last one is row n; it takes part in q and QA_cost only)
+    X_.upload(X, mem_kind, num_points, num_features, static_cast<size_t>(nvec_), stream_);
+
+    // QA_cost = k(x_last, x_last) + 1/C, evaluated on the host in the real type (csvm.cpp:86)
+    std::vector<T> last(num_features);
+    LSSVM_HIP_CHECK(hipMemcpyAsync(last.data(), X_.data.p + static_cast<size_t>(n_) * X_.ldx, num_features * sizeof(T), hipMemcpyDeviceToHost, stream_));
+    LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));
+    QA_cost_ = static_cast<double>(host_self_kernel<T>(params_, last) + T(1) / static_cast<T>(params_.cost));
+
+    // vectors (zero padded to nvec_)
+    for (DevBuf<T> *v : { &q_, &b_, &x_, &r_, &d_, &Ad_, &Kv_, &tmp_ }) v->alloc_zero(nvec_, stream_);
+    ylast_.alloc_zero(num_points, stream_);
+    part_.alloc_zero(static_cast<size_t>(RED_BLOCKS) * 2, stream_);
+    sc_.alloc_zero(SC_COUNT, stream_);
+    partial_.alloc_zero(static_cast<size_t>(std::max(num_jc_, 1)) * std::max(num_ib_, 1) * TILE, stream_);
+    LSSVM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&host_sc_), SC_COUNT * sizeof(double), hipHostMallocDefault));
+
+    // q from the raw (un-centred) data: bit-compatible fma chains (q_kernel.cpp:18-55)
+    {
+        const T *xlast = X_.data.p + static_cast<size_t>(n_) * X_.ldx;
+        const dim3 grid((n_ + 127) / 128), block(128);
+        const T g = static_cast<T>(params_.gamma), c0 = static_cast<T>(params_.coef0);
+        switch (params_.kernel_type) {
+            case LSSVM_KERNEL_LINEAR: hipLaunchKernelGGL((k_q<KT_LINEAR, T>), grid, block, 0, stream_, X_.data.p, X_.ldx, X_.dfeat, n_, xlast, params_.degree, g, c0, q_.p); break;
+            case LSSVM_KERNEL_POLYNOMIAL: hipLaunchKernelGGL((k_q<KT_POLY, T>), grid, block, 0, stream_, X_.data.p, X_.ldx, X_.dfeat, n_, xlast, params_.degree, g, c0, q_.p); break;
+            default: hipLaunchKernelGGL((k_q<KT_RBF, T>), grid, block, 0, stream_, X_.data.p, X_.ldx, X_.dfeat, n_, xlast, params_.degree, g, c0, q_.p); break;
+        }
+        LSSVM_HIP_CHECK(hipGetLastError());
+    }
+    // rbf on the matrix cores: centre the data, then c_i = -|x_i|^2 / 2
+    if (params_.kernel_type == LSSVM_KERNEL_RBF && !rbf_direct_) {
+        center_columns<T>(X_, nullptr, stream_);
+        half_neg_norms<T>(X_, c_, stream_);
+    }
+    events_.resize(4);
+    for (EvPair &e : events_) {
+        LSSVM_HIP_CHECK(hipEventCreate(&e.a));
+        LSSVM_HIP_CHECK(hipEventCreate(&e.b));
+    }
+    LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));
+    setup_ms_ = now_ms() - t0;
+}
+
+template <typename T>
+Problem<T>::~Problem() {
+    (void) hipSetDevice(device_);
+    if (stream_ != nullptr) (void) hipStreamSynchronize(stream_);
+    for (EvPair &e : events_) {
+        if (e.a) (void) hipEventDestroy(e.a);
+        if (e.b) (void) hipEventDestroy(e.b);
+    }
+    if (host_sc_ != nullptr) (void) hipHostFree(host_sc_);
+    if (stream_ != nullptr) (void) hipStreamDestroy(stream_);
+}
+
+template <typename T>
+TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
+    TileArgs<T> a{};
+    a.Xr = X_.data.p;
+    a.Xc = X_.data.p;
+    a.cr = c_.p;
+    a.cc = c_.p;
+    a.dvec = v_dev;
+    a.partial = partial_.p;
+    a.part_stride = static_cast<long>(std::max(num_ib_, 1)) * TILE;
+    a.ldx = X_.ldx;
+    a.kchunks = X_.ldx / kchunk_of<T>();
+    a.ib_begin = ib_begin_;
+    a.num_ib = num_ib_;
+    a.num_jt = num_tiles_;
+    a.jc_tiles = jc_tiles_;
+    a.ncols_valid = n_;
+    set_kernel_scalars(a, params_, rbf_direct_);
+    return a;
+}
+
+template <typename T>
+void Problem<T>::drain_events() {
+    for (EvPair &e : events_) {
+        if (e.pending && hipEventQuery(e.b) == hipSuccess) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+                matvec_ms_ += ms;
+                ++matvec_launches_;
+            }
+            e.pending = false;
+        }
+    }
+}
+
+template <typename T>
+void Problem<T>::apply_K(const T *v_dev) {
+    // the implicit K * v: tile kernel over this device's row blocks, slabs added in a fixed order, slices exchanged
+    EvPair *ev = nullptr;
+    for (EvPair &e : events_) {
+        if (!e.pending) {
+            ev = &e;
+            break;
+        }
+    }
+    if (ev == nullptr) {
+        drain_events();
+        for (EvPair &e : events_) {
+            if (!e.pending) {
+                ev = &e;
+                break;
+            }
+        }
+    }
+    if (num_ib_ > 0) {
+        const TileArgs<T> a = tile_args(v_dev);
+        if (ev != nullptr) LSSVM_HIP_CHECK(hipEventRecord(ev->a, stream_));
+        launch_tile_kernel<T>(a, params_.kernel_type, rbf_direct_, num_jc_, stream_);
+        if (ev != nullptr) {
+            LSSVM_HIP_CHECK(hipEventRecord(ev->b, stream_));
+            ev->pending = true;
+        }
+        const int nrows = num_ib_ * TILE;
+        hipLaunchKernelGGL(k_reduce_partials<T>, dim3((nrows + 255) / 256), dim3(256), 0, stream_, partial_.p, a.part_stride, num_jc_, ib_begin_ * TILE, nrows, Kv_.p);
+        LSSVM_HIP_CHECK(hipGetLastError());
+    }
+    if (world_ > 1) {
+        // one collective per implicit matvec: every rank contributes its contiguous slice of K*v (in place)
+        Comm &c = comm();
+        const size_t slice = static_cast<size_t>(ib_per_rank_) * TILE;
+        const ncclDataType_t dt = std::is_same_v<T, float> ? ncclFloat32 : ncclFloat64;
+        const ncclResult_t rc = c.pAllGather(Kv_.p + static_cast<size_t>(rank_) * slice, Kv_.p, slice, dt, c.comm, stream_);
+        if (rc != ncclSuccess) throw Error(LSSVM_ERR_COMM, std::string("ncclAllGather failed: ") + c.pGetErrorString(rc));
+    }
+}
+
+template <typename T>
+void Problem<T>::sum_and_qdot(const T *v_dev, int slot_sum, int slot_q) {
+    hipLaunchKernelGGL(k_sum_and_qdot<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_, v_dev, q_.p, n_, part_.p);
+    hipLaunchKernelGGL(k_finish2, dim3(1), dim3(RED_THREADS), 0, stream_, part_.p, sc_.p, slot_sum, slot_q);
+    LSSVM_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void Problem<T>::get_q(void *q_out, double *QA_cost_out) {
+    LSSVM_HIP_CHECK(hipSetDevice(device_));
+    if (q_out != nullptr) {
+        LSSVM_HIP_CHECK(hipMemcpyAsync(q_out, q_.p, static_cast<size_t>(n_) * sizeof(T), hipMemcpyDeviceToHost, stream_));
+        LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));
+    }
+    if (QA_cost_out != nullptr) *QA_cost_out = QA_cost_;
+}
+
+template <typename T>
+void Problem<T>::matvec(const void *d, void *ret_inout, double add) {
+    LSSVM_REQUIRE(d != nullptr && ret_inout != nullptr, "The d / ret arrays may not be empty!");              // csvm.cpp:284-286
+    LSSVM_REQUIRE(add == 1.0 || add == -1.0, "add must either be -1.0 or 1.0, but is " + std::to_string(add) + "!");  // svm_kernel.cpp:28
+    LSSVM_HIP_CHECK(hipSetDevice(device_));
+    const size_t bytes = static_cast<size_t>(n_) * sizeof(T);
+    // tmp_ <- d (zero padded), Ad_ <- ret
+    LSSVM_HIP_CHECK(hipMemcpyAsync(tmp_.p, d, bytes, hipMemcpyHostToDevice, stream_));
+    LSSVM_HIP_CHECK(hipMemcpyAsync(Ad_.p, ret_inout, bytes, hipMemcpyHostToDevice, stream_));
+    sum_and_qdot(tmp_.p, SC_S, SC_QD);
+    apply_K(tmp_.p);
+    hipLaunchKernelGGL(k_apply_ret<T>, dim3((n_ + 255) / 256), dim3(256), 0, stream_, Kv_.p, tmp_.p, q_.p, sc_.p, n_, inv_cost_, QA_cost_, add, Ad_.p);
+    LSSVM_HIP_CHECK(hipGetLastError());
+    LSSVM_HIP_CHECK(hipMemcpyAsync(ret_inout, Ad_.p, bytes, hipMemcpyDeviceToHost, stream_));
+    LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));
+    drain_events();
+}
+
+template <typename T>
+void Problem<T>::cg_begin(const void *y, double eps) {
+    LSSVM_REQUIRE(y != nullptr, "The right hand side vector must not be empty!");
+    LSSVM_REQUIRE(static_cast<T>(eps) > T(0), "The stopping criterion in the CG algorithm must be greater than 0.0, but is " + std::to_string(eps) + "!");  // csvm.cpp:77
+    LSSVM_HIP_CHECK(hipSetDevice(device_));
+    cg_t0_ = now_ms();
+    eps_ = eps;
+    iter_ = 0;
+    converged_ = false;
+    matvec_ms_ = 0.0;
+    matvec_launches_ = 0;
+    cg_wall_ms_ = 0.0;
+
+    y_last_ = static_cast<double>(static_cast<const T *>(y)[N_ - 1]);
+    LSSVM_HIP_CHECK(hipMemcpyAsync(ylast_.p, y, N_ * sizeof(T), hipMemcpyHostToDevice, stream_));
+    const dim3 gn((n_ + 255) / 256), bn(256);
+    hipLaunchKernelGGL(k_make_b<T>, gn, bn, 0, stream_, ylast_.p, n_, b_.p);        // csvm.cpp:89-91
+    hipLaunchKernelGGL(k_fill<T>, gn, bn, 0, stream_, x_.p, n_, T(1));              // csvm.cpp:95
+    // r = b - A x   (csvm.cpp:101-104)
+    sum_and_qdot(x_.p, SC_SUMX, SC_QX);
+    apply_K(x_.p);
+    hipLaunchKernelGGL(k_residual<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_, Kv_.p, x_.p, q_.p, b_.p, sc_.p, n_, inv_cost_, QA_cost_, r_.p, part_.p);
+    hipLaunchKernelGGL(k_finish_delta, dim3(1), dim3(RED_THREADS), 0, stream_, part_.p, sc_.p, sc_.p + SC_COUNT - 1, 1);  // csvm.cpp:107-108
+    // d = r   (csvm.cpp:111), and the sums the next matvec needs
+    hipLaunchKernelGGL(k_update_d<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_, d_.p, r_.p, q_.p, sc_.p, n_, 1, part_.p);
+    hipLaunchKernelGGL(k_finish2, dim3(1), dim3(RED_THREADS), 0, stream_, part_.p, sc_.p, static_cast<int>(SC_S), static_cast<int>(SC_QD));
+    LSSVM_HIP_CHECK(hipGetLastError());
+    LSSVM_HIP_CHECK(hipMemcpyAsync(host_sc_, sc_.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));
+    drain_events();
+    delta0_ = static_cast<double>(static_cast<T>(host_sc_[SC_DELTA0]));
+    delta_ = delta0_;
+    begun_ = true;
+    cg_wall_ms_ += now_ms() - cg_t0_;
+}
+
+template <typename T>
+void Problem<T>::cg_step(uint64_t iterations, int *done_out) {
+    LSSVM_REQUIRE(begun_, "cg_step called before cg_begin");
+    LSSVM_HIP_CHECK(hipSetDevice(device_));
+    const double t0 = now_ms();
+    // target residuum in the real type, exactly as the reference evaluates "eps * eps * delta0" (csvm.cpp:155)
+    const T target = static_cast<T>(eps_) * static_cast<T>(eps_) * static_cast<T>(delta0_);
+    for (uint64_t k = 0; k < iterations && !converged_; ++k) {
+        // Ad = A d   (csvm.cpp:131-132)
+        apply_K(d_.p);
+        hipLaunchKernelGGL(k_Ad_and_dAd<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_, Kv_.p, d_.p, q_.p, sc_.p, n_, inv_cost_, QA_cost_, Ad_.p, part_.p);
+        hipLaunchKernelGGL(k_finish_alpha, dim3(1), dim3(RED_THREADS), 0, stream_, part_.p, sc_.p);  // csvm.cpp:135
+        if (iter_ % 50 == 49) {
+            // x += alpha d ; r = b - A x   (csvm.cpp:138-145)
+            hipLaunchKernelGGL(k_update_x_r<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_, x_.p, r_.p, d_.p, Ad_.p, sc_.p, n_, 0, part_.p);
+            sum_and_qdot(x_.p, SC_SUMX, SC_QX);
+            apply_K(x_.p);
+            hipLaunchKernelGGL(k_residual<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_, Kv_.p, x_.p, q_.p, b_.p, sc_.p, n_, inv_cost_, QA_cost_, r_.p, part_.p);
+        } else {
+            // x += alpha d ; r -= alpha Ad   (csvm.cpp:138, :148)
+            hipLaunchKernelGGL(k_update_x_r<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_, x_.p, r_.p, d_.p, Ad_.p, sc_.p, n_, 1, part_.p);
+        }
+        hipLaunchKernelGGL(k_finish_delta, dim3(1), dim3(RED_THREADS), 0, stream_, part_.p, sc_.p, sc_.p + SC_COUNT - 1, 0);  // csvm.cpp:152-153
+        LSSVM_HIP_CHECK(hipGetLastError());
+        LSSVM_HIP_CHECK(hipMemcpyAsync(host_sc_ + SC_DELTA, sc_.p + SC_DELTA, sizeof(double), hipMemcpyDeviceToHost, stream_));
+        LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));
+        drain_events();
+        ++iter_;
+        delta_ = static_cast<double>(static_cast<T>(host_sc_[SC_DELTA]));
+        if (static_cast<T>(delta_) <= target) {  // csvm.cpp:155-158: tested BEFORE the direction update
+            converged_ = true;
+            break;
+        }
+        // d = beta d + r   (csvm.cpp:161-163)
+        hipLaunchKernelGGL(k_update_d<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_, d_.p, r_.p, q_.p, sc_.p, n_, 0, part_.p);
+        hipLaunchKernelGGL(k_finish2, dim3(1), dim3(RED_THREADS), 0, stream_, part_.p, sc_.p, static_cast<int>(SC_S), static_cast<int>(SC_QD));
+        LSSVM_HIP_CHECK(hipGetLastError());
+    }
+    cg_wall_ms_ += now_ms() - t0;
+    if (done_out != nullptr) *done_out = converged_ ? 1 : 0;
+}
+
+template <typename T>
+void Problem<T>::cg_finish(void *alpha_out, double *rho_out, lssvm_cg_info *info) {
+    LSSVM_REQUIRE(begun_, "cg_finish called before cg_begin");
+    LSSVM_REQUIRE(alpha_out != nullptr && rho_out != nullptr, "alpha_out / rho_out must not be NULL");
+    LSSVM_HIP_CHECK(hipSetDevice(device_));
+    const double t0 = now_ms();
+    // bias = y_last + QA_cost * sum(x) - q^T x ; alpha_N = -sum(x) ; rho = -bias   (csvm.cpp:179-182)
+    sum_and_qdot(x_.p, SC_SUMX, SC_QX);
+    LSSVM_HIP_CHECK(hipMemcpyAsync(host_sc_, sc_.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    LSSVM_HIP_CHECK(hipMemcpyAsync(alpha_out, x_.p, static_cast<size_t>(n_) * sizeof(T), hipMemcpyDeviceToHost, stream_));
+    LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));
+    const T sum_x = static_cast<T>(host_sc_[SC_SUMX]);
+    const T bias = static_cast<T>(y_last_ + QA_cost_ * host_sc_[SC_SUMX] - host_sc_[SC_QX]);
+    static_cast<T *>(alpha_out)[n_] = -sum_x;
+    *rho_out = static_cast<double>(-bias);
+    cg_wall_ms_ += now_ms() - t0;
+    if (info != nullptr) fill_info(info);
+}
+
+template <typename T>
+void Problem<T>::synchronize() {
+    LSSVM_HIP_CHECK(hipSetDevice(device_));
+    LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));
+    drain_events();
+}
+
+template <typename T>
+void Problem<T>::fill_info(lssvm_cg_info *info) {
+    std::memset(info, 0, sizeof(*info));
+    info->iterations = iter_;
+    info->max_iterations = 0;
+    info->residuum = delta_;
+    info->initial_residuum = delta0_;
+    info->target_residuum = static_cast<double>(static_cast<T>(eps_) * static_cast<T>(eps_) * static_cast<T>(delta0_));
+    info->epsilon = eps_;
+    info->avg_iteration_ms = iter_ > 0 ? cg_wall_ms_ / static_cast<double>(iter_) : 0.0;
+    info->total_ms = cg_wall_ms_;
+    info->setup_ms = setup_ms_;
+    info->matvec_kernel_ms = matvec_launches_ > 0 ? matvec_ms_ / static_cast<double>(matvec_launches_) : 0.0;
+    info->matvec_launches = matvec_launches_;
+    info->devices_used = world_;
+    info->converged = converged_ ? 1 : 0;
+}
+
+template class Problem<float>;
+template class Problem<double>;
+
+/* ------------------------------------------------------------------ predict path ------------------------------------------------------------------ */
+template <typename T>
+void calculate_w(const T *sv, size_t nsv, size_t nfeat, const T *alpha, T *w_out) {
+    LSSVM_REQUIRE(sv != nullptr && nsv > 0, "The support vectors may not be empty!");                       // csvm.cpp:256
+    LSSVM_REQUIRE(nfeat > 0, "Each support vector must at least contain one feature!");                     // csvm.cpp:257
+    LSSVM_REQUIRE(alpha != nullptr && w_out != nullptr, "The alpha array may not be empty!");               // csvm.cpp:259
+    select_device_checked(0);
+    hipStream_t s = nullptr;
+    DeviceMatrix<T> S;
+    S.upload(sv, LSSVM_MEM_HOST, nsv, nfeat, 0, s);
+    DevBuf<T> a, w;
+    a.alloc_zero(nsv, s);
+    w.alloc_zero(nfeat, s);
+    LSSVM_HIP_CHECK(hipMemcpyAsync(a.p, alpha, nsv * sizeof(T), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_calculate_w<T>, dim3((S.dfeat + 63) / 64), dim3(64), 0, s, S.data.p, S.ldx, S.dfeat, S.rows, a.p, w.p);
+    LSSVM_HIP_CHECK(hipGetLastError());
+    LSSVM_HIP_CHECK(hipMemcpyAsync(w_out, w.p, nfeat * sizeof(T), hipMemcpyDeviceToHost, s));
+    LSSVM_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+template <typename T>
+void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t nfeat, const T *alpha, T rho, T *w_inout, int *w_valid, const T *points,
+                    size_t npoints, T *out) {
+    check_params(&params);
+    LSSVM_REQUIRE(sv != nullptr && nsv > 0, "The support vectors must not be empty!");                       // csvm.cpp:189
+    LSSVM_REQUIRE(nfeat > 0, "The support vectors must contain at least one feature!");                      // csvm.cpp:190
+    LSSVM_REQUIRE(alpha != nullptr, "The number of support vectors and number of weights must be the same!");  // csvm.cpp:192
+    LSSVM_REQUIRE(points != nullptr && npoints > 0, "The data points to predict must not be empty!");        // csvm.cpp:194
+    LSSVM_REQUIRE(out != nullptr && w_valid != nullptr, "out / w_valid must not be NULL");
+    select_device_checked(0);
+    hipStream_t s = nullptr;
+
+    if (params.kernel_type == LSSVM_KERNEL_LINEAR) {
+        LSSVM_REQUIRE(w_inout != nullptr, "w must have num_features entries for the linear kernel");
+        if (!*w_valid) {  // csvm.cpp:204-207
+            calculate_w<T>(sv, nsv, nfeat, alpha, w_inout);
+            *w_valid = 1;
+        }
+        DeviceMatrix<T> P;
+        P.upload(points, LSSVM_MEM_HOST, npoints, nfeat, 0, s);
+        DevBuf<T> w, o;
+        w.alloc_zero(nfeat, s);
+        o.alloc_zero(npoints, s);
+        LSSVM_HIP_CHECK(hipMemcpyAsync(w.p, w_inout, nfeat * sizeof(T), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_predict_linear<T>, dim3((P.rows + 127) / 128), dim3(128), 0, s, P.data.p, P.ldx, P.dfeat, P.rows, w.p, rho, o.p);
+        LSSVM_HIP_CHECK(hipGetLastError());
+        LSSVM_HIP_CHECK(hipMemcpyAsync(out, o.p, npoints * sizeof(T), hipMemcpyDeviceToHost, s));
+        LSSVM_HIP_CHECK(hipStreamSynchronize(s));
+        return;
+    }
+
+    // polynomial / rbf: out_p = sum_i alpha_i k(sv_i, p) - rho : a rectangular instance of the tile kernel
+    DeviceMatrix<T> S, P;
+    S.upload(sv, LSSVM_MEM_HOST, nsv, nfeat, 0, s);
+    P.upload(points, LSSVM_MEM_HOST, npoints, nfeat, 0, s);
+    DevBuf<T> cS, cP;
+    if (params.kernel_type == LSSVM_KERNEL_RBF) {
+        center_columns<T>(S, &P, s);
+        half_neg_norms<T>(S, cS, s);
+        half_neg_norms<T>(P, cP, s);
+    }
+    const int num_jt = S.rows_alloc / TILE;
+    const int num_ib = P.rows_alloc / TILE;
+    const int jc_tiles = static_cast<int>(std::max<int64_t>(1, options().j_chunk_tiles));
+    const int num_jc = (num_jt + jc_tiles - 1) / jc_tiles;
+    DevBuf<T> a, partial, Kv, o;
+    a.alloc_zero(S.rows_alloc, s);
+    partial.alloc_zero(static_cast<size_t>(num_jc) * P.rows_alloc, s);
+    Kv.alloc_zero(P.rows_alloc, s);
+    o.alloc_zero(npoints, s);
+    LSSVM_HIP_CHECK(hipMemcpyAsync(a.p, alpha, nsv * sizeof(T), hipMemcpyHostToDevice, s));
+
+    TileArgs<T> ta{};
+    ta.Xr = P.data.p;
+    ta.Xc = S.data.p;
+    ta.cr = cP.p;
+    ta.cc = cS.p;
+    ta.dvec = a.p;
+    ta.partial = partial.p;
+    ta.part_stride = P.rows_alloc;
+    ta.ldx = S.ldx;
+    ta.kchunks = S.ldx / kchunk_of<T>();
+    ta.ib_begin = 0;
+    ta.num_ib = num_ib;
+    ta.num_jt = num_jt;
+    ta.jc_tiles = jc_tiles;
+    ta.ncols_valid = S.rows;
+    set_kernel_scalars(ta, params, false);
+    launch_tile_kernel<T>(ta, params.kernel_type, false, num_jc, s);
+    hipLaunchKernelGGL(k_reduce_partials<T>, dim3((P.rows_alloc + 255) / 256), dim3(256), 0, s, partial.p, ta.part_stride, num_jc, 0, P.rows_alloc, Kv.p);
+    hipLaunchKernelGGL(k_sub_rho<T>, dim3((P.rows + 255) / 256), dim3(256), 0, s, Kv.p, P.rows, rho, o.p);
+    LSSVM_HIP_CHECK(hipGetLastError());
+    LSSVM_HIP_CHECK(hipMemcpyAsync(out, o.p, npoints * sizeof(T), hipMemcpyDeviceToHost, s));
+    LSSVM_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+template void predict_values<float>(const lssvm_params &, const float *, size_t, size_t, const float *, float, float *, int *, const float *, size_t, float *);
+template void predict_values<double>(const lssvm_params &, const double *, size_t, size_t, const double *, double, double *, int *, const double *, size_t, double *);
+template void calculate_w<float>(const float *, size_t, size_t, const float *, float *);
+template void calculate_w<double>(const double *, size_t, size_t, const double *, double *);
+
+}  // namespace lssvm

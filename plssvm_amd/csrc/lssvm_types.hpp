@@ -1,0 +1,59 @@
+/*
+ * lssvm_types.hpp -- plain types and constants shared by the device kernels (lssvm_kernels.hip.hpp) and the host driver
+ * (lssvm_problem.hip.hpp).  No kernels are defined here.
+ */
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+namespace lssvm {
+
+constexpr int KT_LINEAR = 0;
+constexpr int KT_POLY = 1;
+constexpr int KT_RBF = 2;
+
+constexpr int TILE = 128;          // rows / columns of one workgroup tile of the implicit matrix
+constexpr int TILE_THREADS = 256;  // 4 wave64 arranged 2 x 2, each owning a 64 x 64 sub-tile
+
+using f32x4 = float __attribute__((ext_vector_type(4)));
+using f32x16 = float __attribute__((ext_vector_type(16)));
+using f64x2 = double __attribute__((ext_vector_type(2)));
+using f64x4 = double __attribute__((ext_vector_type(4)));
+
+/* Arguments of the tile kernel.  "rows" = the points whose output is produced (the I side), "cols" = the points summed
+ * over (the J side).  Training matvec: both are the (padded) data matrix.  predict_values: rows = points to predict,
+ * cols = support vectors (HIP/predict_kernel.hip.hpp:63-117 is the reference counterpart). */
+template <typename T>
+struct TileArgs {
+    const T *Xr;      // [>= (ib_begin+num_ib)*TILE][ldx] row side, zero padded
+    const T *Xc;      // [>= num_jt*TILE][ldx]            column side, zero padded
+    const T *cr;      // rbf: -0.5 * |x_i|^2 per row-side point
+    const T *cc;      // rbf: -0.5 * |x_j|^2 per column-side point
+    const T *dvec;    // [num_jt*TILE] vector multiplied from the right, EXACT zeros beyond the valid columns
+    T *partial;       // [num_jc][part_stride] partial row sums, one slab per column chunk, indexed by the LOCAL row
+    long part_stride; // elements between slabs (>= num_ib*TILE)
+    int ldx;          // padded number of features (multiple of the k-chunk)
+    int kchunks;      // ldx / KC
+    int ib_begin;     // first row block of this device (row-block sharding)
+    int num_ib;       // number of row blocks of this device
+    int num_jt;       // number of column tiles in total
+    int jc_tiles;     // column tiles per work item
+    int ncols_valid;  // columns >= this are padding (used only where a padded column could produce inf/nan)
+    int degree;       // polynomial
+    T gamma;          // polynomial: gamma ; rbf: 2 * gamma * log2(e) (f32) or 2 * gamma (f64)
+    T coef0;          // polynomial
+};
+
+constexpr int F32_KC = 32;  // fp32: features per k-chunk (one 128-byte line per row)
+constexpr int F32_LS = 36;  // fp32: padded LDS row stride in floats (144 B: 16-B aligned, conflict-free ds_read_b128)
+constexpr int F64_KC = 16;  // fp64: features per k-chunk (128 bytes)
+constexpr int F64_LS = 18;  // fp64: padded LDS row stride in doubles (144 B: conflict-free ds_read_b64)
+
+constexpr int RED_BLOCKS = 256;   // fixed number of partial sums => reproducible reductions for every n
+constexpr int RED_THREADS = 256;
+
+/* device-resident scalars of the CG recursion (all double) */
+enum ScalarSlot : int { SC_S = 0, SC_QD = 1, SC_DAD = 2, SC_DELTA = 3, SC_DELTA_OLD = 4, SC_ALPHA = 5, SC_BETA = 6, SC_DELTA0 = 7, SC_SUMX = 8, SC_QX = 9, SC_COUNT = 16 };
+
+}  // namespace lssvm
