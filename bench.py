@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- CG-iteration throughput of the MI355X LS-SVM backend on BASELINE.json's metric.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c5]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is ONE CG iteration (one implicit kernel-matrix--vector product + the CG vector updates, plus the residual
+refresh every 50th iteration, src/plssvm/backends/OpenMP/csvm.cpp:125-166) on synthetic data that is already resident in
+HBM when the timed region starts.  With N > 1 the implicit matrix is row-block sharded over the ranks (one process per
+GPU) and every step contains one RCCL all-gather of the K*d slices; the problem size is fixed, i.e. STRONG scaling.
+
+Prints ONE JSON line on rank 0.  `value` = effective K*d GFLOP/s = 2 * n^2 * d * K / t (n = N_points - 1; full square, no
+symmetry credit); `cg_iters_per_s` is the other half of BASELINE.json's metric.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# BASELINE.json configs[1..4]
+WORKLOADS = {
+    "c2": dict(n=50_000, d=128, kernel="rbf", dtype="float32", desc="configs[1]: 50000x128 rbf gamma=1/128 fp32"),
+    "c3": dict(n=200_000, d=256, kernel="linear", dtype="float32", desc="configs[2]: 200000x256 linear fp32"),
+    "c4": dict(n=100_000, d=64, kernel="polynomial", dtype="float64", desc="configs[3]: 100000x64 polynomial degree=3 fp64"),
+    "c5": dict(n=1_000_000, d=128, kernel="rbf", dtype="float32", desc="configs[4]: 1000000x128 rbf gamma=1/128 fp32"),
+}
+# dense matrix-core peaks of the arithmetic type (MI355X_MICROARCH.md, Chip-level parameters / Matrix cores)
+PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6}
+
+
+def cpu_baseline(X, y, kernel, sample_rows, iters):
+    """The CPU oracle (or, where it was built, the reference's own OpenMP kernels) on a bounded sample of the workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+
+    kind = "reference" if oracle_lib.have_ref() else "port"
+    impl = oracle_lib.ref() if kind == "reference" else oracle_lib.oracle()
+    ns = min(sample_rows, X.shape[0])
+    Xs, ys = X[:ns], y[:ns]
+    t0 = time.perf_counter()
+    _, _, info = impl.solve(kernel, Xs, ys, 1e-30, iters, gamma=1.0 / X.shape[1], degree=3, coef0=0.0, cost=1.0)
+    wall = time.perf_counter() - t0
+    its = int(info["iterations"])
+    # the solve runs its + 1 implicit matvecs (one for the initial residual); price an iteration as wall / (its + 1)
+    t_iter = wall / (its + 1)
+    flop = 2.0 * (ns - 1) ** 2 * X.shape[1]
+    return {"value": flop / t_iter / 1e9, "unit": "GFLOP/s", "cores": oracle_lib.oracle().num_threads(), "kind": kind,
+            "sample": f"first {ns} rows of the workload, {its} CG iterations + initial residual ({its + 1} implicit matvecs), "
+                      f"{t_iter * 1e3:.1f} ms per matvec; effective GFLOP/s = 2*n^2*d / t is size independent",
+            "ms_per_step_at_sample": t_iter * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c5", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample-rows", type=int, default=8192)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=42)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+
+    import numpy as np
+    import torch  # plumbing only: device selection, synchronisation, torch.distributed (RCCL) for the barrier / id exchange
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+
+    from plssvm_amd import _capi, backend
+    from plssvm_amd.datagen import make_blobs_pm1
+    from plssvm_amd.parameter import Parameter
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # hand rank 0's RCCL unique id to every rank, then build the library's own communicator (one per process)
+        from plssvm_amd.sharding import init_library_communicator
+
+        init_library_communicator(dist, local_rank)
+
+    wl = WORKLOADS[args.workload]
+    N, d = wl["n"], wl["d"]
+    dt = np.dtype(wl["dtype"])
+    X, y = make_blobs_pm1(N, d, seed=args.seed, dtype=dt)  # identical on every rank (seeded)
+    params = Parameter(kernel_type=wl["kernel"], degree=3, gamma=None, coef0=0.0, cost=1.0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    prob = backend.ResidentProblem(params, X, device=local_rank, rank=rank, world=world)
+    prob.cg_begin(y, 1e-30)  # eps^2 underflows: the loop only stops early on delta == 0 (fixed iteration count)
+    if args.warmup > 0:
+        prob.cg_step(args.warmup)
+    prob.synchronize()
+    i0 = prob.info()
+    barrier()
+    t0 = time.perf_counter()
+    prob.cg_step(args.steps)
+    prob.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    i1 = prob.info()
+
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    steps_done = int(i1["iterations"] - i0["iterations"])
+
+    n = N - 1
+    flop_step = 2.0 * n * n * d
+    value = flop_step * steps_done / elapsed / 1e9
+
+    # roofline of the dominant kernel (the tile kernel of the implicit matvec), from HIP events on the solver stream
+    launches = int(i1["matvec_launches"] - i0["matvec_launches"])
+    kern_ms_total = i1["matvec_kernel_ms"] * i1["matvec_launches"] - i0["matvec_kernel_ms"] * i0["matvec_launches"]
+    kern_ms = kern_ms_total / max(launches, 1)
+    from plssvm_amd.sharding import row_block_partition
+
+    r0, r1 = row_block_partition(n, world)[rank]
+    rows_rank = r1 - r0
+    flop_launch = 2.0 * rows_rank * n * d  # algorithmic flops of ONE launch on this rank
+    achieved = flop_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+    peak = PEAK_TFLOPS[wl["dtype"]]
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.isfile(tfile):
+        try:
+            with open(tfile) as f:
+                traffic = json.load(f).get(f"{args.workload}_n{world}")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        out = {
+            "metric": "effective K*d GFLOP/s of the CG iteration (2*n^2*d per iteration / time), RBF fp32 N x d" if wl["kernel"] == "rbf" and wl["dtype"] == "float32"
+            else f"effective K*d GFLOP/s of the CG iteration, {wl['kernel']} {wl['dtype']}",
+            "value": value, "unit": "GFLOP/s", "cg_iters_per_s": steps_done / elapsed,
+            "n_gpus": world, "steps": steps_done, "warmup": args.warmup, "ms_per_step": elapsed / max(steps_done, 1) * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if wl["dtype"] == "float32" else "f64", "data": "synthetic",
+            "config": {"workload": wl["desc"], "num_points": N, "num_features": d, "kernel": wl["kernel"], "gamma": 1.0 / d, "cost": 1.0,
+                       "seed": args.seed, "parallelism": f"row-block sharding x{world}" if world > 1 else "single GPU",
+                       "residuum_after_timed_steps": i1["residuum"]},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "kernel": "lssvm::tile_matvec (implicit K*d tile kernel)", "launches": launches, "avg_launch_ms": kern_ms,
+                         "algorithmic_flop_per_launch": flop_launch},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(X, y, wl["kernel"], args.cpu_sample_rows, 3)
+        print(json.dumps(out), flush=True)
+
+    prob.close()
+    if dist is not None:
+        backend.comm_destroy()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,63 @@
+"""Row-block sharding of the implicit matrix across the GPUs of one node -- host-side plumbing.
+
+The reference splits the FEATURE dimension across devices, for the linear kernel only, and sums the partial results
+through the host (include/plssvm/backends/gpu_csvm.hpp:283-299, :449-475).  Here every rank (one process per GPU) owns a
+contiguous block of OUTPUT ROWS of the implicit matrix for all three kernels; the data matrix is replicated; one RCCL
+all-gather of the K*d slices per implicit matvec is the only exchange.  This module holds the partition arithmetic
+(identical to ``Problem<T>``'s constructor in plssvm_amd/csrc/lssvm_problem.hip) and the bootstrap of the library's RCCL
+communicator over an existing ``torch.distributed`` process group.
+"""
+
+from __future__ import annotations
+
+TILE = 128  # rows per block of the tile kernel (plssvm_amd/csrc/lssvm_types.hpp)
+
+__all__ = ["TILE", "row_block_partition", "padded_vector_length", "exchange_unique_id", "init_library_communicator"]
+
+
+def row_block_partition(n: int, world: int):
+    """Return ``[(row_begin, row_end), ...]`` per rank for a reduced system of size ``n`` (= num_points - 1).
+
+    Blocks of 128 rows are dealt in equal contiguous runs; trailing ranks may own fewer (or no) rows.  Every evaluated
+    row costs the same (full square, no symmetry), so equal rows == equal work."""
+    if n < 1 or world < 1:
+        raise ValueError("n and world must be positive")
+    tiles = (n + TILE - 1) // TILE
+    per_rank = (tiles + world - 1) // world
+    out = []
+    for r in range(world):
+        b0 = min(r * per_rank, tiles)
+        b1 = min(b0 + per_rank, tiles)
+        out.append((min(b0 * TILE, n), min(b1 * TILE, n)))
+    return out
+
+
+def padded_vector_length(n: int, world: int) -> int:
+    """Length of the device vectors: every rank's all-gather slice has the same size ``per_rank * 128``."""
+    tiles = (n + TILE - 1) // TILE
+    per_rank = (tiles + world - 1) // world
+    return per_rank * world * TILE
+
+
+def exchange_unique_id(dist, get_unique_id, device=None) -> bytes:
+    """Rank 0 draws the 128-byte RCCL unique id, every rank receives it through ``dist.broadcast``.
+
+    ``dist`` is an initialised ``torch.distributed``; ``device`` is the tensor device for the broadcast ("cuda" for the
+    nccl backend, None/"cpu" for gloo)."""
+    import torch
+
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if dist.get_rank() == 0:
+        uid = torch.frombuffer(bytearray(get_unique_id()), dtype=torch.uint8).clone()
+    if device is not None:
+        uid = uid.to(device)
+    dist.broadcast(uid, src=0)
+    return bytes(uid.cpu().numpy().tobytes())
+
+
+def init_library_communicator(dist, local_device: int) -> None:
+    """Create libplssvm_amd's own RCCL communicator for this process from a torch.distributed (nccl) process group."""
+    from . import backend
+
+    uid = exchange_unique_id(dist, backend.comm_get_unique_id, device="cuda")
+    backend.comm_init(local_device, dist.get_rank(), dist.get_world_size(), uid)

@@ -1,0 +1,46 @@
+"""pytest configuration: registers the `gpu` marker and the shared fixtures (golden vectors, oracle access)."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+# parameter sets of the golden vectors (tests/golden/make_golden.py)
+PARAM_SETS = {
+    "ref": dict(degree=2, gamma=0.001, coef0=1.0, cost=0.1),  # the reference's kernel-test parameters (generic_csvm_tests.hpp:372-493)
+    "def": dict(degree=3, gamma=None, coef0=0.0, cost=1.0),   # csvm defaults, gamma = 1 / num_features
+}
+KERNELS = ["linear", "polynomial", "rbf"]
+DATASETS = ["5x4", "blobs263x37", "500x200"]
+DTYPES = {"f32": np.float32, "f64": np.float64}
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return np.load(os.path.join(HERE, "golden", "golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def inputs():
+    return np.load(os.path.join(HERE, "golden", "inputs.npz"))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    return oracle_lib.oracle()
+
+
+def resolved_kw(P, d):
+    return dict(degree=P["degree"], gamma=(P["gamma"] if P["gamma"] is not None else 1.0 / d), coef0=P["coef0"])

@@ -1,0 +1,93 @@
+"""CPU: libplssvm_amd.so loads without a GPU, exports every symbol include/plssvm_amd.h declares, validates arguments
+before touching a device, and FAILS LOUDLY (LSSVM_ERR_NO_DEVICE) instead of falling back to a CPU path."""
+
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from plssvm_amd import _capi, backend
+from plssvm_amd.exceptions import BackendError, InvalidParameterError
+from plssvm_amd.parameter import Parameter
+
+HEADER = os.path.join(ROOT, "include", "plssvm_amd.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lssvm_mi355_\w+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(_capi.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    for name in declared_symbols():
+        assert hasattr(_capi.lib, name), f"{name} is declared in include/plssvm_amd.h but not exported"
+    out = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (lssvm_mi355_\w+)", out))
+    assert exported == set(declared_symbols())
+
+
+def test_no_oracle_or_torch_in_the_product_library():
+    """The product path must not route through the oracle or any CPU fallback."""
+    out = subprocess.run(["ldd", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "lssvm_oracle" not in out and "lssvm_ref" not in out and "torch" not in out
+    assert "libamdhip64" in out
+    pkg = os.path.join(ROOT, "plssvm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle_lib" not in text and "liblssvm_oracle" not in text, f"{f} references the oracle"
+
+
+def test_abi_version_and_struct_layout():
+    assert _capi.lib.lssvm_mi355_abi_version() == 1
+    assert C.sizeof(_capi.LssvmParams) == 32
+    assert C.sizeof(_capi.LssvmShard) == 8
+    assert C.sizeof(_capi.LssvmCgInfo) == 96
+
+
+has_gpu = _capi.device_count() > 0
+
+
+def test_argument_validation_happens_without_a_device():
+    X = np.ones((4, 3))
+    y = np.array([1.0, -1, 1, -1])
+    with pytest.raises(InvalidParameterError, match="stopping criterion"):   # csvm.cpp:77
+        backend.solve_system_of_linear_equations(Parameter(), X, y, 0.0, 4)
+    with pytest.raises(InvalidParameterError, match="CG iterations"):        # csvm.cpp:78
+        backend.solve_system_of_linear_equations(Parameter(), X, y, 1e-3, 0)
+    with pytest.raises(InvalidParameterError, match="right hand side"):      # csvm.cpp:76
+        backend.solve_system_of_linear_equations(Parameter(), X, y[:3], 1e-3, 4)
+    with pytest.raises(InvalidParameterError, match="gamma"):                # svm_kernel.cpp:68
+        ps = _capi.LssvmParams(2, 3, -1.0, 0.0, 1.0)
+        _capi.check(_capi.lib.lssvm_mi355_generate_q_f64(C.byref(ps), _capi.ptr(X), C.c_size_t(4), C.c_size_t(3), _capi.ptr(np.zeros(3))))
+    with pytest.raises(InvalidParameterError, match="cost"):                 # svm_kernel.cpp:27
+        ps = _capi.LssvmParams(0, 3, 1.0, 0.0, 0.0)
+        _capi.check(_capi.lib.lssvm_mi355_generate_q_f64(C.byref(ps), _capi.ptr(X), C.c_size_t(4), C.c_size_t(3), _capi.ptr(np.zeros(3))))
+    with pytest.raises(InvalidParameterError, match="unknown option"):
+        _capi.set_option("no_such_option", 1)
+    assert _capi.get_option("rbf_form") == 0 and _capi.get_option("j_chunk_tiles") == 16
+
+
+@pytest.mark.skipif(has_gpu, reason="only meaningful on a box without a GPU")
+def test_no_device_is_a_loud_error_not_a_fallback():
+    assert _capi.device_count() == 0
+    X = np.ones((4, 3))
+    y = np.array([1.0, -1, 1, -1])
+    with pytest.raises(BackendError, match="no HIP capable devices"):        # csvm.hip.cpp:70-72
+        backend.solve_system_of_linear_equations(Parameter(), X, y, 1e-3, 4)
+    with pytest.raises(BackendError, match="no HIP capable devices"):
+        backend.generate_q(Parameter(kernel_type="rbf"), X)
+    with pytest.raises(BackendError, match="no HIP capable devices"):
+        backend.predict_values(Parameter(), X, y, 0.0, None, X)
+    with pytest.raises(BackendError, match="no HIP capable devices"):
+        backend.ResidentProblem(Parameter(), X)

@@ -1,0 +1,58 @@
+"""GPU (-m gpu): the library next to PyTorch in one process (bench.py imports torch first for torch.distributed), a device
+pointer handed over the C ABI, and bench.py's JSON contract on a small workload."""
+
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_torch_first_then_library_and_device_pointer_input():
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')
+import torch
+assert torch.cuda.is_available()
+from plssvm_amd import backend
+from plssvm_amd.parameter import Parameter
+from plssvm_amd.datagen import make_blobs_pm1
+X, y = make_blobs_pm1(600, 48, seed=1, dtype=np.float32)
+p = Parameter(kernel_type='rbf')
+a, rho, _ = backend.solve_system_of_linear_equations(p, X, y, 1e-30, 5)
+Xd = torch.from_numpy(X).cuda()
+torch.cuda.synchronize()
+prob = backend.ResidentProblem(p, None, device_ptr=Xd.data_ptr(), shape=X.shape, dtype=np.float32)
+prob.cg_begin(y, 1e-30); prob.cg_step(5); a2, rho2, info = prob.cg_finish(); prob.close()
+assert np.array_equal(a, a2) and rho == rho2, 'device-pointer input must give the same bits as host input'
+print('OK')
+""" % (ROOT, ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_bench_json_contract_small_workload():
+    env = dict(os.environ)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c2", "--steps", "3", "--warmup", "1", "--cpu-sample-rows", "2048"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["dtype"] == "f32" and j["data"] == "synthetic" and j["vs_baseline"] is None
+    assert "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.05 < r["frac"] < 1.0
+    c = j["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
+    # value is whole-job: 2 n^2 d per step / ms_per_step
+    n, d = 49_999, 128
+    assert abs(j["value"] - 2.0 * n * n * d / (j["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * j["value"]

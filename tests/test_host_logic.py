@@ -1,0 +1,88 @@
+"""CPU: host-side logic around the hot path -- parameters, LIBSVM reader, synthetic data, row-block partition."""
+
+import os
+
+import numpy as np
+import pytest
+
+from plssvm_amd import sharding
+from plssvm_amd.datagen import generate_libsvm_file, make_blobs_pm1
+from plssvm_amd.exceptions import InvalidFileFormatError, InvalidParameterError, UnsupportedKernelTypeError
+from plssvm_amd.io_libsvm import parse_libsvm_data, write_libsvm_data
+from plssvm_amd.parameter import KernelFunctionType, Parameter, kernel_function_type_from_string
+
+
+def test_parameter_defaults_and_gamma_resolution():
+    p = Parameter()                                         # parameter.hpp:156-165
+    assert (p.kernel_type, p.degree, p.gamma, p.coef0, p.cost) == (KernelFunctionType.LINEAR, 3, None, 0.0, 1.0)
+    assert Parameter(kernel_type="rbf").resolved(128).gamma == 1.0 / 128    # csvm.hpp:303-307
+    assert Parameter(kernel_type="rbf", gamma=0.5).resolved(128).gamma == 0.5
+    with pytest.raises(InvalidParameterError):              # csvm.hpp:384
+        Parameter(kernel_type="rbf", gamma=-1.0)
+    Parameter(kernel_type="linear", gamma=-1.0)             # gamma is ignored by the linear kernel
+    assert kernel_function_type_from_string("poly") == KernelFunctionType.POLYNOMIAL
+    assert kernel_function_type_from_string("2") == KernelFunctionType.RBF
+    with pytest.raises(UnsupportedKernelTypeError):
+        kernel_function_type_from_string("sigmoid")
+    assert str(KernelFunctionType.RBF) == "rbf"
+
+
+def test_libsvm_dense_sparse_and_roundtrip(tmp_path, inputs):
+    # the reference's 5x4.libsvm content is part of the committed inputs; write + re-read it through the LIBSVM text format
+    X, y = inputs["5x4_X"], inputs["5x4_y"]
+    f = tmp_path / "a.libsvm"
+    write_libsvm_data(f, X, labels=[int(v) for v in y], comment="comment")
+    X2, y2 = parse_libsvm_data(f)
+    assert np.allclose(X2, X, rtol=1e-10) and list(y2) == list(y)
+    # sparse lines, blank lines, comments, label-only line (tests/data/libsvm/5x4_sparse.libsvm has the same shapes of line)
+    f.write_text("# c\n1\n1  2:0.5\n-1 1:1.25\n\n-1 1:0.25      3:-0.125\n-1  4:2.0   # trailing\n   # another\n")
+    Xs, ys = parse_libsvm_data(f)
+    assert Xs.shape == (5, 4) and ys == [1, 1, -1, -1, -1]
+    assert Xs[1, 1] == 0.5 and Xs[3, 2] == -0.125 and Xs[4, 3] == 2.0 and Xs[0].sum() == 0
+    f.write_text("1:1.0 2:2.0\n2:3.0\n")
+    Xn, yn = parse_libsvm_data(f)
+    assert yn is None and Xn.shape == (2, 2)
+
+
+@pytest.mark.parametrize("text, msg", [
+    ("1 0:1.0 1:2.0\n", "1-based"),                              # zero_based_features
+    ("1 2:1.0 1:2.0\n", "strictly increasing"),                  # non_increasing_indices
+    ("1 1:1.0 1:2.0\n", "strictly increasing"),                  # non_strictly_increasing_indices
+    ("1 1:1.0\n2:1.0\n", "Inconsistent label"),                  # inconsistent_label_specification
+    ("1 1:a1.0\n", "Can't convert"),                             # feature_with_alpha_char_at_the_beginning
+    ("1 a1:1.0\n", "Can't convert"),                             # index_with_alpha_char_at_the_beginning
+    ("1 1:\n", "Can't convert"),                                 # missing_feature_value
+    ("", "no data points"),
+])
+def test_libsvm_invalid_files(tmp_path, text, msg):
+    f = tmp_path / "bad.libsvm"
+    f.write_text(text)
+    with pytest.raises(InvalidFileFormatError, match=msg):
+        parse_libsvm_data(f)
+
+
+def test_synthetic_data_recipe(tmp_path):
+    X, y = make_blobs_pm1(1000, 16, seed=1, dtype=np.float32)
+    assert X.shape == (1000, 16) and X.dtype == np.float32
+    assert set(np.unique(y)) == {-1.0, 1.0} and abs(y.sum()) == 0           # balanced, labels +-1
+    assert np.allclose(X.min(axis=0), -1, atol=1e-6) and np.allclose(X.max(axis=0), 1, atol=1e-6)  # min-max scaled per feature
+    X2, _ = make_blobs_pm1(1000, 16, seed=1, dtype=np.float32)
+    assert np.array_equal(X, X2)                                            # seeded
+    f = tmp_path / "g.libsvm"
+    generate_libsvm_file(f, 50, 4, seed=2)
+    Xf, yf = parse_libsvm_data(f)
+    assert Xf.shape == (50, 4) and set(yf) == {-1, 1}
+
+
+@pytest.mark.parametrize("n, world", [(1, 1), (127, 2), (128, 2), (129, 2), (499, 3), (49_999, 8), (999_999, 8), (300, 8)])
+def test_row_block_partition_covers_all_rows_once(n, world):
+    parts = sharding.row_block_partition(n, world)
+    assert len(parts) == world and parts[0][0] == 0 and parts[-1][1] == n
+    for (a0, a1), (b0, b1) in zip(parts, parts[1:]):
+        assert a1 == b0 and a0 <= a1
+    # every interior boundary is a multiple of the 128-row block; runs of blocks differ by at most one block run
+    assert all(a % 128 == 0 or a == n for a, _ in parts)
+    sizes = [b - a for a, b in parts]
+    assert max(sizes) <= -(-(-(-n // 128)) // world) * 128
+    assert sharding.padded_vector_length(n, world) % (128 * world) == 0
+    assert sharding.padded_vector_length(n, world) >= n
