@@ -183,6 +183,9 @@ int lssvm_mi355_problem_info(lssvm_mi355_problem *p, lssvm_cg_info *info);
 /* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT):
  *   "rbf_form"      0 = norm expansion on the matrix cores (default), 1 = direct (x_i - x_j)^2 on the vector ALU
  *   "j_chunk_tiles" number of 128-column tiles per work item (default 16)
+ *   "xcd_map"       1 = XCD-aware block -> work item mapping (8 x 8 super-tiles per XCD), 0 = linear (default)
+ *   "debug_ablate"  timing-only ablation bits of the fp32 tile kernel; effective only in -DLSSVM_ENABLE_ABLATION builds
+ *   "force_collective" 1 = run the per-matvec RCCL all-gather even with a world of 1 (testing aid; default 0)
  */
 int lssvm_mi355_set_option(const char *name, int64_t value);
 int lssvm_mi355_get_option(const char *name, int64_t *value_out);

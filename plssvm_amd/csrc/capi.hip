@@ -257,6 +257,12 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
         } else if (n == "j_chunk_tiles") {
             LSSVM_REQUIRE(value >= 1 && value <= (1 << 20), "j_chunk_tiles out of range");
             lssvm::options().j_chunk_tiles = value;
+        } else if (n == "debug_ablate") {
+            lssvm::options().debug_ablate = value;
+        } else if (n == "xcd_map") {
+            lssvm::options().xcd_map = value != 0 ? 1 : 0;
+        } else if (n == "force_collective") {
+            lssvm::options().force_collective = value != 0 ? 1 : 0;
         } else {
             throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "unknown option '" + n + "'");
         }
@@ -270,6 +276,12 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             *value_out = lssvm::options().rbf_form;
         } else if (n == "j_chunk_tiles") {
             *value_out = lssvm::options().j_chunk_tiles;
+        } else if (n == "debug_ablate") {
+            *value_out = lssvm::options().debug_ablate;
+        } else if (n == "xcd_map") {
+            *value_out = lssvm::options().xcd_map;
+        } else if (n == "force_collective") {
+            *value_out = lssvm::options().force_collective;
         } else {
             throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "unknown option '" + n + "'");
         }

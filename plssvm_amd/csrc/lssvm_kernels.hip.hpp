@@ -30,6 +30,14 @@
 #include <cstdint>
 #include <type_traits>
 
+/* timing-only ablations of the fp32 tile kernel (option "debug_ablate"); compiled in only with -DLSSVM_ENABLE_ABLATION so that the
+ * shipped kernel carries no extra branches */
+#ifdef LSSVM_ENABLE_ABLATION
+#define LSSVM_DBG(a, bit) (((a).dbg & (bit)) != 0)
+#else
+#define LSSVM_DBG(a, bit) false
+#endif
+
 namespace lssvm {
 
 /* integer power by repeated squaring; the reference uses pow(real, int) on the GPU (HIP/svm_kernel.hip.hpp:178) and
@@ -45,6 +53,32 @@ __device__ __forceinline__ T ipow(T base, int degree) {
         e >>= 1u;
     }
     return degree < 0 ? T(1) / result : result;
+}
+
+/* blockIdx.x -> (local row block, column chunk).
+ * map_mode 0: consecutive blocks walk the row blocks of one column chunk.
+ * map_mode 1 (XCD aware): the hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with a private
+ *   4 MiB L2 (placement is a speed matter only, never correctness).  The ids that land on one XCD are grouped into 8 x 8
+ *   super-tiles (8 row blocks x 8 column chunks), so that the ~64 workgroups resident on an XCD at a time re-read only 8
+ *   row panels (8 x d x 128 x s bytes) and share every column tile 8 ways -- instead of 64 distinct row panels that alone
+ *   overflow the L2. */
+template <typename T>
+__device__ __forceinline__ bool decode_work_item(const TileArgs<T> &a, int &ibl, int &jc) {
+    const int id = blockIdx.x;
+    if (a.map_mode == 0) {
+        ibl = id % a.num_ib;
+        jc = id / a.num_ib;
+        return true;
+    }
+    const int x = id & 7;
+    const int k = id >> 3;
+    const int l = k & 63;
+    const int S = (k >> 6) * 8 + x;  // super-tile index
+    const int si = S % a.super_i;
+    const int sj = S / a.super_i;
+    ibl = si * 8 + (l & 7);
+    jc = sj * 8 + (l >> 3);
+    return ibl < a.num_ib && jc < a.num_jc;
 }
 
 template <int KT, typename T>
@@ -90,9 +124,8 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32(const TileArg
     const int h = lane >> 5;
 
     // work item -> (row block, column chunk); consecutive blocks share the column chunk (L2 reuse on every XCD)
-    const int item = blockIdx.x;
-    const int ibl = item % a.num_ib;
-    const int jc = item / a.num_ib;
+    int ibl, jc;
+    if (!decode_work_item(a, ibl, jc)) return;
     const int row0 = (a.ib_begin + ibl) * TILE;
     const int jt_begin = jc * a.jc_tiles;
     const int jt_end = min(jt_begin + a.jc_tiles, a.num_jt);
@@ -112,12 +145,11 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32(const TileArg
 #pragma unroll
         for (int i = 0; i < 16; ++i) rowpart[rb][i] = 0.0f;
 
-    float ci[2][16];
+    // rbf: c_i = -|x_i|^2/2 of the tile's 128 rows lives in LDS (re-read by every tile_init as 4-row float4 broadcasts);
+    // keeping the lane's 32 values in registers instead pushes the kernel over the 256-VGPR budget of 2 waves per SIMD
+    float *cis = Bs + 2 * TILE * F32_LS;  // [TILE]
     if constexpr (KT == KT_RBF) {
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) ci[rb][i] = a.cr[row0 + wr * 64 + rb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h];
+        if (tid < TILE) cis[tid] = a.cr[row0 + tid];
     }
 
     f32x16 acc[2][2];
@@ -147,15 +179,24 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32(const TileArg
         }
     };
 
-    float dj[2], cj[2];
+    // per-lane column data of a tile: d_j and (rbf) c_j = -|x_j|^2/2.  They are fetched ONE TILE AHEAD (col_prefetch at the
+    // first k-chunk of the running tile, consumed by tile_init at its end) so their global-load latency is never exposed.
+    float dj[2], cj[2], djn[2], cjn[2];
     bool padcol[2] = { false, false };  // polynomial with a negative degree only: (0*gamma+coef0)^degree may be inf on padding
-    auto tile_init = [&](int jt) {
+    auto col_prefetch = [&](int jt) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             const int j = jt * TILE + wc * 64 + cb * 32 + r;
-            dj[cb] = a.dvec[j];
-            if constexpr (KT == KT_RBF) cj[cb] = a.cc[j];
-            if constexpr (KT == KT_POLY) padcol[cb] = (a.degree < 0) && (j >= a.ncols_valid);
+            djn[cb] = a.dvec[j];
+            if constexpr (KT == KT_RBF) cjn[cb] = a.cc[j];
+        }
+    };
+    auto tile_init = [&](int jt) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            dj[cb] = djn[cb];
+            if constexpr (KT == KT_RBF) cj[cb] = cjn[cb];
+            if constexpr (KT == KT_POLY) padcol[cb] = (a.degree < 0) && (jt * TILE + wc * 64 + cb * 32 + r >= a.ncols_valid);
         }
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
@@ -163,19 +204,29 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32(const TileArg
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    if constexpr (KT == KT_RBF) {
-                        acc[rb][cb][i] = ci[rb][i] + cj[cb];
-                    } else {
-                        acc[rb][cb][i] = 0.0f;
+                    if constexpr (KT != KT_RBF) acc[rb][cb][i] = 0.0f;
+                }
+        if constexpr (KT == KT_RBF) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 civ = *reinterpret_cast<const f32x4 *>(cis + wr * 64 + rb * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[rb][0][4 * g4 + e] = civ[e] + cj[0];
+                        acc[rb][1][4 * g4 + e] = civ[e] + cj[1];
                     }
                 }
+        }
     };
 
     const int nsteps = ntiles * a.kchunks;
     stage_load(jt_begin, 0);
-    tile_init(jt_begin);
+    col_prefetch(jt_begin);
     stage_store(0);
-    __syncthreads();
+    __syncthreads();  // also publishes cis
+    tile_init(jt_begin);
 
     int jt = jt_begin;
     int kc = 0;
@@ -187,7 +238,9 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32(const TileArg
             ++njt;
         }
         const bool has_next = (s + 1 < nsteps);
-        if (has_next) stage_load(njt, nkc);
+        const bool do_stage = has_next && !LSSVM_DBG(a, 1);
+        if (do_stage) stage_load(njt, nkc);
+        if (kc == 0 && jt + 1 < jt_end) col_prefetch(jt + 1);
 
         {
             const float *Ab = As + cur * TILE * F32_LS + (wr * 64 + r) * F32_LS + h * 4;
@@ -208,9 +261,9 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32(const TileArg
             }
         }
 
-        if (has_next) stage_store(cur ^ 1);
+        if (do_stage) stage_store(cur ^ 1);
 
-        if (kc == a.kchunks - 1) {
+        if (kc == a.kchunks - 1 && !LSSVM_DBG(a, 4)) {
             // epilogue of tile jt: K_ij = f(acc), row partial += K_ij * d_j  (vector ALU, fused; nothing is written)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
@@ -218,7 +271,7 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32(const TileArg
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        float kv = apply_kernel_function<KT>(acc[rb][cb][i], a);
+                        float kv = LSSVM_DBG(a, 2) ? acc[rb][cb][i] : apply_kernel_function<KT>(acc[rb][cb][i], a);
                         if constexpr (KT == KT_POLY) {
                             if (padcol[cb]) kv = 0.0f;  // d_j is an exact zero there, but inf * 0 would be nan
                         }
@@ -226,7 +279,7 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32(const TileArg
                     }
             if (has_next) tile_init(njt);
         }
-        __syncthreads();
+        if (!LSSVM_DBG(a, 8)) __syncthreads();
         jt = njt;
         kc = nkc;
     }
@@ -278,9 +331,8 @@ __global__ __launch_bounds__(TILE_THREADS, 1) void tile_matvec_f64(const TileArg
     const int r = lane & 15;
     const int qd = lane >> 4;
 
-    const int item = blockIdx.x;
-    const int ibl = item % a.num_ib;
-    const int jc = item / a.num_ib;
+    int ibl, jc;
+    if (!decode_work_item(a, ibl, jc)) return;
     const int row0 = (a.ib_begin + ibl) * TILE;
     const int jt_begin = jc * a.jc_tiles;
     const int jt_end = min(jt_begin + a.jc_tiles, a.num_jt);
@@ -322,24 +374,37 @@ __global__ __launch_bounds__(TILE_THREADS, 1) void tile_matvec_f64(const TileArg
         }
     };
 
-    double dj[4];
+    double ci[4][4];  // rbf: c_i of this lane's 16 rows (1 wave per SIMD: the register budget is 512)
+    if constexpr (KT == KT_RBF) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ci[mt][i] = a.cr[row0 + wr * 64 + mt * 16 + qd + 4 * i];
+    }
+    double dj[4], cj[4], djn[4], cjn[4];
     bool padcol[4] = { false, false, false, false };
-    auto tile_init = [&](int jt) {
-        double cj[4];
+    auto col_prefetch = [&](int jt) {  // one tile ahead, see the fp32 kernel
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int j = jt * TILE + wc * 64 + nt * 16 + r;
-            dj[nt] = a.dvec[j];
+            djn[nt] = a.dvec[j];
+            if constexpr (KT == KT_RBF) cjn[nt] = a.cc[j];
+        }
+    };
+    auto tile_init = [&](int jt) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            dj[nt] = djn[nt];
             cj[nt] = 0.0;
-            if constexpr (KT == KT_RBF) cj[nt] = a.cc[j];
-            if constexpr (KT == KT_POLY) padcol[nt] = (a.degree < 0) && (j >= a.ncols_valid);
+            if constexpr (KT == KT_RBF) cj[nt] = cjn[nt];
+            if constexpr (KT == KT_POLY) padcol[nt] = (a.degree < 0) && (jt * TILE + wc * 64 + nt * 16 + r >= a.ncols_valid);
         }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 double civ = 0.0;
-                if constexpr (KT == KT_RBF) civ = a.cr[row0 + wr * 64 + mt * 16 + qd + 4 * i];
+                if constexpr (KT == KT_RBF) civ = ci[mt][i];
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) acc[mt][nt][i] = civ + cj[nt];
             }
@@ -347,6 +412,7 @@ __global__ __launch_bounds__(TILE_THREADS, 1) void tile_matvec_f64(const TileArg
 
     const int nsteps = ntiles * a.kchunks;
     stage_load(jt_begin, 0);
+    col_prefetch(jt_begin);
     tile_init(jt_begin);
     stage_store(0);
     __syncthreads();
@@ -362,6 +428,7 @@ __global__ __launch_bounds__(TILE_THREADS, 1) void tile_matvec_f64(const TileArg
         }
         const bool has_next = (s + 1 < nsteps);
         if (has_next) stage_load(njt, nkc);
+        if (kc == 0 && jt + 1 < jt_end) col_prefetch(jt + 1);
 
         {
             const double *Ab = As + cur * TILE * F64_LS + (wr * 64 + r) * F64_LS + qd;
@@ -446,9 +513,8 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_rbf_direct_f32(co
     const int tid = threadIdx.x;
     const int tx = tid & 15;  // column group: columns tx + 16*c
     const int ty = tid >> 4;  // row group:    rows    ty + 16*rr
-    const int item = blockIdx.x;
-    const int ibl = item % a.num_ib;
-    const int jc = item / a.num_ib;
+    int ibl, jc;
+    if (!decode_work_item(a, ibl, jc)) return;
     const int row0 = (a.ib_begin + ibl) * TILE;
     const int jt_begin = jc * a.jc_tiles;
     const int jt_end = min(jt_begin + a.jc_tiles, a.num_jt);

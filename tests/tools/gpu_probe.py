@@ -74,7 +74,33 @@ def perf(N=50000, d=128, kernel="rbf", dt=np.float32, iters=5):
 
 
 if __name__ == "__main__":
-    if "--perf" in sys.argv:
+    if "--items" in sys.argv:
+        for dbg in (13, 0):
+            for xm in (0, 1):
+                for jt in (16, 64, 391):
+                    _capi.set_option("debug_ablate", dbg)
+                    _capi.set_option("xcd_map", xm)
+                    _capi.set_option("j_chunk_tiles", jt)
+                    print(f"dbg={dbg} xcd_map={xm} j_chunk_tiles={jt}: ", end="")
+                    perf(50000, 128, "rbf", np.float32, iters=8)
+        _capi.set_option("debug_ablate", 0)
+    elif "--ablate" in sys.argv:
+        for dbg in (0, 1, 5, 9, 13, 4, 8):
+            _capi.set_option("debug_ablate", dbg)
+            print(f"debug_ablate={dbg}: ", end="")
+            perf(50000, 128, "rbf", np.float32, iters=8)
+        _capi.set_option("debug_ablate", 0)
+    elif "--map" in sys.argv:
+        for N in (50000, 200000):
+            for xm in (0, 1):
+                for jt in (8, 16, 32):
+                    _capi.set_option("xcd_map", xm)
+                    _capi.set_option("j_chunk_tiles", jt)
+                    print(f"xcd_map={xm} j_chunk_tiles={jt}: ", end="")
+                    perf(N, 128, "rbf", np.float32, iters=3 if N > 100000 else 8)
+        _capi.set_option("xcd_map", 1)
+        _capi.set_option("j_chunk_tiles", 16)
+    elif "--perf" in sys.argv:
         perf(50000, 128, "rbf", np.float32)
         perf(50000, 128, "linear", np.float32)
         perf(50000, 128, "polynomial", np.float32)
