@@ -1,0 +1,202 @@
+/*
+ * test_csvm.cpp -- C++ tests of the host-side adaptor (include/plssvm_amd/csvm.hpp) that read like the reference's own
+ * backend tests (tests/backends/generic_csvm_tests.hpp, tests/csvm_factory.cpp), without GoogleTest (not in this image).
+ *
+ *   ./test_csvm            on a GPU box: runs everything            (exit code = number of failed checks)
+ *   ./test_csvm --no-gpu   on a box without a GPU: only the checks that must work there (factory, exceptions, loud failure)
+ */
+#include "plssvm_amd/csvm.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <string>
+#include <tuple>
+#include <vector>
+
+namespace pa = plssvm_amd;
+
+static int g_failed = 0;
+static int g_checks = 0;
+#define EXPECT_TRUE(cond)                                                          \
+    do {                                                                           \
+        ++g_checks;                                                                \
+        if (!(cond)) {                                                             \
+            ++g_failed;                                                            \
+            std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);           \
+        }                                                                          \
+    } while (0)
+#define EXPECT_THROW_WHAT(stmt, extype, text)                                                        \
+    do {                                                                                             \
+        ++g_checks;                                                                                  \
+        bool ok_ = false;                                                                            \
+        try {                                                                                        \
+            stmt;                                                                                    \
+        } catch (const extype &e) {                                                                  \
+            ok_ = std::string{ e.what() }.find(text) != std::string::npos;                           \
+            if (!ok_) std::printf("  what(): %s\n", e.what());                                       \
+        } catch (...) {                                                                              \
+        }                                                                                            \
+        if (!ok_) {                                                                                  \
+            ++g_failed;                                                                              \
+            std::printf("FAILED %s:%d: expected %s containing \"%s\"\n", __FILE__, __LINE__, #extype, text); \
+        }                                                                                            \
+    } while (0)
+
+// EXPECT_FLOATING_POINT_NEAR of the reference (tests/custom_test_macros.hpp:114-137)
+template <typename T>
+static bool fp_near(T a, T b, T factor = T(128)) {
+    if (a == b) return true;
+    const T diff = std::abs(a - b);
+    const T eps = std::numeric_limits<T>::epsilon();
+    return diff < std::max(std::numeric_limits<T>::min(), factor * eps * (std::abs(a) + std::abs(b)));
+}
+template <typename T>
+static bool fp_vec_near(const std::vector<T> &a, const std::vector<T> &b) {
+    if (a.size() != b.size()) return false;
+    for (std::size_t i = 0; i < a.size(); ++i)
+        if (!fp_near(a[i], b[i])) return false;
+    return true;
+}
+
+// re-exports the protected virtuals, exactly like tests/backends/HIP/mock_hip_csvm.hpp:22-44
+class mock_mi355_csvm final : public pa::mi355::csvm {
+  public:
+    using pa::mi355::csvm::csvm;
+    using pa::mi355::csvm::predict_values;
+    using pa::mi355::csvm::solve_system_of_linear_equations;
+};
+
+template <typename T>
+static void test_solve_trivial(pa::kernel_function_type kernel) {
+    // GenericCSVM.solve_system_of_linear_equations_trivial (generic_csvm_tests.hpp:99-137)
+    pa::detail::parameter<T> params;
+    params.kernel_type = kernel;
+    params.cost = T(2.0);
+    if (kernel == pa::kernel_function_type::polynomial) {
+        params.degree = 1;
+        params.set_gamma(T(1.0));
+        params.coef0 = T(0.0);
+    }
+    const T v = std::sqrt(T(1.0) - 1 / params.cost);
+    const std::vector<std::vector<T>> A = { { v, 0, 0, 0 }, { 0, v, 0, 0 }, { 0, 0, v, 0 }, { 0, 0, 0, v } };
+    const std::vector<T> rhs{ T(1.0), T(-1.0), T(1.0), T(-1.0) };
+    const mock_mi355_csvm svm{ static_cast<pa::parameter>(params) };
+    const auto [calculated_x, calculated_rho] = svm.solve_system_of_linear_equations(params, A, rhs, T(0.00001), A.front().size());
+    EXPECT_TRUE(fp_vec_near(calculated_x, rhs));
+    EXPECT_TRUE(std::abs(calculated_rho) < 8 * std::numeric_limits<T>::epsilon());
+    EXPECT_TRUE(svm.last_cg_info().iterations >= 1 && svm.last_cg_info().iterations <= 4);
+}
+
+template <typename T>
+static void test_predict_values(pa::kernel_function_type kernel) {
+    // GenericCSVM.predict_values (generic_csvm_tests.hpp:149-195)
+    pa::detail::parameter<T> params;
+    params.kernel_type = kernel;
+    params.cost = T(2.0);
+    if (kernel == pa::kernel_function_type::polynomial) {
+        params.degree = 1;
+        params.set_gamma(T(1.0));
+        params.coef0 = T(0.0);
+    }
+    const std::vector<std::vector<T>> support_vectors = { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 }, { 0, 0, 0, 1 } };
+    const std::vector<T> weights{ T(1.0), T(-1.0), T(1.0), T(-1.0) };
+    std::vector<T> w{};
+    const std::vector<std::vector<T>> data{ { 1, 1, 1, 1 }, { 1, -1, 1, -1 } };
+    const mock_mi355_csvm svm{ static_cast<pa::parameter>(params) };
+    const std::vector<T> calculated = svm.predict_values(params, support_vectors, weights, T(0.0), w, data);
+    EXPECT_TRUE(calculated.size() == data.size());
+    EXPECT_TRUE(fp_vec_near(calculated, std::vector<T>{ T(0.0), T(4.0) }));
+    if (kernel == pa::kernel_function_type::linear) {
+        EXPECT_TRUE(w.size() == 4 && fp_vec_near(w, weights));
+    } else {
+        EXPECT_TRUE(w.empty());
+    }
+}
+
+template <typename T>
+static void test_fit_predict_score(pa::kernel_function_type kernel) {
+    // two well separated blobs: a fitted model must classify its own training data (cf. GenericCSVM.predict / score,
+    // generic_csvm_tests.hpp:197-247, which use LIBSVM-trained fixtures)
+    std::mt19937 gen(7);
+    std::normal_distribution<T> noise(T(0), T(0.3));
+    const std::size_t N = 400, d = 10;
+    std::vector<std::vector<T>> X(N, std::vector<T>(d));
+    std::vector<T> y(N);
+    for (std::size_t i = 0; i < N; ++i) {
+        y[i] = (i % 2 == 0) ? T(1) : T(-1);
+        for (std::size_t f = 0; f < d; ++f) X[i][f] = y[i] * T(0.5) + noise(gen);
+    }
+    pa::parameter params;
+    params.kernel_type = kernel;
+    const auto svm = pa::make_csvm(pa::backend_type::mi355, params);
+    EXPECT_TRUE(svm->get_target_platform() == pa::target_platform::gpu_amd);
+    auto m = svm->fit(X, y, T(1e-6));
+    EXPECT_TRUE(m.alpha.size() == N);
+    EXPECT_TRUE(std::abs(m.params.gamma - 1.0 / d) < 1e-15);  // default gamma = 1 / num_features (csvm.hpp:303-307)
+    T sum = 0;
+    for (const T a : m.alpha) sum += a;
+    EXPECT_TRUE(std::abs(sum) < T(1e-3));  // alpha_N = -sum(alpha) (csvm.cpp:180)
+    EXPECT_TRUE(svm->score(m, X, y) > T(0.99));
+    const std::vector<T> labels = svm->predict(m, X);
+    EXPECT_TRUE(labels.size() == N && (labels[0] == T(1) || labels[0] == T(-1)));
+}
+
+static void test_factory_and_exceptions(bool have_gpu) {
+    // tests/csvm_factory.cpp:61-212
+    EXPECT_THROW_WHAT((void) pa::make_csvm(pa::backend_type::cuda), pa::unsupported_backend_exception, "No cuda backend available!");
+    EXPECT_THROW_WHAT((void) pa::make_csvm(pa::backend_type::openmp), pa::unsupported_backend_exception, "No openmp backend available!");
+    EXPECT_THROW_WHAT((void) pa::make_csvm(pa::backend_type::sycl), pa::unsupported_backend_exception, "No sycl backend available!");
+    pa::parameter bad;
+    bad.kernel_type = pa::kernel_function_type::rbf;
+    bad.set_gamma(-1.0);
+    EXPECT_THROW_WHAT((void) pa::make_csvm(pa::backend_type::mi355, bad), pa::invalid_parameter_exception, "gamma must be greater than 0.0");  // csvm.hpp:384
+    if (!have_gpu) {
+        // no device: construction must fail loudly (csvm.hip.cpp:70-72), there is no CPU fallback
+        EXPECT_THROW_WHAT((void) pa::make_csvm(pa::backend_type::mi355), pa::mi355::backend_exception, "no HIP capable devices were found");
+        EXPECT_THROW_WHAT((void) pa::make_csvm(), pa::mi355::backend_exception, "no HIP capable devices were found");
+        return;
+    }
+    EXPECT_THROW_WHAT((void) pa::make_csvm(pa::backend_type::mi355, pa::target_platform::cpu), pa::mi355::backend_exception, "Invalid target platform");  // csvm.hip.cpp:49-51
+    const auto a = pa::make_csvm();
+    const auto b = pa::make_csvm(pa::backend_type::hip, pa::target_platform::gpu_amd, pa::parameter{});
+    EXPECT_TRUE(dynamic_cast<pa::mi355::csvm *>(a.get()) != nullptr && dynamic_cast<pa::mi355::csvm *>(b.get()) != nullptr);
+    EXPECT_TRUE(a->get_target_platform() == pa::target_platform::gpu_amd);
+    // fit argument validation (tests/csvm.cpp:196-340)
+    const std::vector<std::vector<double>> X = { { 1, 2 }, { 3, 4 }, { 5, 6 } };
+    const std::vector<double> y = { 1, -1, 1 };
+    EXPECT_THROW_WHAT((void) a->fit(X, y, 0.0), pa::invalid_parameter_exception, "epsilon must be less than 0.0");
+    EXPECT_THROW_WHAT((void) a->fit(X, std::vector<double>{}), pa::invalid_parameter_exception, "No labels given for training");
+    const std::vector<std::vector<double>> ragged = { { 1, 2 }, { 3 }, { 5, 6 } };
+    EXPECT_THROW_WHAT((void) a->fit(ragged, y), pa::invalid_parameter_exception, "same number of features");
+    auto m = a->fit(X, y);
+    const std::vector<std::vector<double>> wrong = { { 1, 2, 3 } };
+    EXPECT_THROW_WHAT((void) a->predict(m, wrong), pa::invalid_parameter_exception, "must match the number of features per support vector");
+}
+
+int main(int argc, char **argv) {
+    const bool no_gpu = argc > 1 && std::strcmp(argv[1], "--no-gpu") == 0;
+    const bool have_gpu = lssvm_mi355_device_count() > 0;
+    if (no_gpu && have_gpu) std::printf("note: --no-gpu given but a device is visible; running the no-GPU subset anyway\n");
+    test_factory_and_exceptions(have_gpu && !no_gpu);
+    if (!no_gpu) {
+        if (!have_gpu) {
+            std::printf("no HIP device visible: run with --no-gpu for the CPU-only subset\n");
+            return 99;
+        }
+        for (const auto k : { pa::kernel_function_type::linear, pa::kernel_function_type::polynomial }) {  // rbf is skipped by the reference (generic_csvm_tests.hpp:110-112)
+            test_solve_trivial<float>(k);
+            test_solve_trivial<double>(k);
+            test_predict_values<float>(k);
+            test_predict_values<double>(k);
+        }
+        for (const auto k : { pa::kernel_function_type::linear, pa::kernel_function_type::polynomial, pa::kernel_function_type::rbf }) {
+            test_fit_predict_score<float>(k);
+            test_fit_predict_score<double>(k);
+        }
+    }
+    std::printf("%d checks, %d failed\n", g_checks, g_failed);
+    return g_failed;
+}

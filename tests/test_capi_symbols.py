@@ -91,3 +91,15 @@ def test_no_device_is_a_loud_error_not_a_fallback():
         backend.predict_values(Parameter(), X, y, 0.0, None, X)
     with pytest.raises(BackendError, match="no HIP capable devices"):
         backend.ResidentProblem(Parameter(), X)
+
+
+def test_cpp_adaptor_factory_and_loud_failure_without_gpu():
+    """tests/cpp/test_csvm --no-gpu: make_csvm / exception behaviour of include/plssvm_amd/csvm.hpp (reads like the reference's
+    tests/csvm_factory.cpp); on a box without a GPU the backend constructor must throw mi355::backend_exception."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_csvm")
+    if not os.path.isfile(exe):
+        subprocess.run(["make", "-C", os.path.dirname(exe)], check=True, capture_output=True)
+    if has_gpu:
+        pytest.skip("covered by the -m gpu run of the full driver")
+    out = subprocess.run([exe, "--no-gpu"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr

@@ -82,3 +82,11 @@ print('OK')
 """ % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_cpp_adaptor_reference_style_tests():
+    """tests/cpp/test_csvm: the reference's GenericCSVM known-answer tests + fit/predict/score through the C++ adaptor."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_csvm")
+    assert os.path.isfile(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
