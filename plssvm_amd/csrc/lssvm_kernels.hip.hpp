@@ -103,10 +103,11 @@ __device__ __forceinline__ T apply_kernel_function(T acc, const TileArgs<T> &a) 
  * fp32 tile kernel: v_mfma_f32_32x32x2_f32
  *   operand maps (cdna_hip_programming.md section 3): lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
  *   the 32x32 result has column j = l&31 on the lane and rows (reg&3) + 8*(reg>>2) + 4*(l>>5) in its 16 registers.
- *   LDS image of a k-chunk: [128 rows][32 floats + 4 pad]; inside every group of 8 floats the order is
- *   k = 0,2,4,6,1,3,5,7 so that ONE ds_read_b128 of lane-half h returns k = h, 2+h, 4+h, 6+h -- the operands of four
- *   consecutive MFMAs -- and the contraction runs through k in ascending order (bit-identical to the fma chain of the
- *   reference's dot product, include/plssvm/detail/operators.hpp:117-126).
+ *   fp32 data is stored in HBM (and hence in LDS) with the features of every aligned group of 8 in the order
+ *   k = 0,2,4,6,1,3,5,7 (k_interleave_features, applied once at set-up), so that ONE 16-byte read of lane-half h returns
+ *   k = h, 2+h, 4+h, 6+h -- the operands of four consecutive MFMAs -- and the contraction runs through k in ascending
+ *   order (bit-identical to the fma chain of the reference's dot product, include/plssvm/detail/operators.hpp:117-126).
+ *   LDS image of a k-chunk (this kernel): [128 rows][32 floats + 4 pad].
  * ===================================================================================================================== */
 
 template <int KT>
@@ -171,11 +172,11 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32(const TileArg
         float *Bw = Bs + buf * TILE * F32_LS + lds_w;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            // k-interleave: even k first, odd k second (see header comment)
-            *reinterpret_cast<f32x4 *>(Aw + p * 64 * F32_LS) = f32x4{ sa[p][0].x, sa[p][0].z, sa[p][1].x, sa[p][1].z };
-            *reinterpret_cast<f32x4 *>(Aw + p * 64 * F32_LS + 4) = f32x4{ sa[p][0].y, sa[p][0].w, sa[p][1].y, sa[p][1].w };
-            *reinterpret_cast<f32x4 *>(Bw + p * 64 * F32_LS) = f32x4{ sb[p][0].x, sb[p][0].z, sb[p][1].x, sb[p][1].z };
-            *reinterpret_cast<f32x4 *>(Bw + p * 64 * F32_LS + 4) = f32x4{ sb[p][0].y, sb[p][0].w, sb[p][1].y, sb[p][1].w };
+            // the k-interleave (even k first, odd k second, see header comment) is already part of the HBM layout (k_interleave_features)
+            *reinterpret_cast<f32x4 *>(Aw + p * 64 * F32_LS) = sa[p][0];
+            *reinterpret_cast<f32x4 *>(Aw + p * 64 * F32_LS + 4) = sa[p][1];
+            *reinterpret_cast<f32x4 *>(Bw + p * 64 * F32_LS) = sb[p][0];
+            *reinterpret_cast<f32x4 *>(Bw + p * 64 * F32_LS + 4) = sb[p][1];
         }
     };
 
@@ -308,6 +309,225 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32(const TileArg
     if (tid < TILE) {
         a.partial[static_cast<size_t>(jc) * a.part_stride + ibl * TILE + tid] = red[tid] + red[TILE + tid];
     }
+}
+
+/* =====================================================================================================================
+ * fp32 tile kernel, version 2 ("resident row panel"): for num_features <= 256.
+ *   - the work item's 128-row panel of X stays in REGISTERS for the whole sweep (flash-style): wave w owns rows 32w..32w+31
+ *     as MFMA A fragments (16 VGPRs per 32 features), so the panel is read from L2 once per work item instead of once
+ *     per column tile, and only the column side is staged on chip;
+ *   - column k-chunks (128 rows x 32 features = 16 KiB) travel HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no
+ *     staging registers, no ds_write), into a 3-slot ring; one chunk is in flight across every barrier (counted
+ *     s_waitcnt vmcnt(4) + raw s_barrier, cdna_hip_programming.md section 5 "Pipelining across barriers");
+ *   - the LDS image is lane-linear (128-byte rows); bank conflicts are avoided by XOR-swizzling the 16-byte slot with
+ *     (row >> 1) & 7 on the SOURCE address of the DMA and on the read address (rule 21 of the guide);
+ *   - d_j and c_j of a tile arrive the same way from a packed [tile][256] array (k_pack_dc), so no ordinary global load
+ *     (whose use would drain the DMA queue) sits inside the loop.
+ * Each wave multiplies its 32 rows with all 128 columns of the tile: 4 accumulators of 32x32, 64 MFMAs + 16 ds_read_b128
+ * per chunk.
+ * ===================================================================================================================== */
+constexpr int V2_RING = 3;                       // chunk slots in LDS
+constexpr int V2_SLOT_BYTES = TILE * 32 * 4;     // 16 KiB
+constexpr int V2_DC_SLOTS = 4;                   // ring of per-tile (d_j | c_j) records, 1 KiB each
+constexpr size_t V2_LDS_BYTES = static_cast<size_t>(V2_RING) * V2_SLOT_BYTES + V2_DC_SLOTS * 1024 + TILE * sizeof(float);
+
+using lds_ptr_t = __attribute__((address_space(3))) void *;
+using gbl_ptr_t = const __attribute__((address_space(1))) void *;
+
+template <int KT, int NKC>
+__global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_f32_v2(const TileArgs<float> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char *ring = smem_raw;                                                          // [V2_RING][128 rows][128 B]
+    char *dcs = smem_raw + V2_RING * V2_SLOT_BYTES;                                 // [V2_DC_SLOTS][256 floats]
+    float *cis = reinterpret_cast<float *>(dcs + V2_DC_SLOTS * 1024);               // [128] c_i of the row panel (rbf)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31;
+    const int h = lane >> 5;
+
+    int ibl, jc;
+    if (!decode_work_item(a, ibl, jc)) return;
+    const int row0 = (a.ib_begin + ibl) * TILE;
+    const int jt_begin = jc * a.jc_tiles;
+    const int jt_end = min(jt_begin + a.jc_tiles, a.num_jt);
+    const int ntiles = jt_end - jt_begin;
+    if (ntiles <= 0) return;
+    const int nsteps = ntiles * NKC;
+
+    // ---- the row panel: A fragments of this wave's 32 rows, all features (HBM layout is k-interleaved) ----
+    f32x4 afrag[4 * NKC];
+    {
+        const float *xr = a.Xr + static_cast<size_t>(row0 + wave * 32 + r) * a.ldx + 4 * h;
+#pragma unroll
+        for (int m = 0; m < 4 * NKC; ++m) afrag[m] = *reinterpret_cast<const f32x4 *>(xr + 8 * m);
+    }
+    if constexpr (KT == KT_RBF) {
+        if (tid < TILE) cis[tid] = a.cr[row0 + tid];
+    }
+    // make the compiler retire these ordinary loads HERE, before any LDS-DMA is in flight
+#pragma unroll
+    for (int m = 0; m < 4 * NKC; ++m) asm volatile("" : "+v"(afrag[m]));
+
+    // ---- LDS-DMA addressing ----
+    // instruction q = 4*wave + i moves rows 8q .. 8q+7 of a chunk; lane L -> row 8q + L/8, physical 16-B slot L%8, which
+    // holds logical slot (L%8) ^ ((row >> 1) & 7)
+    size_t dma_off[4];  // element offset of this lane's 16 bytes inside a (tile, chunk) = row * ldx + 4 * logical_slot
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * (4 * wave + i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        dma_off[i] = static_cast<size_t>(row) * a.ldx + 4 * c;
+    }
+    auto issue_chunk = [&](int step) {  // step = linear (tile, chunk) index of this work item
+        const int t = step / NKC;
+        const int kc = step - t * NKC;
+        const float *base = a.Xc + static_cast<size_t>(jt_begin + t) * TILE * a.ldx + kc * 32;
+        char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + dma_off[i]), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_dc = [&](int t) {  // (d_j | c_j) of tile jt_begin + t: 1 KiB, each wave moves a quarter with 16 lanes
+        if (lane < 16) {
+            const float *src = a.dc + static_cast<size_t>(jt_begin + t) * 256 + wave * 64 + lane * 4;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) src, (lds_ptr_t) (dcs + (t % V2_DC_SLOTS) * 1024 + wave * 256), 16, 0, 0);
+        }
+    };
+
+    // ---- read addressing: lane (r, h) reads 16-B logical slot 2*mm + h of row cb*32 + r (swizzle depends on r only) ----
+    int rd_off[4];
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) rd_off[mm] = r * 128 + (((2 * mm + h) ^ ((r >> 1) & 7)) << 4);
+
+    float rowpart[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rowpart[i] = 0.0f;
+    f32x16 acc[4];
+    float dj[4], cj[4];
+    bool padcol[4] = { false, false, false, false };
+
+    // prologue: tile 0's record and chunks 0, 1
+    issue_dc(0);
+    issue_chunk(0);
+    if (nsteps > 1) {
+        if (NKC == 1) issue_dc(1);
+        issue_chunk(1);
+    }
+
+    // chunk `step` has landed once all but this wave's 4 youngest DMA instructions are done (in-order completion); the
+    // barrier then (1) makes every wave's part of it visible and (2) guarantees that every wave has finished reading chunk
+    // step-1, whose slot the DMA issued right after it overwrites (lgkmcnt(0): this wave's LDS reads of the previous chunk
+    // and its cis write have completed as well)
+    auto sync_and_prefetch = [&](int step) {
+        if (step + 1 < nsteps) {
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (step + 2 < nsteps) {
+            // the record of a tile is issued right BEFORE the first chunk of that tile: "chunk landed" implies "record landed"
+            if ((step + 2) % NKC == 0) issue_dc((step + 2) / NKC);
+            issue_chunk(step + 2);
+        }
+    };
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int s0 = t * NKC;
+        sync_and_prefetch(s0);
+        {
+            // tile_init: per-lane column data + accumulator start values
+            const float *dcr = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                dj[cb] = dcr[cb * 32 + r];
+                if constexpr (KT == KT_RBF) cj[cb] = dcr[128 + cb * 32 + r];
+                if constexpr (KT == KT_POLY) padcol[cb] = (a.degree < 0) && ((jt_begin + t) * TILE + cb * 32 + r >= a.ncols_valid);
+            }
+            if constexpr (KT == KT_RBF) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 civ = *reinterpret_cast<const f32x4 *>(cis + wave * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int cb = 0; cb < 4; ++cb) acc[cb][4 * g4 + e] = civ[e] + cj[cb];
+                }
+            } else {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[cb][i] = 0.0f;
+            }
+        }
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            if (kc > 0) sync_and_prefetch(s0 + kc);
+            const char *slot = ring + ((s0 + kc) % V2_RING) * V2_SLOT_BYTES;
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+                f32x4 b[4];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) b[cb] = *reinterpret_cast<const f32x4 *>(slot + cb * 4096 + rd_off[mm]);
+                const f32x4 av = afrag[4 * kc + mm];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tt], b[cb][tt], acc[cb], 0, 0, 0);
+            }
+        }
+        // epilogue of the tile: K_ij = f(acc), row partial += K_ij * d_j (vector ALU, fused; nothing is written)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float kv = apply_kernel_function<KT>(acc[cb][i], a);
+                if constexpr (KT == KT_POLY) {
+                    if (padcol[cb]) kv = 0.0f;
+                }
+                rowpart[i] = fmaf(kv, dj[cb], rowpart[i]);
+            }
+    }
+
+    // every wave owns its rows: reduce over the 32 lanes of a lane-half and store
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float v = rowpart[i];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 1);
+        rowpart[i] = v;
+    }
+    if (r == 0) {
+        float *dst = a.partial + static_cast<size_t>(jc) * a.part_stride + ibl * TILE + wave * 32 + 4 * h;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[(i & 3) + 8 * (i >> 2)] = rowpart[i];
+    }
+}
+
+/* dc[jt][0..127] = d of tile jt, dc[jt][128..255] = c (rbf: -|x_j|^2/2, else unused): one 1-KiB LDS-DMA record per tile */
+__global__ void k_pack_dc(const float *__restrict__ dvec, const float *__restrict__ cc, int ncols_padded, float *__restrict__ dc) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncols_padded) return;
+    const int jt = j >> 7, l = j & 127;
+    dc[static_cast<size_t>(jt) * 256 + l] = dvec[j];
+    dc[static_cast<size_t>(jt) * 256 + 128 + l] = (cc != nullptr) ? cc[j] : 0.0f;
+}
+
+/* in place: the features of every aligned group of 8 are reordered to 0,2,4,6,1,3,5,7 (fp32 HBM layout, see above) */
+__global__ void k_interleave_features(float *__restrict__ X, size_t ngroups) {
+    const size_t g = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    f32x4 *p = reinterpret_cast<f32x4 *>(X + 8 * g);
+    const f32x4 lo = p[0], hi = p[1];
+    p[0] = f32x4{ lo.x, lo.z, hi.x, hi.z };
+    p[1] = f32x4{ lo.y, lo.w, hi.y, hi.w };
 }
 
 /* =====================================================================================================================

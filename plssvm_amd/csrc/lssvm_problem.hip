@@ -69,6 +69,38 @@ static void ensure_dynamic_lds(K kernel, size_t bytes) {
     LSSVM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
 }
 
+/* fp32 v2 kernel (row panel in registers, LDS-DMA ring): eligible for ldx <= 256 */
+template <int KT>
+static void launch_v2_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
+    const dim3 block(TILE_THREADS);
+    static bool configured = false;
+    if (!configured) {
+        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 1>, V2_LDS_BYTES);
+        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 2>, V2_LDS_BYTES);
+        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 3>, V2_LDS_BYTES);
+        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 4>, V2_LDS_BYTES);
+        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 5>, V2_LDS_BYTES);
+        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 6>, V2_LDS_BYTES);
+        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 7>, V2_LDS_BYTES);
+        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 8>, V2_LDS_BYTES);
+        configured = true;
+    }
+    switch (a.kchunks) {
+        case 1: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 1>), grid, block, V2_LDS_BYTES, s, a); break;
+        case 2: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 2>), grid, block, V2_LDS_BYTES, s, a); break;
+        case 3: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 3>), grid, block, V2_LDS_BYTES, s, a); break;
+        case 4: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 4>), grid, block, V2_LDS_BYTES, s, a); break;
+        case 5: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 5>), grid, block, V2_LDS_BYTES, s, a); break;
+        case 6: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 6>), grid, block, V2_LDS_BYTES, s, a); break;
+        case 7: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 7>), grid, block, V2_LDS_BYTES, s, a); break;
+        default: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 8>), grid, block, V2_LDS_BYTES, s, a); break;
+    }
+}
+
+bool v2_eligible(int ldx, bool rbf_direct) {
+    return !rbf_direct && ldx <= 8 * F32_KC && options().tile_kernel != 1;
+}
+
 /* fills the block -> work item mapping fields and returns the grid size */
 template <typename T>
 static unsigned finish_mapping(TileArgs<T> &a, int num_jc) {
@@ -93,6 +125,15 @@ void launch_tile_kernel<float>(TileArgs<float> &a, int kernel_type, bool rbf_dir
         ensure_dynamic_lds(tile_matvec_f32<KT_POLY>, lds);
         ensure_dynamic_lds(tile_matvec_f32<KT_RBF>, lds);
         configured = true;
+    }
+    if (a.dc != nullptr && v2_eligible(a.ldx, rbf_direct)) {
+        switch (kernel_type) {
+            case KT_LINEAR: launch_v2_kt<KT_LINEAR>(a, grid, s); break;
+            case KT_POLY: launch_v2_kt<KT_POLY>(a, grid, s); break;
+            default: launch_v2_kt<KT_RBF>(a, grid, s); break;
+        }
+        LSSVM_HIP_CHECK(hipGetLastError());
+        return;
     }
     switch (kernel_type) {
         case KT_LINEAR: hipLaunchKernelGGL(tile_matvec_f32<KT_LINEAR>, grid, block, lds, s, a); break;
@@ -166,6 +207,16 @@ void center_columns(DeviceMatrix<T> &M, DeviceMatrix<T> *M2, hipStream_t s) {
     }
     LSSVM_HIP_CHECK(hipGetLastError());
     LSSVM_HIP_CHECK(hipStreamSynchronize(s));  // part / mean are released on return
+}
+
+/* fp32: reorder the features of every group of 8 to 0,2,4,6,1,3,5,7 (the operand order of the MFMA kernels); fp64: nothing */
+template <typename T>
+void interleave_features(DeviceMatrix<T> &M, hipStream_t s) {
+    if constexpr (std::is_same_v<T, float>) {
+        const size_t ngroups = static_cast<size_t>(M.rows_alloc) * M.ldx / 8;
+        hipLaunchKernelGGL(k_interleave_features, dim3(static_cast<unsigned>((ngroups + 255) / 256)), dim3(256), 0, s, M.data.p, ngroups);
+        LSSVM_HIP_CHECK(hipGetLastError());
+    }
 }
 
 template <typename T>
@@ -262,6 +313,10 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
         center_columns<T>(X_, nullptr, stream_);
         half_neg_norms<T>(X_, c_, stream_);
     }
+    interleave_features<T>(X_, stream_);
+    if (std::is_same_v<T, float> && v2_eligible(X_.ldx, rbf_direct_)) {
+        dc_.alloc_zero(static_cast<size_t>(std::max(num_tiles_, 1)) * 256, stream_);
+    }
     events_.resize(4);
     for (EvPair &e : events_) {
         LSSVM_HIP_CHECK(hipEventCreate(&e.a));
@@ -291,6 +346,7 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     a.cr = c_.p;
     a.cc = c_.p;
     a.dvec = v_dev;
+    a.dc = dc_.p;
     a.partial = partial_.p;
     a.part_stride = static_cast<long>(std::max(num_ib_, 1)) * TILE;
     a.ldx = X_.ldx;
@@ -339,6 +395,12 @@ void Problem<T>::apply_K(const T *v_dev) {
     }
     if (num_ib_ > 0) {
         TileArgs<T> a = tile_args(v_dev);
+        if constexpr (std::is_same_v<T, float>) {
+            if (dc_.p != nullptr) {  // v2 kernel: pack (d_j | c_j) records for the LDS-DMA
+                const int ncols = num_tiles_ * TILE;
+                hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, stream_, v_dev, c_.p, ncols, dc_.p);
+            }
+        }
         if (ev != nullptr) LSSVM_HIP_CHECK(hipEventRecord(ev->a, stream_));
         launch_tile_kernel<T>(a, params_.kernel_type, rbf_direct_, num_jc_, stream_);
         if (ev != nullptr) {
@@ -580,6 +642,8 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
         half_neg_norms<T>(S, cS, s);
         half_neg_norms<T>(P, cP, s);
     }
+    interleave_features<T>(S, s);
+    interleave_features<T>(P, s);
     const int num_jt = S.rows_alloc / TILE;
     const int num_ib = P.rows_alloc / TILE;
     const int jc_tiles = static_cast<int>(std::max<int64_t>(1, options().j_chunk_tiles));
@@ -597,6 +661,7 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     ta.cr = cP.p;
     ta.cc = cS.p;
     ta.dvec = a.p;
+    ta.dc = nullptr;  // rectangular instance: generic (v1) tile kernel
     ta.partial = partial.p;
     ta.part_stride = P.rows_alloc;
     ta.ldx = S.ldx;

@@ -56,6 +56,7 @@ struct Error : std::runtime_error {
 struct Options {
     int64_t rbf_form = 0;        // 0: norm expansion on the matrix cores, 1: direct (x_i - x_j)^2 on the vector ALU (fp32 only)
     int64_t j_chunk_tiles = 16;  // 128-column tiles per work item
+    int64_t tile_kernel = 0;       // 0: automatic (fp32: v2 'resident row panel' kernel when num_features <= 256), 1: always the generic v1 kernel
     int64_t xcd_map = 0;           // 1: XCD-aware work item mapping (8 x 8 super-tiles per XCD), 0: linear (default: measured equal, better balanced)
     int64_t debug_ablate = 0;      // diagnostic timing ablations of the fp32 tile kernel (results are wrong when != 0)
     int64_t force_collective = 0;  // testing aid: run the all-gather even for world == 1 (needs lssvm_mi355_comm_init(.., 0, 1, ..))
@@ -140,6 +141,9 @@ template <typename T>
 void center_columns(DeviceMatrix<T> &M, DeviceMatrix<T> *M2, hipStream_t s);
 template <typename T>
 void half_neg_norms(const DeviceMatrix<T> &M, DevBuf<T> &c, hipStream_t s);
+template <typename T>
+void interleave_features(DeviceMatrix<T> &M, hipStream_t s);
+bool v2_eligible(int ldx, bool rbf_direct);
 
 /* ------------------------------------------------------------------ the resident problem ------------------------------------------------------------------ */
 struct ProblemBase {
@@ -191,6 +195,7 @@ class Problem final : public ProblemBase {
     DevBuf<T> c_;  // -0.5 |x|^2 (rbf, centred data)
     DevBuf<T> q_, b_, x_, r_, d_, Ad_, Kv_, tmp_, ylast_;
     DevBuf<T> partial_;
+    DevBuf<T> dc_;  // fp32 v2 kernel: packed (d_j | c_j) records
     DevBuf<double> part_, sc_;
     double *host_sc_ = nullptr;  // pinned, SC_COUNT doubles
     double QA_cost_ = 0.0;

@@ -31,6 +31,7 @@ struct TileArgs {
     const T *cr;      // rbf: -0.5 * |x_i|^2 per row-side point
     const T *cc;      // rbf: -0.5 * |x_j|^2 per column-side point
     const T *dvec;    // [num_jt*TILE] vector multiplied from the right, EXACT zeros beyond the valid columns
+    const T *dc;      // fp32 v2 kernel: packed [num_jt][256] records (d_j | c_j) for LDS-DMA (k_pack_dc)
     T *partial;       // [num_jc][part_stride] partial row sums, one slab per column chunk, indexed by the LOCAL row
     long part_stride; // elements between slabs (>= num_ib*TILE)
     int ldx;          // padded number of features (multiple of the k-chunk)
