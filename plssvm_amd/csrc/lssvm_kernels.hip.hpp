@@ -81,21 +81,44 @@ __device__ __forceinline__ bool decode_work_item(const TileArgs<T> &a, int &ibl,
     return ibl < a.num_ib && jc < a.num_jc;
 }
 
-template <int KT, typename T>
+/* DEG: polynomial degree class resolved OUTSIDE the per-element loop (a uniform switch around the whole epilogue):
+ * 3 = cube, 2 = square, 0 = generic integer power.  Ignored for the other kernels. */
+template <int KT, int DEG, typename T>
 __device__ __forceinline__ T apply_kernel_function(T acc, const TileArgs<T> &a) {
     if constexpr (KT == KT_LINEAR) {
         return acc;
     } else if constexpr (KT == KT_POLY) {
         const T v = acc * a.gamma + a.coef0;  // contracted to one fma, = std::fma(gamma, dot, coef0)
-        if (a.degree == 3) return v * v * v;
-        if (a.degree == 2) return v * v;
-        return ipow(v, a.degree);
+        if constexpr (DEG == 3) {
+            return v * v * v;
+        } else if constexpr (DEG == 2) {
+            return v * v;
+        } else {
+            return ipow(v, a.degree);
+        }
     } else {
         if constexpr (std::is_same_v<T, float>) {
-            return __builtin_amdgcn_exp2f(acc * a.gamma);  // acc = -|xi-xj|^2 / 2 ; gamma field = 2*gamma*log2(e)
+            // fp32: the data was pre-scaled by sqrt(2*gamma*log2(e)) at set-up, so acc = -gamma*log2(e)*|xi-xj|^2 already
+            return __builtin_amdgcn_exp2f(acc);
         } else {
-            return exp(acc * a.gamma);                     // gamma field = 2*gamma
+            return exp(acc * a.gamma);  // acc = -|xi-xj|^2 / 2 ; gamma field = 2*gamma
         }
+    }
+}
+
+/* runs `body(std::integral_constant<int, DEG>)` with the polynomial degree class of `a` (one uniform branch per tile) */
+template <int KT, typename T, typename F>
+__device__ __forceinline__ void with_degree_class(const TileArgs<T> &a, F &&body) {
+    if constexpr (KT == KT_POLY) {
+        if (a.degree == 3) {
+            body(std::integral_constant<int, 3>{});
+        } else if (a.degree == 2) {
+            body(std::integral_constant<int, 2>{});
+        } else {
+            body(std::integral_constant<int, 0>{});
+        }
+    } else {
+        body(std::integral_constant<int, 0>{});
     }
 }
 
@@ -266,18 +289,20 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32(const TileArg
 
         if (kc == a.kchunks - 1 && !LSSVM_DBG(a, 4)) {
             // epilogue of tile jt: K_ij = f(acc), row partial += K_ij * d_j  (vector ALU, fused; nothing is written)
+            with_degree_class<KT>(a, [&](auto degc) {
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
+                    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        float kv = LSSVM_DBG(a, 2) ? acc[rb][cb][i] : apply_kernel_function<KT>(acc[rb][cb][i], a);
-                        if constexpr (KT == KT_POLY) {
-                            if (padcol[cb]) kv = 0.0f;  // d_j is an exact zero there, but inf * 0 would be nan
+                        for (int i = 0; i < 16; ++i) {
+                            float kv = LSSVM_DBG(a, 2) ? acc[rb][cb][i] : apply_kernel_function<KT, decltype(degc)::value>(acc[rb][cb][i], a);
+                            if constexpr (KT == KT_POLY) {
+                                if (padcol[cb]) kv = 0.0f;  // d_j is an exact zero there, but inf * 0 would be nan
+                            }
+                            rowpart[rb][i] = fmaf(kv, dj[cb], rowpart[rb][i]);
                         }
-                        rowpart[rb][i] = fmaf(kv, dj[cb], rowpart[rb][i]);
-                    }
+            });
             if (has_next) tile_init(njt);
         }
         if (!LSSVM_DBG(a, 8)) __syncthreads();
@@ -481,16 +506,18 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
             }
         }
         // epilogue of the tile: K_ij = f(acc), row partial += K_ij * d_j (vector ALU, fused; nothing is written)
+        with_degree_class<KT>(a, [&](auto degc) {
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+            for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float kv = apply_kernel_function<KT>(acc[cb][i], a);
-                if constexpr (KT == KT_POLY) {
-                    if (padcol[cb]) kv = 0.0f;
+                for (int i = 0; i < 16; ++i) {
+                    float kv = apply_kernel_function<KT, decltype(degc)::value>(acc[cb][i], a);
+                    if constexpr (KT == KT_POLY) {
+                        if (padcol[cb]) kv = 0.0f;
+                    }
+                    rowpart[i] = fmaf(kv, dj[cb], rowpart[i]);
                 }
-                rowpart[i] = fmaf(kv, dj[cb], rowpart[i]);
-            }
+        });
     }
 
     // every wave owns its rows: reduce over the 32 lanes of a lane-half and store
@@ -671,18 +698,20 @@ __global__ __launch_bounds__(TILE_THREADS, 1) void tile_matvec_f64(const TileArg
         if (has_next) stage_store(cur ^ 1);
 
         if (kc == a.kchunks - 1) {
+            with_degree_class<KT>(a, [&](auto degc) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        double kv = apply_kernel_function<KT>(acc[mt][nt][i], a);
-                        if constexpr (KT == KT_POLY) {
-                            if (padcol[nt]) kv = 0.0;
+                        for (int i = 0; i < 4; ++i) {
+                            double kv = apply_kernel_function<KT, decltype(degc)::value>(acc[mt][nt][i], a);
+                            if constexpr (KT == KT_POLY) {
+                                if (padcol[nt]) kv = 0.0;
+                            }
+                            rowpart[mt][i] = fma(kv, dj[nt], rowpart[mt][i]);
                         }
-                        rowpart[mt][i] = fma(kv, dj[nt], rowpart[mt][i]);
-                    }
+            });
             if (has_next) tile_init(njt);
         }
         __syncthreads();
@@ -1054,12 +1083,12 @@ __global__ void k_colsum_stage2(const double *__restrict__ part, int nblocks, in
     for (int b = 0; b < nblocks; ++b) s += part[static_cast<size_t>(b) * ldx + f];
     mean[f] = static_cast<T>(s / static_cast<double>(nrows));
 }
-/* X[i][f] -= mean[f] for the valid rows / features only (padding stays exactly zero) */
+/* X[i][f] = (X[i][f] - mean[f]) * scale for the valid rows / features only (padding stays exactly zero) */
 template <typename T>
-__global__ void k_center(T *__restrict__ X, int ldx, int dfeat, int nrows, const T *__restrict__ mean) {
+__global__ void k_center(T *__restrict__ X, int ldx, int dfeat, int nrows, const T *__restrict__ mean, T scale) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
-    if (f < dfeat && i < nrows) X[static_cast<size_t>(i) * ldx + f] -= mean[f];
+    if (f < dfeat && i < nrows) X[static_cast<size_t>(i) * ldx + f] = (X[static_cast<size_t>(i) * ldx + f] - mean[f]) * scale;
 }
 /* c_i = -0.5 * |x_i|^2 (one wave per row, coalesced) */
 template <typename T>

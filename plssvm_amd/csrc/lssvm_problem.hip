@@ -181,7 +181,7 @@ static void set_kernel_scalars(TileArgs<T> &a, const lssvm_params &p, bool rbf_d
         if (rbf_direct) {
             a.gamma = static_cast<T>(-static_cast<double>(g) * log2e);
         } else if (std::is_same_v<T, float>) {
-            a.gamma = static_cast<T>(2.0 * static_cast<double>(g) * log2e);
+            a.gamma = T(1);  // folded into the data (rbf_prescale)
         } else {
             a.gamma = static_cast<T>(2.0 * static_cast<double>(g));
         }
@@ -190,8 +190,20 @@ static void set_kernel_scalars(TileArgs<T> &a, const lssvm_params &p, bool rbf_d
     }
 }
 
+/* rbf, matrix-core form: the (centred) data is pre-scaled so that the MFMA chain directly produces the exponent:
+ * fp32: x' = sqrt(2 gamma log2 e) (x - mean)  =>  x_i'.x_j' - (|x_i'|^2 + |x_j'|^2)/2 = -gamma log2(e) |x_i - x_j|^2 ; fp64: unscaled */
 template <typename T>
-void center_columns(DeviceMatrix<T> &M, DeviceMatrix<T> *M2, hipStream_t s) {
+T rbf_prescale(const lssvm_params &p) {
+    if constexpr (std::is_same_v<T, float>) {
+        constexpr double log2e = 1.4426950408889634073599246810019;
+        return static_cast<T>(std::sqrt(2.0 * static_cast<double>(static_cast<T>(p.gamma)) * log2e));
+    } else {
+        return T(1);
+    }
+}
+
+template <typename T>
+void center_columns(DeviceMatrix<T> &M, DeviceMatrix<T> *M2, T scale, hipStream_t s) {
     const int rows_per_block = 256;
     const int nblocks = (M.rows + rows_per_block - 1) / rows_per_block;
     DevBuf<double> part;
@@ -201,9 +213,9 @@ void center_columns(DeviceMatrix<T> &M, DeviceMatrix<T> *M2, hipStream_t s) {
     const dim3 g1(nblocks, (M.ldx + 255) / 256);
     hipLaunchKernelGGL(k_colsum_stage1<T>, g1, dim3(256), 0, s, M.data.p, M.ldx, M.rows, rows_per_block, part.p);
     hipLaunchKernelGGL(k_colsum_stage2<T>, dim3((M.ldx + 255) / 256), dim3(256), 0, s, part.p, nblocks, M.ldx, M.rows, mean.p);
-    hipLaunchKernelGGL(k_center<T>, dim3((M.dfeat + 255) / 256, M.rows), dim3(256), 0, s, M.data.p, M.ldx, M.dfeat, M.rows, mean.p);
+    hipLaunchKernelGGL(k_center<T>, dim3((M.dfeat + 255) / 256, M.rows), dim3(256), 0, s, M.data.p, M.ldx, M.dfeat, M.rows, mean.p, scale);
     if (M2 != nullptr) {
-        hipLaunchKernelGGL(k_center<T>, dim3((M2->dfeat + 255) / 256, M2->rows), dim3(256), 0, s, M2->data.p, M2->ldx, M2->dfeat, M2->rows, mean.p);
+        hipLaunchKernelGGL(k_center<T>, dim3((M2->dfeat + 255) / 256, M2->rows), dim3(256), 0, s, M2->data.p, M2->ldx, M2->dfeat, M2->rows, mean.p, scale);
     }
     LSSVM_HIP_CHECK(hipGetLastError());
     LSSVM_HIP_CHECK(hipStreamSynchronize(s));  // part / mean are released on return
@@ -310,7 +322,7 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
     }
     // rbf on the matrix cores: centre the data, then c_i = -|x_i|^2 / 2
     if (params_.kernel_type == LSSVM_KERNEL_RBF && !rbf_direct_) {
-        center_columns<T>(X_, nullptr, stream_);
+        center_columns<T>(X_, nullptr, rbf_prescale<T>(params_), stream_);
         half_neg_norms<T>(X_, c_, stream_);
     }
     interleave_features<T>(X_, stream_);
@@ -638,7 +650,7 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     P.upload(points, LSSVM_MEM_HOST, npoints, nfeat, 0, s);
     DevBuf<T> cS, cP;
     if (params.kernel_type == LSSVM_KERNEL_RBF) {
-        center_columns<T>(S, &P, s);
+        center_columns<T>(S, &P, rbf_prescale<T>(params), s);
         half_neg_norms<T>(S, cS, s);
         half_neg_norms<T>(P, cP, s);
     }

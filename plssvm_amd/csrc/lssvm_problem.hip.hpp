@@ -138,7 +138,7 @@ void launch_tile_kernel(TileArgs<T> &a, int kernel_type, bool rbf_direct, int nu
 
 /* centre `M` (and optionally `M2` with the same means) by the column means of M's valid rows; rbf only */
 template <typename T>
-void center_columns(DeviceMatrix<T> &M, DeviceMatrix<T> *M2, hipStream_t s);
+void center_columns(DeviceMatrix<T> &M, DeviceMatrix<T> *M2, T scale, hipStream_t s);
 template <typename T>
 void half_neg_norms(const DeviceMatrix<T> &M, DevBuf<T> &c, hipStream_t s);
 template <typename T>

@@ -46,7 +46,7 @@ struct TileArgs {
     int dbg;          // diagnostic ablations (timing only, results wrong): 1 = no global re-loads, 2 = no kernel function in the epilogue
     int ncols_valid;  // columns >= this are padding (used only where a padded column could produce inf/nan)
     int degree;       // polynomial
-    T gamma;          // polynomial: gamma ; rbf: 2 * gamma * log2(e) (f32) or 2 * gamma (f64)
+    T gamma;          // polynomial: gamma ; rbf fp64: 2 * gamma ; rbf fp32: unused (folded into the pre-scaled data) ; direct rbf: -gamma*log2(e)
     T coef0;          // polynomial
 };
 
