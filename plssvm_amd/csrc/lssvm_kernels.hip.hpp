@@ -745,6 +745,201 @@ __global__ __launch_bounds__(TILE_THREADS, 1) void tile_matvec_f64(const TileArg
 }
 
 /* =====================================================================================================================
+ * fp64 tile kernel, version 2: the fp32 v2 structure (row panel resident in registers, LDS-DMA ring, swizzled lane-linear
+ * LDS image, packed (d_j | c_j) records) on v_mfma_f64_16x16x4_f64, for num_features <= 128.
+ *   A column tile of 128 is processed as two 64-column SUB-TILES so that a wave's accumulators (32 rows x 64 columns =
+ *   8 tiles of 16x16 = 64 VGPRs) plus its row panel leave room for two workgroups per CU: the second workgroup's MFMAs
+ *   cover the first one's double-precision epilogue.  Chunk = 64 rows x 16 doubles = 8 KiB, 32 MFMAs per wave and barrier.
+ * ===================================================================================================================== */
+constexpr int V2D_RING = 3;
+constexpr int V2D_SLOT_BYTES = 64 * 128;  // 8 KiB
+constexpr int V2D_DC_SLOTS = 4;           // (64 d_j | 64 c_j) doubles = 1 KiB per sub-tile
+constexpr size_t V2D_LDS_BYTES = static_cast<size_t>(V2D_RING) * V2D_SLOT_BYTES + V2D_DC_SLOTS * 1024 + TILE * sizeof(double);
+
+template <int KT, int NKC>
+__global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_f64_v2(const TileArgs<double> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char *ring = smem_raw;
+    char *dcs = smem_raw + V2D_RING * V2D_SLOT_BYTES;
+    double *cis = reinterpret_cast<double *>(dcs + V2D_DC_SLOTS * 1024);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15;
+    const int q = lane >> 4;
+
+    int ibl, jc;
+    if (!decode_work_item(a, ibl, jc)) return;
+    const int row0 = (a.ib_begin + ibl) * TILE;
+    const int jt_begin = jc * a.jc_tiles;
+    const int jt_end = min(jt_begin + a.jc_tiles, a.num_jt);
+    const int nsub = 2 * (jt_end - jt_begin);  // 64-column sub-tiles
+    if (nsub <= 0) return;
+    const int st_begin = 2 * jt_begin;
+    const int nsteps = nsub * NKC;
+
+    // row panel: A operand of lane (r, q) for k-step s is X[row][4 s + q]
+    double afrag[2][4 * NKC];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const double *xr = a.Xr + static_cast<size_t>(row0 + wave * 32 + rb * 16 + r) * a.ldx + q;
+#pragma unroll
+        for (int s = 0; s < 4 * NKC; ++s) afrag[rb][s] = xr[4 * s];
+    }
+    if constexpr (KT == KT_RBF) {
+        if (tid < TILE) cis[tid] = a.cr[row0 + tid];
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int s = 0; s < 4 * NKC; ++s) asm volatile("" : "+v"(afrag[rb][s]));
+
+    // LDS-DMA: instruction qd = 2*wave + i moves rows 8 qd .. 8 qd + 7 of a 64-row chunk
+    size_t dma_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 8 * (2 * wave + i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        dma_off[i] = static_cast<size_t>(row) * a.ldx + 2 * c;  // in doubles: a 16-byte slot = 2 doubles
+    }
+    auto issue_chunk = [&](int step) {
+        const int t = step / NKC;
+        const int kc = step - t * NKC;
+        const double *base = a.Xc + static_cast<size_t>(st_begin + t) * 64 * a.ldx + kc * 16;
+        char *slot = ring + (step % V2D_RING) * V2D_SLOT_BYTES + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + dma_off[i]), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_dc = [&](int t) {
+        if (lane < 16) {
+            const double *src = a.dc + static_cast<size_t>(st_begin + t) * 128 + wave * 32 + lane * 2;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) src, (lds_ptr_t) (dcs + (t % V2D_DC_SLOTS) * 1024 + wave * 256), 16, 0, 0);
+        }
+    };
+
+    // read addressing: lane (r, q), k-step s of a chunk: double 4 s + q of row cb*16 + r -> 16-B slot 2 s + (q >> 1), half q & 1
+    int rd_off[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) rd_off[s] = r * 128 + (((2 * s + (q >> 1)) ^ ((r >> 1) & 7)) << 4) + ((q & 1) << 3);
+
+    double rowpart[2][4];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rowpart[rb][i] = 0.0;
+    f64x4 acc[2][4];
+    double dj[4], cj[4];
+    bool padcol[4] = { false, false, false, false };
+
+    issue_dc(0);
+    issue_chunk(0);
+    if (nsteps > 1) {
+        if (NKC == 1) issue_dc(1);
+        issue_chunk(1);
+    }
+
+    auto sync_and_prefetch = [&](int step) {  // see tile_matvec_f32_v2; 2 DMA instructions per wave and chunk here
+        if (step + 1 < nsteps) {
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (step + 2 < nsteps) {
+            if ((step + 2) % NKC == 0) issue_dc((step + 2) / NKC);
+            issue_chunk(step + 2);
+        }
+    };
+
+    for (int t = 0; t < nsub; ++t) {
+        const int s0 = t * NKC;
+        sync_and_prefetch(s0);
+        {
+            const double *dcr = reinterpret_cast<const double *>(dcs + (t % V2D_DC_SLOTS) * 1024);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                dj[cb] = dcr[cb * 16 + r];
+                cj[cb] = 0.0;
+                if constexpr (KT == KT_RBF) cj[cb] = dcr[64 + cb * 16 + r];
+                if constexpr (KT == KT_POLY) padcol[cb] = (a.degree < 0) && ((st_begin + t) * 64 + cb * 16 + r >= a.ncols_valid);
+            }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double civ = 0.0;
+                    if constexpr (KT == KT_RBF) civ = cis[wave * 32 + rb * 16 + q + 4 * i];
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) acc[rb][cb][i] = civ + cj[cb];
+                }
+        }
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            if (kc > 0) sync_and_prefetch(s0 + kc);
+            const char *slot = ring + ((s0 + kc) % V2D_RING) * V2D_SLOT_BYTES;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                double b[4];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) b[cb] = *reinterpret_cast<const double *>(slot + cb * 2048 + rd_off[s]);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[rb][4 * kc + s], b[cb], acc[rb][cb], 0, 0, 0);
+            }
+        }
+        with_degree_class<KT>(a, [&](auto degc) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        double kv = apply_kernel_function<KT, decltype(degc)::value>(acc[rb][cb][i], a);
+                        if constexpr (KT == KT_POLY) {
+                            if (padcol[cb]) kv = 0.0;
+                        }
+                        rowpart[rb][i] = fma(kv, dj[cb], rowpart[rb][i]);
+                    }
+        });
+    }
+
+    // rows are shared by the 16 lanes of a quarter-wave
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double v = rowpart[rb][i];
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 1);
+            rowpart[rb][i] = v;
+        }
+    if (r == 0) {
+        double *dst = a.partial + static_cast<size_t>(jc) * a.part_stride + ibl * TILE + wave * 32 + q;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[rb * 16 + 4 * i] = rowpart[rb][i];
+    }
+}
+
+/* fp64 records of the v2 kernel: per 64-column sub-tile st: dc[st][0..63] = d, dc[st][64..127] = c */
+__global__ void k_pack_dc_f64(const double *__restrict__ dvec, const double *__restrict__ cc, int ncols_padded, double *__restrict__ dc) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncols_padded) return;
+    const int st = j >> 6, l = j & 63;
+    dc[static_cast<size_t>(st) * 128 + l] = dvec[j];
+    dc[static_cast<size_t>(st) * 128 + 64 + l] = (cc != nullptr) ? cc[j] : 0.0;
+}
+
+/* =====================================================================================================================
  * Direct-form RBF on the vector ALU (fp32): accumulates (x_i - x_j)^2 exactly as the reference does
  * (HIP/svm_kernel.hip.hpp:247, operators.hpp:161-171).  1 sub + 1 fma per (i, j, feature): at most half of the fp32 FMA
  * peak.  Kept as the formula-exact alternative to the matrix-core path (option "rbf_form" = 1) and as its on-device

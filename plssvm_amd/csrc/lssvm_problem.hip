@@ -100,6 +100,24 @@ static void launch_v2_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
 bool v2_eligible(int ldx, bool rbf_direct) {
     return !rbf_direct && ldx <= 8 * F32_KC && options().tile_kernel != 1;
 }
+bool v2_eligible_f64(int ldx) {
+    return ldx <= 8 * F64_KC && options().tile_kernel != 1;
+}
+
+template <int KT>
+static void launch_v2d_kt(const TileArgs<double> &a, dim3 grid, hipStream_t s) {
+    const dim3 block(TILE_THREADS);
+    switch (a.kchunks) {
+        case 1: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 1>), grid, block, V2D_LDS_BYTES, s, a); break;
+        case 2: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 2>), grid, block, V2D_LDS_BYTES, s, a); break;
+        case 3: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 3>), grid, block, V2D_LDS_BYTES, s, a); break;
+        case 4: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 4>), grid, block, V2D_LDS_BYTES, s, a); break;
+        case 5: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 5>), grid, block, V2D_LDS_BYTES, s, a); break;
+        case 6: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 6>), grid, block, V2D_LDS_BYTES, s, a); break;
+        case 7: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 7>), grid, block, V2D_LDS_BYTES, s, a); break;
+        default: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 8>), grid, block, V2D_LDS_BYTES, s, a); break;
+    }
+}
 
 /* fills the block -> work item mapping fields and returns the grid size */
 template <typename T>
@@ -161,6 +179,15 @@ void launch_tile_kernel<double>(TileArgs<double> &a, int kernel_type, bool /*rbf
         ensure_dynamic_lds(tile_matvec_f64<KT_POLY>, lds);
         ensure_dynamic_lds(tile_matvec_f64<KT_RBF>, lds);
         configured = true;
+    }
+    if (a.dc != nullptr && v2_eligible_f64(a.ldx)) {  // V2D_LDS_BYTES < 64 KiB: no opt-in needed
+        switch (kernel_type) {
+            case KT_LINEAR: launch_v2d_kt<KT_LINEAR>(a, grid, s); break;
+            case KT_POLY: launch_v2d_kt<KT_POLY>(a, grid, s); break;
+            default: launch_v2d_kt<KT_RBF>(a, grid, s); break;
+        }
+        LSSVM_HIP_CHECK(hipGetLastError());
+        return;
     }
     switch (kernel_type) {
         case KT_LINEAR: hipLaunchKernelGGL(tile_matvec_f64<KT_LINEAR>, grid, block, lds, s, a); break;
@@ -326,8 +353,8 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
         half_neg_norms<T>(X_, c_, stream_);
     }
     interleave_features<T>(X_, stream_);
-    if (std::is_same_v<T, float> && v2_eligible(X_.ldx, rbf_direct_)) {
-        dc_.alloc_zero(static_cast<size_t>(std::max(num_tiles_, 1)) * 256, stream_);
+    if ((std::is_same_v<T, float> && v2_eligible(X_.ldx, rbf_direct_)) || (std::is_same_v<T, double> && v2_eligible_f64(X_.ldx))) {
+        dc_.alloc_zero(static_cast<size_t>(std::max(num_tiles_, 1)) * 256, stream_);  // (d_j | c_j) records: 256 reals per 128 columns
     }
     events_.resize(4);
     for (EvPair &e : events_) {
@@ -407,10 +434,12 @@ void Problem<T>::apply_K(const T *v_dev) {
     }
     if (num_ib_ > 0) {
         TileArgs<T> a = tile_args(v_dev);
-        if constexpr (std::is_same_v<T, float>) {
-            if (dc_.p != nullptr) {  // v2 kernel: pack (d_j | c_j) records for the LDS-DMA
-                const int ncols = num_tiles_ * TILE;
+        if (dc_.p != nullptr) {  // v2 kernels: pack (d_j | c_j) records for the LDS-DMA
+            const int ncols = num_tiles_ * TILE;
+            if constexpr (std::is_same_v<T, float>) {
                 hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, stream_, v_dev, c_.p, ncols, dc_.p);
+            } else {
+                hipLaunchKernelGGL(k_pack_dc_f64, dim3((ncols + 255) / 256), dim3(256), 0, stream_, v_dev, c_.p, ncols, dc_.p);
             }
         }
         if (ev != nullptr) LSSVM_HIP_CHECK(hipEventRecord(ev->a, stream_));

@@ -144,6 +144,7 @@ void half_neg_norms(const DeviceMatrix<T> &M, DevBuf<T> &c, hipStream_t s);
 template <typename T>
 void interleave_features(DeviceMatrix<T> &M, hipStream_t s);
 bool v2_eligible(int ldx, bool rbf_direct);
+bool v2_eligible_f64(int ldx);
 
 /* ------------------------------------------------------------------ the resident problem ------------------------------------------------------------------ */
 struct ProblemBase {
