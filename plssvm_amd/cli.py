@@ -1,0 +1,163 @@
+"""``plssvm-train`` / ``plssvm-predict`` compatible command lines (src/main_train.cpp:24-70, src/main_predict.cpp:29-100,
+src/plssvm/detail/cmd/parser_train.cpp:41-73, parser_predict.cpp:44-60) on top of the MI355X backend.
+
+    python -m plssvm_amd.train   [-t -d -g -r -c -e -i -b -p --use_strings_as_labels --use_float_as_real_type --verbosity -q] training_set_file [model_file]
+    python -m plssvm_amd.predict [-b -p --use_strings_as_labels --use_float_as_real_type --verbosity -q] test_file model_file [output_file]
+"""
+
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+from .csvm import BackendType, TargetPlatform, make_csvm
+from .data_set import DataSet
+from .exceptions import PlssvmError
+from .model import Model
+from .parameter import Parameter
+
+VERBOSITY = ("full", "timing", "libsvm", "quiet")
+
+
+def _common(ap):
+    ap.add_argument("-b", "--backend", default="automatic", help="choose the backend: automatic|mi355|hip (the reference's other backends are not built here)")
+    ap.add_argument("-p", "--target_platform", default="automatic", help="choose the target platform: automatic|gpu_amd")
+    ap.add_argument("--use_strings_as_labels", action="store_true", help="use strings as labels instead of plane numbers")
+    ap.add_argument("--use_float_as_real_type", action="store_true", help="use floats as real types instead of doubles")
+    ap.add_argument("--verbosity", choices=VERBOSITY, default=None, help="choose the level of verbosity: full|timing|libsvm|quiet (default: full)")
+    ap.add_argument("-q", "--quiet", action="store_true", help="quiet mode (no outputs regardless the provided verbosity level!)")
+    ap.add_argument("-v", "--version", action="store_true", help="print version information")
+
+
+def _verbosity(args):
+    if args.quiet:
+        if args.verbosity not in (None, "quiet"):
+            print(f'WARNING: explicitly set the -q/--quiet flag, but the provided verbosity level isn\'t "quiet"; setting --verbosity={args.verbosity} to --verbosity=quiet',
+                  file=sys.stderr)
+        return "quiet"
+    return args.verbosity or "full"
+
+
+def _log(verb, levels, text):
+    """detail::log(verbosity_level, ...) (logger.hpp:109-123): printed iff the active level is one of `levels`."""
+    if verb != "quiet" and verb in levels:
+        print(text, flush=True)
+
+
+def train_main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="plssvm-train", description="LS-SVM with multiple (GPU-)backends")
+    ap.add_argument("-t", "--kernel_type", default="0", help="set type of kernel function. 0 -- linear: u'*v, 1 -- polynomial: (gamma*u'*v + coef0)^degree, 2 -- radial basis function: exp(-gamma*|u-v|^2)")
+    ap.add_argument("-d", "--degree", type=int, default=3, help="set degree in kernel function")
+    ap.add_argument("-g", "--gamma", type=float, default=None, help="set gamma in kernel function (default: 1 / num_features)")
+    ap.add_argument("-r", "--coef0", type=float, default=0.0, help="set coef0 in kernel function")
+    ap.add_argument("-c", "--cost", type=float, default=1.0, help="set the parameter C")
+    ap.add_argument("-e", "--epsilon", type=float, default=0.001, help="set the tolerance of termination criterion")
+    ap.add_argument("-i", "--max_iter", type=int, default=None, help="set the maximum number of CG iterations (default: num_features)")
+    _common(ap)
+    ap.add_argument("input", nargs="?", help="training_set_file")
+    ap.add_argument("model", nargs="?", help="model_file")
+    args = ap.parse_args(argv)
+    if args.version:
+        print("plssvm_amd (MI355X-native LS-SVM CG backend), C ABI version 1")
+        return 0
+    if args.input is None:
+        print("Error missing input file!", file=sys.stderr)
+        ap.print_help()
+        return 1
+    if args.max_iter is not None and args.max_iter <= 0:
+        print(f"max_iter must be greater than 0, but is {args.max_iter}!", file=sys.stderr)  # parser_train.cpp:130-133
+        return 1
+    verb = _verbosity(args)
+    model_file = args.model if args.model is not None else os.path.basename(args.input) + ".model"  # parser_train.cpp:220-226
+    try:
+        t0 = time.perf_counter()
+        real_type = np.float32 if args.use_float_as_real_type else np.float64
+        params = Parameter(kernel_type=args.kernel_type, degree=args.degree, gamma=args.gamma, coef0=args.coef0, cost=args.cost)
+        _log(verb, ("full",), f"\ntask: training\nkernel_type: {params.kernel_type}\ncost: {params.cost}\nepsilon: {args.epsilon}\n"
+                              f"real_type: {np.dtype(real_type).name}\ninput file (data set): '{args.input}'\noutput file (model): '{model_file}'\n")
+        data = DataSet(filename=args.input, real_type=real_type, label_type=str if args.use_strings_as_labels else float)
+        _log(verb, ("full", "timing"), f"Read {data.num_data_points()} data points with {data.num_features()} features using the libsvm parser from file '{args.input}'.")
+        svm = make_csvm(args.backend, TargetPlatform(args.target_platform), params)
+        _log(verb, ("full",), f"\nUsing MI355 as backend.\nFound {svm.num_devices} HIP device(s).\n")
+        model = svm.fit(data, epsilon=args.epsilon, max_iter=args.max_iter)
+        info = svm.last_cg_info
+        _log(verb, ("full", "timing"), f"Finished after {info['iterations']}/{info['max_iterations']} iterations with a residuum of {info['residuum']} "
+                                      f"(target: {info['target_residuum']}) and an average iteration time of {info['avg_iteration_ms']:.3f}ms.")
+        _log(verb, ("full", "libsvm"), f"optimization finished, #iter = {info['iterations']}")  # csvm.cpp:175-176
+        _log(verb, ("full", "timing"), f"Solved minimization problem (r = b - Ax) using the Conjugate Gradient (CG) methode in {info['total_runtime_ms']:.0f}ms.\n")
+        model.save(model_file)
+        _log(verb, ("full", "timing"), f"Write {model.num_support_vectors()} support vectors with {model.num_features()} features to the libsvm model file '{model_file}'.")
+        _log(verb, ("full",), f"\nTotal runtime: {(time.perf_counter() - t0) * 1e3:.0f}ms")
+    except PlssvmError as e:
+        print(f"{e}\nException type: {type(e).__name__}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def predict_main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="plssvm-predict", description="LS-SVM with multiple (GPU-)backends")
+    _common(ap)
+    ap.add_argument("test", nargs="?", help="test_file")
+    ap.add_argument("model", nargs="?", help="model_file")
+    ap.add_argument("output", nargs="?", help="output_file")
+    args = ap.parse_args(argv)
+    if args.version:
+        print("plssvm_amd (MI355X-native LS-SVM CG backend), C ABI version 1")
+        return 0
+    if args.test is None:
+        print("Error missing test file!", file=sys.stderr)
+        return 1
+    if args.model is None:
+        print("Error missing model file!", file=sys.stderr)
+        return 1
+    verb = _verbosity(args)
+    out_file = args.output if args.output is not None else os.path.basename(args.test) + ".predict"  # parser_predict.cpp:150-156
+    try:
+        t0 = time.perf_counter()
+        real_type = np.float32 if args.use_float_as_real_type else np.float64
+        label_type = str if args.use_strings_as_labels else float
+        data = DataSet(filename=args.test, real_type=real_type, label_type=label_type) if _has_two_labels(args.test, label_type) else _unlabeled(args.test, real_type)
+        model = Model.load(args.model, real_type=real_type, label_type=label_type)
+        svm = make_csvm(args.backend, TargetPlatform(args.target_platform))
+        predicted = svm.predict(model, data)
+        with open(out_file, "w") as f:
+            f.write("\n".join(_fmt(p) for p in predicted))
+        _log(verb, ("full", "timing"), f"Write {len(predicted)} predictions to the file '{out_file}'.")
+        if data.has_labels():
+            correct = sum(1 for p, c in zip(predicted, data.labels()) if p == c)
+            _log(verb, ("full", "libsvm"), f"Accuracy = {100.0 * correct / len(predicted)}% ({correct}/{len(predicted)}) (classification)")  # main_predict.cpp:78-84
+        _log(verb, ("full", "timing"), f"\nTotal runtime: {(time.perf_counter() - t0) * 1e3:.0f}ms")
+    except PlssvmError as e:
+        print(f"{e}\nException type: {type(e).__name__}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def _fmt(label):
+    if isinstance(label, str):
+        return label
+    f = float(label)
+    return str(int(f)) if f.is_integer() else repr(f)
+
+
+def _has_two_labels(filename, label_type):
+    from .io_libsvm import parse_libsvm_data
+    _, labels = parse_libsvm_data(filename, label_type=label_type)
+    return labels is not None and len(set(labels)) == 2
+
+
+class _Unlabeled(DataSet):
+    pass
+
+
+def _unlabeled(filename, real_type):
+    """a test file without labels, or with a single class: usable for prediction only (labels kept for the accuracy line)"""
+    from .io_libsvm import parse_libsvm_data
+    X, labels = parse_libsvm_data(filename, dtype=real_type)
+    ds = DataSet(X, None, real_type=real_type)
+    ds._labels = labels
+    return ds
