@@ -284,3 +284,19 @@ def test_linearity_and_symmetry_at_scale(kernel, dt, N, d):
     assert np.max(np.abs(Aw - (2 * Au.astype(np.float64) - 3 * Av.astype(np.float64)))) < 2e3 * eps * scale
     uAv, vAu = float(u.astype(np.float64) @ Av.astype(np.float64)), float(v.astype(np.float64) @ Au.astype(np.float64))
     assert abs(uAv - vAu) < 2e3 * eps * (np.abs(u) @ np.abs(Av) + np.abs(v) @ np.abs(Au))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_predict_and_score_on_the_reference_fixture(kernel, dt):
+    """GenericCSVM.predict / score (generic_csvm_tests.hpp:197-247) on the reference's LIBSVM-trained 500x200 models:
+    predicted labels equal tests/data/predict/500x200.libsvm.predict exactly, score == 1.0."""
+    import os
+    from conftest import HERE
+    fx = np.load(os.path.join(HERE, "golden", "predict_500x200.npz"))
+    gamma = float(fx[f"{kernel}_gamma"])
+    p = Parameter(kernel_type=kernel, degree=int(fx[f"{kernel}_degree"]), gamma=(gamma if gamma == gamma else None), coef0=float(fx[f"{kernel}_coef0"]))
+    out, w = backend.predict_values(p, fx[f"{kernel}_sv"].astype(dt), fx[f"{kernel}_alpha"].astype(dt), float(fx[f"{kernel}_rho"]), None, fx["test_X"].astype(dt))
+    labels = np.where(out > 0, 1, -1)
+    assert np.array_equal(labels, fx["expected"])
+    assert float(np.mean(labels == fx["test_y"].astype(int))) == 1.0

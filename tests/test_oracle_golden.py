@@ -129,3 +129,17 @@ def test_oracle_vs_live_reference(oracle, kernel, dt):
     po, _ = oracle.predict_values(kernel, sv, al, 0.25, pts, **kw)
     pr, _ = ref.predict_values(kernel, sv, al, 0.25, pts, **kw)
     assert ol.rel_inf(po, pr) < 64 * np.finfo(dt).eps
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_oracle_predict_reproduces_reference_fixture(oracle, kernel, dt):
+    """GenericCSVM.predict / score (generic_csvm_tests.hpp:197-247): LIBSVM-trained models, exact labels, score == 1."""
+    import os
+    from conftest import HERE
+    fx = np.load(os.path.join(HERE, "golden", "predict_500x200.npz"))
+    gamma = float(fx[f"{kernel}_gamma"])
+    kw = dict(degree=int(fx[f"{kernel}_degree"]), gamma=(gamma if gamma == gamma else 1.0 / 200), coef0=float(fx[f"{kernel}_coef0"]))
+    out, _ = oracle.predict_values(kernel, fx[f"{kernel}_sv"].astype(dt), fx[f"{kernel}_alpha"].astype(dt), float(fx[f"{kernel}_rho"]), fx["test_X"].astype(dt), **kw)
+    labels = np.where(out > 0, 1, -1)
+    assert np.array_equal(labels, fx["expected"]) and np.array_equal(labels, fx["test_y"].astype(int))
