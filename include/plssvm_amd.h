@@ -185,6 +185,7 @@ int lssvm_mi355_problem_info(lssvm_mi355_problem *p, lssvm_cg_info *info);
  *   "j_chunk_tiles" number of 128-column tiles per work item (default 16)
  *   "tile_kernel"   0 = automatic: fp32 with num_features <= 256 uses the "resident row panel" kernel (default), 1 = always the generic kernel
  *   "xcd_map"       1 = XCD-aware block -> work item mapping (8 x 8 super-tiles per XCD), 0 = linear (default)
+ *   "lds_extra_kb"  experiment knob: extra dynamic LDS (KiB) per workgroup of the fp32 v2 kernel, lowers the workgroups per CU
  *   "debug_ablate"  timing-only ablation bits of the fp32 tile kernel; effective only in -DLSSVM_ENABLE_ABLATION builds
  *   "force_collective" 1 = run the per-matvec RCCL all-gather even with a world of 1 (testing aid; default 0)
  */

@@ -260,6 +260,9 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
         } else if (n == "tile_kernel") {
             LSSVM_REQUIRE(value == 0 || value == 1, "tile_kernel must be 0 (automatic) or 1 (generic kernel)");
             lssvm::options().tile_kernel = value;
+        } else if (n == "lds_extra_kb") {
+            LSSVM_REQUIRE(value >= 0 && value <= 88, "lds_extra_kb out of range");
+            lssvm::options().lds_extra_kb = value;
         } else if (n == "debug_ablate") {
             lssvm::options().debug_ablate = value;
         } else if (n == "xcd_map") {
@@ -281,6 +284,8 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             *value_out = lssvm::options().j_chunk_tiles;
         } else if (n == "tile_kernel") {
             *value_out = lssvm::options().tile_kernel;
+        } else if (n == "lds_extra_kb") {
+            *value_out = lssvm::options().lds_extra_kb;
         } else if (n == "debug_ablate") {
             *value_out = lssvm::options().debug_ablate;
         } else if (n == "xcd_map") {

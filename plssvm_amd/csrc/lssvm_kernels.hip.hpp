@@ -342,8 +342,9 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32(const TileArg
  *     as MFMA A fragments (16 VGPRs per 32 features), so the panel is read from L2 once per work item instead of once
  *     per column tile, and only the column side is staged on chip;
  *   - column k-chunks (128 rows x 32 features = 16 KiB) travel HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no
- *     staging registers, no ds_write), into a 3-slot ring; one chunk is in flight across every barrier (counted
- *     s_waitcnt vmcnt(4) + raw s_barrier, cdna_hip_programming.md section 5 "Pipelining across barriers");
+ *     staging registers, no ds_write), into a 4-slot ring, two chunks ahead; the hand-over of chunk s+1 (counted
+ *     s_waitcnt vmcnt(4) + raw s_barrier, cdna_hip_programming.md section 5 "Pipelining across barriers") is executed in
+ *     the MIDDLE of step s, in the shadow of its MFMAs, so a step starts reading its chunk with no wait at its head;
  *   - the LDS image is lane-linear (128-byte rows); bank conflicts are avoided by XOR-swizzling the 16-byte slot with
  *     (row >> 1) & 7 on the SOURCE address of the DMA and on the read address (rule 21 of the guide);
  *   - d_j and c_j of a tile arrive the same way from a packed [tile][256] array (k_pack_dc), so no ordinary global load
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32(const TileArg
  * Each wave multiplies its 32 rows with all 128 columns of the tile: 4 accumulators of 32x32, 64 MFMAs + 16 ds_read_b128
  * per chunk.
  * ===================================================================================================================== */
-constexpr int V2_RING = 3;                       // chunk slots in LDS
+constexpr int V2_RING = 4;                       // chunk slots in LDS
 constexpr int V2_SLOT_BYTES = TILE * 32 * 4;     // 16 KiB
 constexpr int V2_DC_SLOTS = 4;                   // ring of per-tile (d_j | c_j) records, 1 KiB each
 constexpr size_t V2_LDS_BYTES = static_cast<size_t>(V2_RING) * V2_SLOT_BYTES + V2_DC_SLOTS * 1024 + TILE * sizeof(float);
@@ -406,8 +407,9 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
         dma_off[i] = static_cast<size_t>(row) * a.ldx + 4 * c;
     }
     auto issue_chunk = [&](int step) {  // step = linear (tile, chunk) index of this work item
-        const int t = step / NKC;
-        const int kc = step - t * NKC;
+        if (LSSVM_DBG(a, 16) && step > 3) return;  // ablation: no DMA after the prologue
+        const int t = LSSVM_DBG(a, 1) ? 0 : step / NKC;  // ablation bit 1: always the same (L2-resident) tile
+        const int kc = LSSVM_DBG(a, 1) ? 0 : step - t * NKC;
         const float *base = a.Xc + static_cast<size_t>(jt_begin + t) * TILE * a.ldx + kc * 32;
         char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES + wave * 4096;
 #pragma unroll
@@ -434,38 +436,69 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
     float dj[4], cj[4];
     bool padcol[4] = { false, false, false, false };
 
-    // prologue: tile 0's record and chunks 0, 1
+    // ---- prologue: chunks 0, 1, 2 (each preceded by the record of the tile that starts with it) ----
     issue_dc(0);
     issue_chunk(0);
-    if (nsteps > 1) {
-        if (NKC == 1) issue_dc(1);
-        issue_chunk(1);
-    }
-
-    // chunk `step` has landed once all but this wave's 4 youngest DMA instructions are done (in-order completion); the
-    // barrier then (1) makes every wave's part of it visible and (2) guarantees that every wave has finished reading chunk
-    // step-1, whose slot the DMA issued right after it overwrites (lgkmcnt(0): this wave's LDS reads of the previous chunk
-    // and its cis write have completed as well)
-    auto sync_and_prefetch = [&](int step) {
-        if (step + 1 < nsteps) {
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int pre = 1; pre <= 2; ++pre) {
+        if (pre < nsteps) {
+            if (pre % NKC == 0) issue_dc(pre / NKC);
+            issue_chunk(pre);
         }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (step + 2 < nsteps) {
+    }
+    // chunk 0 (and record 0, and cis) complete: everything but the DMA instructions of the younger chunks is done
+    if (nsteps >= 3) {
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    } else if (nsteps == 2) {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    f32x4 bcur[4];  // B fragments of the group about to be multiplied (double buffered against bnext in the loop)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) bcur[cb] = *reinterpret_cast<const f32x4 *>(ring + cb * 4096 + rd_off[0]);
+
+    // ---- hand-over of the NEXT chunk, executed in the MIDDLE of a step (in the shadow of that step's MFMAs) ----
+    // Called half-way through step `step`: this wave's DMA of chunk step+1 (issued 2 steps ago) is complete once all but its
+    // 4 youngest DMA instructions (chunk step+2) are done; the barrier makes every wave's part visible, so the next step
+    // starts reading at once, with no wait and no barrier at its head.  Ring of 4 slots: the DMA issued here (chunk step+3)
+    // overwrites the slot of chunk step-1, which every wave finished reading before it arrived at this barrier.
+    // CHECKED = false: steady state, step + 3 < nsteps is known, the code is branch free (one basic block per tile, so the
+    // compiler can place the scalar address arithmetic and the DMA issue in the shadow of the MFMAs); CHECKED = true: the
+    // last tiles of the work item.
+    auto handover = [&](int step, int kc_plus3_mod, auto checked) {
+        constexpr bool CHECKED = decltype(checked)::value;
+        if constexpr (!CHECKED) {
+            if (!LSSVM_DBG(a, 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (!LSSVM_DBG(a, 8)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             // the record of a tile is issued right BEFORE the first chunk of that tile: "chunk landed" implies "record landed"
-            if ((step + 2) % NKC == 0) issue_dc((step + 2) / NKC);
-            issue_chunk(step + 2);
+            if (kc_plus3_mod == 0) issue_dc((step + 3) / NKC);
+            issue_chunk(step + 3);
+        } else {
+            if (step + 1 < nsteps) {
+                if (step + 2 < nsteps) {
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (step + 3 < nsteps) {
+                    if (kc_plus3_mod == 0) issue_dc((step + 3) / NKC);
+                    issue_chunk(step + 3);
+                }
+            }
         }
     };
 
-    for (int t = 0; t < ntiles; ++t) {
+    auto tile_body = [&](int t, auto checked) {
         const int s0 = t * NKC;
-        sync_and_prefetch(s0);
         {
-            // tile_init: per-lane column data + accumulator start values
+            // tile_init: per-lane column data + accumulator start values (the record became visible at the last hand-over)
             const float *dcr = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
@@ -491,21 +524,34 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
         }
 #pragma unroll
         for (int kc = 0; kc < NKC; ++kc) {
-            if (kc > 0) sync_and_prefetch(s0 + kc);
-            const char *slot = ring + ((s0 + kc) % V2_RING) * V2_SLOT_BYTES;
+            const int step = s0 + kc;
+            const char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES;
+            const char *slot_next = ring + ((step + 1) % V2_RING) * V2_SLOT_BYTES;
 #pragma unroll
             for (int mm = 0; mm < 4; ++mm) {
-                f32x4 b[4];
+                // software prefetch of the NEXT group's B fragments (next chunk for mm == 3: visible since this step's hand-over),
+                // issued before the hand-over barrier so that LDS latency and barrier skew hide behind the 16 MFMAs below
+                f32x4 bnext[4];
+                if (mm < 3) {
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) b[cb] = *reinterpret_cast<const f32x4 *>(slot + cb * 4096 + rd_off[mm]);
+                    for (int cb = 0; cb < 4; ++cb) bnext[cb] = *reinterpret_cast<const f32x4 *>(slot + cb * 4096 + rd_off[mm + 1]);
+                }
+                if (mm == 2) handover(step, (kc + 3) % NKC, checked);
+                if (mm == 3) {
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) bnext[cb] = *reinterpret_cast<const f32x4 *>(slot_next + cb * 4096 + rd_off[0]);
+                }
                 const f32x4 av = afrag[4 * kc + mm];
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tt], b[cb][tt], acc[cb], 0, 0, 0);
+                    for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tt], bcur[cb][tt], acc[cb], 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) bcur[cb] = bnext[cb];
             }
         }
         // epilogue of the tile: K_ij = f(acc), row partial += K_ij * d_j (vector ALU, fused; nothing is written)
+        if (!LSSVM_DBG(a, 4))
         with_degree_class<KT>(a, [&](auto degc) {
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb)
@@ -518,7 +564,14 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
                     rowpart[i] = fmaf(kv, dj[cb], rowpart[i]);
                 }
         });
-    }
+    };
+
+    // steady state: every tile whose last step still has step + 3 < nsteps; then the (1..3) tail tiles with the checked hand-over
+    constexpr int TAIL_TILES = (3 + NKC - 1) / NKC;
+    const int nmain = ntiles > TAIL_TILES ? ntiles - TAIL_TILES : 0;
+    int t = 0;
+    for (; t < nmain; ++t) tile_body(t, std::false_type{});
+    for (; t < ntiles; ++t) tile_body(t, std::true_type{});
 
     // every wave owns its rows: reduce over the 32 lanes of a lane-half and store
 #pragma unroll

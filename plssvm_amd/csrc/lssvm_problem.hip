@@ -73,7 +73,10 @@ static void ensure_dynamic_lds(K kernel, size_t bytes) {
 template <int KT>
 static void launch_v2_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
     const dim3 block(TILE_THREADS);
-    static bool configured = false;
+    const size_t V2_LDS_BYTES = lssvm::V2_LDS_BYTES + static_cast<size_t>(options().lds_extra_kb) * 1024;  // experiment knob: limits workgroups per CU
+    static size_t configured_for = 0;
+    const bool configured = (configured_for == V2_LDS_BYTES);
+    configured_for = V2_LDS_BYTES;
     if (!configured) {
         ensure_dynamic_lds(tile_matvec_f32_v2<KT, 1>, V2_LDS_BYTES);
         ensure_dynamic_lds(tile_matvec_f32_v2<KT, 2>, V2_LDS_BYTES);
@@ -83,7 +86,6 @@ static void launch_v2_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
         ensure_dynamic_lds(tile_matvec_f32_v2<KT, 6>, V2_LDS_BYTES);
         ensure_dynamic_lds(tile_matvec_f32_v2<KT, 7>, V2_LDS_BYTES);
         ensure_dynamic_lds(tile_matvec_f32_v2<KT, 8>, V2_LDS_BYTES);
-        configured = true;
     }
     switch (a.kchunks) {
         case 1: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 1>), grid, block, V2_LDS_BYTES, s, a); break;

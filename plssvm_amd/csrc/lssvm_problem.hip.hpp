@@ -58,6 +58,7 @@ struct Options {
     int64_t j_chunk_tiles = 16;  // 128-column tiles per work item
     int64_t tile_kernel = 0;       // 0: automatic (fp32: v2 'resident row panel' kernel when num_features <= 256), 1: always the generic v1 kernel
     int64_t xcd_map = 0;           // 1: XCD-aware work item mapping (8 x 8 super-tiles per XCD), 0: linear (default: measured equal, better balanced)
+    int64_t lds_extra_kb = 0;      // experiment knob: extra dynamic LDS per workgroup of the fp32 v2 kernel (lowers workgroups per CU)
     int64_t debug_ablate = 0;      // diagnostic timing ablations of the fp32 tile kernel (results are wrong when != 0)
     int64_t force_collective = 0;  // testing aid: run the all-gather even for world == 1 (needs lssvm_mi355_comm_init(.., 0, 1, ..))
 };

@@ -74,7 +74,20 @@ def perf(N=50000, d=128, kernel="rbf", dt=np.float32, iters=5):
 
 
 if __name__ == "__main__":
-    if "--items" in sys.argv:
+    if "--ablate2" in sys.argv:
+        for dbg in (0, 1, 4, 5, 16, 20, 28):
+            _capi.set_option("debug_ablate", dbg)
+            print(f"debug_ablate={dbg}: ", end="")
+            perf(100000, 128, "rbf", np.float32, iters=4)
+        _capi.set_option("debug_ablate", 0)
+    elif "--occ" in sys.argv:
+        for extra in (0, 20, 88):
+            for kern in ("linear", "rbf"):
+                _capi.set_option("lds_extra_kb", extra)
+                print(f"lds_extra_kb={extra}: ", end="")
+                perf(100000, 128, kern, np.float32, iters=4)
+        _capi.set_option("lds_extra_kb", 0)
+    elif "--items" in sys.argv:
         for dbg in (13, 0):
             for xm in (0, 1):
                 for jt in (16, 64, 391):

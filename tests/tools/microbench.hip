@@ -90,6 +90,67 @@ __global__ __launch_bounds__(256, 2) void k_mfma_lds(float *out, int iters, int 
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+
+// the production v2 pattern: A fragments resident in registers, B fragments from a swizzled lane-linear LDS image (4 x b128 per 16
+// MFMAs), 4 accumulators of 32x32, one barrier per 64 MFMAs; optional LDS-DMA of the next chunk (dma = 1) from a small L2-resident buffer
+using lds_ptr_t = __attribute__((address_space(3))) void *;
+using gbl_ptr_t = const __attribute__((address_space(1))) void *;
+template <int SPREAD, int PRIO>
+__global__ __launch_bounds__(256, 2) void k_v2_like(float *out, const float *src, int iters, int use_barrier, int dma) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 4 * 16384 / 4; i += 256) reinterpret_cast<float *>(smem)[i] = (i % 19) * 0.01f;
+    __syncthreads();
+    f32x4 afrag[16];
+    for (int m = 0; m < 16; ++m) afrag[m] = f32x4{ 0.01f * m, 0.02f * lane, 0.5f, 0.25f };
+    int rd_off[4];
+    for (int mm = 0; mm < 4; ++mm) rd_off[mm] = r * 128 + (((2 * mm + h) ^ ((r >> 1) & 7)) << 4);
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    const float *gsrc = src + (size_t) (blockIdx.x % 64) * 4096 + wave * 1024 + lane * 4;
+    for (int it4 = 0; it4 < iters; it4 += 4) {
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const int it = it4 + kc;
+            const char *slot = smem + kc * 16384;
+            char *dst = smem + ((kc + 3) & 3) * 16384 + wave * 4096;
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+                if (mm == 2) {
+                    if (dma) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    if (use_barrier) __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (dma && !SPREAD) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((gbl_ptr_t) (gsrc + i * 256), (lds_ptr_t) (dst + i * 1024), 16, 0, 0);
+                    }
+                }
+                f32x4 b[4];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) b[cb] = *reinterpret_cast<const f32x4 *>(slot + cb * 4096 + rd_off[mm]);
+                const f32x4 av = afrag[4 * kc + mm];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tt], b[cb][tt], acc[cb], 0, 0, 0);
+                    if (PRIO) __builtin_amdgcn_s_setprio(0);
+                    if (SPREAD && dma && mm >= 2 && (tt & 1) == 0) {
+                        const int i = (mm - 2) * 2 + (tt >> 1);
+                        __builtin_amdgcn_global_load_lds((gbl_ptr_t) (gsrc + i * 256), (lds_ptr_t) (dst + i * 1024), 16, 0, 0);
+                    }
+                }
+            }
+            (void) it;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ void k_valu_fma_f32(float *out, int iters, float a0) {
     float x[16];
     for (int i = 0; i < 16; ++i) x[i] = a0 + i + threadIdx.x;
@@ -165,6 +226,17 @@ int main() {
             double ms = time_ms([&] { hipLaunchKernelGGL(k_mfma_lds, dim3(blocks), dim3(threads), lds, 0, (float *) buf, iters / 4, bar); });
             double flop = 2.0 * 32 * 32 * 2 * 64.0 * (iters / 4) * (double) blocks * 4;
             printf("mfma_f32 fed from LDS (prod. pattern), barrier=%d, %d wave/SIMD: %.1f TFLOP/s\n", bar, wps, flop / ms / 1e9);
+        }
+
+        for (int variant = 0; variant < 3; ++variant) {
+            for (int mode = 0; mode < 3; ++mode) {  // 0: no barrier, 1: barrier, 2: barrier + LDS-DMA
+                const size_t lds = 4 * 16384;
+                auto fn = variant == 0 ? k_v2_like<0, 0> : (variant == 1 ? k_v2_like<1, 0> : k_v2_like<1, 1>);
+                hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+                double ms = time_ms([&] { hipLaunchKernelGGL(fn, dim3(blocks), dim3(threads), lds, 0, (float *) buf, (const float *) buf + (32u << 20), iters / 4, mode >= 1, mode == 2); });
+                double flop = 2.0 * 32 * 32 * 2 * 64.0 * (iters / 4) * (double) blocks * 4;
+                printf("v2-like variant %d (0 burst DMA, 1 spread DMA, 2 spread+setprio) mode=%d (0 none,1 barrier,2 barrier+DMA), %d wave/SIMD: %.1f TFLOP/s\n", variant, mode, wps, flop / ms / 1e9);
+            }
         }
     }
     for (int wps : {2, 4, 8}) {
