@@ -73,6 +73,8 @@ typedef struct lssvm_cg_info {
     uint64_t matvec_launches;
     int32_t devices_used;    /* world size of the row-block sharding (1 = single GPU) */
     int32_t converged;       /* 1 if the stop test delta <= eps^2 * delta0 fired */
+    int32_t symmetric;       /* 1 if the implicit matvec evaluated only the tiles on/below the diagonal (half the multiply-adds) */
+    int32_t reserved;
 } lssvm_cg_info;
 
 /* ------------------------------------------------------------------------------------------------------------------ */
@@ -183,6 +185,8 @@ int lssvm_mi355_problem_info(lssvm_mi355_problem *p, lssvm_cg_info *info);
 /* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT):
  *   "rbf_form"      0 = norm expansion on the matrix cores (default), 1 = direct (x_i - x_j)^2 on the vector ALU
  *   "j_chunk_tiles" number of 128-column tiles per work item (default 16)
+ *   "symmetric"     1 = evaluate only the kernel-matrix tiles on/below the diagonal and mirror them (default; fp32, num_features <= 256),
+ *                   0 = full square (row-owned sums, results independent of the GPU count)
  *   "tile_kernel"   0 = automatic: fp32 with num_features <= 256 uses the "resident row panel" kernel (default), 1 = always the generic kernel
  *   "xcd_map"       1 = XCD-aware block -> work item mapping (8 x 8 super-tiles per XCD), 0 = linear (default)
  *   "lds_extra_kb"  experiment knob: extra dynamic LDS (KiB) per workgroup of the fp32 v2 kernel, lowers the workgroups per CU

@@ -257,6 +257,8 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
         } else if (n == "j_chunk_tiles") {
             LSSVM_REQUIRE(value >= 1 && value <= (1 << 20), "j_chunk_tiles out of range");
             lssvm::options().j_chunk_tiles = value;
+        } else if (n == "symmetric") {
+            lssvm::options().symmetric = value != 0 ? 1 : 0;
         } else if (n == "tile_kernel") {
             LSSVM_REQUIRE(value == 0 || value == 1, "tile_kernel must be 0 (automatic) or 1 (generic kernel)");
             lssvm::options().tile_kernel = value;
@@ -282,6 +284,8 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             *value_out = lssvm::options().rbf_form;
         } else if (n == "j_chunk_tiles") {
             *value_out = lssvm::options().j_chunk_tiles;
+        } else if (n == "symmetric") {
+            *value_out = lssvm::options().symmetric;
         } else if (n == "tile_kernel") {
             *value_out = lssvm::options().tile_kernel;
         } else if (n == "lds_extra_kb") {

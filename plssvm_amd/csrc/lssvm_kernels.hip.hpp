@@ -379,17 +379,19 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32(const TileArg
 constexpr int V2_RING = 4;                       // chunk slots in LDS
 constexpr int V2_SLOT_BYTES = TILE * 32 * 4;     // 16 KiB
 constexpr int V2_DC_SLOTS = 4;                   // ring of per-tile (d_j | c_j) records, 1 KiB each
-constexpr size_t V2_LDS_BYTES = static_cast<size_t>(V2_RING) * V2_SLOT_BYTES + V2_DC_SLOTS * 1024 + TILE * sizeof(float);
+constexpr size_t V2_LDS_BYTES = static_cast<size_t>(V2_RING) * V2_SLOT_BYTES + V2_DC_SLOTS * 1024 + (2 * TILE + 2 * 4 * TILE) * sizeof(float);  // ring + records + cis, dis, colred
 
 using lds_ptr_t = __attribute__((address_space(3))) void *;
 using gbl_ptr_t = const __attribute__((address_space(1))) void *;
 
-template <int KT, int NKC>
+template <int KT, int NKC, bool SYM>
 __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_f32_v2(const TileArgs<float> a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char *ring = smem_raw;                                                          // [V2_RING][128 rows][128 B]
     char *dcs = smem_raw + V2_RING * V2_SLOT_BYTES;                                 // [V2_DC_SLOTS][256 floats]
     float *cis = reinterpret_cast<float *>(dcs + V2_DC_SLOTS * 1024);               // [128] c_i of the row panel (rbf)
+    float *dis = cis + TILE;                                                        // [128] d_i of the row panel (SYM)
+    float *colred = dis + TILE;                                                     // [2][4 waves][128] column sums of a tile (SYM)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -397,14 +399,26 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
     const int r = lane & 31;
     const int h = lane >> 5;
 
+    // SYM: the kernel matrix is symmetric, so only the tiles on or below the diagonal are evaluated (as the reference does,
+    // svm_kernel.cpp:39); an off-diagonal tile K_IJ contributes K_IJ d_J to the rows of I AND K_IJ^T d_I to the rows of J.
+    // Work items come from a host-built list of the non-empty (row block, column chunk) pairs.
     int ibl, jc;
-    if (!decode_work_item(a, ibl, jc)) return;
-    const int row0 = (a.ib_begin + ibl) * TILE;
+    if constexpr (SYM) {
+        const int2 it = a.items[blockIdx.x];
+        ibl = it.x;
+        jc = it.y;
+    } else {
+        if (!decode_work_item(a, ibl, jc)) return;
+    }
+    const int ib = a.ib_begin + ibl;
+    const int row0 = ib * TILE;
     const int jt_begin = jc * a.jc_tiles;
-    const int jt_end = min(jt_begin + a.jc_tiles, a.num_jt);
+    const int jt_end = SYM ? min(jt_begin + a.jc_tiles, ib + 1) : min(jt_begin + a.jc_tiles, a.num_jt);
     const int ntiles = jt_end - jt_begin;
     if (ntiles <= 0) return;
     const int nsteps = ntiles * NKC;
+    // record index of (ib, jt) in the packed strictly-lower-triangular column slab of this device
+    const long rec0 = SYM ? (static_cast<long>(ib) * (ib - 1) / 2 - a.pair_origin) : 0;
 
     // ---- the row panel: A fragments of this wave's 32 rows, all features (HBM layout is k-interleaved) ----
     f32x4 afrag[4 * NKC];
@@ -415,6 +429,9 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
     }
     if constexpr (KT == KT_RBF) {
         if (tid < TILE) cis[tid] = a.cr[row0 + tid];
+    }
+    if constexpr (SYM) {
+        if (tid < TILE) dis[tid] = a.dvec[row0 + tid];
     }
     // make the compiler retire these ordinary loads HERE, before any LDS-DMA is in flight
 #pragma unroll
@@ -528,8 +545,19 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
         }
     };
 
+    // SYM: the four waves' column sums of tile t (written to colred by its epilogue, made visible by the next barrier) are
+    // added in a fixed order and stored to the tile's record of the column slab
+    auto flush_cols = [&](int t) {
+        if (tid < TILE) {
+            const float *cr_ = colred + (t & 1) * 512;
+            const float sum = (cr_[tid] + cr_[128 + tid]) + (cr_[256 + tid] + cr_[384 + tid]);
+            a.colslab[(rec0 + jt_begin + t) * TILE + tid] = sum;
+        }
+    };
+
     auto tile_body = [&](int t, auto checked) {
         const int s0 = t * NKC;
+        const bool tile_sym = SYM && (jt_begin + t < ib);  // strictly below the diagonal
         {
             // tile_init: per-lane column data + accumulator start values (the record became visible at the last hand-over)
             const float *dcr = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);
@@ -569,7 +597,16 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
 #pragma unroll
                     for (int cb = 0; cb < 4; ++cb) bnext[cb] = *reinterpret_cast<const f32x4 *>(slot + cb * 4096 + rd_off[mm + 1]);
                 }
-                if (mm == 2) handover(step, (kc + 3) % NKC, checked);
+                if (mm == 2) {
+                    if constexpr (SYM) {
+                        // the colred writes of the previous tile's epilogue must have completed before the barrier publishes them
+                        if (kc == 0 && t > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    handover(step, (kc + 3) % NKC, checked);
+                    if constexpr (SYM) {
+                        if (kc == 0 && t > 0) flush_cols(t - 1);  // every tile before the last one of an item is off-diagonal
+                    }
+                }
                 if (mm == 3) {
 #pragma unroll
                     for (int cb = 0; cb < 4; ++cb) bnext[cb] = *reinterpret_cast<const f32x4 *>(slot_next + cb * 4096 + rd_off[0]);
@@ -587,19 +624,47 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
                 for (int cb = 0; cb < 4; ++cb) bcur[cb] = bnext[cb];
             }
         }
-        // epilogue of the tile: K_ij = f(acc), row partial += K_ij * d_j (vector ALU, fused; nothing is written)
+        // epilogue of the tile: K_ij = f(acc), row partial += K_ij * d_j; SYM, off-diagonal tile: column partial += K_ij * d_i
+        // (vector ALU, fused; the Gram tile itself is never written)
         if (!LSSVM_DBG(a, 4))
         with_degree_class<KT>(a, [&](auto degc) {
+            auto epilogue = [&](auto with_cols) {
+                constexpr bool COLS = decltype(with_cols)::value;
+                float di[16];
+                float colacc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+                if constexpr (COLS) {
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4 dv = *reinterpret_cast<const f32x4 *>(dis + wave * 32 + 8 * g4 + 4 * h);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float kv = apply_kernel_function<KT, decltype(degc)::value>(acc[cb][i], a);
-                    if constexpr (KT == KT_POLY) {
-                        if (padcol[cb]) kv = 0.0f;
+                        for (int e = 0; e < 4; ++e) di[4 * g4 + e] = dv[e];
                     }
-                    rowpart[i] = fmaf(kv, dj[cb], rowpart[i]);
                 }
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float kv = apply_kernel_function<KT, decltype(degc)::value>(acc[cb][i], a);
+                        if constexpr (KT == KT_POLY) {
+                            if (padcol[cb]) kv = 0.0f;
+                        }
+                        rowpart[i] = fmaf(kv, dj[cb], rowpart[i]);
+                        if constexpr (COLS) colacc[cb] = fmaf(kv, di[i], colacc[cb]);
+                    }
+                if constexpr (COLS) {
+                    float *cw = colred + (t & 1) * 512 + wave * 128;
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        const float v = colacc[cb] + __shfl_xor(colacc[cb], 32);  // the two lane halves hold different rows
+                        if (h == 0) cw[cb * 32 + r] = v;
+                    }
+                }
+            };
+            if (tile_sym) {
+                epilogue(std::true_type{});
+            } else {
+                epilogue(std::false_type{});
+            }
         });
     };
 
@@ -609,6 +674,14 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
     int t = 0;
     for (; t < nmain; ++t) tile_body(t, std::false_type{});
     for (; t < ntiles; ++t) tile_body(t, std::true_type{});
+    if constexpr (SYM) {
+        if (jt_begin + ntiles - 1 < ib) {  // the last tile was off-diagonal: publish its column sums
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            flush_cols(ntiles - 1);
+        }
+    }
 
     // every wave owns its rows: reduce over the 32 lanes of a lane-half and store
 #pragma unroll
@@ -1177,6 +1250,34 @@ __global__ void k_reduce_partials(const T *__restrict__ partial, long part_strid
         T s = partial[i];
         for (int c = 1; c < num_jc; ++c) s += partial[static_cast<size_t>(c) * part_stride + i];
         Kv[row_begin + i] = s;
+    }
+}
+
+/* SYM: Kv[j] += sum over the row blocks ib > jt of this device of colslab[(ib, jt)][j % 128], ib ascending (fixed order).
+ * One block per column tile; the records of one column tile are 512-byte (fp32) lines. */
+template <typename T>
+__global__ void k_reduce_colslab(const T *__restrict__ colslab, long pair_origin, int ib_begin, int ib_end, T *__restrict__ Kv) {
+    const int jt = blockIdx.x;
+    const int l = threadIdx.x;  // TILE threads
+    T s = T(0);
+    for (int ib = max(jt + 1, ib_begin); ib < ib_end; ++ib) {
+        const long rec = static_cast<long>(ib) * (ib - 1) / 2 - pair_origin + jt;
+        s += colslab[rec * TILE + l];
+    }
+    Kv[jt * TILE + l] += s;
+}
+
+/* SYM: Kv[row_begin + i] = sum of the row slabs of the column chunks that exist for the row's block (chunks 0 .. ib / jc_tiles) */
+template <typename T>
+__global__ void k_reduce_partials_sym(const T *__restrict__ partial, long part_stride, int jc_tiles, int ib_begin, int nrows, T *__restrict__ Kv, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nrows) {
+        const int ib = ib_begin + i / TILE;
+        const int nchunks = ib / jc_tiles + 1;
+        T s = partial[i];
+        for (int c = 1; c < nchunks; ++c) s += partial[static_cast<size_t>(c) * part_stride + i];
+        const int row = ib_begin * TILE + i;
+        Kv[row] = accumulate ? Kv[row] + s : s;
     }
 }
 

@@ -34,8 +34,9 @@ void comm_load() {
     c.pCommInitRank = reinterpret_cast<decltype(c.pCommInitRank)>(dlsym(c.lib, "ncclCommInitRank"));
     c.pCommDestroy = reinterpret_cast<decltype(c.pCommDestroy)>(dlsym(c.lib, "ncclCommDestroy"));
     c.pAllGather = reinterpret_cast<decltype(c.pAllGather)>(dlsym(c.lib, "ncclAllGather"));
+    c.pAllReduce = reinterpret_cast<decltype(c.pAllReduce)>(dlsym(c.lib, "ncclAllReduce"));
     c.pGetErrorString = reinterpret_cast<decltype(c.pGetErrorString)>(dlsym(c.lib, "ncclGetErrorString"));
-    if (!c.pGetUniqueId || !c.pCommInitRank || !c.pCommDestroy || !c.pAllGather || !c.pGetErrorString) {
+    if (!c.pGetUniqueId || !c.pCommInitRank || !c.pCommDestroy || !c.pAllGather || !c.pAllReduce || !c.pGetErrorString) {
         throw Error(LSSVM_ERR_COMM, "the loaded RCCL library lacks a required symbol");
     }
 }
@@ -70,32 +71,31 @@ static void ensure_dynamic_lds(K kernel, size_t bytes) {
 }
 
 /* fp32 v2 kernel (row panel in registers, LDS-DMA ring): eligible for ldx <= 256 */
-template <int KT>
+template <int KT, bool SYM>
 static void launch_v2_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
     const dim3 block(TILE_THREADS);
     const size_t V2_LDS_BYTES = lssvm::V2_LDS_BYTES + static_cast<size_t>(options().lds_extra_kb) * 1024;  // experiment knob: limits workgroups per CU
     static size_t configured_for = 0;
-    const bool configured = (configured_for == V2_LDS_BYTES);
-    configured_for = V2_LDS_BYTES;
-    if (!configured) {
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 1>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 2>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 3>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 4>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 5>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 6>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 7>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 8>, V2_LDS_BYTES);
+    if (configured_for != V2_LDS_BYTES) {
+        configured_for = V2_LDS_BYTES;
+        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 1, SYM>, V2_LDS_BYTES);
+        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 2, SYM>, V2_LDS_BYTES);
+        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 3, SYM>, V2_LDS_BYTES);
+        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 4, SYM>, V2_LDS_BYTES);
+        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 5, SYM>, V2_LDS_BYTES);
+        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 6, SYM>, V2_LDS_BYTES);
+        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 7, SYM>, V2_LDS_BYTES);
+        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 8, SYM>, V2_LDS_BYTES);
     }
     switch (a.kchunks) {
-        case 1: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 1>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 2: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 2>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 3: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 3>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 4: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 4>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 5: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 5>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 6: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 6>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 7: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 7>), grid, block, V2_LDS_BYTES, s, a); break;
-        default: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 8>), grid, block, V2_LDS_BYTES, s, a); break;
+        case 1: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 1, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
+        case 2: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 2, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
+        case 3: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 3, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
+        case 4: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 4, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
+        case 5: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 5, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
+        case 6: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 6, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
+        case 7: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 7, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
+        default: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 8, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
     }
 }
 
@@ -147,10 +147,19 @@ void launch_tile_kernel<float>(TileArgs<float> &a, int kernel_type, bool rbf_dir
         configured = true;
     }
     if (a.dc != nullptr && v2_eligible(a.ldx, rbf_direct)) {
-        switch (kernel_type) {
-            case KT_LINEAR: launch_v2_kt<KT_LINEAR>(a, grid, s); break;
-            case KT_POLY: launch_v2_kt<KT_POLY>(a, grid, s); break;
-            default: launch_v2_kt<KT_RBF>(a, grid, s); break;
+        if (a.items != nullptr) {  // symmetric variant: one block per listed work item
+            const dim3 sgrid(static_cast<unsigned>(a.num_items));
+            switch (kernel_type) {
+                case KT_LINEAR: launch_v2_kt<KT_LINEAR, true>(a, sgrid, s); break;
+                case KT_POLY: launch_v2_kt<KT_POLY, true>(a, sgrid, s); break;
+                default: launch_v2_kt<KT_RBF, true>(a, sgrid, s); break;
+            }
+        } else {
+            switch (kernel_type) {
+                case KT_LINEAR: launch_v2_kt<KT_LINEAR, false>(a, grid, s); break;
+                case KT_POLY: launch_v2_kt<KT_POLY, false>(a, grid, s); break;
+                default: launch_v2_kt<KT_RBF, false>(a, grid, s); break;
+            }
         }
         LSSVM_HIP_CHECK(hipGetLastError());
         return;
@@ -200,6 +209,14 @@ void launch_tile_kernel<double>(TileArgs<double> &a, int kernel_type, bool /*rbf
 }
 
 /* kernel-function specific scalars of TileArgs */
+/* first row block of rank r when the lower triangle is dealt by equal area: round(tiles * sqrt(r / world)) */
+int sym_block_boundary(int num_tiles, int r, int world) {
+    if (r <= 0) return 0;
+    if (r >= world) return num_tiles;
+    const int b = static_cast<int>(std::llround(static_cast<double>(num_tiles) * std::sqrt(static_cast<double>(r) / static_cast<double>(world))));
+    return std::min(std::max(b, 0), num_tiles);
+}
+
 template <typename T>
 static void set_kernel_scalars(TileArgs<T> &a, const lssvm_params &p, bool rbf_direct) {
     a.degree = p.degree;
@@ -312,9 +329,19 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
     n_ = static_cast<int>(num_points - 1);
     num_tiles_ = (n_ + TILE - 1) / TILE;
     ib_per_rank_ = (num_tiles_ + world_ - 1) / world_;
-    ib_begin_ = std::min(rank_ * ib_per_rank_, num_tiles_);
-    num_ib_ = std::min(ib_begin_ + ib_per_rank_, num_tiles_) - ib_begin_;
     nvec_ = ib_per_rank_ * world_ * TILE;
+    // symmetric variant: fp32 v2 kernel only; a negative polynomial degree can give inf on zero-padded rows -> full square
+    sym_ = options().symmetric != 0 && std::is_same_v<T, float> && options().rbf_form == 0
+           && v2_eligible(round_up(static_cast<long>(num_features), kchunk_of<T>()), false)
+           && !(params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree < 0);
+    if (sym_) {
+        // the work of row block ib is proportional to ib + 1 (tiles on or below the diagonal): equal AREAS per rank
+        ib_begin_ = sym_block_boundary(num_tiles_, rank_, world_);
+        num_ib_ = sym_block_boundary(num_tiles_, rank_ + 1, world_) - ib_begin_;
+    } else {
+        ib_begin_ = std::min(rank_ * ib_per_rank_, num_tiles_);
+        num_ib_ = std::min(ib_begin_ + ib_per_rank_, num_tiles_) - ib_begin_;
+    }
     jc_tiles_ = static_cast<int>(std::max<int64_t>(1, options().j_chunk_tiles));
     num_jc_ = (num_tiles_ + jc_tiles_ - 1) / jc_tiles_;
     rbf_direct_ = (params_.kernel_type == LSSVM_KERNEL_RBF) && (options().rbf_form == 1) && std::is_same_v<T, float>;
@@ -358,6 +385,23 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
     if ((std::is_same_v<T, float> && v2_eligible(X_.ldx, rbf_direct_)) || (std::is_same_v<T, double> && v2_eligible_f64(X_.ldx))) {
         dc_.alloc_zero(static_cast<size_t>(std::max(num_tiles_, 1)) * 256, stream_);  // (d_j | c_j) records: 256 reals per 128 columns
     }
+    if (sym_) {
+        // work items = the non-empty (row block, column chunk) pairs, column chunk major (concurrent workgroups share the chunk)
+        std::vector<int2> items;
+        for (int jc = 0; jc < num_jc_; ++jc) {
+            for (int ibl = 0; ibl < num_ib_; ++ibl) {
+                if (jc * jc_tiles_ <= ib_begin_ + ibl) items.push_back(make_int2(ibl, jc));
+            }
+        }
+        num_items_ = static_cast<int>(items.size());
+        items_.alloc_zero(std::max<size_t>(items.size(), 1), stream_);
+        if (!items.empty()) LSSVM_HIP_CHECK(hipMemcpyAsync(items_.p, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice, stream_));
+        const long ib_end = ib_begin_ + num_ib_;
+        pair_origin_ = static_cast<long>(ib_begin_) * (ib_begin_ - 1) / 2;
+        const long records = ib_end * (ib_end - 1) / 2 - pair_origin_;
+        colslab_.alloc_zero(static_cast<size_t>(std::max<long>(records, 1)) * TILE, stream_);
+        LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));  // `items` goes out of scope
+    }
     events_.resize(4);
     for (EvPair &e : events_) {
         LSSVM_HIP_CHECK(hipEventCreate(&e.a));
@@ -388,6 +432,10 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     a.cc = c_.p;
     a.dvec = v_dev;
     a.dc = dc_.p;
+    a.items = sym_ ? items_.p : nullptr;
+    a.num_items = num_items_;
+    a.colslab = colslab_.p;
+    a.pair_origin = pair_origin_;
     a.partial = partial_.p;
     a.part_stride = static_cast<long>(std::max(num_ib_, 1)) * TILE;
     a.ldx = X_.ldx;
@@ -434,6 +482,11 @@ void Problem<T>::apply_K(const T *v_dev) {
             }
         }
     }
+    const bool collective = world_ > 1 || (options().force_collective != 0 && comm().comm != nullptr && comm().world == 1);
+    if (sym_ && collective) {
+        // every rank adds row sums of its blocks and column sums into all earlier rows: start from zero, all-reduce at the end
+        LSSVM_HIP_CHECK(hipMemsetAsync(Kv_.p, 0, static_cast<size_t>(nvec_) * sizeof(T), stream_));
+    }
     if (num_ib_ > 0) {
         TileArgs<T> a = tile_args(v_dev);
         if (dc_.p != nullptr) {  // v2 kernels: pack (d_j | c_j) records for the LDS-DMA
@@ -451,16 +504,32 @@ void Problem<T>::apply_K(const T *v_dev) {
             ev->pending = true;
         }
         const int nrows = num_ib_ * TILE;
-        hipLaunchKernelGGL(k_reduce_partials<T>, dim3((nrows + 255) / 256), dim3(256), 0, stream_, partial_.p, a.part_stride, num_jc_, ib_begin_ * TILE, nrows, Kv_.p);
+        if (sym_) {
+            // rows of this device's blocks (slabs of the chunks that exist for each block), then the mirrored column sums
+            hipLaunchKernelGGL(k_reduce_partials_sym<T>, dim3((nrows + 255) / 256), dim3(256), 0, stream_, partial_.p, a.part_stride, jc_tiles_, ib_begin_, nrows, Kv_.p, 0);
+            const int ib_end = ib_begin_ + num_ib_;
+            if (ib_end > 1) {
+                hipLaunchKernelGGL(k_reduce_colslab<T>, dim3(ib_end - 1), dim3(TILE), 0, stream_, colslab_.p, pair_origin_, ib_begin_, ib_end, Kv_.p);
+            }
+        } else {
+            hipLaunchKernelGGL(k_reduce_partials<T>, dim3((nrows + 255) / 256), dim3(256), 0, stream_, partial_.p, a.part_stride, num_jc_, ib_begin_ * TILE, nrows, Kv_.p);
+        }
         LSSVM_HIP_CHECK(hipGetLastError());
     }
-    if (world_ > 1 || (options().force_collective != 0 && comm().comm != nullptr && comm().world == 1)) {
-        // one collective per implicit matvec: every rank contributes its contiguous slice of K*v (in place)
+    if (collective) {
+        // one collective per implicit matvec
         Comm &c = comm();
-        const size_t slice = static_cast<size_t>(ib_per_rank_) * TILE;
         const ncclDataType_t dt = std::is_same_v<T, float> ? ncclFloat32 : ncclFloat64;
-        const ncclResult_t rc = c.pAllGather(Kv_.p + static_cast<size_t>(rank_) * slice, Kv_.p, slice, dt, c.comm, stream_);
-        if (rc != ncclSuccess) throw Error(LSSVM_ERR_COMM, std::string("ncclAllGather failed: ") + c.pGetErrorString(rc));
+        if (sym_) {
+            // symmetric variant: every rank holds partial sums for all rows up to its last block -> sum (in place)
+            const ncclResult_t rc = c.pAllReduce(Kv_.p, Kv_.p, static_cast<size_t>(num_tiles_) * TILE, dt, ncclSum, c.comm, stream_);
+            if (rc != ncclSuccess) throw Error(LSSVM_ERR_COMM, std::string("ncclAllReduce failed: ") + c.pGetErrorString(rc));
+        } else {
+            // full square: every rank contributes its contiguous slice of K*v (in place)
+            const size_t slice = static_cast<size_t>(ib_per_rank_) * TILE;
+            const ncclResult_t rc = c.pAllGather(Kv_.p + static_cast<size_t>(rank_) * slice, Kv_.p, slice, dt, c.comm, stream_);
+            if (rc != ncclSuccess) throw Error(LSSVM_ERR_COMM, std::string("ncclAllGather failed: ") + c.pGetErrorString(rc));
+        }
     }
 }
 
@@ -619,6 +688,7 @@ void Problem<T>::fill_info(lssvm_cg_info *info) {
     info->matvec_launches = matvec_launches_;
     info->devices_used = world_;
     info->converged = converged_ ? 1 : 0;
+    info->symmetric = sym_ ? 1 : 0;
 }
 
 template class Problem<float>;

@@ -56,6 +56,7 @@ struct Error : std::runtime_error {
 struct Options {
     int64_t rbf_form = 0;        // 0: norm expansion on the matrix cores, 1: direct (x_i - x_j)^2 on the vector ALU (fp32 only)
     int64_t j_chunk_tiles = 16;  // 128-column tiles per work item
+    int64_t symmetric = 1;         // 1: evaluate only the tiles on/below the diagonal and mirror them (fp32 v2 kernel), 0: full square
     int64_t tile_kernel = 0;       // 0: automatic (fp32: v2 'resident row panel' kernel when num_features <= 256), 1: always the generic v1 kernel
     int64_t xcd_map = 0;           // 1: XCD-aware work item mapping (8 x 8 super-tiles per XCD), 0: linear (default: measured equal, better balanced)
     int64_t lds_extra_kb = 0;      // experiment knob: extra dynamic LDS per workgroup of the fp32 v2 kernel (lowers workgroups per CU)
@@ -73,6 +74,7 @@ struct Comm {
     decltype(&ncclCommInitRank) pCommInitRank = nullptr;
     decltype(&ncclCommDestroy) pCommDestroy = nullptr;
     decltype(&ncclAllGather) pAllGather = nullptr;
+    decltype(&ncclAllReduce) pAllReduce = nullptr;
     decltype(&ncclGetErrorString) pGetErrorString = nullptr;
 };
 Comm &comm();
@@ -146,6 +148,7 @@ template <typename T>
 void interleave_features(DeviceMatrix<T> &M, hipStream_t s);
 bool v2_eligible(int ldx, bool rbf_direct);
 bool v2_eligible_f64(int ldx);
+int sym_block_boundary(int num_tiles, int r, int world);
 
 /* ------------------------------------------------------------------ the resident problem ------------------------------------------------------------------ */
 struct ProblemBase {
@@ -198,6 +201,12 @@ class Problem final : public ProblemBase {
     DevBuf<T> q_, b_, x_, r_, d_, Ad_, Kv_, tmp_, ylast_;
     DevBuf<T> partial_;
     DevBuf<T> dc_;  // fp32 v2 kernel: packed (d_j | c_j) records
+    // symmetric variant
+    bool sym_ = false;
+    DevBuf<int2> items_;
+    int num_items_ = 0;
+    DevBuf<T> colslab_;
+    long pair_origin_ = 0;
     DevBuf<double> part_, sc_;
     double *host_sc_ = nullptr;  // pinned, SC_COUNT doubles
     double QA_cost_ = 0.0;

@@ -4,6 +4,8 @@
  */
 #pragma once
 
+#include <hip/hip_runtime.h>
+
 #include <cstddef>
 #include <cstdint>
 
@@ -32,6 +34,10 @@ struct TileArgs {
     const T *cc;      // rbf: -0.5 * |x_j|^2 per column-side point
     const T *dvec;    // [num_jt*TILE] vector multiplied from the right, EXACT zeros beyond the valid columns
     const T *dc;      // fp32 v2 kernel: packed [num_jt][256] records (d_j | c_j) for LDS-DMA (k_pack_dc)
+    const int2 *items; // symmetric variant: list of the non-empty (local row block, column chunk) work items
+    int num_items;    // symmetric variant: length of `items` = grid size
+    T *colslab;       // symmetric variant: [packed (ib, jt) pairs with jt < ib][TILE] column sums of the off-diagonal tiles
+    long pair_origin; // symmetric variant: ib_begin * (ib_begin - 1) / 2, the record index of this device's first pair
     T *partial;       // [num_jc][part_stride] partial row sums, one slab per column chunk, indexed by the LOCAL row
     long part_stride; // elements between slabs (>= num_ib*TILE)
     int ldx;          // padded number of features (multiple of the k-chunk)

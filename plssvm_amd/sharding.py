@@ -12,7 +12,7 @@ from __future__ import annotations
 
 TILE = 128  # rows per block of the tile kernel (plssvm_amd/csrc/lssvm_types.hpp)
 
-__all__ = ["TILE", "row_block_partition", "padded_vector_length", "exchange_unique_id", "init_library_communicator"]
+__all__ = ["TILE", "row_block_partition", "sym_block_partition", "work_share", "padded_vector_length", "exchange_unique_id", "init_library_communicator"]
 
 
 def row_block_partition(n: int, world: int):
@@ -30,6 +30,35 @@ def row_block_partition(n: int, world: int):
         b1 = min(b0 + per_rank, tiles)
         out.append((min(b0 * TILE, n), min(b1 * TILE, n)))
     return out
+
+
+def sym_block_partition(n: int, world: int):
+    """Symmetric variant (only the tiles on/below the diagonal are evaluated): row block ``ib`` costs ``ib + 1`` tiles, so the
+    blocks are dealt by equal AREA -- boundary of rank r = round(tiles * sqrt(r / world)) (``sym_block_boundary`` in
+    plssvm_amd/csrc/lssvm_problem.hip).  Returns ``[(block_begin, block_end), ...]``."""
+    import math
+
+    tiles = (n + TILE - 1) // TILE
+    bounds = [0] + [min(max(int(math.floor(tiles * math.sqrt(r / world) + 0.5)), 0), tiles) for r in range(1, world)] + [tiles]
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+def work_share(n: int, world: int, rank: int, symmetric: bool):
+    """(algorithmic, executed) multiply-add counts per feature of one implicit matvec launch on ``rank``.
+
+    Algorithmic = this rank's share of the full n x n square (SURVEY.md 8d: no symmetry credit in the metric);
+    executed = the tile elements it really evaluates (half of it, plus the diagonal, in the symmetric variant)."""
+    if not symmetric:
+        r0, r1 = row_block_partition(n, world)[rank]
+        return float(r1 - r0) * n, float(r1 - r0) * n
+    tiles = (n + TILE - 1) // TILE
+    b0, b1 = sym_block_partition(n, world)[rank]
+    evaluated_tiles = (b1 * (b1 + 1) - b0 * (b0 + 1)) // 2          # sum of (ib + 1)
+    mirrored_tiles = (b1 * (b1 - 1) - b0 * (b0 - 1)) // 2           # strictly lower tiles count twice in the square
+    full_tiles = float(tiles) * tiles
+    algorithmic = (evaluated_tiles + mirrored_tiles) / full_tiles * float(n) * n
+    executed = evaluated_tiles * float(TILE) * TILE
+    return algorithmic, executed
 
 
 def padded_vector_length(n: int, world: int) -> int:

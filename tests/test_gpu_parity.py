@@ -218,7 +218,7 @@ def test_results_are_bitwise_reproducible_and_independent_of_the_work_split(kern
     the fixed slab order (the chunking changes the association, hence allclose; equal chunking => equal bits)."""
     X, y = make_blobs_pm1(1500, 40, seed=8, dtype=np.float32)
     p = Parameter(kernel_type=kernel)
-    a1, r1, _ = backend.solve_system_of_linear_equations(p, X, y, 1e-30, 7)
+    a1, r1, _ = backend.solve_system_of_linear_equations(p, X, y, 1e-30, 7)  # default (symmetric) variant: fixed-order slabs, no atomics
     a2, r2, _ = backend.solve_system_of_linear_equations(p, X, y, 1e-30, 7)
     assert np.array_equal(a1, a2) and r1 == r2
     _capi.set_option("j_chunk_tiles", 3)
@@ -300,3 +300,32 @@ def test_predict_and_score_on_the_reference_fixture(kernel, dt):
     labels = np.where(out > 0, 1, -1)
     assert np.array_equal(labels, fx["expected"])
     assert float(np.mean(labels == fx["test_y"].astype(int))) == 1.0
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("N, d", [(300, 7), (1500, 40), (4097, 128), (2300, 200)])
+def test_symmetric_and_full_square_variants_agree(oracle, kernel, N, d):
+    """The default fp32 path evaluates only the tiles on/below the diagonal and mirrors them (as the reference does); the
+    full-square variant (option symmetric=0) sums every row independently.  Both must match the oracle and each other."""
+    X, y = make_blobs_pm1(N, d, seed=21, dtype=np.float32)
+    p = Parameter(kernel_type=kernel)
+    rhs = np.random.default_rng(5).uniform(-1, 1, size=N - 1).astype(np.float32)
+    out = {}
+    for sym in (1, 0):
+        _capi.set_option("symmetric", sym)
+        try:
+            with backend.ResidentProblem(p, X) as prob:
+                q, QA = prob.q()
+                out[sym] = prob.matvec(rhs, np.zeros(N - 1, np.float32), 1.0)
+                prob.cg_begin(y, 1e-30)
+                prob.cg_step(5)
+                out[("a", sym)] = prob.cg_finish()[0]
+        finally:
+            _capi.set_option("symmetric", 1)
+    kw = dict(degree=3, gamma=1.0 / d, coef0=0.0)
+    want = oracle.matvec(kernel, X, q, rhs, np.zeros(N - 1, np.float32), QA, 1.0, 1.0, **kw)
+    scale = np.max(np.abs(want))
+    eps = np.finfo(np.float32).eps
+    assert np.max(np.abs(out[1] - want)) < 64 * eps * scale and np.max(np.abs(out[0] - want)) < 64 * eps * scale
+    assert np.max(np.abs(out[1] - out[0])) < 64 * eps * scale
+    assert np.all(np.isfinite(out[("a", 1)]))
