@@ -139,14 +139,21 @@ def main():
     launches = int(i1["matvec_launches"] - i0["matvec_launches"])
     kern_ms_total = i1["matvec_kernel_ms"] * i1["matvec_launches"] - i0["matvec_kernel_ms"] * i0["matvec_launches"]
     kern_ms = kern_ms_total / max(launches, 1)
-    from plssvm_amd.sharding import work_share
+    from plssvm_amd.sharding import triangle_share, work_share
 
+    # Three flop counts of one tile-kernel launch on this rank:
+    #   square   = its share of the full n x n square, 2 n^2 d in total: the convention of `value` ("no symmetry credit")
+    #   executed = what the matrix cores really do (symmetric variant: tiles on/below the diagonal, whole tiles incl. padding)
+    #   useful   = the algorithm's own count: the full square for the full-square variant; entries j <= i for the symmetric one
+    #              (the reference's count, svm_kernel.cpp:36-39).  `roofline.achieved` = useful / kernel time, so frac <= 1.
     symmetric = bool(i1.get("symmetric", 0))
-    alg_mac, exe_mac = work_share(n, world, rank, symmetric)
-    flop_launch = 2.0 * alg_mac * d   # ALGORITHMIC flops of one launch on this rank: its share of the full n x n square
-    exec_launch = 2.0 * exe_mac * d   # multiply-adds the matrix cores really execute (symmetric variant: half + diagonal)
-    achieved = flop_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-    executed = exec_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+    sq_mac, exe_mac = work_share(n, world, rank, symmetric)
+    use_mac = triangle_share(n, world, rank) if symmetric else sq_mac
+    kern_s = kern_ms * 1e-3
+    square_launch, exec_launch, useful_launch = 2.0 * sq_mac * d, 2.0 * exe_mac * d, 2.0 * use_mac * d
+    achieved = useful_launch / kern_s / 1e12 if kern_ms > 0 else 0.0
+    executed = exec_launch / kern_s / 1e12 if kern_ms > 0 else 0.0
+    effective = square_launch / kern_s / 1e12 if kern_ms > 0 else 0.0
     peak = PEAK_TFLOPS[wl["dtype"]]
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -170,11 +177,10 @@ def main():
                        "residuum_after_timed_steps": i1["residuum"]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "kernel": "lssvm::tile_matvec (implicit K*d tile kernel)", "launches": launches, "avg_launch_ms": kern_ms,
-                         "algorithmic_flop_per_launch": flop_launch,
-                         # the kernel matrix is symmetric: the default variant evaluates only the tiles on/below the diagonal (like the
-                         # reference, svm_kernel.cpp:39) and mirrors them, so `achieved` (algorithmic, full square) can exceed the peak;
-                         # `executed*` is what the matrix cores really do and is the fraction to compare with the hardware roof
-                         "symmetric": symmetric, "executed_flop_per_launch": exec_launch, "executed": executed, "executed_frac": executed / peak},
+                         "algorithmic_flop_per_launch": useful_launch, "symmetric": symmetric,
+                         "executed_flop_per_launch": exec_launch, "executed": executed, "executed_frac": executed / peak,
+                         # the same launch priced with the full-square convention of `value` (can exceed the peak when symmetric)
+                         "full_square_flop_per_launch": square_launch, "effective_full_square": effective},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(X, y, wl["kernel"], args.cpu_sample_rows, 3)

@@ -917,14 +917,16 @@ __global__ __launch_bounds__(TILE_THREADS, 1) void tile_matvec_f64(const TileArg
 constexpr int V2D_RING = 3;
 constexpr int V2D_SLOT_BYTES = 64 * 128;  // 8 KiB
 constexpr int V2D_DC_SLOTS = 4;           // (64 d_j | 64 c_j) doubles = 1 KiB per sub-tile
-constexpr size_t V2D_LDS_BYTES = static_cast<size_t>(V2D_RING) * V2D_SLOT_BYTES + V2D_DC_SLOTS * 1024 + TILE * sizeof(double);
+constexpr size_t V2D_LDS_BYTES = static_cast<size_t>(V2D_RING) * V2D_SLOT_BYTES + V2D_DC_SLOTS * 1024 + (2 * TILE + 2 * 4 * 64) * sizeof(double);  // ring + records + cis, dis, colred
 
-template <int KT, int NKC>
+template <int KT, int NKC, bool SYM>
 __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_f64_v2(const TileArgs<double> a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char *ring = smem_raw;
     char *dcs = smem_raw + V2D_RING * V2D_SLOT_BYTES;
-    double *cis = reinterpret_cast<double *>(dcs + V2D_DC_SLOTS * 1024);
+    double *cis = reinterpret_cast<double *>(dcs + V2D_DC_SLOTS * 1024);  // [128] c_i of the row panel (rbf)
+    double *dis = cis + TILE;                                              // [128] d_i of the row panel (SYM)
+    double *colred = dis + TILE;                                           // [2][4 waves][64] column sums of a sub-tile (SYM)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -932,15 +934,26 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
     const int r = lane & 15;
     const int q = lane >> 4;
 
+    // SYM: see tile_matvec_f32_v2.  A sub-tile st is strictly below the diagonal block of row block ib iff st < 2 ib; the two
+    // sub-tiles of the diagonal tile are evaluated in full and contribute to the rows only.
     int ibl, jc;
-    if (!decode_work_item(a, ibl, jc)) return;
-    const int row0 = (a.ib_begin + ibl) * TILE;
+    if constexpr (SYM) {
+        const int2 it = a.items[blockIdx.x];
+        ibl = it.x;
+        jc = it.y;
+    } else {
+        if (!decode_work_item(a, ibl, jc)) return;
+    }
+    const int ib = a.ib_begin + ibl;
+    const int row0 = ib * TILE;
     const int jt_begin = jc * a.jc_tiles;
-    const int jt_end = min(jt_begin + a.jc_tiles, a.num_jt);
+    const int jt_end = SYM ? min(jt_begin + a.jc_tiles, ib + 1) : min(jt_begin + a.jc_tiles, a.num_jt);
     const int nsub = 2 * (jt_end - jt_begin);  // 64-column sub-tiles
     if (nsub <= 0) return;
     const int st_begin = 2 * jt_begin;
     const int nsteps = nsub * NKC;
+    // record index of (ib, st) in this device's packed column slab: row block b owns the 2 b sub-tiles below its diagonal
+    const long rec0 = SYM ? (static_cast<long>(ib) * (ib - 1) - 2 * a.pair_origin) : 0;
 
     // row panel: A operand of lane (r, q) for k-step s is X[row][4 s + q]
     double afrag[2][4 * NKC];
@@ -952,6 +965,9 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
     }
     if constexpr (KT == KT_RBF) {
         if (tid < TILE) cis[tid] = a.cr[row0 + tid];
+    }
+    if constexpr (SYM) {
+        if (tid < TILE) dis[tid] = a.dvec[row0 + tid];
     }
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -1018,9 +1034,21 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
         }
     };
 
+    auto flush_cols = [&](int t) {  // fixed-order sum of the four waves' column sums of sub-tile t -> its slab record
+        if (tid < 64) {
+            const double *cr_ = colred + (t & 1) * 256;
+            a.colslab[(rec0 + st_begin + t) * 64 + tid] = (cr_[tid] + cr_[64 + tid]) + (cr_[128 + tid] + cr_[192 + tid]);
+        }
+    };
+
     for (int t = 0; t < nsub; ++t) {
         const int s0 = t * NKC;
+        const bool tile_sym = SYM && (st_begin + t < 2 * ib);
         sync_and_prefetch(s0);
+        if constexpr (SYM) {
+            // sub-tile t - 1 was off-diagonal unless it is the first of the diagonal pair (which is then t - 1 = nsub - 2)
+            if (t > 0 && (st_begin + t - 1 < 2 * ib)) flush_cols(t - 1);
+        }
         {
             const double *dcr = reinterpret_cast<const double *>(dcs + (t % V2D_DC_SLOTS) * 1024);
 #pragma unroll
@@ -1057,19 +1085,50 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
             }
         }
         with_degree_class<KT>(a, [&](auto degc) {
+            auto epilogue = [&](auto with_cols) {
+                constexpr bool COLS = decltype(with_cols)::value;
+                double colacc[4] = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
+                for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        double kv = apply_kernel_function<KT, decltype(degc)::value>(acc[rb][cb][i], a);
-                        if constexpr (KT == KT_POLY) {
-                            if (padcol[cb]) kv = 0.0;
+                        double di = 0.0;
+                        if constexpr (COLS) di = dis[wave * 32 + rb * 16 + q + 4 * i];
+#pragma unroll
+                        for (int cb = 0; cb < 4; ++cb) {
+                            double kv = apply_kernel_function<KT, decltype(degc)::value>(acc[rb][cb][i], a);
+                            if constexpr (KT == KT_POLY) {
+                                if (padcol[cb]) kv = 0.0;
+                            }
+                            rowpart[rb][i] = fma(kv, dj[cb], rowpart[rb][i]);
+                            if constexpr (COLS) colacc[cb] = fma(kv, di, colacc[cb]);
                         }
-                        rowpart[rb][i] = fma(kv, dj[cb], rowpart[rb][i]);
                     }
+                if constexpr (COLS) {
+                    double *cw = colred + (t & 1) * 256 + wave * 64;
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        double v = colacc[cb];
+                        v += __shfl_xor(v, 16);  // the four quarter-waves hold different rows of the same column
+                        v += __shfl_xor(v, 32);
+                        if (q == 0) cw[cb * 16 + r] = v;
+                    }
+                }
+            };
+            if (tile_sym) {
+                epilogue(std::true_type{});
+            } else {
+                epilogue(std::false_type{});
+            }
         });
+    }
+    if constexpr (SYM) {
+        if (st_begin + nsub - 1 < 2 * ib) {  // the last sub-tile was off-diagonal: publish its column sums
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            flush_cols(nsub - 1);
+        }
     }
 
     // rows are shared by the 16 lanes of a quarter-wave
@@ -1265,6 +1324,19 @@ __global__ void k_reduce_colslab(const T *__restrict__ colslab, long pair_origin
         s += colslab[rec * TILE + l];
     }
     Kv[jt * TILE + l] += s;
+}
+
+/* fp64 flavour: records are per 64-column sub-tile st, row block ib owns the 2 ib sub-tiles below its diagonal */
+template <typename T>
+__global__ void k_reduce_colslab_sub(const T *__restrict__ colslab, long pair_origin, int ib_begin, int ib_end, T *__restrict__ Kv) {
+    const int st = blockIdx.x;
+    const int l = threadIdx.x;  // 64 threads
+    T s = T(0);
+    for (int ib = max(st / 2 + 1, ib_begin); ib < ib_end; ++ib) {
+        const long rec = static_cast<long>(ib) * (ib - 1) - 2 * pair_origin + st;
+        s += colslab[rec * 64 + l];
+    }
+    Kv[st * 64 + l] += s;
 }
 
 /* SYM: Kv[row_begin + i] = sum of the row slabs of the column chunks that exist for the row's block (chunks 0 .. ib / jc_tiles) */

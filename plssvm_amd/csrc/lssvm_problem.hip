@@ -106,18 +106,18 @@ bool v2_eligible_f64(int ldx) {
     return ldx <= 8 * F64_KC && options().tile_kernel != 1;
 }
 
-template <int KT>
+template <int KT, bool SYM>
 static void launch_v2d_kt(const TileArgs<double> &a, dim3 grid, hipStream_t s) {
     const dim3 block(TILE_THREADS);
     switch (a.kchunks) {
-        case 1: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 1>), grid, block, V2D_LDS_BYTES, s, a); break;
-        case 2: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 2>), grid, block, V2D_LDS_BYTES, s, a); break;
-        case 3: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 3>), grid, block, V2D_LDS_BYTES, s, a); break;
-        case 4: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 4>), grid, block, V2D_LDS_BYTES, s, a); break;
-        case 5: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 5>), grid, block, V2D_LDS_BYTES, s, a); break;
-        case 6: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 6>), grid, block, V2D_LDS_BYTES, s, a); break;
-        case 7: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 7>), grid, block, V2D_LDS_BYTES, s, a); break;
-        default: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 8>), grid, block, V2D_LDS_BYTES, s, a); break;
+        case 1: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 1, SYM>), grid, block, V2D_LDS_BYTES, s, a); break;
+        case 2: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 2, SYM>), grid, block, V2D_LDS_BYTES, s, a); break;
+        case 3: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 3, SYM>), grid, block, V2D_LDS_BYTES, s, a); break;
+        case 4: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 4, SYM>), grid, block, V2D_LDS_BYTES, s, a); break;
+        case 5: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 5, SYM>), grid, block, V2D_LDS_BYTES, s, a); break;
+        case 6: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 6, SYM>), grid, block, V2D_LDS_BYTES, s, a); break;
+        case 7: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 7, SYM>), grid, block, V2D_LDS_BYTES, s, a); break;
+        default: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 8, SYM>), grid, block, V2D_LDS_BYTES, s, a); break;
     }
 }
 
@@ -192,10 +192,19 @@ void launch_tile_kernel<double>(TileArgs<double> &a, int kernel_type, bool /*rbf
         configured = true;
     }
     if (a.dc != nullptr && v2_eligible_f64(a.ldx)) {  // V2D_LDS_BYTES < 64 KiB: no opt-in needed
-        switch (kernel_type) {
-            case KT_LINEAR: launch_v2d_kt<KT_LINEAR>(a, grid, s); break;
-            case KT_POLY: launch_v2d_kt<KT_POLY>(a, grid, s); break;
-            default: launch_v2d_kt<KT_RBF>(a, grid, s); break;
+        if (a.items != nullptr) {
+            const dim3 sgrid(static_cast<unsigned>(a.num_items));
+            switch (kernel_type) {
+                case KT_LINEAR: launch_v2d_kt<KT_LINEAR, true>(a, sgrid, s); break;
+                case KT_POLY: launch_v2d_kt<KT_POLY, true>(a, sgrid, s); break;
+                default: launch_v2d_kt<KT_RBF, true>(a, sgrid, s); break;
+            }
+        } else {
+            switch (kernel_type) {
+                case KT_LINEAR: launch_v2d_kt<KT_LINEAR, false>(a, grid, s); break;
+                case KT_POLY: launch_v2d_kt<KT_POLY, false>(a, grid, s); break;
+                default: launch_v2d_kt<KT_RBF, false>(a, grid, s); break;
+            }
         }
         LSSVM_HIP_CHECK(hipGetLastError());
         return;
@@ -330,10 +339,10 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
     num_tiles_ = (n_ + TILE - 1) / TILE;
     ib_per_rank_ = (num_tiles_ + world_ - 1) / world_;
     nvec_ = ib_per_rank_ * world_ * TILE;
-    // symmetric variant: fp32 v2 kernel only; a negative polynomial degree can give inf on zero-padded rows -> full square
-    sym_ = options().symmetric != 0 && std::is_same_v<T, float> && options().rbf_form == 0
-           && v2_eligible(round_up(static_cast<long>(num_features), kchunk_of<T>()), false)
-           && !(params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree < 0);
+    // symmetric variant: v2 kernels only; a negative polynomial degree can give inf on zero-padded rows -> full square
+    const int ldx_probe = round_up(static_cast<long>(num_features), kchunk_of<T>());
+    const bool v2_ok = std::is_same_v<T, float> ? (options().rbf_form == 0 && v2_eligible(ldx_probe, false)) : v2_eligible_f64(ldx_probe);
+    sym_ = options().symmetric != 0 && v2_ok && !(params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree < 0);
     if (sym_) {
         // the work of row block ib is proportional to ib + 1 (tiles on or below the diagonal): equal AREAS per rank
         ib_begin_ = sym_block_boundary(num_tiles_, rank_, world_);
@@ -509,7 +518,11 @@ void Problem<T>::apply_K(const T *v_dev) {
             hipLaunchKernelGGL(k_reduce_partials_sym<T>, dim3((nrows + 255) / 256), dim3(256), 0, stream_, partial_.p, a.part_stride, jc_tiles_, ib_begin_, nrows, Kv_.p, 0);
             const int ib_end = ib_begin_ + num_ib_;
             if (ib_end > 1) {
-                hipLaunchKernelGGL(k_reduce_colslab<T>, dim3(ib_end - 1), dim3(TILE), 0, stream_, colslab_.p, pair_origin_, ib_begin_, ib_end, Kv_.p);
+                if constexpr (std::is_same_v<T, float>) {
+                    hipLaunchKernelGGL(k_reduce_colslab<T>, dim3(ib_end - 1), dim3(TILE), 0, stream_, colslab_.p, pair_origin_, ib_begin_, ib_end, Kv_.p);
+                } else {  // fp64: records per 64-column sub-tile
+                    hipLaunchKernelGGL(k_reduce_colslab_sub<T>, dim3(2 * (ib_end - 1)), dim3(64), 0, stream_, colslab_.p, pair_origin_, ib_begin_, ib_end, Kv_.p);
+                }
             }
         } else {
             hipLaunchKernelGGL(k_reduce_partials<T>, dim3((nrows + 255) / 256), dim3(256), 0, stream_, partial_.p, a.part_stride, num_jc_, ib_begin_ * TILE, nrows, Kv_.p);

@@ -12,7 +12,7 @@ from __future__ import annotations
 
 TILE = 128  # rows per block of the tile kernel (plssvm_amd/csrc/lssvm_types.hpp)
 
-__all__ = ["TILE", "row_block_partition", "sym_block_partition", "work_share", "padded_vector_length", "exchange_unique_id", "init_library_communicator"]
+__all__ = ["TILE", "row_block_partition", "sym_block_partition", "work_share", "triangle_share", "padded_vector_length", "exchange_unique_id", "init_library_communicator"]
 
 
 def row_block_partition(n: int, world: int):
@@ -59,6 +59,14 @@ def work_share(n: int, world: int, rank: int, symmetric: bool):
     algorithmic = (evaluated_tiles + mirrored_tiles) / full_tiles * float(n) * n
     executed = evaluated_tiles * float(TILE) * TILE
     return algorithmic, executed
+
+
+def triangle_share(n: int, world: int, rank: int) -> float:
+    """Multiply-adds per feature of the reference's own algorithm (kernel entries with j <= i only,
+    src/plssvm/backends/OpenMP/svm_kernel.cpp:36-39) that fall into ``rank``'s row blocks of the symmetric partition."""
+    b0, b1 = sym_block_partition(n, world)[rank]
+    r0, r1 = min(b0 * TILE, n), min(b1 * TILE, n)
+    return (r1 * (r1 + 1) - r0 * (r0 + 1)) / 2.0
 
 
 def padded_vector_length(n: int, world: int) -> int:

@@ -2,8 +2,9 @@
 
 Every rank evaluates ITS row block of K*d (here with the CPU oracle's row-owned statement of the product), the slices are
 exchanged with one all-gather, and every rank must hold the same full vector as the unsharded product -- exactly the
-exchange libplssvm_amd performs with ncclAllGather on the GPU box.  Also covers the unique-id hand-off used to bootstrap
-the library's communicator."""
+exchange libplssvm_amd performs with ncclAllGather on the GPU box (full-square variant).  The default symmetric variant
+(tiles on/below the diagonal only, row blocks dealt by equal area, mirrored column sums, one all-reduce) is restated the
+same way.  Also covers the unique-id hand-off used to bootstrap the library's communicator."""
 
 import os
 import socket
@@ -73,3 +74,76 @@ def test_row_sharded_matvec_world2(tmp_path, kernel, dtype_name):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, kernel, dtype_name, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def _sym_worker(rank, world, port, kernel, dtype_name, result_dir):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    import oracle_lib as ol
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dt = np.dtype(dtype_name)
+        rng = np.random.default_rng(13)
+        N, d = 700, 6
+        X = rng.uniform(-1, 1, size=(N, d)).astype(dt)
+        dvec = rng.uniform(1, 2, size=N - 1).astype(dt)
+        kw = dict(degree=3, gamma=1.0 / d, coef0=0.25)
+        o = ol.oracle()
+        q = o.q(kernel, X, **kw)
+        n = N - 1
+        T = sharding.TILE
+        # explicit matrix of the reduced system (column j = A-bar e_j), from the oracle's row-owned product
+        A = np.empty((n, n), dt)
+        for j in range(n):
+            e = np.zeros(n, dt)
+            e[j] = 1
+            A[:, j] = o.matvec_rows(kernel, X, q, e, np.zeros(n, dt), 2.0, 1.0, 1.0, 0, n, **kw)
+        b0, b1 = sharding.sym_block_partition(n, world)[rank]
+        part = np.zeros(sharding.padded_vector_length(n, 1), np.float64)  # starts from zero, like Kv before the all-reduce
+        for ib in range(b0, b1):
+            rows = slice(ib * T, min((ib + 1) * T, n))
+            for jt in range(ib + 1):
+                cols = slice(jt * T, min((jt + 1) * T, n))
+                blk = A[rows, cols].astype(np.float64)
+                part[rows] += blk @ dvec[cols]
+                if jt < ib:  # strictly below the diagonal: the mirrored tile (jt, ib) is never evaluated
+                    part[cols] += blk.T @ dvec[rows]
+        t = torch.from_numpy(part)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        want = A.astype(np.float64) @ dvec
+        assert np.max(np.abs(t.numpy()[:n] - want)) < 1e-9 * np.max(np.abs(want))
+        # every tile on or below the diagonal is owned by exactly one rank, and the areas are balanced
+        alg = [sharding.work_share(n, world, r, True) for r in range(world)]
+        tiles = -(-n // T)
+        assert abs(sum(a for a, _ in alg) - float(n) * n) < 1e-6 * n * n
+        assert sum(e for _, e in alg) == tiles * (tiles + 1) // 2 * T * T
+        assert abs(sum(sharding.triangle_share(n, world, r) for r in range(world)) - n * (n + 1) / 2) < 0.5
+        open(os.path.join(result_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kernel, dtype_name", [("rbf", "float64"), ("polynomial", "float64")])
+def test_symmetric_sharded_matvec_world2(tmp_path, kernel, dtype_name):
+    world = 2
+    port = _free_port()
+    mp.spawn(_sym_worker, args=(world, port, kernel, dtype_name, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+@pytest.mark.parametrize("n", [1, 127, 128, 129, 390, 49_999, 999_999])
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_symmetric_partition_is_a_balanced_cover(n, world):
+    parts = sharding.sym_block_partition(n, world)
+    tiles = -(-n // sharding.TILE)
+    assert parts[0][0] == 0 and parts[-1][1] == tiles and all(a1 == b0 and a0 <= a1 for (a0, a1), (b0, _) in zip(parts, parts[1:]))
+    executed = [sharding.work_share(n, world, r, True)[1] for r in range(world)]
+    assert sum(executed) == tiles * (tiles + 1) // 2 * sharding.TILE ** 2
+    if tiles >= 64 * world:  # enough blocks: every rank's area is within a few percent of the mean
+        mean = sum(executed) / world
+        assert max(abs(e - mean) for e in executed) < 0.05 * mean

@@ -51,8 +51,10 @@ def test_bench_json_contract_small_workload():
     assert "workload" in j["config"] and "model" not in j["config"]
     r = j["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    # `achieved` counts the ALGORITHMIC flops (full square); the default symmetric variant executes about half of them
-    assert 0.05 < r["executed_frac"] < 1.0 and r["executed_frac"] <= r["frac"] < 2.1 and r["symmetric"] in (True, False)
+    # `achieved` counts the algorithm's own flops (entries j <= i in the default symmetric variant), `executed` whole tiles,
+    # `effective_full_square` prices the launch like `value` does (2 n^2 d)
+    assert 0.05 < r["frac"] <= r["executed_frac"] < 1.0 and r["symmetric"] in (True, False)
+    assert r["effective_full_square"] >= r["achieved"] and r["full_square_flop_per_launch"] >= r["executed_flop_per_launch"] * 0.99
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
     # value is whole-job: 2 n^2 d per step / ms_per_step

@@ -302,30 +302,35 @@ def test_predict_and_score_on_the_reference_fixture(kernel, dt):
     assert float(np.mean(labels == fx["test_y"].astype(int))) == 1.0
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("N, d", [(300, 7), (1500, 40), (4097, 128), (2300, 200)])
-def test_symmetric_and_full_square_variants_agree(oracle, kernel, N, d):
-    """The default fp32 path evaluates only the tiles on/below the diagonal and mirrors them (as the reference does); the
-    full-square variant (option symmetric=0) sums every row independently.  Both must match the oracle and each other."""
-    X, y = make_blobs_pm1(N, d, seed=21, dtype=np.float32)
+def test_symmetric_and_full_square_variants_agree(oracle, kernel, N, d, dtype):
+    """The default path evaluates only the tiles on/below the diagonal and mirrors them (as the reference does); the
+    full-square variant (option symmetric=0) sums every row independently.  Both must match the oracle and each other.
+    (fp64 with more than 128 features runs the v1 kernel, which has no symmetric variant: both settings then take the same path.)"""
+    X, y = make_blobs_pm1(N, d, seed=21, dtype=dtype)
     p = Parameter(kernel_type=kernel)
-    rhs = np.random.default_rng(5).uniform(-1, 1, size=N - 1).astype(np.float32)
+    rhs = np.random.default_rng(5).uniform(-1, 1, size=N - 1).astype(dtype)
     out = {}
     for sym in (1, 0):
         _capi.set_option("symmetric", sym)
         try:
             with backend.ResidentProblem(p, X) as prob:
                 q, QA = prob.q()
-                out[sym] = prob.matvec(rhs, np.zeros(N - 1, np.float32), 1.0)
+                out[sym] = prob.matvec(rhs, np.zeros(N - 1, dtype), 1.0)
                 prob.cg_begin(y, 1e-30)
                 prob.cg_step(5)
                 out[("a", sym)] = prob.cg_finish()[0]
+                out[("sym", sym)] = prob.info()["symmetric"]
         finally:
             _capi.set_option("symmetric", 1)
+    assert out[("sym", 0)] == 0
+    assert out[("sym", 1)] == (1 if (dtype == np.float32 or d <= 128) else 0)
     kw = dict(degree=3, gamma=1.0 / d, coef0=0.0)
-    want = oracle.matvec(kernel, X, q, rhs, np.zeros(N - 1, np.float32), QA, 1.0, 1.0, **kw)
+    want = oracle.matvec(kernel, X, q, rhs, np.zeros(N - 1, dtype), QA, 1.0, 1.0, **kw)
     scale = np.max(np.abs(want))
-    eps = np.finfo(np.float32).eps
+    eps = np.finfo(dtype).eps
     assert np.max(np.abs(out[1] - want)) < 64 * eps * scale and np.max(np.abs(out[0] - want)) < 64 * eps * scale
     assert np.max(np.abs(out[1] - out[0])) < 64 * eps * scale
     assert np.all(np.isfinite(out[("a", 1)]))

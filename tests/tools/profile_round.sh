@@ -1,0 +1,30 @@
+#!/bin/bash
+# One GPU-box call that produces everything profiles/ holds for a round: bench lines for the four GPU workloads, the
+# rocprofv3 kernel-trace summaries of the same commands, and the PMC passes (separate runs, counters only).
+# usage: tests/tools/profile_round.sh <tag>      (outputs under gpurun_out/<tag>_*)
+TAG=${1:-rXX}
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+O=gpurun_out
+mkdir -p $O
+for wl in c2 c3 c4 c5; do
+  st=10; [ $wl = c5 ] && st=5
+  python3 bench.py --workload $wl --steps $st --warmup 2 > $O/${TAG}_bench_${wl}_n1.json 2> $O/${TAG}_bench_${wl}.err
+done
+for wl in c2 c4 c5; do
+  rm -rf $O/prof_$wl
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -- python3 bench.py --workload $wl --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_$wl.log 2>&1
+  f=$(find $O/prof_$wl -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" $O/${TAG}_rocprofv3_kernel_stats_bench_${wl}.csv
+  tail -1 $O/prof_$wl.log > $O/${TAG}_rocprofv3_bench_line_${wl}.json
+done
+: > $O/${TAG}_pmc_tile_matvec.txt
+for wl in c2 c4 c5; do
+  rm -rf $O/pmc_$wl
+  bash tests/tools/pmc_passes.sh $wl 3 $O/pmc_$wl
+  python3 tests/tools/pmc_summarize.py $wl $O/pmc_$wl --json $O/${TAG}_hbm_traffic.json --key ${wl}_n1 >> $O/${TAG}_pmc_tile_matvec.txt 2>&1
+  echo >> $O/${TAG}_pmc_tile_matvec.txt
+  rm -rf $O/pmc_$wl   # raw per-dispatch CSVs are large; the summary is what is kept
+done
+cat $O/${TAG}_pmc_tile_matvec.txt | grep "=>"
+for wl in c2 c3 c4 c5; do cat $O/${TAG}_bench_${wl}_n1.json; done
