@@ -191,6 +191,8 @@ int lssvm_mi355_problem_info(lssvm_mi355_problem *p, lssvm_cg_info *info);
  *   "xcd_map"       1 = XCD-aware block -> work item mapping (8 x 8 super-tiles per XCD), 0 = linear (default)
  *   "lds_extra_kb"  experiment knob: extra dynamic LDS (KiB) per workgroup of the fp32 v2 kernel, lowers the workgroups per CU
  *   "debug_ablate"  timing-only ablation bits of the fp32 tile kernel; effective only in -DLSSVM_ENABLE_ABLATION builds
+ *   "item_order"    symmetric variant: 0 = work items in column-chunk major order, 1 = the same with the short items that end on the
+ *                   diagonal moved to the end, longest first (default: shortens the last dispatch round), 2 = 1 with row blocks descending
  *   "force_collective" 1 = run the per-matvec RCCL all-gather even with a world of 1 (testing aid; default 0)
  */
 int lssvm_mi355_set_option(const char *name, int64_t value);

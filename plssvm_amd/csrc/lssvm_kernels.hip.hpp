@@ -146,6 +146,31 @@ __device__ __forceinline__ void with_degree_class(const TileArgs<T> &a, F &&body
     }
 }
 
+/* Pins a uniform pointer into an SGPR pair at this point of the program: "uniform base + 32-bit lane offset" is then selected
+ * as the saddr form of global_load_lds / global_store (no 64-bit vector address arithmetic, one VGPR per lane offset), and the
+ * compiler cannot re-associate the base into several vector adds. */
+__device__ __forceinline__ const char *sgpr_ptr(const void *p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<unsigned>(v))));  // (the builtin returns int:
+    const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<unsigned>(v >> 32))));  // no sign extension)
+    unsigned long long u = (static_cast<unsigned long long>(hi) << 32) | lo;
+    asm volatile("" : "+s"(u));
+    return reinterpret_cast<const char *>(u);
+}
+
+/* Keeps the 32-bit -> 64-bit extension of a lane offset in the basic block of its use (instruction selection is per block:
+ * a zext hoisted out of the loop hides the "SGPR base + 32-bit VGPR offset" addressing mode from it). */
+__device__ __forceinline__ unsigned lane_off(unsigned v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+/* The v2 kernels take the polynomial degree class as part of their kernel-type template parameter, so every instantiation
+ * carries ONE epilogue (the three-way runtime switch of with_degree_class made the register allocator budget for the generic
+ * integer-power path and spill in the cube path). */
+__host__ __device__ constexpr int v2_base_kt(int kt) { return (kt == KT_POLY2 || kt == KT_POLY3) ? KT_POLY : kt; }
+__host__ __device__ constexpr int v2_degree_class(int kt) { return kt == KT_POLY3 ? 3 : (kt == KT_POLY2 ? 2 : 0); }
+
 /* =====================================================================================================================
  * fp32 tile kernel: v_mfma_f32_32x32x2_f32
  *   operand maps (cdna_hip_programming.md section 3): lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
@@ -405,8 +430,8 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
     int ibl, jc;
     if constexpr (SYM) {
         const int2 it = a.items[blockIdx.x];
-        ibl = it.x;
-        jc = it.y;
+        ibl = __builtin_amdgcn_readfirstlane(it.x);  // uniform, but loaded through the vector memory path: move to SGPRs so
+        jc = __builtin_amdgcn_readfirstlane(it.y);   // that everything derived from it is scalar arithmetic
     } else {
         if (!decode_work_item(a, ibl, jc)) return;
     }
@@ -417,6 +442,18 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
     const int ntiles = jt_end - jt_begin;
     if (ntiles <= 0) return;
     const int nsteps = ntiles * NKC;
+#ifdef LSSVM_ENABLE_ABLATION
+    {   // experiment: phase-shift the two workgroups that share a CU by about half a tile (first dispatch round only)
+        bool shift = false;
+        if (LSSVM_DBG(a, 32)) shift = blockIdx.x >= 256 && blockIdx.x < 512;
+        if (LSSVM_DBG(a, 64)) shift = blockIdx.x < 512 && (blockIdx.x & 1);
+        if (LSSVM_DBG(a, 128)) shift = blockIdx.x < 512 && ((blockIdx.x >> 3) & 1);
+        if (shift) {
+            __builtin_amdgcn_s_sleep(127);
+            __builtin_amdgcn_s_sleep(127);
+        }
+    }
+#endif
     // record index of (ib, jt) in the packed strictly-lower-triangular column slab of this device
     const long rec0 = SYM ? (static_cast<long>(ib) * (ib - 1) / 2 - a.pair_origin) : 0;
 
@@ -440,22 +477,24 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
     // ---- LDS-DMA addressing ----
     // instruction q = 4*wave + i moves rows 8q .. 8q+7 of a chunk; lane L -> row 8q + L/8, physical 16-B slot L%8, which
     // holds logical slot (L%8) ^ ((row >> 1) & 7)
-    size_t dma_off[4];  // element offset of this lane's 16 bytes inside a (tile, chunk) = row * ldx + 4 * logical_slot
+    // The source address of a DMA is (uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset): the saddr form of
+    // global_load_lds, so a piece costs no 64-bit vector address arithmetic and one VGPR
+    unsigned dma_off[4];  // byte offset of this lane's 16 bytes inside a (tile, chunk) = 4 * (row * ldx + 4 * logical_slot)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = 8 * (4 * wave + i) + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        dma_off[i] = static_cast<size_t>(row) * a.ldx + 4 * c;
+        dma_off[i] = 4u * static_cast<unsigned>(row * a.ldx + 4 * c);
     }
     auto issue_chunk = [&](int step) {  // step = linear (tile, chunk) index of this work item
         if (LSSVM_DBG(a, 16) && step > 3) return;  // ablation: no DMA after the prologue
         const int t = LSSVM_DBG(a, 1) ? 0 : step / NKC;  // ablation bit 1: always the same (L2-resident) tile
         const int kc = LSSVM_DBG(a, 1) ? 0 : step - t * NKC;
-        const float *base = a.Xc + static_cast<size_t>(jt_begin + t) * TILE * a.ldx + kc * 32;
+        const char *base = sgpr_ptr(a.Xc + static_cast<size_t>(jt_begin + t) * TILE * a.ldx + kc * 32);
         char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES + wave * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + dma_off[i]), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + lane_off(dma_off[i])), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
         }
     };
     // one of the four DMA instructions of a chunk (steady state: spread over the MFMA groups that follow the hand-over, an
@@ -463,14 +502,14 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
     auto issue_chunk_part = [&](int step, int i) {
         const int t = step / NKC;
         const int kc = step - t * NKC;
-        const float *base = a.Xc + static_cast<size_t>(jt_begin + t) * TILE * a.ldx + kc * 32;
+        const char *base = sgpr_ptr(a.Xc + static_cast<size_t>(jt_begin + t) * TILE * a.ldx + kc * 32);
         char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES + wave * 4096;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + dma_off[i]), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + lane_off(dma_off[i])), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
     };
     auto issue_dc = [&](int t) {  // (d_j | c_j) of tile jt_begin + t: 1 KiB, each wave moves a quarter with 16 lanes
         if (lane < 16) {
-            const float *src = a.dc + static_cast<size_t>(jt_begin + t) * 256 + wave * 64 + lane * 4;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) src, (lds_ptr_t) (dcs + (t % V2_DC_SLOTS) * 1024 + wave * 256), 16, 0, 0);
+            const char *src = sgpr_ptr(a.dc + static_cast<size_t>(jt_begin + t) * 256) + __builtin_amdgcn_readfirstlane(wave * 256);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (src + 16u * (lane_off(threadIdx.x) & 15u)), (lds_ptr_t) (dcs + (t % V2_DC_SLOTS) * 1024 + wave * 256), 16, 0, 0);
         }
     };
 
@@ -551,7 +590,8 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
         if (tid < TILE) {
             const float *cr_ = colred + (t & 1) * 512;
             const float sum = (cr_[tid] + cr_[128 + tid]) + (cr_[256 + tid] + cr_[384 + tid]);
-            a.colslab[(rec0 + jt_begin + t) * TILE + tid] = sum;
+            float *rec = a.colslab + (rec0 + jt_begin + t) * TILE;  // uniform base + 32-bit lane offset
+            rec[static_cast<unsigned>(tid)] = sum;
         }
     };
 
@@ -627,7 +667,7 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
         // epilogue of the tile: K_ij = f(acc), row partial += K_ij * d_j; SYM, off-diagonal tile: column partial += K_ij * d_i
         // (vector ALU, fused; the Gram tile itself is never written)
         if (!LSSVM_DBG(a, 4))
-        with_degree_class<KT>(a, [&](auto degc) {
+        {  // (the polynomial degree class is a template parameter here: KT_POLY2 / KT_POLY3 / generic KT_POLY)
             auto epilogue = [&](auto with_cols) {
                 constexpr bool COLS = decltype(with_cols)::value;
                 float di[16];
@@ -644,7 +684,7 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
                 for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        float kv = apply_kernel_function<KT, decltype(degc)::value>(acc[cb][i], a);
+                        float kv = apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(acc[cb][i], a);
                         if constexpr (KT == KT_POLY) {
                             if (padcol[cb]) kv = 0.0f;
                         }
@@ -665,7 +705,7 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
             } else {
                 epilogue(std::false_type{});
             }
-        });
+        }
     };
 
     // steady state: every tile whose last step still has step + 3 < nsteps; then the (1..3) tail tiles with the checked hand-over
@@ -939,8 +979,8 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
     int ibl, jc;
     if constexpr (SYM) {
         const int2 it = a.items[blockIdx.x];
-        ibl = it.x;
-        jc = it.y;
+        ibl = __builtin_amdgcn_readfirstlane(it.x);  // uniform, but loaded through the vector memory path: move to SGPRs so
+        jc = __builtin_amdgcn_readfirstlane(it.y);   // that everything derived from it is scalar arithmetic
     } else {
         if (!decode_work_item(a, ibl, jc)) return;
     }
@@ -975,34 +1015,40 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
         for (int s = 0; s < 4 * NKC; ++s) asm volatile("" : "+v"(afrag[rb][s]));
 
     // LDS-DMA: instruction qd = 2*wave + i moves rows 8 qd .. 8 qd + 7 of a 64-row chunk
-    size_t dma_off[2];
+    unsigned dma_off[2];  // byte offsets (saddr form: uniform base in SGPRs + 32-bit lane offset, see tile_matvec_f32_v2)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = 8 * (2 * wave + i) + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        dma_off[i] = static_cast<size_t>(row) * a.ldx + 2 * c;  // in doubles: a 16-byte slot = 2 doubles
+        dma_off[i] = 8u * static_cast<unsigned>(row * a.ldx + 2 * c);  // a 16-byte slot = 2 doubles
     }
     auto issue_chunk = [&](int step) {
         const int t = step / NKC;
         const int kc = step - t * NKC;
-        const double *base = a.Xc + static_cast<size_t>(st_begin + t) * 64 * a.ldx + kc * 16;
+        const char *base = sgpr_ptr(a.Xc + static_cast<size_t>(st_begin + t) * 64 * a.ldx + kc * 16);
         char *slot = ring + (step % V2D_RING) * V2D_SLOT_BYTES + wave * 2048;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + dma_off[i]), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + lane_off(dma_off[i])), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
         }
     };
     auto issue_dc = [&](int t) {
         if (lane < 16) {
-            const double *src = a.dc + static_cast<size_t>(st_begin + t) * 128 + wave * 32 + lane * 2;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) src, (lds_ptr_t) (dcs + (t % V2D_DC_SLOTS) * 1024 + wave * 256), 16, 0, 0);
+            const char *src = sgpr_ptr(a.dc + static_cast<size_t>(st_begin + t) * 128) + __builtin_amdgcn_readfirstlane(wave * 256);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (src + 16u * (lane_off(threadIdx.x) & 15u)), (lds_ptr_t) (dcs + (t % V2D_DC_SLOTS) * 1024 + wave * 256), 16, 0, 0);
         }
     };
 
     // read addressing: lane (r, q), k-step s of a chunk: double 4 s + q of row cb*16 + r -> 16-B slot 2 s + (q >> 1), half q & 1
-    int rd_off[4];
+    // One opaque address register per column block; the k-step s only flips bits 5-6 of the swizzled slot ((2 s + q/2) ^ swz =
+    // (q/2 ^ swz) ^ 2 s), applied with one v_xor per read.  With a common base and immediate offsets the compiler fuses pairs of
+    // reads into ds_read2st64_b64, which is banked modulo 32 dwords (the swizzle assumes ds_read_b64's 64) and runs at half rate.
+    int rd_cb[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) rd_off[s] = r * 128 + (((2 * s + (q >> 1)) ^ ((r >> 1) & 7)) << 4) + ((q & 1) << 3);
+    for (int cb = 0; cb < 4; ++cb) {
+        rd_cb[cb] = cb * 2048 + r * 128 + ((((q >> 1)) ^ ((r >> 1) & 7)) << 4) + ((q & 1) << 3);
+        asm volatile("" : "+v"(rd_cb[cb]));
+    }
 
     double rowpart[2][4];
 #pragma unroll
@@ -1037,7 +1083,8 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
     auto flush_cols = [&](int t) {  // fixed-order sum of the four waves' column sums of sub-tile t -> its slab record
         if (tid < 64) {
             const double *cr_ = colred + (t & 1) * 256;
-            a.colslab[(rec0 + st_begin + t) * 64 + tid] = (cr_[tid] + cr_[64 + tid]) + (cr_[128 + tid] + cr_[192 + tid]);
+            double *rec = a.colslab + (rec0 + st_begin + t) * 64;  // uniform base + 32-bit lane offset
+            rec[static_cast<unsigned>(tid)] = (cr_[tid] + cr_[64 + tid]) + (cr_[128 + tid] + cr_[192 + tid]);
         }
     };
 
@@ -1053,10 +1100,8 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
             const double *dcr = reinterpret_cast<const double *>(dcs + (t % V2D_DC_SLOTS) * 1024);
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
-                dj[cb] = dcr[cb * 16 + r];
                 cj[cb] = 0.0;
                 if constexpr (KT == KT_RBF) cj[cb] = dcr[64 + cb * 16 + r];
-                if constexpr (KT == KT_POLY) padcol[cb] = (a.degree < 0) && ((st_begin + t) * 64 + cb * 16 + r >= a.ncols_valid);
             }
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
@@ -1076,7 +1121,7 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
             for (int s = 0; s < 4; ++s) {
                 double b[4];
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) b[cb] = *reinterpret_cast<const double *>(slot + cb * 2048 + rd_off[s]);
+                for (int cb = 0; cb < 4; ++cb) b[cb] = *reinterpret_cast<const double *>(slot + (rd_cb[cb] ^ (s << 5)));
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -1084,7 +1129,17 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
                         acc[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[rb][4 * kc + s], b[cb], acc[rb][cb], 0, 0, 0);
             }
         }
-        with_degree_class<KT>(a, [&](auto degc) {
+        // d_j is fetched from the tile's record only now: it need not occupy registers during the MFMA loop (2 workgroups per CU
+        // leave 256 VGPRs per wave, the row panel and the accumulators take 128 of them at 64 features)
+        {
+            const double *dcr = reinterpret_cast<const double *>(dcs + (t % V2D_DC_SLOTS) * 1024);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                dj[cb] = dcr[cb * 16 + r];
+                if constexpr (KT == KT_POLY) padcol[cb] = (a.degree < 0) && ((st_begin + t) * 64 + cb * 16 + r >= a.ncols_valid);
+            }
+        }
+        {  // (the polynomial degree class is a template parameter here: KT_POLY2 / KT_POLY3 / generic KT_POLY)
             auto epilogue = [&](auto with_cols) {
                 constexpr bool COLS = decltype(with_cols)::value;
                 double colacc[4] = { 0.0, 0.0, 0.0, 0.0 };
@@ -1096,7 +1151,7 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
                         if constexpr (COLS) di = dis[wave * 32 + rb * 16 + q + 4 * i];
 #pragma unroll
                         for (int cb = 0; cb < 4; ++cb) {
-                            double kv = apply_kernel_function<KT, decltype(degc)::value>(acc[rb][cb][i], a);
+                            double kv = apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(acc[rb][cb][i], a);
                             if constexpr (KT == KT_POLY) {
                                 if (padcol[cb]) kv = 0.0;
                             }
@@ -1120,7 +1175,7 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
             } else {
                 epilogue(std::false_type{});
             }
-        });
+        }
     }
     if constexpr (SYM) {
         if (st_begin + nsub - 1 < 2 * ib) {  // the last sub-tile was off-diagonal: publish its column sums

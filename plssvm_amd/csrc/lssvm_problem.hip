@@ -8,6 +8,8 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
+
 namespace lssvm {
 
 Options &options() {
@@ -151,13 +153,29 @@ void launch_tile_kernel<float>(TileArgs<float> &a, int kernel_type, bool rbf_dir
             const dim3 sgrid(static_cast<unsigned>(a.num_items));
             switch (kernel_type) {
                 case KT_LINEAR: launch_v2_kt<KT_LINEAR, true>(a, sgrid, s); break;
-                case KT_POLY: launch_v2_kt<KT_POLY, true>(a, sgrid, s); break;
+                case KT_POLY:
+                    if (a.degree == 3) {
+                        launch_v2_kt<KT_POLY3, true>(a, sgrid, s);
+                    } else if (a.degree == 2) {
+                        launch_v2_kt<KT_POLY2, true>(a, sgrid, s);
+                    } else {
+                        launch_v2_kt<KT_POLY, true>(a, sgrid, s);
+                    }
+                    break;
                 default: launch_v2_kt<KT_RBF, true>(a, sgrid, s); break;
             }
         } else {
             switch (kernel_type) {
                 case KT_LINEAR: launch_v2_kt<KT_LINEAR, false>(a, grid, s); break;
-                case KT_POLY: launch_v2_kt<KT_POLY, false>(a, grid, s); break;
+                case KT_POLY:
+                    if (a.degree == 3) {
+                        launch_v2_kt<KT_POLY3, false>(a, grid, s);
+                    } else if (a.degree == 2) {
+                        launch_v2_kt<KT_POLY2, false>(a, grid, s);
+                    } else {
+                        launch_v2_kt<KT_POLY, false>(a, grid, s);
+                    }
+                    break;
                 default: launch_v2_kt<KT_RBF, false>(a, grid, s); break;
             }
         }
@@ -196,13 +214,29 @@ void launch_tile_kernel<double>(TileArgs<double> &a, int kernel_type, bool /*rbf
             const dim3 sgrid(static_cast<unsigned>(a.num_items));
             switch (kernel_type) {
                 case KT_LINEAR: launch_v2d_kt<KT_LINEAR, true>(a, sgrid, s); break;
-                case KT_POLY: launch_v2d_kt<KT_POLY, true>(a, sgrid, s); break;
+                case KT_POLY:
+                    if (a.degree == 3) {
+                        launch_v2d_kt<KT_POLY3, true>(a, sgrid, s);
+                    } else if (a.degree == 2) {
+                        launch_v2d_kt<KT_POLY2, true>(a, sgrid, s);
+                    } else {
+                        launch_v2d_kt<KT_POLY, true>(a, sgrid, s);
+                    }
+                    break;
                 default: launch_v2d_kt<KT_RBF, true>(a, sgrid, s); break;
             }
         } else {
             switch (kernel_type) {
                 case KT_LINEAR: launch_v2d_kt<KT_LINEAR, false>(a, grid, s); break;
-                case KT_POLY: launch_v2d_kt<KT_POLY, false>(a, grid, s); break;
+                case KT_POLY:
+                    if (a.degree == 3) {
+                        launch_v2d_kt<KT_POLY3, false>(a, grid, s);
+                    } else if (a.degree == 2) {
+                        launch_v2d_kt<KT_POLY2, false>(a, grid, s);
+                    } else {
+                        launch_v2d_kt<KT_POLY, false>(a, grid, s);
+                    }
+                    break;
                 default: launch_v2d_kt<KT_RBF, false>(a, grid, s); break;
             }
         }
@@ -396,12 +430,23 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
     }
     if (sym_) {
         // work items = the non-empty (row block, column chunk) pairs, column chunk major (concurrent workgroups share the chunk)
-        std::vector<int2> items;
+        // (the hardware dispatches workgroups in item order as CU slots free up).  item_order >= 1: the items cut short by the
+        // diagonal go last, longest first, so the final dispatch round is made of the shortest items.
+        std::vector<int2> items, cut;
+        const int order = static_cast<int>(options().item_order);
         for (int jc = 0; jc < num_jc_; ++jc) {
-            for (int ibl = 0; ibl < num_ib_; ++ibl) {
-                if (jc * jc_tiles_ <= ib_begin_ + ibl) items.push_back(make_int2(ibl, jc));
+            for (int k = 0; k < num_ib_; ++k) {
+                const int ibl = order == 2 ? num_ib_ - 1 - k : k;
+                const int ib = ib_begin_ + ibl;
+                if (jc * jc_tiles_ > ib) continue;
+                const bool is_cut = (jc + 1) * jc_tiles_ > ib + 1;  // fewer than jc_tiles tiles
+                (order >= 1 && is_cut ? cut : items).push_back(make_int2(ibl, jc));
             }
         }
+        std::stable_sort(cut.begin(), cut.end(), [&](const int2 &x, const int2 &y) {
+            return (ib_begin_ + x.x + 1 - x.y * jc_tiles_) > (ib_begin_ + y.x + 1 - y.y * jc_tiles_);
+        });
+        items.insert(items.end(), cut.begin(), cut.end());
         num_items_ = static_cast<int>(items.size());
         items_.alloc_zero(std::max<size_t>(items.size(), 1), stream_);
         if (!items.empty()) LSSVM_HIP_CHECK(hipMemcpyAsync(items_.p, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice, stream_));

@@ -14,6 +14,8 @@ namespace lssvm {
 constexpr int KT_LINEAR = 0;
 constexpr int KT_POLY = 1;
 constexpr int KT_RBF = 2;
+constexpr int KT_POLY2 = 3;  // v2 tile kernels only: polynomial with degree 2 / 3 (KT_POLY = any other integer degree)
+constexpr int KT_POLY3 = 4;
 
 constexpr int TILE = 128;          // rows / columns of one workgroup tile of the implicit matrix
 constexpr int TILE_THREADS = 256;  // 4 wave64 arranged 2 x 2, each owning a 64 x 64 sub-tile

@@ -74,7 +74,31 @@ def perf(N=50000, d=128, kernel="rbf", dt=np.float32, iters=5):
 
 
 if __name__ == "__main__":
-    if "--ablate2" in sys.argv:
+    if "--sched" in sys.argv:
+        # scheduling experiments on the symmetric kernels: phase shift of co-resident workgroups (ablation build only), item order,
+        # items per column chunk
+        for N in (50000, 100000):
+            for dbg in (0, 32, 64, 128):
+                _capi.set_option("debug_ablate", dbg)
+                print(f"N={N} debug_ablate={dbg}: ", end="")
+                perf(N, 128, "rbf", np.float32, iters=6)
+            _capi.set_option("debug_ablate", 0)
+            for order in (0, 1, 2):
+                for jt in (8, 16, 32):
+                    _capi.set_option("item_order", order)
+                    _capi.set_option("j_chunk_tiles", jt)
+                    print(f"N={N} item_order={order} j_chunk_tiles={jt}: ", end="")
+                    perf(N, 128, "rbf", np.float32, iters=6)
+            _capi.set_option("item_order", 1)
+            _capi.set_option("j_chunk_tiles", 16)
+        for jt in (8, 16, 32):
+            _capi.set_option("j_chunk_tiles", jt)
+            print(f"j_chunk_tiles={jt}: ", end="")
+            perf(100000, 64, "polynomial", np.float64, iters=6)
+            print(f"j_chunk_tiles={jt}: ", end="")
+            perf(100000, 64, "rbf", np.float64, iters=6)
+        _capi.set_option("j_chunk_tiles", 16)
+    elif "--ablate2" in sys.argv:
         for dbg in (0, 1, 4, 5, 16, 20, 28):
             _capi.set_option("debug_ablate", dbg)
             print(f"debug_ablate={dbg}: ", end="")
