@@ -130,6 +130,18 @@ __device__ __forceinline__ T apply_kernel_function(T acc, const TileArgs<T> &a) 
     }
 }
 
+/* v^degree for the degree class DEG (3, 2, or 0 = any integer degree) */
+template <int DEG, typename T>
+__device__ __forceinline__ T poly_power(T v, int degree) {
+    if constexpr (DEG == 3) {
+        return v * v * v;
+    } else if constexpr (DEG == 2) {
+        return v * v;
+    } else {
+        return ipow(v, degree);
+    }
+}
+
 /* runs `body(std::integral_constant<int, DEG>)` with the polynomial degree class of `a` (one uniform branch per tile) */
 template <int KT, typename T, typename F>
 __device__ __forceinline__ void with_degree_class(const TileArgs<T> &a, F &&body) {
@@ -948,13 +960,17 @@ __global__ __launch_bounds__(TILE_THREADS, 1) void tile_matvec_f64(const TileArg
 }
 
 /* =====================================================================================================================
- * fp64 tile kernel, version 2: the fp32 v2 structure (row panel resident in registers, LDS-DMA ring, swizzled lane-linear
- * LDS image, packed (d_j | c_j) records) on v_mfma_f64_16x16x4_f64, for num_features <= 128.
+ * fp64 tile kernel, version 2: the fp32 v2 pipeline (row panel resident in registers, LDS-DMA ring two chunks ahead, chunk
+ * hand-over in the middle of a step, packed (d_j | c_j) records) on v_mfma_f64_16x16x4_f64, for num_features <= 128.
  *   A column tile of 128 is processed as two 64-column SUB-TILES so that a wave's accumulators (32 rows x 64 columns =
- *   8 tiles of 16x16 = 64 VGPRs) plus its row panel leave room for two workgroups per CU: the second workgroup's MFMAs
- *   cover the first one's double-precision epilogue.  Chunk = 64 rows x 16 doubles = 8 KiB, 32 MFMAs per wave and barrier.
+ *   8 tiles of 16x16 = 64 VGPRs) plus its row panel leave room for two workgroups per CU.
+ *   Chunk = 64 columns x 16 features = 8 KiB = 4 k-steps of 8 MFMAs per wave.
+ *   v_mfma_f64 does NOT overlap with vector ALU instructions (tests/tools/microbench_f64.hip: one integer VALU op per MFMA
+ *   costs 9 % of the matrix-core rate, one v_fma_f64 15 %), so the chunk loop consists of MFMAs, LDS reads with immediate
+ *   offsets, LDS-DMA with scalar base addresses and scalar instructions only, the accumulators start from the constant 0 as
+ *   the C operand of the first MFMA, and the polynomial kernel runs on data pre-scaled by sqrt(gamma).
  * ===================================================================================================================== */
-constexpr int V2D_RING = 3;
+constexpr int V2D_RING = 4;
 constexpr int V2D_SLOT_BYTES = 64 * 128;  // 8 KiB
 constexpr int V2D_DC_SLOTS = 4;           // (64 d_j | 64 c_j) doubles = 1 KiB per sub-tile
 constexpr size_t V2D_LDS_BYTES = static_cast<size_t>(V2D_RING) * V2D_SLOT_BYTES + V2D_DC_SLOTS * 1024 + (2 * TILE + 2 * 4 * 64) * sizeof(double);  // ring + records + cis, dis, colred
@@ -1014,15 +1030,19 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
 #pragma unroll
         for (int s = 0; s < 4 * NKC; ++s) asm volatile("" : "+v"(afrag[rb][s]));
 
-    // LDS-DMA: instruction qd = 2*wave + i moves rows 8 qd .. 8 qd + 7 of a 64-row chunk
+    // LDS image of a chunk (64 columns x 16 features, 8 KiB): [column block cb = 0..3][16-byte k-slot ks = 0..7][column r = 0..15],
+    // i.e. byte cb * 2048 + ks * 256 + r * 16 holds features 2 ks, 2 ks + 1 of column cb * 16 + r.  Piece 2 * wave + i of the DMA
+    // (1 KiB, lane-linear in LDS) is block cb = wave, k-slots 4 i .. 4 i + 3: lane L fetches the 16 bytes of column L % 16, k-slot
+    // 4 i + L / 16 -- a gather on the SOURCE side (16 rows x 64 contiguous bytes per piece).
     unsigned dma_off[2];  // byte offsets (saddr form: uniform base in SGPRs + 32-bit lane offset, see tile_matvec_f32_v2)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int row = 8 * (2 * wave + i) + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        dma_off[i] = 8u * static_cast<unsigned>(row * a.ldx + 2 * c);  // a 16-byte slot = 2 doubles
+        const int col = wave * 16 + (lane & 15);
+        const int ks = 4 * i + (lane >> 4);
+        dma_off[i] = 8u * static_cast<unsigned>(col * a.ldx + 2 * ks);
     }
     auto issue_chunk = [&](int step) {
+        if (LSSVM_DBG(a, 16) && step > 2) return;  // ablation: no DMA after the prologue
         const int t = step / NKC;
         const int kc = step - t * NKC;
         const char *base = sgpr_ptr(a.Xc + static_cast<size_t>(st_begin + t) * 64 * a.ldx + kc * 16);
@@ -1039,16 +1059,14 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
         }
     };
 
-    // read addressing: lane (r, q), k-step s of a chunk: double 4 s + q of row cb*16 + r -> 16-B slot 2 s + (q >> 1), half q & 1
-    // One opaque address register per column block; the k-step s only flips bits 5-6 of the swizzled slot ((2 s + q/2) ^ swz =
-    // (q/2 ^ swz) ^ 2 s), applied with one v_xor per read.  With a common base and immediate offsets the compiler fuses pairs of
-    // reads into ds_read2st64_b64, which is banked modulo 32 dwords (the swizzle assumes ds_read_b64's 64) and runs at half rate.
-    int rd_cb[4];
+    // Read addressing: lane (r, q) needs feature 4 s + q of column cb * 16 + r for k-step s = k-slot 2 s + q / 2, half q % 2:
+    // byte (q / 2) * 256 + r * 16 + (q % 2) * 8 [per lane, constant] + cb * 2048 + s * 512 [immediates] + ring slot [one add per
+    // chunk].  The 32 lanes of a ds_read_b64 group (q / 2 fixed) read 256 contiguous bytes: conflict free without a swizzle.
+    const int lane_base = (q >> 1) * 256 + r * 16 + (q & 1) * 8;
+    auto read_group = [&](const char *slot, int s, double (&b)[4]) {
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        rd_cb[cb] = cb * 2048 + r * 128 + ((((q >> 1)) ^ ((r >> 1) & 7)) << 4) + ((q & 1) << 3);
-        asm volatile("" : "+v"(rd_cb[cb]));
-    }
+        for (int cb = 0; cb < 4; ++cb) b[cb] = *reinterpret_cast<const double *>(slot + cb * 2048 + s * 512);
+    };
 
     double rowpart[2][4];
 #pragma unroll
@@ -1059,24 +1077,56 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
     double dj[4], cj[4];
     bool padcol[4] = { false, false, false, false };
 
+    // ---- prologue: chunks 0, 1, 2 (each preceded by the record of the sub-tile that starts with it) ----
     issue_dc(0);
     issue_chunk(0);
-    if (nsteps > 1) {
-        if (NKC == 1) issue_dc(1);
-        issue_chunk(1);
-    }
-
-    auto sync_and_prefetch = [&](int step) {  // see tile_matvec_f32_v2; 2 DMA instructions per wave and chunk here
-        if (step + 1 < nsteps) {
-            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int pre = 1; pre <= 2; ++pre) {
+        if (pre < nsteps) {
+            if (pre % NKC == 0) issue_dc(pre / NKC);
+            issue_chunk(pre);
         }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (step + 2 < nsteps) {
-            if ((step + 2) % NKC == 0) issue_dc((step + 2) / NKC);
-            issue_chunk(step + 2);
+    }
+    // chunk 0 (and record 0, cis, dis) complete: everything but the DMA pieces of the younger chunks is done
+    if (nsteps >= 3) {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    } else if (nsteps == 2) {
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    double bcur[4];  // B fragments of the k-step about to be multiplied (double buffered against bnext in the loop)
+    read_group(ring + lane_base, 0, bcur);
+
+    // ---- hand-over of the NEXT chunk in the MIDDLE of a step (see tile_matvec_f32_v2): called in k-step 2 of chunk `step`.  This
+    // wave's two pieces of chunk step + 1 are complete once all but its 2 youngest DMA instructions (chunk step + 2) are; the barrier
+    // makes every wave's pieces visible, so k-step 3 can already prefetch the first fragments of chunk step + 1.  Ring of 4 slots:
+    // the DMA issued here (chunk step + 3) overwrites the slot of chunk step - 1, which every wave finished before this barrier.
+    auto handover = [&](int step, int kc_plus3_mod, auto checked) {
+        constexpr bool CHECKED = decltype(checked)::value;
+        if constexpr (!CHECKED) {
+            if (!LSSVM_DBG(a, 16)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (!LSSVM_DBG(a, 8)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kc_plus3_mod == 0) issue_dc((step + 3) / NKC);
+            issue_chunk(step + 3);
+        } else {
+            if (step + 1 < nsteps) {
+                if (step + 2 < nsteps) {
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (step + 3 < nsteps) {
+                    if (kc_plus3_mod == 0) issue_dc((step + 3) / NKC);
+                    issue_chunk(step + 3);
+                }
+            }
         }
     };
 
@@ -1088,58 +1138,79 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
         }
     };
 
-    for (int t = 0; t < nsub; ++t) {
+    auto tile_body = [&](int t, auto checked) {
         const int s0 = t * NKC;
         const bool tile_sym = SYM && (st_begin + t < 2 * ib);
-        sync_and_prefetch(s0);
-        if constexpr (SYM) {
-            // sub-tile t - 1 was off-diagonal unless it is the first of the diagonal pair (which is then t - 1 = nsub - 2)
-            if (t > 0 && (st_begin + t - 1 < 2 * ib)) flush_cols(t - 1);
-        }
-        {
-            const double *dcr = reinterpret_cast<const double *>(dcs + (t % V2D_DC_SLOTS) * 1024);
+        const double *dcr = reinterpret_cast<const double *>(dcs + (t % V2D_DC_SLOTS) * 1024);
+        // rbf: the accumulators start at c_i + c_j; the other kernels start the chain with the constant 0 as the C operand of the
+        // first MFMA (no register initialisation: 64 v_mov per sub-tile would cost as much matrix-core time as the cube)
+        if constexpr (KT == KT_RBF) {
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                cj[cb] = 0.0;
-                if constexpr (KT == KT_RBF) cj[cb] = dcr[64 + cb * 16 + r];
-            }
+            for (int cb = 0; cb < 4; ++cb) cj[cb] = dcr[64 + cb * 16 + r];
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    double civ = 0.0;
-                    if constexpr (KT == KT_RBF) civ = cis[wave * 32 + rb * 16 + q + 4 * i];
+                    const double civ = cis[wave * 32 + rb * 16 + q + 4 * i];
 #pragma unroll
                     for (int cb = 0; cb < 4; ++cb) acc[rb][cb][i] = civ + cj[cb];
                 }
         }
 #pragma unroll
         for (int kc = 0; kc < NKC; ++kc) {
-            if (kc > 0) sync_and_prefetch(s0 + kc);
-            const char *slot = ring + ((s0 + kc) % V2D_RING) * V2D_SLOT_BYTES;
+            const int step = s0 + kc;
+            const char *slot = ring + (step % V2D_RING) * V2D_SLOT_BYTES + lane_base;
+            const char *slot_next = ring + ((step + 1) % V2D_RING) * V2D_SLOT_BYTES + lane_base;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                double b[4];
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) b[cb] = *reinterpret_cast<const double *>(slot + (rd_cb[cb] ^ (s << 5)));
+                // software prefetch of the next k-step's B fragments (next chunk for s == 3: visible since this step's hand-over)
+                double bnext[4];
+                if (s < 3) read_group(slot, s + 1, bnext);
+                if (s == 2) {
+                    if constexpr (SYM) {
+                        // the colred writes of the previous sub-tile's epilogue must have completed before the barrier publishes them
+                        if (kc == 0 && t > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    handover(step, (kc + 3) % NKC, checked);
+                    if constexpr (SYM) {
+                        // sub-tile t - 1 was off-diagonal unless it is the first of the diagonal pair
+                        if (kc == 0 && t > 0 && (st_begin + t - 1 < 2 * ib)) flush_cols(t - 1);
+                    }
+                }
+                if (s == 3) read_group(slot_next, 0, bnext);
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                    for (int cb = 0; cb < 4; ++cb)
-                        acc[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[rb][4 * kc + s], b[cb], acc[rb][cb], 0, 0, 0);
+                    for (int cb = 0; cb < 4; ++cb) {
+                        if (KT != KT_RBF && kc == 0 && s == 0) {
+                            const f64x4 zero = { 0.0, 0.0, 0.0, 0.0 };
+                            acc[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[rb][0], bcur[cb], zero, 0, 0, 0);
+                        } else {
+                            acc[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[rb][4 * kc + s], bcur[cb], acc[rb][cb], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) bcur[cb] = bnext[cb];
             }
         }
-        // d_j is fetched from the tile's record only now: it need not occupy registers during the MFMA loop (2 workgroups per CU
-        // leave 256 VGPRs per wave, the row panel and the accumulators take 128 of them at 64 features)
-        {
-            const double *dcr = reinterpret_cast<const double *>(dcs + (t % V2D_DC_SLOTS) * 1024);
+        // ---- epilogue of the sub-tile (vector ALU; every instruction here costs matrix-core time, see the header) ----
+        if (!LSSVM_DBG(a, 4)) {
+            // d_j is fetched from the sub-tile's record only now: it need not occupy registers during the MFMA loop
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
                 dj[cb] = dcr[cb * 16 + r];
                 if constexpr (KT == KT_POLY) padcol[cb] = (a.degree < 0) && ((st_begin + t) * 64 + cb * 16 + r >= a.ncols_valid);
             }
-        }
-        {  // (the polynomial degree class is a template parameter here: KT_POLY2 / KT_POLY3 / generic KT_POLY)
+            if constexpr (v2_base_kt(KT) == KT_POLY) {
+                if (a.coef0 != 0.0) {  // uniform; the common coef0 = 0 costs nothing
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[rb][cb][i] += a.coef0;
+                }
+            }
             auto epilogue = [&](auto with_cols) {
                 constexpr bool COLS = decltype(with_cols)::value;
                 double colacc[4] = { 0.0, 0.0, 0.0, 0.0 };
@@ -1151,7 +1222,13 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
                         if constexpr (COLS) di = dis[wave * 32 + rb * 16 + q + 4 * i];
 #pragma unroll
                         for (int cb = 0; cb < 4; ++cb) {
-                            double kv = apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(acc[rb][cb][i], a);
+                            double kv;
+                            if constexpr (v2_base_kt(KT) == KT_POLY) {
+                                // the data carries sqrt(gamma) (Problem<double> pre-scales it for this kernel) and coef0 was added above
+                                kv = poly_power<v2_degree_class(KT)>(acc[rb][cb][i], a.degree);
+                            } else {
+                                kv = apply_kernel_function<KT, 0>(acc[rb][cb][i], a);
+                            }
                             if constexpr (KT == KT_POLY) {
                                 if (padcol[cb]) kv = 0.0;
                             }
@@ -1176,7 +1253,14 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
                 epilogue(std::false_type{});
             }
         }
-    }
+    };
+
+    // steady state: every sub-tile whose last step still has step + 3 < nsteps; then the tail sub-tiles with the checked hand-over
+    constexpr int TAIL_TILES = (3 + NKC - 1) / NKC;
+    const int nmain = nsub > TAIL_TILES ? nsub - TAIL_TILES : 0;
+    int t = 0;
+    for (; t < nmain; ++t) tile_body(t, std::false_type{});
+    for (; t < nsub; ++t) tile_body(t, std::true_type{});
     if constexpr (SYM) {
         if (st_begin + nsub - 1 < 2 * ib) {  // the last sub-tile was off-diagonal: publish its column sums
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1367,31 +1451,38 @@ __global__ void k_reduce_partials(const T *__restrict__ partial, long part_strid
     }
 }
 
-/* SYM: Kv[j] += sum over the row blocks ib > jt of this device of colslab[(ib, jt)][j % 128], ib ascending (fixed order).
- * One block per column tile; the records of one column tile are 512-byte (fp32) lines. */
-template <typename T>
-__global__ void k_reduce_colslab(const T *__restrict__ colslab, long pair_origin, int ib_begin, int ib_end, T *__restrict__ Kv) {
-    const int jt = blockIdx.x;
-    const int l = threadIdx.x;  // TILE threads
-    T s = T(0);
-    for (int ib = max(jt + 1, ib_begin); ib < ib_end; ++ib) {
-        const long rec = static_cast<long>(ib) * (ib - 1) / 2 - pair_origin + jt;
-        s += colslab[rec * TILE + l];
+/* SYM: Kv[column c] += sum over the row blocks ib (of this device) below column record c of colslab[(ib, c)], in a FIXED order.
+ * Records are W columns wide, SUB = 128 / W records per 128-column tile (fp32: W = 128, fp64: W = 64); row block ib owns the
+ * SUB * ib records below its diagonal tile, packed triangularly.  One block of 1024 threads per record column: 1024 / W groups
+ * walk the row blocks with stride 1024 / W (four independent partial sums each, for memory-level parallelism), then the groups'
+ * sums are added in group order -- the order depends only on the shape, never on timing. */
+template <typename T, int W>
+__global__ __launch_bounds__(1024) void k_reduce_colslab(const T *__restrict__ colslab, long pair_origin, int ib_begin, int ib_end, T *__restrict__ Kv) {
+    constexpr int SUB = TILE / W;
+    constexpr int G = 1024 / W;
+    __shared__ T red[G][W];
+    const int c = blockIdx.x;
+    const int l = threadIdx.x % W;
+    const int g = threadIdx.x / W;
+    const int first = max(c / SUB + 1, ib_begin);
+    auto rec = [&](int ib) { return colslab[(SUB * (static_cast<long>(ib) * (ib - 1) / 2 - pair_origin) + c) * W + l]; };
+    T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
+    int ib = first + g;
+    for (; ib + 3 * G < ib_end; ib += 4 * G) {
+        s0 += rec(ib);
+        s1 += rec(ib + G);
+        s2 += rec(ib + 2 * G);
+        s3 += rec(ib + 3 * G);
     }
-    Kv[jt * TILE + l] += s;
-}
-
-/* fp64 flavour: records are per 64-column sub-tile st, row block ib owns the 2 ib sub-tiles below its diagonal */
-template <typename T>
-__global__ void k_reduce_colslab_sub(const T *__restrict__ colslab, long pair_origin, int ib_begin, int ib_end, T *__restrict__ Kv) {
-    const int st = blockIdx.x;
-    const int l = threadIdx.x;  // 64 threads
-    T s = T(0);
-    for (int ib = max(st / 2 + 1, ib_begin); ib < ib_end; ++ib) {
-        const long rec = static_cast<long>(ib) * (ib - 1) - 2 * pair_origin + st;
-        s += colslab[rec * 64 + l];
+    for (; ib < ib_end; ib += G) s0 += rec(ib);
+    red[g][l] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0) {
+        T s = red[0][l];
+#pragma unroll
+        for (int k = 1; k < G; ++k) s += red[k][l];
+        Kv[c * W + l] += s;
     }
-    Kv[st * 64 + l] += s;
 }
 
 /* SYM: Kv[row_begin + i] = sum of the row slabs of the column chunks that exist for the row's block (chunks 0 .. ib / jc_tiles) */
@@ -1601,7 +1692,7 @@ template <typename T>
 __global__ void k_center(T *__restrict__ X, int ldx, int dfeat, int nrows, const T *__restrict__ mean, T scale) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
-    if (f < dfeat && i < nrows) X[static_cast<size_t>(i) * ldx + f] = (X[static_cast<size_t>(i) * ldx + f] - mean[f]) * scale;
+    if (f < dfeat && i < nrows) X[static_cast<size_t>(i) * ldx + f] = (X[static_cast<size_t>(i) * ldx + f] - (mean != nullptr ? mean[f] : T(0))) * scale;
 }
 /* c_i = -0.5 * |x_i|^2 (one wave per row, coalesced) */
 template <typename T>

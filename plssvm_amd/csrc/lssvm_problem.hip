@@ -424,6 +424,17 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
         center_columns<T>(X_, nullptr, rbf_prescale<T>(params_), stream_);
         half_neg_norms<T>(X_, c_, stream_);
     }
+    // polynomial in fp64 on the v2 kernel: fold gamma into the data (x' = sqrt(gamma) x, after q was computed from the raw data), so
+    // that the MFMA chain leaves gamma * <x_i, x_j> and the epilogue is the bare integer power -- every vector ALU instruction
+    // beside v_mfma_f64 costs matrix-core time (gamma > 0 is a precondition of the kernel, parameter.hpp / csvm.cpp:77)
+    if constexpr (std::is_same_v<T, double>) {
+        if (params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && v2_eligible_f64(X_.ldx) && params_.gamma > 0.0) {
+            hipLaunchKernelGGL(k_center<T>, dim3((X_.dfeat + 255) / 256, X_.rows), dim3(256), 0, stream_, X_.data.p, X_.ldx, X_.dfeat, X_.rows,
+                               static_cast<const T *>(nullptr), static_cast<T>(std::sqrt(params_.gamma)));
+            LSSVM_HIP_CHECK(hipGetLastError());
+            poly_prescaled_ = true;
+        }
+    }
     interleave_features<T>(X_, stream_);
     if ((std::is_same_v<T, float> && v2_eligible(X_.ldx, rbf_direct_)) || (std::is_same_v<T, double> && v2_eligible_f64(X_.ldx))) {
         dc_.alloc_zero(static_cast<size_t>(std::max(num_tiles_, 1)) * 256, stream_);  // (d_j | c_j) records: 256 reals per 128 columns
@@ -500,6 +511,7 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     a.jc_tiles = jc_tiles_;
     a.ncols_valid = n_;
     set_kernel_scalars(a, params_, rbf_direct_);
+    if (poly_prescaled_) a.gamma = T(1);
     return a;
 }
 
@@ -564,9 +576,9 @@ void Problem<T>::apply_K(const T *v_dev) {
             const int ib_end = ib_begin_ + num_ib_;
             if (ib_end > 1) {
                 if constexpr (std::is_same_v<T, float>) {
-                    hipLaunchKernelGGL(k_reduce_colslab<T>, dim3(ib_end - 1), dim3(TILE), 0, stream_, colslab_.p, pair_origin_, ib_begin_, ib_end, Kv_.p);
+                    hipLaunchKernelGGL((k_reduce_colslab<T, 128>), dim3(ib_end - 1), dim3(1024), 0, stream_, colslab_.p, pair_origin_, ib_begin_, ib_end, Kv_.p);
                 } else {  // fp64: records per 64-column sub-tile
-                    hipLaunchKernelGGL(k_reduce_colslab_sub<T>, dim3(2 * (ib_end - 1)), dim3(64), 0, stream_, colslab_.p, pair_origin_, ib_begin_, ib_end, Kv_.p);
+                    hipLaunchKernelGGL((k_reduce_colslab<T, 64>), dim3(2 * (ib_end - 1)), dim3(1024), 0, stream_, colslab_.p, pair_origin_, ib_begin_, ib_end, Kv_.p);
                 }
             }
         } else {

@@ -196,6 +196,7 @@ class Problem final : public ProblemBase {
     int jc_tiles_ = 16, num_jc_ = 1;
     int nvec_ = 0;  // allocated vector length (multiple of TILE * world)
     bool rbf_direct_ = false;
+    bool poly_prescaled_ = false;  // fp64 polynomial on the v2 kernel: X_ carries sqrt(gamma), the kernel sees gamma = 1
 
     DeviceMatrix<T> X_;
     DevBuf<T> c_;  // -0.5 |x|^2 (rbf, centred data)

@@ -6,6 +6,10 @@ import sys
 import numpy as np
 import pytest
 
+# The CPU oracle mirrors the reference's `omp atomic` updates; on a 128-core GPU box they contend so badly that small problems
+# run slower than on 8 cores.  Cap the oracle's threads for the tests (bench.py's cpu_baseline leg is a separate process setting).
+os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 for p in (ROOT, HERE):

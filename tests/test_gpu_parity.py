@@ -331,6 +331,14 @@ def test_symmetric_and_full_square_variants_agree(oracle, kernel, N, d, dtype):
     want = oracle.matvec(kernel, X, q, rhs, np.zeros(N - 1, dtype), QA, 1.0, 1.0, **kw)
     scale = np.max(np.abs(want))
     eps = np.finfo(dtype).eps
-    assert np.max(np.abs(out[1] - want)) < 64 * eps * scale and np.max(np.abs(out[0] - want)) < 64 * eps * scale
-    assert np.max(np.abs(out[1] - out[0])) < 64 * eps * scale
+    # yardstick: the distance of the oracle (run in `dtype`) from the same product in float64 with the same q -- a few thousand
+    # terms with cancellation make every fp32 evaluation order deviate by more than a fixed multiple of eps * max|result|
+    if dtype == np.float32:
+        truth = oracle.matvec(kernel, X.astype(np.float64), q.astype(np.float64), rhs.astype(np.float64), np.zeros(N - 1), float(QA), 1.0, 1.0, **kw)
+        tol = max(4.0 * np.max(np.abs(want - truth)), 64 * eps * scale)
+    else:
+        truth = want
+        tol = 64 * eps * scale
+    assert np.max(np.abs(out[1] - truth)) < tol and np.max(np.abs(out[0] - truth)) < tol
+    assert np.max(np.abs(out[1] - out[0])) < 2 * tol
     assert np.all(np.isfinite(out[("a", 1)]))

@@ -74,7 +74,15 @@ def perf(N=50000, d=128, kernel="rbf", dt=np.float32, iters=5):
 
 
 if __name__ == "__main__":
-    if "--sched" in sys.argv:
+    if "--ablate64" in sys.argv:
+        # fp64 v2 kernel (ablation build): 4 = no epilogue, 16 = no LDS-DMA after the prologue, 8 = no barrier
+        for kern in ("polynomial", "rbf", "linear"):
+            for dbg in (0, 4, 16, 20, 28):
+                _capi.set_option("debug_ablate", dbg)
+                print(f"debug_ablate={dbg}: ", end="")
+                perf(100000, 64, kern, np.float64, iters=4)
+        _capi.set_option("debug_ablate", 0)
+    elif "--sched" in sys.argv:
         # scheduling experiments on the symmetric kernels: phase shift of co-resident workgroups (ablation build only), item order,
         # items per column chunk
         for N in (50000, 100000):
