@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
     const int lane_base = (q >> 1) * 256 + r * 16 + (q & 1) * 8;
     auto read_group = [&](const char *slot, int s, double (&b)[4]) {
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) b[cb] = *reinterpret_cast<const double *>(slot + cb * 2048 + s * 512);
+        for (int cb = 0; cb < 4; ++cb) b[cb] = *((const volatile __attribute__((address_space(3))) double *) (slot + cb * 2048 + s * 512));  // volatile: keeps ds_read_b64 (a fused ds_read2st64_b64 is banked modulo 32 dwords: 2-way conflicts here)
     };
 
     double rowpart[2][4];
