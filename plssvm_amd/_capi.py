@@ -14,7 +14,7 @@ import numpy as np
 from .exceptions import BackendError, InvalidParameterError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libplssvm_amd.so")
+LIB_PATH = os.environ.get("PLSSVM_AMD_LIBRARY") or os.path.join(_HERE, "lib", "libplssvm_amd.so")  # (the variable lets a developer A/B two builds)
 
 LSSVM_DTYPE_F32 = 0
 LSSVM_DTYPE_F64 = 1

@@ -619,6 +619,8 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
                 if constexpr (KT == KT_RBF) cj[cb] = dcr[128 + cb * 32 + r];
                 if constexpr (KT == KT_POLY) padcol[cb] = (a.degree < 0) && ((jt_begin + t) * TILE + cb * 32 + r >= a.ncols_valid);
             }
+            // rbf: the accumulators start at c_i + c_j (vector adds; producing the sum with one extra MFMA per accumulator --
+            // A = (c_i, 1), B = (1, c_j) -- was measured 0.8 % slower at c5: the adds overlap with the other workgroup's MFMAs)
             if constexpr (KT == KT_RBF) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
@@ -628,12 +630,8 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
 #pragma unroll
                         for (int cb = 0; cb < 4; ++cb) acc[cb][4 * g4 + e] = civ[e] + cj[cb];
                 }
-            } else {
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[cb][i] = 0.0f;
             }
+            // the other kernels start the chain with the constant 0 as the C operand of the first MFMA (no v_mov per register)
         }
 #pragma unroll
         for (int kc = 0; kc < NKC; ++kc) {
@@ -667,7 +665,14 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
 #pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tt], bcur[cb][tt], acc[cb], 0, 0, 0);
+                    for (int cb = 0; cb < 4; ++cb) {
+                        if (KT != KT_RBF && kc == 0 && mm == 0 && tt == 0) {
+                            const f32x16 zero = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+                            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tt], bcur[cb][tt], zero, 0, 0, 0);
+                        } else {
+                            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tt], bcur[cb][tt], acc[cb], 0, 0, 0);
+                        }
+                    }
                     if constexpr (!decltype(checked)::value) {
                         if (mm >= 2 && (tt & 1) == 0) issue_chunk_part(step + 3, (mm - 2) * 2 + (tt >> 1));
                     }
