@@ -68,6 +68,43 @@ __global__ __launch_bounds__(256, 2) void k_loop(double *out, int steps, int rin
     out[blockIdx.x * 256 + tid] = sum;
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// fp32 counterpart: v_mfma_f32_32x32x2_f32, 4 accumulators, operands in registers; IVALU integer VALU ops, EXPS v_exp_f32 and
+// FMAS v_fma_f32 per MFMA
+template <int IVALU, int EXPS, int FMAS>
+__global__ __launch_bounds__(256, 2) void k_loop32(float *out, int steps) {
+    const int lane = threadIdx.x & 63;
+    f32x16 acc[4];
+    for (int cb = 0; cb < 4; ++cb)
+        for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+    float av[4], bv[4];
+    for (int i = 0; i < 4; ++i) {
+        av[i] = 1.f + 1e-3f * (lane + i);
+        bv[i] = 0.5f + 1e-3f * i;
+    }
+    int iv = lane;
+    float ev = 1e-3f * lane, fv = 1.0f + lane * 1e-6f;
+    for (int st = 0; st < steps; ++st) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tt], bv[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < IVALU; ++k) asm volatile("v_xor_b32 %0, 0x55, %0" : "+v"(iv));
+#pragma unroll
+                for (int k = 0; k < EXPS; ++k) asm volatile("v_exp_f32 %0, %0" : "+v"(ev));
+#pragma unroll
+                for (int k = 0; k < FMAS; ++k) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(fv) : "v"(ev));
+            }
+    }
+    float sum = ev + fv + iv;
+    for (int cb = 0; cb < 4; ++cb)
+        for (int i = 0; i < 16; ++i) sum += acc[cb][i];
+    out[blockIdx.x * 256 + threadIdx.x] = sum;
+}
+
 template <typename F>
 static double time_ms(F &&launch) {
     hipEvent_t a, b;
@@ -100,6 +137,17 @@ static void run(const char *what, double *buf, int cus) {
     }
 }
 
+template <int IVALU, int EXPS, int FMAS>
+static void run32(const char *what, double *buf, int cus) {
+    const int steps = 4000;
+    for (int wps = 1; wps <= 2; ++wps) {
+        const int blocks = cus * wps;
+        const double ms = time_ms([&] { hipLaunchKernelGGL((k_loop32<IVALU, EXPS, FMAS>), dim3(blocks), dim3(256), 0, 0, reinterpret_cast<float *>(buf), steps); });
+        const double flop = 2.0 * 32 * 32 * 2 * 16.0 * steps * (double) blocks * 4;
+        printf("%-64s %d wave/SIMD: %6.1f TFLOP/s\n", what, wps, flop / ms / 1e9);
+    }
+}
+
 int main() {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
@@ -118,5 +166,13 @@ int main() {
     run<0, 0, 1, 0>("f64 mfma + 1 v_fma_f64 per MFMA", buf, cus);
     run<0, 0, 2, 0>("f64 mfma + 2 v_fma_f64 per MFMA", buf, cus);
     run<0, 0, 4, 0>("f64 mfma + 4 v_fma_f64 per MFMA", buf, cus);
+    run32<0, 0, 0>("f32 mfma 32x32x2, operands in registers", buf, cus);
+    run32<1, 0, 0>("f32 mfma + 1 int VALU per MFMA", buf, cus);
+    run32<2, 0, 0>("f32 mfma + 2 int VALU per MFMA", buf, cus);
+    run32<4, 0, 0>("f32 mfma + 4 int VALU per MFMA", buf, cus);
+    run32<8, 0, 0>("f32 mfma + 8 int VALU per MFMA", buf, cus);
+    run32<0, 1, 0>("f32 mfma + 1 v_exp_f32 per MFMA", buf, cus);
+    run32<0, 1, 2>("f32 mfma + 1 v_exp_f32 + 2 v_fma_f32 per MFMA", buf, cus);
+    run32<0, 0, 4>("f32 mfma + 4 v_fma_f32 per MFMA", buf, cus);
     return 0;
 }
