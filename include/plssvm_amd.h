@@ -185,7 +185,8 @@ int lssvm_mi355_problem_info(lssvm_mi355_problem *p, lssvm_cg_info *info);
 /* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT):
  *   "rbf_form"      0 = norm expansion on the matrix cores (default), 1 = direct (x_i - x_j)^2 on the vector ALU
  *   "j_chunk_tiles" number of 128-column tiles per work item (default 16)
- *   "symmetric"     1 = evaluate only the kernel-matrix tiles on/below the diagonal and mirror them (default; fp32, num_features <= 256),
+ *   "symmetric"     1 = evaluate only the kernel-matrix tiles on/below the diagonal and mirror them (default; num_features <= 256 in fp32,
+ *                   <= 128 in fp64; a negative polynomial degree always runs the full square),
  *                   0 = full square (row-owned sums, results independent of the GPU count)
  *   "tile_kernel"   0 = automatic: fp32 with num_features <= 256 uses the "resident row panel" kernel (default), 1 = always the generic kernel
  *   "xcd_map"       1 = XCD-aware block -> work item mapping (8 x 8 super-tiles per XCD), 0 = linear (default)
@@ -193,7 +194,7 @@ int lssvm_mi355_problem_info(lssvm_mi355_problem *p, lssvm_cg_info *info);
  *   "debug_ablate"  timing-only ablation bits of the fp32 tile kernel; effective only in -DLSSVM_ENABLE_ABLATION builds
  *   "item_order"    symmetric variant: 0 = work items in column-chunk major order, 1 = the same with the short items that end on the
  *                   diagonal moved to the end, longest first (default: shortens the last dispatch round), 2 = 1 with row blocks descending
- *   "force_collective" 1 = run the per-matvec RCCL all-gather even with a world of 1 (testing aid; default 0)
+ *   "force_collective" 1 = run the per-matvec RCCL collective even with a world of 1 (testing aid; default 0)
  */
 int lssvm_mi355_set_option(const char *name, int64_t value);
 int lssvm_mi355_get_option(const char *name, int64_t *value_out);

@@ -454,18 +454,6 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
     const int ntiles = jt_end - jt_begin;
     if (ntiles <= 0) return;
     const int nsteps = ntiles * NKC;
-#ifdef LSSVM_ENABLE_ABLATION
-    {   // experiment: phase-shift the two workgroups that share a CU by about half a tile (first dispatch round only)
-        bool shift = false;
-        if (LSSVM_DBG(a, 32)) shift = blockIdx.x >= 256 && blockIdx.x < 512;
-        if (LSSVM_DBG(a, 64)) shift = blockIdx.x < 512 && (blockIdx.x & 1);
-        if (LSSVM_DBG(a, 128)) shift = blockIdx.x < 512 && ((blockIdx.x >> 3) & 1);
-        if (shift) {
-            __builtin_amdgcn_s_sleep(127);
-            __builtin_amdgcn_s_sleep(127);
-        }
-    }
-#endif
     // record index of (ib, jt) in the packed strictly-lower-triangular column slab of this device
     const long rec0 = SYM ? (static_cast<long>(ib) * (ib - 1) / 2 - a.pair_origin) : 0;
 

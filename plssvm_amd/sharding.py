@@ -2,10 +2,12 @@
 
 The reference splits the FEATURE dimension across devices, for the linear kernel only, and sums the partial results
 through the host (include/plssvm/backends/gpu_csvm.hpp:283-299, :449-475).  Here every rank (one process per GPU) owns a
-contiguous block of OUTPUT ROWS of the implicit matrix for all three kernels; the data matrix is replicated; one RCCL
-all-gather of the K*d slices per implicit matvec is the only exchange.  This module holds the partition arithmetic
-(identical to ``Problem<T>``'s constructor in plssvm_amd/csrc/lssvm_problem.hip) and the bootstrap of the library's RCCL
-communicator over an existing ``torch.distributed`` process group.
+contiguous run of 128-row blocks of the implicit matrix for all three kernels; the data matrix is replicated.  Default
+(symmetric variant: only the tiles on/below the diagonal are evaluated): blocks dealt by equal AREA, one RCCL all-reduce of
+the partial K*d vectors per implicit matvec.  Full-square variant: equal runs of blocks, one all-gather of the K*d slices.
+This module holds the partition arithmetic (identical to ``Problem<T>``'s constructor in plssvm_amd/csrc/lssvm_problem.hip),
+the flop accounting bench.py uses, and the bootstrap of the library's RCCL communicator over an existing
+``torch.distributed`` process group.
 """
 
 from __future__ import annotations

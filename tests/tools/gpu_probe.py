@@ -83,14 +83,8 @@ if __name__ == "__main__":
                 perf(100000, 64, kern, np.float64, iters=4)
         _capi.set_option("debug_ablate", 0)
     elif "--sched" in sys.argv:
-        # scheduling experiments on the symmetric kernels: phase shift of co-resident workgroups (ablation build only), item order,
-        # items per column chunk
+        # scheduling experiments on the symmetric kernels: item order, items per column chunk
         for N in (50000, 100000):
-            for dbg in (0, 32, 64, 128):
-                _capi.set_option("debug_ablate", dbg)
-                print(f"N={N} debug_ablate={dbg}: ", end="")
-                perf(N, 128, "rbf", np.float32, iters=6)
-            _capi.set_option("debug_ablate", 0)
             for order in (0, 1, 2):
                 for jt in (8, 16, 32):
                     _capi.set_option("item_order", order)
