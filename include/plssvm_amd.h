@@ -195,6 +195,8 @@ int lssvm_mi355_problem_info(lssvm_mi355_problem *p, lssvm_cg_info *info);
  *   "item_order"    symmetric variant: 0 = work items in column-chunk major order, 1 = the same with the short items that end on the
  *                   diagonal moved to the end, longest first (default: shortens the last dispatch round), 2 = 1 with row blocks descending
  *   "force_collective" 1 = run the per-matvec RCCL collective even with a world of 1 (testing aid; default 0)
+ *   "skip_collective"  1 = problems created with world > 1 need no communicator and do NOT exchange their partial K*v (testing aid:
+ *                      lets one GPU evaluate every rank's share in turn; default 0)
  */
 int lssvm_mi355_set_option(const char *name, int64_t value);
 int lssvm_mi355_get_option(const char *name, int64_t *value_out);

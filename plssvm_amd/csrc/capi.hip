@@ -271,6 +271,8 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
             lssvm::options().xcd_map = value != 0 ? 1 : 0;
         } else if (n == "force_collective") {
             lssvm::options().force_collective = value != 0 ? 1 : 0;
+        } else if (n == "skip_collective") {
+            lssvm::options().skip_collective = value != 0 ? 1 : 0;
         } else if (n == "item_order") {
             LSSVM_REQUIRE(value >= 0 && value <= 2, "item_order must be 0, 1 or 2");
             lssvm::options().item_order = value;
@@ -299,6 +301,8 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             *value_out = lssvm::options().xcd_map;
         } else if (n == "force_collective") {
             *value_out = lssvm::options().force_collective;
+        } else if (n == "skip_collective") {
+            *value_out = lssvm::options().skip_collective;
         } else if (n == "item_order") {
             *value_out = lssvm::options().item_order;
         } else {

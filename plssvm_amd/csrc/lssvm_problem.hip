@@ -358,7 +358,7 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
         LSSVM_REQUIRE(shard->world >= 1 && shard->rank >= 0 && shard->rank < shard->world, "invalid shard descriptor");
         rank_ = shard->rank;
         world_ = shard->world;
-        if (world_ > 1) {
+        if (world_ > 1 && options().skip_collective == 0) {
             LSSVM_REQUIRE(comm().comm != nullptr && comm().world == world_ && comm().rank == rank_,
                           "row-block sharding requested but lssvm_mi355_comm_init was not called with the same rank/world");
             LSSVM_REQUIRE(comm().device == device, "the communicator was created for another device");
@@ -548,8 +548,9 @@ void Problem<T>::apply_K(const T *v_dev) {
             }
         }
     }
-    const bool collective = world_ > 1 || (options().force_collective != 0 && comm().comm != nullptr && comm().world == 1);
-    if (sym_ && collective) {
+    const bool skip = world_ > 1 && options().skip_collective != 0;  // testing aid: this rank's share only
+    const bool collective = !skip && (world_ > 1 || (options().force_collective != 0 && comm().comm != nullptr && comm().world == 1));
+    if ((sym_ && collective) || skip) {
         // every rank adds row sums of its blocks and column sums into all earlier rows: start from zero, all-reduce at the end
         LSSVM_HIP_CHECK(hipMemsetAsync(Kv_.p, 0, static_cast<size_t>(nvec_) * sizeof(T), stream_));
     }

@@ -342,3 +342,42 @@ def test_symmetric_and_full_square_variants_agree(oracle, kernel, N, d, dtype):
     assert np.max(np.abs(out[1] - truth)) < tol and np.max(np.abs(out[0] - truth)) < tol
     assert np.max(np.abs(out[1] - out[0])) < 2 * tol
     assert np.all(np.isfinite(out[("a", 1)]))
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("sym", [1, 0])
+@pytest.mark.parametrize("kernel, dtype, N, d", [("rbf", np.float32, 3000, 128), ("linear", np.float32, 2100, 200), ("polynomial", np.float64, 2500, 64),
+                                                 ("rbf", np.float64, 1300, 40), ("polynomial", np.float32, 700, 9)])
+def test_every_ranks_share_on_one_gpu(kernel, dtype, N, d, sym, world):
+    """The sharded path (row blocks of rank r of `world`, offsets into the work-item list, the packed column slab, zero-initialised
+    partial vectors) evaluated rank by rank on ONE GPU with the exchange switched off (option skip_collective): the partial
+    products must add up to the unsharded product.  Every rank adds the rank-1 terms of A-bar itself, so the sum holds them
+    `world` times."""
+    X, _ = make_blobs_pm1(N, d, seed=33, dtype=dtype)
+    p = Parameter(kernel_type=kernel, cost=2.0)
+    n = N - 1
+    v = np.random.default_rng(9).uniform(-1, 1, size=n).astype(dtype)
+    zero = np.zeros(n, dtype)
+    _capi.set_option("symmetric", sym)
+    try:
+        with backend.ResidentProblem(p, X) as prob:
+            q, QA = prob.q()
+            single = prob.matvec(v, zero, 1.0)
+        _capi.set_option("skip_collective", 1)
+        total = np.zeros(n, np.float64)
+        shares = []
+        for rank in range(world):
+            with backend.ResidentProblem(p, X, rank=rank, world=world) as prob:
+                part = prob.matvec(v, zero, 1.0)
+                shares.append(float(np.max(np.abs(part))))
+                total += part
+    finally:
+        _capi.set_option("skip_collective", 0)
+        _capi.set_option("symmetric", 1)
+    q64, v64 = q.astype(np.float64), v.astype(np.float64)
+    S = v64.sum()
+    rank1 = v64 / 2.0 + (float(QA) * S - q64 @ v64) - S * q64  # v / C + (QA_cost * S - q.v) * 1 - S * q
+    got = total - (world - 1) * rank1
+    scale = np.max(np.abs(single)) + np.max(np.abs(rank1))
+    assert np.max(np.abs(got - single)) < 256 * np.finfo(dtype).eps * scale
+    assert all(s > 0 for s in shares[: min(world, (n + 127) // 128)])
