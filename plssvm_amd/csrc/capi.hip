@@ -255,7 +255,7 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
             LSSVM_REQUIRE(value == 0 || value == 1, "rbf_form must be 0 or 1");
             lssvm::options().rbf_form = value;
         } else if (n == "j_chunk_tiles") {
-            LSSVM_REQUIRE(value >= 1 && value <= (1 << 20), "j_chunk_tiles out of range");
+            LSSVM_REQUIRE(value >= 0 && value <= (1 << 20), "j_chunk_tiles out of range");
             lssvm::options().j_chunk_tiles = value;
         } else if (n == "symmetric") {
             lssvm::options().symmetric = value != 0 ? 1 : 0;

@@ -385,7 +385,16 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
         ib_begin_ = std::min(rank_ * ib_per_rank_, num_tiles_);
         num_ib_ = std::min(ib_begin_ + ib_per_rank_, num_tiles_) - ib_begin_;
     }
-    jc_tiles_ = static_cast<int>(std::max<int64_t>(1, options().j_chunk_tiles));
+    if (options().j_chunk_tiles > 0) {
+        jc_tiles_ = static_cast<int>(options().j_chunk_tiles);
+    } else {
+        // automatic: long chunks amortise a work item's prologue (row panel load) and keep its row sums in registers, but the grid
+        // must fill 256 CUs x 2 workgroups several times over.  Measured optimum (tests/tools/gpu_probe.py --small, 3 000 ... 50 000
+        // points): about 4096 work items, between 2 and 16 tiles each.
+        const long ib_end = ib_begin_ + num_ib_;
+        const long area = sym_ ? (ib_end * (ib_end + 1) - static_cast<long>(ib_begin_) * (ib_begin_ + 1)) / 2 : static_cast<long>(num_ib_) * num_tiles_;
+        jc_tiles_ = static_cast<int>(std::min<long>(16, std::max<long>(2, (area + 2048) / 4096)));
+    }
     num_jc_ = (num_tiles_ + jc_tiles_ - 1) / jc_tiles_;
     rbf_direct_ = (params_.kernel_type == LSSVM_KERNEL_RBF) && (options().rbf_form == 1) && std::is_same_v<T, float>;
     inv_cost_ = static_cast<double>(T(1) / static_cast<T>(params_.cost));  // "1 / params.cost" in real_type, csvm.cpp:297
@@ -830,7 +839,10 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     interleave_features<T>(P, s);
     const int num_jt = S.rows_alloc / TILE;
     const int num_ib = P.rows_alloc / TILE;
-    const int jc_tiles = static_cast<int>(std::max<int64_t>(1, options().j_chunk_tiles));
+    // column tiles per work item: the option, or automatically about 4096 work items (see Problem<T>'s constructor)
+    const int jc_tiles = options().j_chunk_tiles > 0
+                             ? static_cast<int>(options().j_chunk_tiles)
+                             : static_cast<int>(std::min<long>(16, std::max<long>(2, (static_cast<long>(num_ib) * num_jt + 2048) / 4096)));
     const int num_jc = (num_jt + jc_tiles - 1) / jc_tiles;
     DevBuf<T> a, partial, Kv, o;
     a.alloc_zero(S.rows_alloc, s);

@@ -55,7 +55,7 @@ struct Error : std::runtime_error {
 /* ------------------------------------------------------------------ options ------------------------------------------------------------------ */
 struct Options {
     int64_t rbf_form = 0;        // 0: norm expansion on the matrix cores, 1: direct (x_i - x_j)^2 on the vector ALU (fp32 only)
-    int64_t j_chunk_tiles = 16;  // 128-column tiles per work item
+    int64_t j_chunk_tiles = 0;   // 128-column tiles per work item; 0 = automatic (2 ... 16, about 4096 work items per device)
     int64_t symmetric = 1;         // 1: evaluate only the tiles on/below the diagonal and mirror them (fp32 v2 kernel), 0: full square
     int64_t tile_kernel = 0;       // 0: automatic (fp32: v2 'resident row panel' kernel when num_features <= 256), 1: always the generic v1 kernel
     int64_t xcd_map = 0;           // 1: XCD-aware work item mapping (8 x 8 super-tiles per XCD), 0: linear (default: measured equal, better balanced)

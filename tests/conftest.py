@@ -9,6 +9,9 @@ import pytest
 # The CPU oracle mirrors the reference's `omp atomic` updates; on a 128-core GPU box they contend so badly that small problems
 # run slower than on 8 cores.  Cap the oracle's threads for the tests (bench.py's cpu_baseline leg is a separate process setting).
 os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
+# idle OpenMP workers must sleep, not spin: once a test has imported torch its runtime's spinning threads starve the oracle's
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -24,6 +27,13 @@ PARAM_SETS = {
 KERNELS = ["linear", "polynomial", "rbf"]
 DATASETS = ["5x4", "blobs263x37", "500x200"]
 DTYPES = {"f32": np.float32, "f64": np.float64}
+
+
+def pytest_collection_modifyitems(config, items):
+    """Tests that import torch (and create an RCCL communicator) run last: see the OpenMP note above."""
+    late = [it for it in items if "test_gpu_interop" in it.nodeid]
+    if late:
+        items[:] = [it for it in items if "test_gpu_interop" not in it.nodeid] + late
 
 
 def pytest_configure(config):

@@ -75,7 +75,7 @@ def test_argument_validation_happens_without_a_device():
         _capi.check(_capi.lib.lssvm_mi355_generate_q_f64(C.byref(ps), _capi.ptr(X), C.c_size_t(4), C.c_size_t(3), _capi.ptr(np.zeros(3))))
     with pytest.raises(InvalidParameterError, match="unknown option"):
         _capi.set_option("no_such_option", 1)
-    assert _capi.get_option("rbf_form") == 0 and _capi.get_option("j_chunk_tiles") == 16
+    assert _capi.get_option("rbf_form") == 0 and _capi.get_option("j_chunk_tiles") == 0
 
 
 @pytest.mark.skipif(has_gpu, reason="only meaningful on a box without a GPU")

@@ -227,7 +227,7 @@ def test_results_are_bitwise_reproducible_and_independent_of_the_work_split(kern
         rhs = np.linspace(1, 2, 1499).astype(np.float32)
         m3 = backend.run_device_kernel(p, q, np.zeros(1499, np.float32), rhs, X, 2.0, 1.0)
     finally:
-        _capi.set_option("j_chunk_tiles", 16)
+        _capi.set_option("j_chunk_tiles", 0)
     m16 = backend.run_device_kernel(p, q, np.zeros(1499, np.float32), rhs, X, 2.0, 1.0)
     assert ol.rel_inf(m3, m16) < 16 * np.finfo(np.float32).eps
 

@@ -74,7 +74,15 @@ def perf(N=50000, d=128, kernel="rbf", dt=np.float32, iters=5):
 
 
 if __name__ == "__main__":
-    if "--ablate64" in sys.argv:
+    if "--small" in sys.argv:
+        # column-chunk length for small and mid-size problems (the grid must fill 256 CUs x 2 workgroups)
+        for N in (3000, 6400, 12800, 25600):
+            for jt in (1, 2, 4, 8, 16):
+                _capi.set_option("j_chunk_tiles", jt)
+                print(f"N={N} j_chunk_tiles={jt}: ", end="")
+                perf(N, 128, "rbf", np.float32, iters=20)
+        _capi.set_option("j_chunk_tiles", 0)
+    elif "--ablate64" in sys.argv:
         # fp64 v2 kernel (ablation build): 4 = no epilogue, 16 = no LDS-DMA after the prologue, 8 = no barrier
         for kern in ("polynomial", "rbf", "linear"):
             for dbg in (0, 4, 16, 20, 28):
@@ -92,14 +100,14 @@ if __name__ == "__main__":
                     print(f"N={N} item_order={order} j_chunk_tiles={jt}: ", end="")
                     perf(N, 128, "rbf", np.float32, iters=6)
             _capi.set_option("item_order", 1)
-            _capi.set_option("j_chunk_tiles", 16)
+            _capi.set_option("j_chunk_tiles", 0)
         for jt in (8, 16, 32):
             _capi.set_option("j_chunk_tiles", jt)
             print(f"j_chunk_tiles={jt}: ", end="")
             perf(100000, 64, "polynomial", np.float64, iters=6)
             print(f"j_chunk_tiles={jt}: ", end="")
             perf(100000, 64, "rbf", np.float64, iters=6)
-        _capi.set_option("j_chunk_tiles", 16)
+        _capi.set_option("j_chunk_tiles", 0)
     elif "--ablate2" in sys.argv:
         for dbg in (0, 1, 4, 5, 16, 20, 28):
             _capi.set_option("debug_ablate", dbg)
@@ -138,7 +146,7 @@ if __name__ == "__main__":
                     print(f"xcd_map={xm} j_chunk_tiles={jt}: ", end="")
                     perf(N, 128, "rbf", np.float32, iters=3 if N > 100000 else 8)
         _capi.set_option("xcd_map", 1)
-        _capi.set_option("j_chunk_tiles", 16)
+        _capi.set_option("j_chunk_tiles", 0)
     elif "--perf" in sys.argv:
         perf(50000, 128, "rbf", np.float32)
         perf(50000, 128, "linear", np.float32)
