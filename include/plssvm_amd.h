@@ -182,6 +182,19 @@ int lssvm_mi355_problem_synchronize(lssvm_mi355_problem *p);
 /* timing / counters accumulated since cg_begin (same struct as cg_finish fills); does not synchronize */
 int lssvm_mi355_problem_info(lssvm_mi355_problem *p, lssvm_cg_info *info);
 
+/* ---- LIBSVM data files (the input format of plssvm-train, include/plssvm/detail/io/libsvm_parsing.hpp:47-229) ----
+ * Multi-threaded fast path for WELL-FORMED files: `open` reads and validates the file (labels on every line or on none; one-based,
+ * strictly increasing indices; every token converts) and reports its shape, `fill` writes the dense row-major matrix (missing
+ * features = 0; ldx >= num_features, in elements) and the labels (always double; may be NULL; ignored for unlabelled files).  Any irregularity
+ * -> LSSVM_ERR_INVALID_ARGUMENT without a diagnosis: callers re-parse with their reference-exact parser for the error message
+ * (plssvm_amd/io_libsvm.py does).  Host code only, no device needed. */
+typedef struct lssvm_mi355_libsvm_file lssvm_mi355_libsvm_file;
+int lssvm_mi355_libsvm_open(const char *path, uint64_t skipped_lines, lssvm_mi355_libsvm_file **file_out, uint64_t *num_points, uint64_t *num_features,
+                            int *has_label);
+int lssvm_mi355_libsvm_fill_f32(lssvm_mi355_libsvm_file *file, float *X, uint64_t ldx, double *labels);
+int lssvm_mi355_libsvm_fill_f64(lssvm_mi355_libsvm_file *file, double *X, uint64_t ldx, double *labels);
+int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
+
 /* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT):
  *   "rbf_form"      0 = norm expansion on the matrix cores (default), 1 = direct (x_i - x_j)^2 on the vector ALU
  *   "j_chunk_tiles" number of 128-column tiles per work item; 0 = automatic (default: 2 ... 16, about 4096 work items per device)

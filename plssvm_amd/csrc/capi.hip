@@ -5,6 +5,8 @@
  */
 #include "lssvm_problem.hip.hpp"
 
+#include "libsvm_reader.hpp"
+
 #include <memory>
 #include <new>
 
@@ -309,6 +311,42 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "unknown option '" + n + "'");
         }
     });
+}
+
+/* ---- LIBSVM data files: fast reader for well-formed files (libsvm_reader.hpp) ---- */
+struct lssvm_mi355_libsvm_file {
+    lssvm::LibsvmFile impl;
+};
+
+int lssvm_mi355_libsvm_open(const char *path, uint64_t skipped_lines, lssvm_mi355_libsvm_file **file_out, uint64_t *num_points, uint64_t *num_features,
+                            int *has_label) {
+    return guarded([&] {
+        LSSVM_REQUIRE(path != nullptr && file_out != nullptr && num_points != nullptr && num_features != nullptr && has_label != nullptr,
+                      "path / output pointers must not be NULL");
+        *file_out = nullptr;
+        auto f = std::make_unique<lssvm_mi355_libsvm_file>();
+        if (!f->impl.open(path, skipped_lines)) throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, std::string("Couldn't find file: '") + path + "'!");
+        if (!f->impl.scan()) throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "not a well-formed LIBSVM data file for the fast reader");
+        *num_points = f->impl.num_points();
+        *num_features = f->impl.num_features();
+        *has_label = f->impl.has_label() ? 1 : 0;
+        *file_out = f.release();
+    });
+}
+int lssvm_mi355_libsvm_fill_f32(lssvm_mi355_libsvm_file *file, float *X, uint64_t ldx, double *labels) {
+    return guarded([&] {
+        LSSVM_REQUIRE(file != nullptr && X != nullptr, "file / X must not be NULL");
+        if (!file->impl.fill<float>(X, ldx, labels)) throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "not a well-formed LIBSVM data file for the fast reader");
+    });
+}
+int lssvm_mi355_libsvm_fill_f64(lssvm_mi355_libsvm_file *file, double *X, uint64_t ldx, double *labels) {
+    return guarded([&] {
+        LSSVM_REQUIRE(file != nullptr && X != nullptr, "file / X must not be NULL");
+        if (!file->impl.fill<double>(X, ldx, labels)) throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "not a well-formed LIBSVM data file for the fast reader");
+    });
+}
+int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file) {
+    return guarded([&] { delete file; });
 }
 
 }  // extern "C"

@@ -47,8 +47,46 @@ def _to_index(token: str) -> int:
     return int(t)
 
 
-def parse_libsvm_data(filename, dtype=np.float64, skipped_lines: int = 0, label_type=float):
+def _parse_native(filename, dtype, skipped_lines, label_type):
+    """Fast path: libplssvm_amd's multi-threaded reader for well-formed files (csrc/libsvm_reader.hpp).  Returns None when the
+    library is not built or the file is anything but plainly well formed -- the Python parser below then decides (and words
+    the error exactly like the reference)."""
+    dtype = np.dtype(dtype)
+    if label_type not in (float, int) or dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+        return None
+    try:
+        import ctypes as C
+
+        from . import _capi
+    except (ImportError, OSError):
+        return None
+    lib = _capi.lib
+    handle = C.c_void_p()
+    npts, nfeat, has_label = C.c_uint64(), C.c_uint64(), C.c_int()
+    if lib.lssvm_mi355_libsvm_open(os.fsencode(filename), C.c_uint64(skipped_lines), C.byref(handle), C.byref(npts), C.byref(nfeat), C.byref(has_label)) != 0:
+        return None
+    try:
+        X = np.empty((npts.value, nfeat.value), dtype=dtype)
+        y = np.empty(npts.value, dtype=np.float64) if has_label.value else None
+        fill = lib.lssvm_mi355_libsvm_fill_f32 if dtype == np.float32 else lib.lssvm_mi355_libsvm_fill_f64
+        if fill(handle, _capi.ptr(X), C.c_uint64(nfeat.value), _capi.ptr(y) if y is not None else None) != 0:
+            return None
+    finally:
+        lib.lssvm_mi355_libsvm_close(handle)
+    labels = None
+    if y is not None:
+        labels = [label_type(v) for v in y.tolist()]  # double, like float(token) in the Python path
+    return X, labels
+
+
+def parse_libsvm_data(filename, dtype=np.float64, skipped_lines: int = 0, label_type=float, use_native: bool = True):
     """Parse a LIBSVM file into ``(X[num_points, num_features], labels | None)`` (libsvm_parsing.hpp:118-229)."""
+    if not os.path.isfile(filename):
+        raise FileNotFoundPlssvmError(f"Couldn't find file: '{filename}'!")
+    if use_native:
+        fast = _parse_native(filename, dtype, skipped_lines, label_type)
+        if fast is not None:
+            return fast
     lines = read_lines(filename)[skipped_lines:]
     if not lines:
         raise InvalidFileFormatError("Can't parse file: no data points are given!")

@@ -86,3 +86,43 @@ def test_row_block_partition_covers_all_rows_once(n, world):
     assert max(sizes) <= -(-(-(-n // 128)) // world) * 128
     assert sharding.padded_vector_length(n, world) % (128 * world) == 0
     assert sharding.padded_vector_length(n, world) >= n
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_native_libsvm_reader_equals_python_parser(tmp_path, dtype):
+    """libplssvm_amd's multi-threaded reader (fast path for well-formed files) against the line-by-line Python parser, on the
+    reference's own data files' shapes: dense, sparse with gaps, unlabelled, comments and blank lines, CRLF, skipped lines."""
+    from plssvm_amd import _capi  # noqa: F401  (the library must be loadable for the fast path to be exercised)
+    from plssvm_amd.io_libsvm import _parse_native
+
+    cases = {
+        "dense": "1 1:0.5 2:-1.25e-3 3:7\n-1 1:1 2:2 3:3\n",
+        "sparse": "# header comment\n\n1 2:0.25 7:1e10\r\n  -1 1:3\n1 5:-0.0 9:4.5\n",
+        "unlabelled": "1:1.5 4:2\n2:3 3:4\n",
+        "float_labels": "0.5 1:1\n-2.25 2:1\n",
+    }
+    for name, text in cases.items():
+        f = tmp_path / f"{name}.libsvm"
+        f.write_text(text)
+        for skipped in (0, 1):
+            fast = _parse_native(str(f), dtype, skipped, float)
+            assert fast is not None, name
+            slow = parse_libsvm_data(f, dtype=dtype, skipped_lines=skipped, use_native=False)
+            assert fast[0].dtype == slow[0].dtype and np.array_equal(fast[0], slow[0]), name
+            assert fast[1] == slow[1], name
+    # a larger generated file: many lines per thread
+    g = tmp_path / "gen.libsvm"
+    generate_libsvm_file(g, 5000, 17, seed=3)
+    A, a = parse_libsvm_data(g, dtype=dtype)
+    B, b = parse_libsvm_data(g, dtype=dtype, use_native=False)
+    assert np.array_equal(A, B) and a == b
+
+
+@pytest.mark.parametrize("text", ["1 1:1 1:2\n", "1 0:1\n", "1 1:abc\n", "1 1:1\n2:2\n", "1 1:1 # trailing comment\n", "1\t1:2\n", "1 2:1 1:1\n", "x 1:1\n"])
+def test_native_libsvm_reader_declines_what_it_cannot_vouch_for(tmp_path, text):
+    """Irregular input is never accepted by the fast path: it reports failure and the Python parser decides."""
+    from plssvm_amd.io_libsvm import _parse_native
+
+    f = tmp_path / "bad.libsvm"
+    f.write_text(text)
+    assert _parse_native(str(f), np.float64, 0, float) is None
