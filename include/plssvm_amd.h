@@ -198,10 +198,10 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
 /* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT):
  *   "rbf_form"      0 = norm expansion on the matrix cores (default), 1 = direct (x_i - x_j)^2 on the vector ALU
  *   "j_chunk_tiles" number of 128-column tiles per work item; 0 = automatic (default: 2 ... 16, about 4096 work items per device)
- *   "symmetric"     1 = evaluate only the kernel-matrix tiles on/below the diagonal and mirror them (default; num_features <= 256 in fp32,
- *                   <= 128 in fp64; a negative polynomial degree always runs the full square),
+ *   "symmetric"     1 = evaluate only the kernel-matrix tiles on/below the diagonal and mirror them (default; num_features <= 512 in fp32,
+ *                   <= 256 in fp64; a negative polynomial degree always runs the full square),
  *                   0 = full square (row-owned sums, results independent of the GPU count)
- *   "tile_kernel"   0 = automatic: fp32 with num_features <= 256 uses the "resident row panel" kernel (default), 1 = always the generic kernel
+ *   "tile_kernel"   0 = automatic: the "resident row panel" kernels for num_features <= 512 (fp32) / 256 (fp64) (default), 1 = always the generic kernel
  *   "xcd_map"       1 = XCD-aware block -> work item mapping (8 x 8 super-tiles per XCD), 0 = linear (default)
  *   "lds_extra_kb"  experiment knob: extra dynamic LDS (KiB) per workgroup of the fp32 v2 kernel, lowers the workgroups per CU
  *   "debug_ablate"  timing-only ablation bits of the fp32 tile kernel; effective only in -DLSSVM_ENABLE_ABLATION builds

@@ -1,0 +1,172 @@
+/*
+ * lssvm_device_common.hip.hpp -- device helpers shared by the gfx950 kernels of the LS-SVM CG hot path: kernel functions
+ * (include/plssvm/kernel_function_types.hpp:75-97 of the reference), work-item decoding, scalar-base addressing for LDS-DMA.
+ * Everything here is a template or __forceinline__, so the header can be included by several translation units.
+ */
+#pragma once
+
+#include "lssvm_types.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <type_traits>
+
+/* timing-only ablations of the tile kernels (option "debug_ablate"); compiled in only with -DLSSVM_ENABLE_ABLATION so that the
+ * shipped kernels carry no extra branches */
+#ifdef LSSVM_ENABLE_ABLATION
+#define LSSVM_DBG(a, bit) (((a).dbg & (bit)) != 0)
+#else
+#define LSSVM_DBG(a, bit) false
+#endif
+
+namespace lssvm {
+
+using lds_ptr_t = __attribute__((address_space(3))) void *;
+using gbl_ptr_t = const __attribute__((address_space(1))) void *;
+
+/* integer power by repeated squaring; the reference uses pow(real, int) on the GPU (HIP/svm_kernel.hip.hpp:178) and
+ * std::pow(real, real(degree)) on the CPU (kernel_function_types.hpp:86-89): equal up to rounding for integer degrees. */
+template <typename T>
+__device__ __forceinline__ T ipow(T base, int degree) {
+    unsigned e = degree < 0 ? static_cast<unsigned>(-(long) degree) : static_cast<unsigned>(degree);
+    T result = T(1);
+    T b = base;
+    while (e != 0u) {
+        if (e & 1u) result *= b;
+        b *= b;
+        e >>= 1u;
+    }
+    return degree < 0 ? T(1) / result : result;
+}
+
+/* blockIdx.x -> (local row block, column chunk).
+ * map_mode 0: consecutive blocks walk the row blocks of one column chunk.
+ * map_mode 1 (XCD aware): the hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with a private
+ *   4 MiB L2 (placement is a speed matter only, never correctness).  The ids that land on one XCD are grouped into 8 x 8
+ *   super-tiles (8 row blocks x 8 column chunks), so that the ~64 workgroups resident on an XCD at a time re-read only 8
+ *   row panels (8 x d x 128 x s bytes) and share every column tile 8 ways -- instead of 64 distinct row panels that alone
+ *   overflow the L2. */
+template <typename T>
+__device__ __forceinline__ bool decode_work_item(const TileArgs<T> &a, int &ibl, int &jc) {
+    const int id = blockIdx.x;
+    if (a.map_mode == 0) {
+        ibl = id % a.num_ib;
+        jc = id / a.num_ib;
+        return true;
+    }
+    const int x = id & 7;
+    const int k = id >> 3;
+    const int l = k & 63;
+    const int S = (k >> 6) * 8 + x;  // super-tile index
+    const int si = S % a.super_i;
+    const int sj = S / a.super_i;
+    ibl = si * 8 + (l & 7);
+    jc = sj * 8 + (l >> 3);
+    return ibl < a.num_ib && jc < a.num_jc;
+}
+
+/* exp(x) in double for the rbf epilogue: 2^k * p(r), k = rint(x log2 e), r = x - k ln2 (two-part ln2), p = degree-13 Taylor
+ * polynomial on |r| <= 0.347 (truncation 4e-18), 19 double-precision VALU operations instead of libm's ~40 with its
+ * special-case branches; v_ldexp_f64 handles underflow to 0 for very negative x.  Relative error < 2 ulp. */
+__device__ __forceinline__ double fast_exp_f64(double x) {
+    const double k = __builtin_rint(x * 1.4426950408889634074);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;
+    p = fma(p, r, 2.08767569878681e-09);
+    p = fma(p, r, 2.505210838544172e-08);
+    p = fma(p, r, 2.755731922398589e-07);
+    p = fma(p, r, 2.7557319223985893e-06);
+    p = fma(p, r, 2.48015873015873e-05);
+    p = fma(p, r, 1.984126984126984e-04);
+    p = fma(p, r, 1.388888888888889e-03);
+    p = fma(p, r, 8.333333333333333e-03);
+    p = fma(p, r, 4.1666666666666664e-02);
+    p = fma(p, r, 1.6666666666666666e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return __builtin_ldexp(p, static_cast<int>(k));
+}
+
+/* DEG: polynomial degree class resolved OUTSIDE the per-element loop (a uniform switch around the whole epilogue):
+ * 3 = cube, 2 = square, 0 = generic integer power.  Ignored for the other kernels. */
+template <int KT, int DEG, typename T>
+__device__ __forceinline__ T apply_kernel_function(T acc, const TileArgs<T> &a) {
+    if constexpr (KT == KT_LINEAR) {
+        return acc;
+    } else if constexpr (KT == KT_POLY) {
+        const T v = acc * a.gamma + a.coef0;  // contracted to one fma, = std::fma(gamma, dot, coef0)
+        if constexpr (DEG == 3) {
+            return v * v * v;
+        } else if constexpr (DEG == 2) {
+            return v * v;
+        } else {
+            return ipow(v, a.degree);
+        }
+    } else {
+        if constexpr (std::is_same_v<T, float>) {
+            // fp32: the data was pre-scaled by sqrt(2*gamma*log2(e)) at set-up, so acc = -gamma*log2(e)*|xi-xj|^2 already
+            return __builtin_amdgcn_exp2f(acc);
+        } else {
+            return fast_exp_f64(acc * a.gamma);  // acc = -|xi-xj|^2 / 2 ; gamma field = 2*gamma
+        }
+    }
+}
+
+/* v^degree for the degree class DEG (3, 2, or 0 = any integer degree) */
+template <int DEG, typename T>
+__device__ __forceinline__ T poly_power(T v, int degree) {
+    if constexpr (DEG == 3) {
+        return v * v * v;
+    } else if constexpr (DEG == 2) {
+        return v * v;
+    } else {
+        return ipow(v, degree);
+    }
+}
+
+/* runs `body(std::integral_constant<int, DEG>)` with the polynomial degree class of `a` (one uniform branch per tile) */
+template <int KT, typename T, typename F>
+__device__ __forceinline__ void with_degree_class(const TileArgs<T> &a, F &&body) {
+    if constexpr (KT == KT_POLY) {
+        if (a.degree == 3) {
+            body(std::integral_constant<int, 3>{});
+        } else if (a.degree == 2) {
+            body(std::integral_constant<int, 2>{});
+        } else {
+            body(std::integral_constant<int, 0>{});
+        }
+    } else {
+        body(std::integral_constant<int, 0>{});
+    }
+}
+
+/* Pins a uniform pointer into an SGPR pair at this point of the program: "uniform base + 32-bit lane offset" is then selected
+ * as the saddr form of global_load_lds / global_store (no 64-bit vector address arithmetic, one VGPR per lane offset), and the
+ * compiler cannot re-associate the base into several vector adds. */
+__device__ __forceinline__ const char *sgpr_ptr(const void *p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<unsigned>(v))));  // (the builtin returns int:
+    const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<unsigned>(v >> 32))));  // no sign extension)
+    unsigned long long u = (static_cast<unsigned long long>(hi) << 32) | lo;
+    asm volatile("" : "+s"(u));
+    return reinterpret_cast<const char *>(u);
+}
+
+/* Keeps the 32-bit -> 64-bit extension of a lane offset in the basic block of its use (instruction selection is per block:
+ * a zext hoisted out of the loop hides the "SGPR base + 32-bit VGPR offset" addressing mode from it). */
+__device__ __forceinline__ unsigned lane_off(unsigned v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+/* The v2 kernels take the polynomial degree class as part of their kernel-type template parameter, so every instantiation
+ * carries ONE epilogue (the three-way runtime switch of with_degree_class made the register allocator budget for the generic
+ * integer-power path and spill in the cube path). */
+__host__ __device__ constexpr int v2_base_kt(int kt) { return (kt == KT_POLY2 || kt == KT_POLY3) ? KT_POLY : kt; }
+__host__ __device__ constexpr int v2_degree_class(int kt) { return kt == KT_POLY3 ? 3 : (kt == KT_POLY2 ? 2 : 0); }
+
+}  // namespace lssvm

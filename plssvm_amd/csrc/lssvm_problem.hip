@@ -65,190 +65,16 @@ int select_device_checked(int device) {
     return count;
 }
 
-/* ------------------------------------------------------------------ tile kernel launch ------------------------------------------------------------------ */
-template <typename K>
-static void ensure_dynamic_lds(K kernel, size_t bytes) {
-    // dynamic LDS above 64 KiB must be opted into once per kernel
-    LSSVM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+/* ------------------------------------------------------------------ tile kernel selection ------------------------------------------------------------------ */
+/* the v2 kernels exist for 1..8 and 10, 12, 14, 16 k-chunks (padded_features() never produces an odd count above 8) */
+static bool v2_chunk_count_ok(int kchunks) {
+    return kchunks <= 8 || (kchunks <= 16 && kchunks % 2 == 0);
 }
-
-/* fp32 v2 kernel (row panel in registers, LDS-DMA ring): eligible for ldx <= 256 */
-template <int KT, bool SYM>
-static void launch_v2_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
-    const dim3 block(TILE_THREADS);
-    const size_t V2_LDS_BYTES = lssvm::V2_LDS_BYTES + static_cast<size_t>(options().lds_extra_kb) * 1024;  // experiment knob: limits workgroups per CU
-    static size_t configured_for = 0;
-    if (configured_for != V2_LDS_BYTES) {
-        configured_for = V2_LDS_BYTES;
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 1, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 2, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 3, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 4, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 5, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 6, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 7, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 8, SYM>, V2_LDS_BYTES);
-    }
-    switch (a.kchunks) {
-        case 1: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 1, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 2: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 2, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 3: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 3, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 4: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 4, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 5: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 5, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 6: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 6, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 7: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 7, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        default: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 8, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-    }
-}
-
 bool v2_eligible(int ldx, bool rbf_direct) {
-    return !rbf_direct && ldx <= 8 * F32_KC && options().tile_kernel != 1;
+    return !rbf_direct && v2_chunk_count_ok(ldx / F32_KC) && options().tile_kernel != 1;
 }
 bool v2_eligible_f64(int ldx) {
-    return ldx <= 8 * F64_KC && options().tile_kernel != 1;
-}
-
-template <int KT, bool SYM>
-static void launch_v2d_kt(const TileArgs<double> &a, dim3 grid, hipStream_t s) {
-    const dim3 block(TILE_THREADS);
-    switch (a.kchunks) {
-        case 1: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 1, SYM>), grid, block, V2D_LDS_BYTES, s, a); break;
-        case 2: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 2, SYM>), grid, block, V2D_LDS_BYTES, s, a); break;
-        case 3: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 3, SYM>), grid, block, V2D_LDS_BYTES, s, a); break;
-        case 4: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 4, SYM>), grid, block, V2D_LDS_BYTES, s, a); break;
-        case 5: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 5, SYM>), grid, block, V2D_LDS_BYTES, s, a); break;
-        case 6: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 6, SYM>), grid, block, V2D_LDS_BYTES, s, a); break;
-        case 7: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 7, SYM>), grid, block, V2D_LDS_BYTES, s, a); break;
-        default: hipLaunchKernelGGL((tile_matvec_f64_v2<KT, 8, SYM>), grid, block, V2D_LDS_BYTES, s, a); break;
-    }
-}
-
-/* fills the block -> work item mapping fields and returns the grid size */
-template <typename T>
-static unsigned finish_mapping(TileArgs<T> &a, int num_jc) {
-    a.num_jc = num_jc;
-    a.dbg = static_cast<int>(options().debug_ablate);
-    a.map_mode = options().xcd_map != 0 ? 1 : 0;
-    a.super_i = (a.num_ib + 7) / 8;
-    if (a.map_mode == 0) return static_cast<unsigned>(a.num_ib) * static_cast<unsigned>(num_jc);
-    const long supers = static_cast<long>(a.super_i) * ((num_jc + 7) / 8);
-    return static_cast<unsigned>(((supers + 7) / 8) * 8 * 64);
-}
-
-template <>
-void launch_tile_kernel<float>(TileArgs<float> &a, int kernel_type, bool rbf_direct, int num_jc, hipStream_t s) {
-    const dim3 grid(a.num_ib > 0 && num_jc > 0 ? finish_mapping(a, num_jc) : 0u);
-    const dim3 block(TILE_THREADS);
-    if (grid.x == 0) return;
-    constexpr size_t lds = static_cast<size_t>(4) * TILE * F32_LS * sizeof(float) + TILE * sizeof(float);  // staging ring + c_i of the row block
-    static bool configured = false;
-    if (!configured) {
-        ensure_dynamic_lds(tile_matvec_f32<KT_LINEAR>, lds);
-        ensure_dynamic_lds(tile_matvec_f32<KT_POLY>, lds);
-        ensure_dynamic_lds(tile_matvec_f32<KT_RBF>, lds);
-        configured = true;
-    }
-    if (a.dc != nullptr && v2_eligible(a.ldx, rbf_direct)) {
-        if (a.items != nullptr) {  // symmetric variant: one block per listed work item
-            const dim3 sgrid(static_cast<unsigned>(a.num_items));
-            switch (kernel_type) {
-                case KT_LINEAR: launch_v2_kt<KT_LINEAR, true>(a, sgrid, s); break;
-                case KT_POLY:
-                    if (a.degree == 3) {
-                        launch_v2_kt<KT_POLY3, true>(a, sgrid, s);
-                    } else if (a.degree == 2) {
-                        launch_v2_kt<KT_POLY2, true>(a, sgrid, s);
-                    } else {
-                        launch_v2_kt<KT_POLY, true>(a, sgrid, s);
-                    }
-                    break;
-                default: launch_v2_kt<KT_RBF, true>(a, sgrid, s); break;
-            }
-        } else {
-            switch (kernel_type) {
-                case KT_LINEAR: launch_v2_kt<KT_LINEAR, false>(a, grid, s); break;
-                case KT_POLY:
-                    if (a.degree == 3) {
-                        launch_v2_kt<KT_POLY3, false>(a, grid, s);
-                    } else if (a.degree == 2) {
-                        launch_v2_kt<KT_POLY2, false>(a, grid, s);
-                    } else {
-                        launch_v2_kt<KT_POLY, false>(a, grid, s);
-                    }
-                    break;
-                default: launch_v2_kt<KT_RBF, false>(a, grid, s); break;
-            }
-        }
-        LSSVM_HIP_CHECK(hipGetLastError());
-        return;
-    }
-    switch (kernel_type) {
-        case KT_LINEAR: hipLaunchKernelGGL(tile_matvec_f32<KT_LINEAR>, grid, block, lds, s, a); break;
-        case KT_POLY: hipLaunchKernelGGL(tile_matvec_f32<KT_POLY>, grid, block, lds, s, a); break;
-        default:
-            if (rbf_direct) {
-                hipLaunchKernelGGL(tile_matvec_rbf_direct_f32, grid, block, 0, s, a);
-            } else {
-                hipLaunchKernelGGL(tile_matvec_f32<KT_RBF>, grid, block, lds, s, a);
-            }
-            break;
-    }
-    LSSVM_HIP_CHECK(hipGetLastError());
-}
-
-template <>
-void launch_tile_kernel<double>(TileArgs<double> &a, int kernel_type, bool /*rbf_direct*/, int num_jc, hipStream_t s) {
-    const dim3 grid(a.num_ib > 0 && num_jc > 0 ? finish_mapping(a, num_jc) : 0u);
-    const dim3 block(TILE_THREADS);
-    if (grid.x == 0) return;
-    constexpr size_t lds = static_cast<size_t>(4) * TILE * F64_LS * sizeof(double);
-    static bool configured = false;
-    if (!configured) {
-        ensure_dynamic_lds(tile_matvec_f64<KT_LINEAR>, lds);
-        ensure_dynamic_lds(tile_matvec_f64<KT_POLY>, lds);
-        ensure_dynamic_lds(tile_matvec_f64<KT_RBF>, lds);
-        configured = true;
-    }
-    if (a.dc != nullptr && v2_eligible_f64(a.ldx)) {  // V2D_LDS_BYTES < 64 KiB: no opt-in needed
-        if (a.items != nullptr) {
-            const dim3 sgrid(static_cast<unsigned>(a.num_items));
-            switch (kernel_type) {
-                case KT_LINEAR: launch_v2d_kt<KT_LINEAR, true>(a, sgrid, s); break;
-                case KT_POLY:
-                    if (a.degree == 3) {
-                        launch_v2d_kt<KT_POLY3, true>(a, sgrid, s);
-                    } else if (a.degree == 2) {
-                        launch_v2d_kt<KT_POLY2, true>(a, sgrid, s);
-                    } else {
-                        launch_v2d_kt<KT_POLY, true>(a, sgrid, s);
-                    }
-                    break;
-                default: launch_v2d_kt<KT_RBF, true>(a, sgrid, s); break;
-            }
-        } else {
-            switch (kernel_type) {
-                case KT_LINEAR: launch_v2d_kt<KT_LINEAR, false>(a, grid, s); break;
-                case KT_POLY:
-                    if (a.degree == 3) {
-                        launch_v2d_kt<KT_POLY3, false>(a, grid, s);
-                    } else if (a.degree == 2) {
-                        launch_v2d_kt<KT_POLY2, false>(a, grid, s);
-                    } else {
-                        launch_v2d_kt<KT_POLY, false>(a, grid, s);
-                    }
-                    break;
-                default: launch_v2d_kt<KT_RBF, false>(a, grid, s); break;
-            }
-        }
-        LSSVM_HIP_CHECK(hipGetLastError());
-        return;
-    }
-    switch (kernel_type) {
-        case KT_LINEAR: hipLaunchKernelGGL(tile_matvec_f64<KT_LINEAR>, grid, block, lds, s, a); break;
-        case KT_POLY: hipLaunchKernelGGL(tile_matvec_f64<KT_POLY>, grid, block, lds, s, a); break;
-        default: hipLaunchKernelGGL(tile_matvec_f64<KT_RBF>, grid, block, lds, s, a); break;
-    }
-    LSSVM_HIP_CHECK(hipGetLastError());
+    return v2_chunk_count_ok(ldx / F64_KC) && options().tile_kernel != 1;
 }
 
 /* kernel-function specific scalars of TileArgs */
@@ -374,7 +200,7 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
     ib_per_rank_ = (num_tiles_ + world_ - 1) / world_;
     nvec_ = ib_per_rank_ * world_ * TILE;
     // symmetric variant: v2 kernels only; a negative polynomial degree can give inf on zero-padded rows -> full square
-    const int ldx_probe = round_up(static_cast<long>(num_features), kchunk_of<T>());
+    const int ldx_probe = padded_features<T>(num_features);
     const bool v2_ok = std::is_same_v<T, float> ? (options().rbf_form == 0 && v2_eligible(ldx_probe, false)) : v2_eligible_f64(ldx_probe);
     sym_ = options().symmetric != 0 && v2_ok && !(params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree < 0);
     if (sym_) {

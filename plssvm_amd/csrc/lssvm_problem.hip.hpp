@@ -57,7 +57,7 @@ struct Options {
     int64_t rbf_form = 0;        // 0: norm expansion on the matrix cores, 1: direct (x_i - x_j)^2 on the vector ALU (fp32 only)
     int64_t j_chunk_tiles = 0;   // 128-column tiles per work item; 0 = automatic (2 ... 16, about 4096 work items per device)
     int64_t symmetric = 1;         // 1: evaluate only the tiles on/below the diagonal and mirror them (fp32 v2 kernel), 0: full square
-    int64_t tile_kernel = 0;       // 0: automatic (fp32: v2 'resident row panel' kernel when num_features <= 256), 1: always the generic v1 kernel
+    int64_t tile_kernel = 0;       // 0: automatic (v2 'resident row panel' kernels when num_features <= 512 in fp32 / 256 in fp64), 1: always the generic v1 kernel
     int64_t xcd_map = 0;           // 1: XCD-aware work item mapping (8 x 8 super-tiles per XCD), 0: linear (default: measured equal, better balanced)
     int64_t lds_extra_kb = 0;      // experiment knob: extra dynamic LDS per workgroup of the fp32 v2 kernel (lowers workgroups per CU)
     int64_t debug_ablate = 0;      // diagnostic timing ablations of the fp32 tile kernel (results are wrong when != 0)
@@ -116,6 +116,15 @@ constexpr int kchunk_of() {
     return std::is_same_v<T, float> ? F32_KC : F64_KC;
 }
 
+/* Padded feature count: a multiple of the k-chunk; between 8 and 16 chunks a multiple of TWO chunks, so that the v2 tile kernels
+ * (instantiated for 1..8 and 10, 12, 14, 16 chunks) cover num_features <= 512 in fp32 / <= 256 in fp64. */
+template <typename T>
+inline int padded_features(size_t nfeat) {
+    const int kc = kchunk_of<T>();
+    const int ldx = round_up(static_cast<long>(nfeat), kc);
+    return (ldx > 8 * kc && ldx <= 16 * kc) ? round_up(static_cast<long>(nfeat), 2 * kc) : ldx;
+}
+
 /* A dense row-major point set in HBM: rows padded to a multiple of 128, features padded to a multiple of the k-chunk
  * (zeros), so that every global load of the tile kernel is an aligned 16-byte load of a full 128-byte line. */
 template <typename T>
@@ -129,7 +138,7 @@ struct DeviceMatrix {
     void upload(const void *src, int mem_kind, size_t nrows, size_t nfeat, size_t min_rows_alloc, hipStream_t s) {
         rows = static_cast<int>(nrows);
         dfeat = static_cast<int>(nfeat);
-        ldx = round_up(static_cast<long>(nfeat), kchunk_of<T>());
+        ldx = padded_features<T>(nfeat);
         rows_alloc = std::max(round_up(static_cast<long>(nrows), TILE), round_up(static_cast<long>(min_rows_alloc), TILE));
         data.alloc_zero(static_cast<size_t>(rows_alloc) * ldx, s);
         LSSVM_HIP_CHECK(hipMemcpy2DAsync(data.p, static_cast<size_t>(ldx) * sizeof(T), src, nfeat * sizeof(T), nfeat * sizeof(T), nrows,
@@ -140,6 +149,10 @@ struct DeviceMatrix {
 /* ------------------------------------------------------------------ tile kernel launch ------------------------------------------------------------------ */
 template <typename T>
 void launch_tile_kernel(TileArgs<T> &a, int kernel_type, bool rbf_direct, int num_jc, hipStream_t s);
+template <>
+void launch_tile_kernel<float>(TileArgs<float> &a, int kernel_type, bool rbf_direct, int num_jc, hipStream_t s);   // tile_launch_f32.hip
+template <>
+void launch_tile_kernel<double>(TileArgs<double> &a, int kernel_type, bool rbf_direct, int num_jc, hipStream_t s);  // tile_launch_f64.hip
 
 /* centre `M` (and optionally `M2` with the same means) by the column means of M's valid rows; rbf only */
 template <typename T>

@@ -1,0 +1,29 @@
+/*
+ * tile_launch.hip.hpp -- host-side helpers shared by the two tile-kernel translation units (tile_launch_f32.hip,
+ * tile_launch_f64.hip): the kernels are compiled in two units so that the fp32 and fp64 instantiations build in parallel.
+ */
+#pragma once
+
+#include "lssvm_problem.hip.hpp"
+
+namespace lssvm {
+
+template <typename K>
+static void ensure_dynamic_lds(K kernel, size_t bytes) {
+    // dynamic LDS above 64 KiB must be opted into once per kernel
+    LSSVM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+}
+
+/* fills the block -> work item mapping fields and returns the grid size */
+template <typename T>
+static unsigned finish_mapping(TileArgs<T> &a, int num_jc) {
+    a.num_jc = num_jc;
+    a.dbg = static_cast<int>(options().debug_ablate);
+    a.map_mode = options().xcd_map != 0 ? 1 : 0;
+    a.super_i = (a.num_ib + 7) / 8;
+    if (a.map_mode == 0) return static_cast<unsigned>(a.num_ib) * static_cast<unsigned>(num_jc);
+    const long supers = static_cast<long>(a.super_i) * ((num_jc + 7) / 8);
+    return static_cast<unsigned>(((supers + 7) / 8) * 8 * 64);
+}
+
+}  // namespace lssvm

@@ -304,11 +304,12 @@ def test_predict_and_score_on_the_reference_fixture(kernel, dt):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("kernel", KERNELS)
-@pytest.mark.parametrize("N, d", [(300, 7), (1500, 40), (4097, 128), (2300, 200)])
+@pytest.mark.parametrize("N, d", [(300, 7), (1500, 40), (4097, 128), (2300, 200), (1100, 300), (900, 512), (700, 600)])
 def test_symmetric_and_full_square_variants_agree(oracle, kernel, N, d, dtype):
     """The default path evaluates only the tiles on/below the diagonal and mirrors them (as the reference does); the
     full-square variant (option symmetric=0) sums every row independently.  Both must match the oracle and each other.
-    (fp64 with more than 128 features runs the v1 kernel, which has no symmetric variant: both settings then take the same path.)"""
+    (More than 512 features in fp32 / 256 in fp64 run the v1 kernel, which has no symmetric variant: both settings then take the
+    same path.)"""
     X, y = make_blobs_pm1(N, d, seed=21, dtype=dtype)
     p = Parameter(kernel_type=kernel)
     rhs = np.random.default_rng(5).uniform(-1, 1, size=N - 1).astype(dtype)
@@ -326,7 +327,7 @@ def test_symmetric_and_full_square_variants_agree(oracle, kernel, N, d, dtype):
         finally:
             _capi.set_option("symmetric", 1)
     assert out[("sym", 0)] == 0
-    assert out[("sym", 1)] == (1 if (dtype == np.float32 or d <= 128) else 0)
+    assert out[("sym", 1)] == (1 if d <= (512 if dtype == np.float32 else 256) else 0)
     kw = dict(degree=3, gamma=1.0 / d, coef0=0.0)
     want = oracle.matvec(kernel, X, q, rhs, np.zeros(N - 1, dtype), QA, 1.0, 1.0, **kw)
     scale = np.max(np.abs(want))

@@ -74,7 +74,15 @@ def perf(N=50000, d=128, kernel="rbf", dt=np.float32, iters=5):
 
 
 if __name__ == "__main__":
-    if "--small" in sys.argv:
+    if "--wide" in sys.argv:
+        # more than 8 k-chunks: v2 kernels with 10..16 chunks against the generic v1 kernel
+        for (N, d, kern, dt) in ((60000, 384, "rbf", np.float32), (60000, 512, "linear", np.float32), (40000, 192, "polynomial", np.float64), (40000, 256, "rbf", np.float64)):
+            for tk in (0, 1):
+                _capi.set_option("tile_kernel", tk)
+                print(f"tile_kernel={tk}: ", end="")
+                perf(N, d, kern, dt, iters=4)
+        _capi.set_option("tile_kernel", 0)
+    elif "--small" in sys.argv:
         # column-chunk length for small and mid-size problems (the grid must fill 256 CUs x 2 workgroups)
         for N in (3000, 6400, 12800, 25600):
             for jt in (1, 2, 4, 8, 16):
