@@ -661,6 +661,18 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
         half_neg_norms<T>(S, cS, s);
         half_neg_norms<T>(P, cP, s);
     }
+    const bool v2 = std::is_same_v<T, float> ? v2_eligible(S.ldx, false) : v2_eligible_f64(S.ldx);
+    bool poly_prescaled = false;
+    if constexpr (std::is_same_v<T, double>) {
+        // the fp64 v2 kernel evaluates the polynomial on data that carries sqrt(gamma) (see Problem<T>'s constructor)
+        if (v2 && params.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params.gamma > 0.0) {
+            const T sc = static_cast<T>(std::sqrt(params.gamma));
+            hipLaunchKernelGGL(k_center<T>, dim3((S.dfeat + 255) / 256, S.rows), dim3(256), 0, s, S.data.p, S.ldx, S.dfeat, S.rows, static_cast<const T *>(nullptr), sc);
+            hipLaunchKernelGGL(k_center<T>, dim3((P.dfeat + 255) / 256, P.rows), dim3(256), 0, s, P.data.p, P.ldx, P.dfeat, P.rows, static_cast<const T *>(nullptr), sc);
+            LSSVM_HIP_CHECK(hipGetLastError());
+            poly_prescaled = true;
+        }
+    }
     interleave_features<T>(S, s);
     interleave_features<T>(P, s);
     const int num_jt = S.rows_alloc / TILE;
@@ -683,7 +695,20 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     ta.cr = cP.p;
     ta.cc = cS.p;
     ta.dvec = a.p;
-    ta.dc = nullptr;  // rectangular instance: generic (v1) tile kernel
+    // rectangular instance of the tile kernel (full square variant): the v2 kernel when the feature count allows, with the
+    // (alpha_j | c_j) records of the support vectors packed for its LDS-DMA
+    DevBuf<T> dc;
+    if (v2 && !(std::is_same_v<T, double> && params.kernel_type == LSSVM_KERNEL_POLYNOMIAL && !poly_prescaled)) {
+        dc.alloc_zero(static_cast<size_t>(num_jt) * 256, s);
+        const int ncols = num_jt * TILE;
+        if constexpr (std::is_same_v<T, float>) {
+            hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, s, a.p, cS.p, ncols, dc.p);
+        } else {
+            hipLaunchKernelGGL(k_pack_dc_f64, dim3((ncols + 255) / 256), dim3(256), 0, s, a.p, cS.p, ncols, dc.p);
+        }
+        LSSVM_HIP_CHECK(hipGetLastError());
+    }
+    ta.dc = dc.p;
     ta.partial = partial.p;
     ta.part_stride = P.rows_alloc;
     ta.ldx = S.ldx;
@@ -694,6 +719,7 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     ta.jc_tiles = jc_tiles;
     ta.ncols_valid = S.rows;
     set_kernel_scalars(ta, params, false);
+    if (poly_prescaled) ta.gamma = T(1);
     launch_tile_kernel<T>(ta, params.kernel_type, false, num_jc, s);
     hipLaunchKernelGGL(k_reduce_partials<T>, dim3((P.rows_alloc + 255) / 256), dim3(256), 0, s, partial.p, ta.part_stride, num_jc, 0, P.rows_alloc, Kv.p);
     hipLaunchKernelGGL(k_sub_rho<T>, dim3((P.rows + 255) / 256), dim3(256), 0, s, Kv.p, P.rows, rho, o.p);
