@@ -207,6 +207,8 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *   "debug_ablate"  timing-only ablation bits of the fp32 tile kernel; effective only in -DLSSVM_ENABLE_ABLATION builds
  *   "item_order"    symmetric variant: 0 = work items in column-chunk major order, 1 = the same with the short items that end on the
  *                   diagonal moved to the end, longest first (default: shortens the last dispatch round), 2 = 1 with row blocks descending
+ *   "colslab_limit_mb" the symmetric variant needs n_tiles^2 / 2 column records of 128 reals (15.6 GB at 1M points in fp32, divided
+ *                   by the number of ranks); above this many MiB per device the full square is evaluated instead (default 98304)
  *   "force_collective" 1 = run the per-matvec RCCL collective even with a world of 1 (testing aid; default 0)
  *   "skip_collective"  1 = problems created with world > 1 need no communicator and do NOT exchange their partial K*v (testing aid:
  *                      lets one GPU evaluate every rank's share in turn; default 0)

@@ -204,6 +204,13 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
     const bool v2_ok = std::is_same_v<T, float> ? (options().rbf_form == 0 && v2_eligible(ldx_probe, false)) : v2_eligible_f64(ldx_probe);
     sym_ = options().symmetric != 0 && v2_ok && !(params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree < 0);
     if (sym_) {
+        // the symmetric variant keeps one 128-entry record per evaluated off-diagonal tile (15.6 GB for 1M points in fp32, spread
+        // over the ranks by area).  Beyond the budget fall back to the full square -- a rule in n, world and sizeof(T) only, so
+        // that every rank of a sharded solve takes the same decision.
+        const double slab_bytes = 0.5 * static_cast<double>(num_tiles_) * static_cast<double>(num_tiles_) * TILE * sizeof(T) / static_cast<double>(world_);
+        if (slab_bytes > static_cast<double>(options().colslab_limit_mb) * 1048576.0) sym_ = false;
+    }
+    if (sym_) {
         // the work of row block ib is proportional to ib + 1 (tiles on or below the diagonal): equal AREAS per rank
         ib_begin_ = sym_block_boundary(num_tiles_, rank_, world_);
         num_ib_ = sym_block_boundary(num_tiles_, rank_ + 1, world_) - ib_begin_;

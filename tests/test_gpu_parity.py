@@ -382,3 +382,21 @@ def test_every_ranks_share_on_one_gpu(kernel, dtype, N, d, sym, world):
     scale = np.max(np.abs(single)) + np.max(np.abs(rank1))
     assert np.max(np.abs(got - single)) < 256 * np.finfo(dtype).eps * scale
     assert all(s > 0 for s in shares[: min(world, (n + 127) // 128)])
+
+
+def test_column_slab_budget_falls_back_to_the_full_square():
+    """Above the column-slab budget (option colslab_limit_mb; the default 96 GiB is reached near 2.5M points in fp32) the solver
+    evaluates the full square instead of failing to allocate."""
+    X, y = make_blobs_pm1(3000, 16, seed=4, dtype=np.float32)
+    p = Parameter(kernel_type="rbf")
+    with backend.ResidentProblem(p, X) as prob:
+        assert prob.info()["symmetric"] == 1
+        ref = prob.matvec(np.ones(2999, np.float32), np.zeros(2999, np.float32), 1.0)
+    _capi.set_option("colslab_limit_mb", 0)
+    try:
+        with backend.ResidentProblem(p, X) as prob:
+            assert prob.info()["symmetric"] == 0
+            got = prob.matvec(np.ones(2999, np.float32), np.zeros(2999, np.float32), 1.0)
+    finally:
+        _capi.set_option("colslab_limit_mb", 98304)
+    assert ol.rel_inf(got, ref) < 64 * np.finfo(np.float32).eps
