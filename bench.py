@@ -32,7 +32,7 @@ WORKLOADS = {
     "c5": dict(n=1_000_000, d=128, kernel="rbf", dtype="float32", desc="configs[4]: 1000000x128 rbf gamma=1/128 fp32"),
 }
 # dense matrix-core peaks of the arithmetic type (MI355X_MICROARCH.md, Chip-level parameters / Matrix cores)
-PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6}
+PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6, "bf16": 16 * 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md (bf16 = 16 x the f32 MFMA rate, ~2.5 PF)
 
 
 def cpu_baseline(X, y, kernel, sample_rows, iters):
@@ -155,6 +155,16 @@ def main():
     executed = exec_launch / kern_s / 1e12 if kern_ms > 0 else 0.0
     effective = square_launch / kern_s / 1e12 if kern_ms > 0 else 0.0
     peak = PEAK_TFLOPS[wl["dtype"]]
+    # fp32 default "bf16x6": every fp32 multiply-add runs as SIX bf16 plane products on v_mfma_f32_32x32x16_bf16 (exact 3-way split of
+    # the operands, fp32 accumulation, fp32-equivalent accuracy: DESIGN.md 4.1).  The roofline of that kernel is the dense bf16 MFMA
+    # peak (16 x the f32 MFMA rate, MI355X_MICROARCH.md "Matrix cores"), and the algorithm's own flop count is 6 x the fp32 count.
+    bf16x6 = bool(i1.get("gram_mode", 0))
+    plane_products = 6.0 if bf16x6 else 1.0
+    fp32_equivalent = achieved
+    if bf16x6:
+        peak = PEAK_TFLOPS["bf16"]
+        achieved *= plane_products
+        executed *= plane_products
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.isfile(tfile):
@@ -172,13 +182,16 @@ def main():
             "n_gpus": world, "steps": steps_done, "warmup": args.warmup, "ms_per_step": elapsed / max(steps_done, 1) * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if wl["dtype"] == "float32" else "f64", "data": "synthetic",
+            "arithmetic": ("fp32 operands split exactly into 3 bf16 planes, 6 plane products per multiply-add accumulated in fp32 on the bf16 matrix cores"
+                           if bf16x6 else "native " + wl["dtype"] + " matrix-core fma chains"),
             "config": {"workload": wl["desc"], "num_points": N, "num_features": d, "kernel": wl["kernel"], "gamma": 1.0 / d, "cost": 1.0,
                        "seed": args.seed, "parallelism": f"row-block sharding x{world}" if world > 1 else "single GPU",
                        "residuum_after_timed_steps": i1["residuum"]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "kernel": "lssvm::tile_matvec (implicit K*d tile kernel)", "launches": launches, "avg_launch_ms": kern_ms,
-                         "algorithmic_flop_per_launch": useful_launch, "symmetric": symmetric,
-                         "executed_flop_per_launch": exec_launch, "executed": executed, "executed_frac": executed / peak,
+                         "algorithmic_flop_per_launch": useful_launch * plane_products, "symmetric": symmetric,
+                         "executed_flop_per_launch": exec_launch * plane_products, "executed": executed, "executed_frac": executed / peak,
+                         "gram_mode": "bf16x6" if bf16x6 else "native", "fp32_equivalent": fp32_equivalent, "fp32_mfma_peak": PEAK_TFLOPS["float32"],
                          # the same launch priced with the full-square convention of `value` (can exceed the peak when symmetric)
                          "full_square_flop_per_launch": square_launch, "effective_full_square": effective},
         }

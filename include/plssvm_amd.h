@@ -74,7 +74,7 @@ typedef struct lssvm_cg_info {
     int32_t devices_used;    /* world size of the row-block sharding (1 = single GPU) */
     int32_t converged;       /* 1 if the stop test delta <= eps^2 * delta0 fired */
     int32_t symmetric;       /* 1 if the implicit matvec evaluated only the tiles on/below the diagonal (half the multiply-adds) */
-    int32_t reserved;
+    int32_t gram_mode;       /* fp32: 1 if the Gram tiles ran as the exact 3-way bf16 split on the bf16 matrix cores ("bf16x6"), else 0 */
 } lssvm_cg_info;
 
 /* ------------------------------------------------------------------------------------------------------------------ */
@@ -207,6 +207,9 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *   "debug_ablate"  timing-only ablation bits of the fp32 tile kernel; effective only in -DLSSVM_ENABLE_ABLATION builds
  *   "item_order"    symmetric variant: 0 = work items in column-chunk major order, 1 = the same with the short items that end on the
  *                   diagonal moved to the end, longest first (default: shortens the last dispatch round), 2 = 1 with row blocks descending
+ *   "gram_mode"     fp32, num_features <= 256: 1 = "bf16x6" (default): every operand is split EXACTLY into three bf16 planes and the
+ *                   six significant plane products are accumulated in fp32 on v_mfma_f32_32x32x16_bf16 -- fp32-equivalent accuracy,
+ *                   different summation order; 0 = Gram tiles on v_mfma_f32_32x32x2_f32 (exact fmaf chains)
  *   "colslab_limit_mb" the symmetric variant needs n_tiles^2 / 2 column records of 128 reals (15.6 GB at 1M points in fp32, divided
  *                   by the number of ranks); above this many MiB per device the full square is evaluated instead (default 98304)
  *   "force_collective" 1 = run the per-matvec RCCL collective even with a world of 1 (testing aid; default 0)

@@ -48,7 +48,7 @@ class LssvmCgInfo(C.Structure):
     _fields_ = [("iterations", C.c_uint64), ("max_iterations", C.c_uint64), ("residuum", C.c_double), ("initial_residuum", C.c_double),
                 ("target_residuum", C.c_double), ("epsilon", C.c_double), ("avg_iteration_ms", C.c_double), ("total_ms", C.c_double),
                 ("setup_ms", C.c_double), ("matvec_kernel_ms", C.c_double), ("matvec_launches", C.c_uint64), ("devices_used", C.c_int32),
-                ("converged", C.c_int32), ("symmetric", C.c_int32), ("reserved", C.c_int32)]
+                ("converged", C.c_int32), ("symmetric", C.c_int32), ("gram_mode", C.c_int32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

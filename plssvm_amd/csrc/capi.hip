@@ -273,6 +273,9 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
             lssvm::options().xcd_map = value != 0 ? 1 : 0;
         } else if (n == "force_collective") {
             lssvm::options().force_collective = value != 0 ? 1 : 0;
+        } else if (n == "gram_mode") {
+            LSSVM_REQUIRE(value == 0 || value == 1, "gram_mode must be 0 or 1");
+            lssvm::options().gram_mode = value;
         } else if (n == "colslab_limit_mb") {
             LSSVM_REQUIRE(value >= 0, "colslab_limit_mb must not be negative");
             lssvm::options().colslab_limit_mb = value;
@@ -306,6 +309,8 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             *value_out = lssvm::options().xcd_map;
         } else if (n == "force_collective") {
             *value_out = lssvm::options().force_collective;
+        } else if (n == "gram_mode") {
+            *value_out = lssvm::options().gram_mode;
         } else if (n == "colslab_limit_mb") {
             *value_out = lssvm::options().colslab_limit_mb;
         } else if (n == "skip_collective") {

@@ -169,4 +169,10 @@ __device__ __forceinline__ unsigned lane_off(unsigned v) {
 __host__ __device__ constexpr int v2_base_kt(int kt) { return (kt == KT_POLY2 || kt == KT_POLY3) ? KT_POLY : kt; }
 __host__ __device__ constexpr int v2_degree_class(int kt) { return kt == KT_POLY3 ? 3 : (kt == KT_POLY2 ? 2 : 0); }
 
+/* LDS geometry of the fp32 v2 kernels (tile_matvec_f32_v2, tile_matvec_f32_s6) */
+constexpr int V2_RING = 4;                       // chunk slots in LDS
+constexpr int V2_SLOT_BYTES = TILE * 32 * 4;     // 16 KiB
+constexpr int V2_DC_SLOTS = 4;                   // ring of per-tile (d_j | c_j) records, 1 KiB each
+constexpr size_t V2_LDS_BYTES = static_cast<size_t>(V2_RING) * V2_SLOT_BYTES + V2_DC_SLOTS * 1024 + (2 * TILE + 2 * 4 * TILE) * sizeof(float);  // ring + records + cis, dis, colred
+
 }  // namespace lssvm

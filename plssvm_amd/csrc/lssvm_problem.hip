@@ -277,6 +277,16 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
             poly_prescaled_ = true;
         }
     }
+    if constexpr (std::is_same_v<T, float>) {
+        // option gram_mode = 1: the (centred, scaled) data once more as three bf16 planes, features in natural order
+        const int ldx16 = round_up(static_cast<long>(num_features), 64);
+        if (options().gram_mode == 1 && !rbf_direct_ && v2_eligible(X_.ldx, false) && ldx16 <= 256) {
+            ldx16_ = ldx16;
+            const size_t plane_stride = static_cast<size_t>(X_.rows_alloc) * ldx16;
+            planes_.alloc_zero(3 * plane_stride, stream_);
+            split_bf16_planes(X_.data.p, X_.ldx, X_.dfeat, static_cast<size_t>(X_.rows_alloc), ldx16, planes_.p, plane_stride, stream_);
+        }
+    }
     interleave_features<T>(X_, stream_);
     if ((std::is_same_v<T, float> && v2_eligible(X_.ldx, rbf_direct_)) || (std::is_same_v<T, double> && v2_eligible_f64(X_.ldx))) {
         dc_.alloc_zero(static_cast<size_t>(std::max(num_tiles_, 1)) * 256, stream_);  // (d_j | c_j) records: 256 reals per 128 columns
@@ -339,6 +349,10 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     a.cc = c_.p;
     a.dvec = v_dev;
     a.dc = dc_.p;
+    a.Xr16 = planes_.p;
+    a.Xc16 = planes_.p;
+    a.plane_stride = static_cast<size_t>(X_.rows_alloc) * ldx16_;
+    a.ldx16 = ldx16_;
     a.items = sym_ ? items_.p : nullptr;
     a.num_items = num_items_;
     a.colslab = colslab_.p;
@@ -602,6 +616,7 @@ void Problem<T>::fill_info(lssvm_cg_info *info) {
     info->devices_used = world_;
     info->converged = converged_ ? 1 : 0;
     info->symmetric = sym_ ? 1 : 0;
+    info->gram_mode = planes_.p != nullptr ? 1 : 0;
 }
 
 template class Problem<float>;

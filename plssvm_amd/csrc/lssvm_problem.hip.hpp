@@ -62,6 +62,7 @@ struct Options {
     int64_t lds_extra_kb = 0;      // experiment knob: extra dynamic LDS per workgroup of the fp32 v2 kernel (lowers workgroups per CU)
     int64_t debug_ablate = 0;      // diagnostic timing ablations of the fp32 tile kernel (results are wrong when != 0)
     int64_t item_order = 1;        // symmetric variant, order of the work items: 0 column-chunk major, 1 = 0 with the short (diagonal) items moved to the end, longest first
+    int64_t gram_mode = 1;         // fp32, <= 256 features: 1 = exact 3-way bf16 split of the operands, six plane products on the bf16 MFMA (default), 0 = v_mfma_f32
     int64_t colslab_limit_mb = 98304;  // symmetric variant only while its column slab (per device) stays below this many MiB (96 GiB of the 288 GB)
     int64_t force_collective = 0;
     int64_t skip_collective = 0;   // testing aid: sharded problems (world > 1) need no communicator and leave their PARTIAL K*v un-exchanged  // testing aid: run the all-gather even for world == 1 (needs lssvm_mi355_comm_init(.., 0, 1, ..))
@@ -163,6 +164,7 @@ void half_neg_norms(const DeviceMatrix<T> &M, DevBuf<T> &c, hipStream_t s);
 template <typename T>
 void interleave_features(DeviceMatrix<T> &M, hipStream_t s);
 bool v2_eligible(int ldx, bool rbf_direct);
+void split_bf16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, uint16_t *planes, size_t plane_stride, hipStream_t s);  // tile_launch_f32s.hip
 bool v2_eligible_f64(int ldx);
 int sym_block_boundary(int num_tiles, int r, int world);
 
@@ -211,7 +213,9 @@ class Problem final : public ProblemBase {
     int jc_tiles_ = 16, num_jc_ = 1;
     int nvec_ = 0;  // allocated vector length (multiple of TILE * world)
     bool rbf_direct_ = false;
-    bool poly_prescaled_ = false;  // fp64 polynomial on the v2 kernel: X_ carries sqrt(gamma), the kernel sees gamma = 1
+    bool poly_prescaled_ = false;
+    DevBuf<uint16_t> planes_;      // gram_mode 1: X as three bf16 planes [3][rows_alloc][ldx16]
+    int ldx16_ = 0;  // fp64 polynomial on the v2 kernel: X_ carries sqrt(gamma), the kernel sees gamma = 1
 
     DeviceMatrix<T> X_;
     DevBuf<T> c_;  // -0.5 |x|^2 (rbf, centred data)

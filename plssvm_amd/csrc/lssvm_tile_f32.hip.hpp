@@ -239,10 +239,7 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32(const TileArg
  * Each wave multiplies its 32 rows with all 128 columns of the tile: 4 accumulators of 32x32, 64 MFMAs + 16 ds_read_b128
  * per chunk.
  * ===================================================================================================================== */
-constexpr int V2_RING = 4;                       // chunk slots in LDS
-constexpr int V2_SLOT_BYTES = TILE * 32 * 4;     // 16 KiB
-constexpr int V2_DC_SLOTS = 4;                   // ring of per-tile (d_j | c_j) records, 1 KiB each
-constexpr size_t V2_LDS_BYTES = static_cast<size_t>(V2_RING) * V2_SLOT_BYTES + V2_DC_SLOTS * 1024 + (2 * TILE + 2 * 4 * TILE) * sizeof(float);  // ring + records + cis, dis, colred
+// (V2_RING, V2_SLOT_BYTES, V2_DC_SLOTS, V2_LDS_BYTES: lssvm_device_common.hip.hpp -- shared with the split kernel)
 
 
 template <int KT, int NKC, bool SYM>

@@ -1,0 +1,375 @@
+/*
+ * lssvm_tile_f32_split.hip.hpp -- fp32 tile kernel on the bf16 matrix cores ("bf16x6", option gram_mode = 1, OPT-IN).
+ *
+ * Every fp32 operand is split EXACTLY into three bf16 planes, x = hi + mid + lo (8 + 8 + 8 mantissa bits), once at set-up
+ * (k_split_bf16x3).  The Gram tile is accumulated in fp32 from the six plane products of significance >= 2^-16,
+ *     hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid,
+ * on v_mfma_f32_32x32x16_bf16 (products of two bf16 are exact in fp32; the dropped products are below 2^-24 |x||y|, the size
+ * of one fp32 rounding).  Numerically this is an fp32 contraction with a different summation order: its distance from the
+ * float64 Gram matrix equals that of the v_mfma_f32_32x32x2_f32 chain (tests/test_gpu_parity.py asserts the
+ * same 32-eps kernel-level bar).  Why: the bf16 MFMA moves 16x the multiply-adds per instruction (6 of them = 3/8 of the time of
+ * the f32 MFMAs) AND, unlike the f32 MFMA, co-issues with the vector ALU (tests/tools/microbench_f64.hip), so the epilogue hides.
+ * Structure: tile_matvec_f32_v2 with (64-feature chunk, plane) as the step -- same LDS-DMA ring, swizzle, hand-over, records,
+ * epilogue and symmetric variant.  For num_features <= 256.
+ */
+#pragma once
+
+#include "lssvm_device_common.hip.hpp"
+
+namespace lssvm {
+
+template <int KT, int NK64, bool SYM>
+__global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec_f32_s6(const TileArgs<float> a) {
+    constexpr int NKC = 3 * NK64;  // plane-chunks (steps) per tile: for every 64-feature chunk the planes hi, mid, lo
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char *ring = smem_raw;                                                          // [V2_RING][128 rows][128 B]
+    char *dcs = smem_raw + V2_RING * V2_SLOT_BYTES;                                 // [V2_DC_SLOTS][256 floats]
+    float *cis = reinterpret_cast<float *>(dcs + V2_DC_SLOTS * 1024);               // [128] c_i of the row panel (rbf)
+    float *dis = cis + TILE;                                                        // [128] d_i of the row panel (SYM)
+    float *colred = dis + TILE;                                                     // [2][4 waves][128] column sums of a tile (SYM)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31;
+    const int h = lane >> 5;
+
+    // SYM: the kernel matrix is symmetric, so only the tiles on or below the diagonal are evaluated (as the reference does,
+    // svm_kernel.cpp:39); an off-diagonal tile K_IJ contributes K_IJ d_J to the rows of I AND K_IJ^T d_I to the rows of J.
+    // Work items come from a host-built list of the non-empty (row block, column chunk) pairs.
+    int ibl, jc;
+    if constexpr (SYM) {
+        const int2 it = a.items[blockIdx.x];
+        ibl = __builtin_amdgcn_readfirstlane(it.x);  // uniform, but loaded through the vector memory path: move to SGPRs so
+        jc = __builtin_amdgcn_readfirstlane(it.y);   // that everything derived from it is scalar arithmetic
+    } else {
+        if (!decode_work_item(a, ibl, jc)) return;
+    }
+    const int ib = a.ib_begin + ibl;
+    const int row0 = ib * TILE;
+    const int jt_begin = jc * a.jc_tiles;
+    const int jt_end = SYM ? min(jt_begin + a.jc_tiles, ib + 1) : min(jt_begin + a.jc_tiles, a.num_jt);
+    const int ntiles = jt_end - jt_begin;
+    if (ntiles <= 0) return;
+    const int nsteps = ntiles * NKC;
+    // record index of (ib, jt) in the packed strictly-lower-triangular column slab of this device
+    const long rec0 = SYM ? (static_cast<long>(ib) * (ib - 1) / 2 - a.pair_origin) : 0;
+
+    // ---- the row panel: A fragments of this wave's 32 rows, all features, all three planes: lane (r, h) holds features
+    // 16 s + 8 h .. + 7 of row r for k-step s (cdna_hip_programming.md, operand map of v_mfma_f32_32x32x16_bf16) ----
+    bf16x8 afrag[3][4 * NK64];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const uint16_t *xr = a.Xr16 + p * a.plane_stride + static_cast<size_t>(row0 + wave * 32 + r) * a.ldx16 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4 * NK64; ++s) afrag[p][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(xr + 16 * s));
+    }
+    if constexpr (KT == KT_RBF) {
+        if (tid < TILE) cis[tid] = a.cr[row0 + tid];
+    }
+    if constexpr (SYM) {
+        if (tid < TILE) dis[tid] = a.dvec[row0 + tid];
+    }
+    // make the compiler retire these ordinary loads HERE, before any LDS-DMA is in flight
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int s = 0; s < 4 * NK64; ++s) asm volatile("" : "+v"(afrag[p][s]));
+
+    // ---- LDS-DMA addressing ----
+    // instruction q = 4*wave + i moves rows 8q .. 8q+7 of a chunk; lane L -> row 8q + L/8, physical 16-B slot L%8, which
+    // holds logical slot (L%8) ^ ((row >> 1) & 7)
+    // The source address of a DMA is (uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset): the saddr form of
+    // global_load_lds, so a piece costs no 64-bit vector address arithmetic and one VGPR
+    unsigned dma_off[4];  // byte offset of this lane's 16 bytes inside a (tile, chunk) = 4 * (row * ldx + 4 * logical_slot)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * (4 * wave + i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        dma_off[i] = 2u * static_cast<unsigned>(row * a.ldx16 + 8 * c);
+    }
+    auto issue_chunk = [&](int step) {  // step = linear (tile, chunk) index of this work item
+        if (LSSVM_DBG(a, 16) && step > 3) return;  // ablation: no DMA after the prologue
+        const int t = LSSVM_DBG(a, 1) ? 0 : step / NKC;  // ablation bit 1: always the same (L2-resident) tile
+        const int kc = LSSVM_DBG(a, 1) ? 0 : step - t * NKC;
+        const char *base = sgpr_ptr(a.Xc16 + (kc % 3) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (kc / 3) * 64);
+        char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + lane_off(dma_off[i])), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
+        }
+    };
+    // one of the four DMA instructions of a chunk (steady state: spread over the MFMA groups that follow the hand-over, an
+    // LDS-DMA issue costs the wave ~60-100 cycles, MI355X_MICROARCH.md "LDS-DMA piece issue cost")
+    auto issue_chunk_part = [&](int step, int i) {
+        const int t = step / NKC;
+        const int kc = step - t * NKC;
+        const char *base = sgpr_ptr(a.Xc16 + (kc % 3) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (kc / 3) * 64);
+        char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES + wave * 4096;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + lane_off(dma_off[i])), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
+    };
+    auto issue_dc = [&](int t) {  // (d_j | c_j) of tile jt_begin + t: 1 KiB, each wave moves a quarter with 16 lanes
+        if (lane < 16) {
+            const char *src = sgpr_ptr(a.dc + static_cast<size_t>(jt_begin + t) * 256) + __builtin_amdgcn_readfirstlane(wave * 256);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (src + 16u * (lane_off(threadIdx.x) & 15u)), (lds_ptr_t) (dcs + (t % V2_DC_SLOTS) * 1024 + wave * 256), 16, 0, 0);
+        }
+    };
+
+    // ---- read addressing: lane (r, h) reads 16-B logical slot 2*mm + h of row cb*32 + r (swizzle depends on r only) ----
+    int rd_off[4];
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) rd_off[mm] = r * 128 + (((2 * mm + h) ^ ((r >> 1) & 7)) << 4);
+
+    float rowpart[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rowpart[i] = 0.0f;
+    f32x16 acc[4];
+    float dj[4], cj[4];
+    bool padcol[4] = { false, false, false, false };
+
+    // ---- prologue: chunks 0, 1, 2 (each preceded by the record of the tile that starts with it) ----
+    issue_dc(0);
+    issue_chunk(0);
+#pragma unroll
+    for (int pre = 1; pre <= 2; ++pre) {
+        if (pre < nsteps) {
+            if (pre % NKC == 0) issue_dc(pre / NKC);
+            issue_chunk(pre);
+        }
+    }
+    // chunk 0 (and record 0, and cis) complete: everything but the DMA instructions of the younger chunks is done
+    if (nsteps >= 3) {
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    } else if (nsteps == 2) {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    f32x4 bcur[4];  // B fragments of the group about to be multiplied (double buffered against bnext in the loop)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) bcur[cb] = *reinterpret_cast<const f32x4 *>(ring + cb * 4096 + rd_off[0]);
+
+    // ---- hand-over of the NEXT chunk, executed in the MIDDLE of a step (in the shadow of that step's MFMAs) ----
+    // Called half-way through step `step`: this wave's DMA of chunk step+1 (issued 2 steps ago) is complete once all but its
+    // 4 youngest DMA instructions (chunk step+2) are done; the barrier makes every wave's part visible, so the next step
+    // starts reading at once, with no wait and no barrier at its head.  Ring of 4 slots: the DMA issued here (chunk step+3)
+    // overwrites the slot of chunk step-1, which every wave finished reading before it arrived at this barrier.
+    // CHECKED = false: steady state, step + 3 < nsteps is known, the code is branch free (one basic block per tile, so the
+    // compiler can place the scalar address arithmetic and the DMA issue in the shadow of the MFMAs); CHECKED = true: the
+    // last tiles of the work item.
+    auto handover = [&](int step, int kc_plus3_mod, auto checked) {
+        constexpr bool CHECKED = decltype(checked)::value;
+        if constexpr (!CHECKED) {
+            if (!LSSVM_DBG(a, 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (!LSSVM_DBG(a, 8)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // the record of a tile is issued right BEFORE the first chunk of that tile: "chunk landed" implies "record landed"
+            if (kc_plus3_mod == 0) issue_dc((step + 3) / NKC);
+            // the four DMA instructions of chunk step+3 follow one by one between the MFMAs of this step's second half
+        } else {
+            if (step + 1 < nsteps) {
+                if (step + 2 < nsteps) {
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (step + 3 < nsteps) {
+                    if (kc_plus3_mod == 0) issue_dc((step + 3) / NKC);
+                    issue_chunk(step + 3);
+                }
+            }
+        }
+    };
+
+    // SYM: the four waves' column sums of tile t (written to colred by its epilogue, made visible by the next barrier) are
+    // added in a fixed order and stored to the tile's record of the column slab
+    auto flush_cols = [&](int t) {
+        if (tid < TILE) {
+            const float *cr_ = colred + (t & 1) * 512;
+            const float sum = (cr_[tid] + cr_[128 + tid]) + (cr_[256 + tid] + cr_[384 + tid]);
+            float *rec = a.colslab + (rec0 + jt_begin + t) * TILE;  // uniform base + 32-bit lane offset
+            rec[static_cast<unsigned>(tid)] = sum;
+        }
+    };
+
+    auto tile_body = [&](int t, auto checked) {
+        const int s0 = t * NKC;
+        const bool tile_sym = SYM && (jt_begin + t < ib);  // strictly below the diagonal
+        {
+            // tile_init: per-lane column data + accumulator start values (the record became visible at the last hand-over)
+            const float *dcr = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                dj[cb] = dcr[cb * 32 + r];
+                if constexpr (KT == KT_RBF) cj[cb] = dcr[128 + cb * 32 + r];
+                if constexpr (KT == KT_POLY) padcol[cb] = (a.degree < 0) && ((jt_begin + t) * TILE + cb * 32 + r >= a.ncols_valid);
+            }
+            // rbf: the accumulators start at c_i + c_j (vector adds; producing the sum with one extra MFMA per accumulator --
+            // A = (c_i, 1), B = (1, c_j) -- was measured 0.8 % slower at c5: the adds overlap with the other workgroup's MFMAs)
+            if constexpr (KT == KT_RBF) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 civ = *reinterpret_cast<const f32x4 *>(cis + wave * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int cb = 0; cb < 4; ++cb) acc[cb][4 * g4 + e] = civ[e] + cj[cb];
+                }
+            }
+            // the other kernels start the chain with the constant 0 as the C operand of the first MFMA (no v_mov per register)
+        }
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            const int step = s0 + kc;
+            const char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES;
+            const char *slot_next = ring + ((step + 1) % V2_RING) * V2_SLOT_BYTES;
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+                // software prefetch of the NEXT group's B fragments (next chunk for mm == 3: visible since this step's hand-over),
+                // issued before the hand-over barrier so that LDS latency and barrier skew hide behind the 16 MFMAs below
+                f32x4 bnext[4];
+                if (mm < 3) {
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) bnext[cb] = *reinterpret_cast<const f32x4 *>(slot + cb * 4096 + rd_off[mm + 1]);
+                }
+                if (mm == 2) {
+                    if constexpr (SYM) {
+                        // the colred writes of the previous tile's epilogue must have completed before the barrier publishes them
+                        if (kc == 0 && t > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    handover(step, (kc + 3) % NKC, checked);
+                    if constexpr (SYM) {
+                        if (kc == 0 && t > 0) flush_cols(t - 1);  // every tile before the last one of an item is off-diagonal
+                    }
+                }
+                if (mm == 3) {
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) bnext[cb] = *reinterpret_cast<const f32x4 *>(slot_next + cb * 4096 + rd_off[0]);
+                }
+                // plane p of the column chunk meets the row planes q with p + q <= 2: hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid --
+                // every product of significance >= 2^-16 relative to x*y, the dropped ones (mid*lo, lo*mid, lo*lo) are below 2^-24
+                const int chunk = kc / 3, plane = kc % 3;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if (q + plane > 2) continue;
+                    const bf16x8 av = afrag[q][4 * chunk + mm];
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        const bf16x8 bv = __builtin_bit_cast(bf16x8, bcur[cb]);
+                        if (KT != KT_RBF && kc == 0 && mm == 0 && q == 0) {
+                            const f32x16 zero = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+                            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, zero, 0, 0, 0);
+                        } else {
+                            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[cb], 0, 0, 0);
+                        }
+                        if constexpr (!decltype(checked)::value) {
+                            if (q == 0 && mm >= 2 && (cb & 1) == 0) issue_chunk_part(step + 3, (mm - 2) * 2 + (cb >> 1));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) bcur[cb] = bnext[cb];
+            }
+        }
+        // epilogue of the tile: K_ij = f(acc), row partial += K_ij * d_j; SYM, off-diagonal tile: column partial += K_ij * d_i
+        // (vector ALU, fused; the Gram tile itself is never written)
+        if (!LSSVM_DBG(a, 4))
+        {  // (the polynomial degree class is a template parameter here: KT_POLY2 / KT_POLY3 / generic KT_POLY)
+            auto epilogue = [&](auto with_cols) {
+                constexpr bool COLS = decltype(with_cols)::value;
+                float di[16];
+                float colacc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+                if constexpr (COLS) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4 dv = *reinterpret_cast<const f32x4 *>(dis + wave * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) di[4 * g4 + e] = dv[e];
+                    }
+                }
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float kv = apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(acc[cb][i], a);
+                        if constexpr (KT == KT_POLY) {
+                            if (padcol[cb]) kv = 0.0f;
+                        }
+                        rowpart[i] = fmaf(kv, dj[cb], rowpart[i]);
+                        if constexpr (COLS) colacc[cb] = fmaf(kv, di[i], colacc[cb]);
+                    }
+                if constexpr (COLS) {
+                    float *cw = colred + (t & 1) * 512 + wave * 128;
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        const float v = colacc[cb] + __shfl_xor(colacc[cb], 32);  // the two lane halves hold different rows
+                        if (h == 0) cw[cb * 32 + r] = v;
+                    }
+                }
+            };
+            if (tile_sym) {
+                epilogue(std::true_type{});
+            } else {
+                epilogue(std::false_type{});
+            }
+        }
+    };
+
+    // steady state: every tile whose last step still has step + 3 < nsteps; then the (1..3) tail tiles with the checked hand-over
+    constexpr int TAIL_TILES = (3 + NKC - 1) / NKC;
+    const int nmain = ntiles > TAIL_TILES ? ntiles - TAIL_TILES : 0;
+    int t = 0;
+    for (; t < nmain; ++t) tile_body(t, std::false_type{});
+    for (; t < ntiles; ++t) tile_body(t, std::true_type{});
+    if constexpr (SYM) {
+        if (jt_begin + ntiles - 1 < ib) {  // the last tile was off-diagonal: publish its column sums
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            flush_cols(ntiles - 1);
+        }
+    }
+
+    // every wave owns its rows: reduce over the 32 lanes of a lane-half and store
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float v = rowpart[i];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 1);
+        rowpart[i] = v;
+    }
+    if (r == 0) {
+        float *dst = a.partial + static_cast<size_t>(jc) * a.part_stride + ibl * TILE + wave * 32 + 4 * h;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[(i & 3) + 8 * (i >> 2)] = rowpart[i];
+    }
+}
+
+/* x = hi + mid + lo, each rounded to nearest-even bf16 of the remainder (exact: the remainders are representable in fp32).
+ * X: [rows][ldx] fp32, features in natural order; planes: [3][rows][ldx16] bf16, zero padded. */
+__global__ void k_split_bf16x3(const float *__restrict__ X, int ldx, int dfeat, size_t rows, int ldx16, uint16_t *__restrict__ planes, size_t plane_stride) {
+    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t total = rows * static_cast<size_t>(ldx16);
+    if (idx >= total) return;
+    const size_t row = idx / ldx16;
+    const int f = static_cast<int>(idx - row * ldx16);
+    const float x = f < dfeat ? X[row * ldx + f] : 0.0f;
+    const __bf16 hi = static_cast<__bf16>(x);
+    const float r1 = x - static_cast<float>(hi);
+    const __bf16 mid = static_cast<__bf16>(r1);
+    const float r2 = r1 - static_cast<float>(mid);
+    const __bf16 lo = static_cast<__bf16>(r2);
+    planes[idx] = __builtin_bit_cast(uint16_t, hi);
+    planes[plane_stride + idx] = __builtin_bit_cast(uint16_t, mid);
+    planes[2 * plane_stride + idx] = __builtin_bit_cast(uint16_t, lo);
+}
+
+}  // namespace lssvm

@@ -22,6 +22,7 @@ constexpr int TILE_THREADS = 256;  // 4 wave64 arranged 2 x 2, each owning a 64 
 
 using f32x4 = float __attribute__((ext_vector_type(4)));
 using f32x16 = float __attribute__((ext_vector_type(16)));
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
 using f64x2 = double __attribute__((ext_vector_type(2)));
 using f64x4 = double __attribute__((ext_vector_type(4)));
 
@@ -36,6 +37,10 @@ struct TileArgs {
     const T *cc;      // rbf: -0.5 * |x_j|^2 per column-side point
     const T *dvec;    // [num_jt*TILE] vector multiplied from the right, EXACT zeros beyond the valid columns
     const T *dc;      // fp32 v2 kernel: packed [num_jt][256] records (d_j | c_j) for LDS-DMA (k_pack_dc)
+    const uint16_t *Xr16;  // fp32 split kernel: the row side as three bf16 planes [3][rows][ldx16] (hi, mid, lo: x = hi + mid + lo exactly)
+    const uint16_t *Xc16;  // fp32 split kernel: the column side, same layout
+    size_t plane_stride;   // elements between the planes
+    int ldx16;             // padded features of the planes (multiple of 64)
     const int2 *items; // symmetric variant: list of the non-empty (local row block, column chunk) work items
     int num_items;    // symmetric variant: length of `items` = grid size
     T *colslab;       // symmetric variant: [packed (ib, jt) pairs with jt < ib][TILE] column sums of the off-diagonal tiles

@@ -26,4 +26,7 @@ static unsigned finish_mapping(TileArgs<T> &a, int num_jc) {
     return static_cast<unsigned>(((supers + 7) / 8) * 8 * 64);
 }
 
+/* fp32 "bf16x6" split kernel (tile_launch_f32s.hip); `grid` is used by the full-square variant only */
+void launch_split_tile_kernel(const TileArgs<float> &a, int kernel_type, dim3 grid, hipStream_t s);
+
 }  // namespace lssvm

@@ -59,6 +59,10 @@ void launch_tile_kernel<float>(TileArgs<float> &a, int kernel_type, bool rbf_dir
         ensure_dynamic_lds(tile_matvec_f32<KT_RBF>, lds);
         configured = true;
     }
+    if (a.dc != nullptr && a.Xc16 != nullptr) {  // option gram_mode = 1: the three-plane bf16 data exists
+        launch_split_tile_kernel(a, kernel_type, grid, s);
+        return;
+    }
     if (a.dc != nullptr && v2_eligible(a.ldx, rbf_direct)) {
         if (a.items != nullptr) {  // symmetric variant: one block per listed work item
             const dim3 sgrid(static_cast<unsigned>(a.num_items));

@@ -1,0 +1,63 @@
+/*
+ * tile_launch_f32s.hip -- instantiates and launches the fp32 "bf16x6" split tile kernel (lssvm_tile_f32_split.hip.hpp; option
+ * gram_mode = 1) and the plane-splitting set-up kernel.  Compiled for gfx950 only.
+ */
+#include "tile_launch.hip.hpp"
+
+#include "lssvm_tile_f32_split.hip.hpp"
+
+namespace lssvm {
+
+template <int KT, bool SYM>
+static void launch_s6_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
+    const dim3 block(TILE_THREADS);
+    static bool configured = false;
+    if (!configured) {
+        configured = true;
+        ensure_dynamic_lds(tile_matvec_f32_s6<KT, 1, SYM>, V2_LDS_BYTES);
+        ensure_dynamic_lds(tile_matvec_f32_s6<KT, 2, SYM>, V2_LDS_BYTES);
+        ensure_dynamic_lds(tile_matvec_f32_s6<KT, 3, SYM>, V2_LDS_BYTES);
+        ensure_dynamic_lds(tile_matvec_f32_s6<KT, 4, SYM>, V2_LDS_BYTES);
+    }
+    switch (a.ldx16 / 64) {
+        case 1: hipLaunchKernelGGL((tile_matvec_f32_s6<KT, 1, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
+        case 2: hipLaunchKernelGGL((tile_matvec_f32_s6<KT, 2, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
+        case 3: hipLaunchKernelGGL((tile_matvec_f32_s6<KT, 3, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
+        case 4: hipLaunchKernelGGL((tile_matvec_f32_s6<KT, 4, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
+        default: throw Error(LSSVM_ERR_INTERNAL, "no split tile kernel for this number of features");
+    }
+}
+
+template <bool SYM>
+static void launch_s6(const TileArgs<float> &a, int kernel_type, dim3 grid, hipStream_t s) {
+    switch (kernel_type) {
+        case KT_LINEAR: launch_s6_kt<KT_LINEAR, SYM>(a, grid, s); break;
+        case KT_POLY:
+            if (a.degree == 3) {
+                launch_s6_kt<KT_POLY3, SYM>(a, grid, s);
+            } else if (a.degree == 2) {
+                launch_s6_kt<KT_POLY2, SYM>(a, grid, s);
+            } else {
+                launch_s6_kt<KT_POLY, SYM>(a, grid, s);
+            }
+            break;
+        default: launch_s6_kt<KT_RBF, SYM>(a, grid, s); break;
+    }
+}
+
+void launch_split_tile_kernel(const TileArgs<float> &a, int kernel_type, dim3 grid, hipStream_t s) {
+    if (a.items != nullptr) {
+        launch_s6<true>(a, kernel_type, dim3(static_cast<unsigned>(a.num_items)), s);
+    } else {
+        launch_s6<false>(a, kernel_type, grid, s);
+    }
+    LSSVM_HIP_CHECK(hipGetLastError());
+}
+
+void split_bf16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, uint16_t *planes, size_t plane_stride, hipStream_t s) {
+    const size_t total = rows * static_cast<size_t>(ldx16);
+    hipLaunchKernelGGL(k_split_bf16x3, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, X, ldx, dfeat, rows, ldx16, planes, plane_stride);
+    LSSVM_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace lssvm

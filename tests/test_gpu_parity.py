@@ -400,3 +400,37 @@ def test_column_slab_budget_falls_back_to_the_full_square():
     finally:
         _capi.set_option("colslab_limit_mb", 98304)
     assert ol.rel_inf(got, ref) < 64 * np.finfo(np.float32).eps
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("N, d", [(300, 7), (1500, 64), (4097, 128), (2300, 200), (1100, 256)])
+@pytest.mark.parametrize("sym", [1, 0])
+def test_bf16_split_gram_mode_is_fp32_accurate(oracle, kernel, N, d, sym):
+    """Option gram_mode = 1 (opt-in): the fp32 operands are split exactly into three bf16 planes and the six significant plane
+    products are accumulated in fp32 on the bf16 matrix cores.  The product must meet the same bar as the default fp32 path: no
+    farther from the float64 product than 4x the fp32 CPU oracle (or 64 eps), and the two GPU paths within that of each other."""
+    X, y = make_blobs_pm1(N, d, seed=27, dtype=np.float32)
+    p = Parameter(kernel_type=kernel)
+    rhs = np.random.default_rng(6).uniform(-1, 1, size=N - 1).astype(np.float32)
+    zero = np.zeros(N - 1, np.float32)
+    out = {}
+    _capi.set_option("symmetric", sym)
+    try:
+        for mode in (0, 1):
+            _capi.set_option("gram_mode", mode)
+            with backend.ResidentProblem(p, X) as prob:
+                q, QA = prob.q()
+                out[mode] = prob.matvec(rhs, zero, 1.0)
+                prob.cg_begin(y, 1e-30)
+                prob.cg_step(5)
+                out[("a", mode)] = prob.cg_finish()[0]
+    finally:
+        _capi.set_option("gram_mode", 0)
+        _capi.set_option("symmetric", 1)
+    kw = dict(degree=3, gamma=1.0 / d, coef0=0.0)
+    want = oracle.matvec(kernel, X, q, rhs, zero, QA, 1.0, 1.0, **kw)
+    truth = oracle.matvec(kernel, X.astype(np.float64), q.astype(np.float64), rhs.astype(np.float64), np.zeros(N - 1), float(QA), 1.0, 1.0, **kw)
+    scale = np.max(np.abs(truth))
+    tol = max(4.0 * np.max(np.abs(want - truth)), 64 * np.finfo(np.float32).eps * scale)
+    assert np.max(np.abs(out[1] - truth)) < tol and np.max(np.abs(out[0] - truth)) < tol
+    assert np.all(np.isfinite(out[("a", 1)]))

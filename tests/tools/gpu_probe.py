@@ -74,7 +74,15 @@ def perf(N=50000, d=128, kernel="rbf", dt=np.float32, iters=5):
 
 
 if __name__ == "__main__":
-    if "--wide" in sys.argv:
+    if "--split" in sys.argv:
+        # opt-in bf16x6 split (gram_mode 1) against the default f32 MFMA path
+        for (N, d, kern) in ((50000, 128, "rbf"), (100000, 128, "rbf"), (100000, 128, "linear"), (100000, 64, "polynomial"), (60000, 256, "linear")):
+            for gm in (0, 1):
+                _capi.set_option("gram_mode", gm)
+                print(f"gram_mode={gm}: ", end="")
+                perf(N, d, kern, np.float32, iters=6)
+        _capi.set_option("gram_mode", 0)
+    elif "--wide" in sys.argv:
         # more than 8 k-chunks: v2 kernels with 10..16 chunks against the generic v1 kernel
         for (N, d, kern, dt) in ((60000, 384, "rbf", np.float32), (60000, 512, "linear", np.float32), (40000, 192, "polynomial", np.float64), (40000, 256, "rbf", np.float64)):
             for tk in (0, 1):

@@ -105,6 +105,43 @@ __global__ __launch_bounds__(256, 2) void k_loop32(float *out, int steps) {
     out[blockIdx.x * 256 + threadIdx.x] = sum;
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// bf16 counterpart: v_mfma_f32_32x32x16_bf16 (the instruction a 3-way bf16 split of fp32 operands would run on)
+template <int IVALU, int EXPS, int FMAS>
+__global__ __launch_bounds__(256, 2) void k_loop_bf16(float *out, int steps) {
+    const int lane = threadIdx.x & 63;
+    f32x16 acc[4];
+    for (int cb = 0; cb < 4; ++cb)
+        for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+    bf16x8 av[4], bv[4];
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 8; ++e) {
+            av[i][e] = static_cast<__bf16>(1.f + 1e-2f * ((lane + i + e) & 7));
+            bv[i][e] = static_cast<__bf16>(0.5f + 1e-2f * ((i + e) & 7));
+        }
+    int iv = lane;
+    float ev = 1e-3f * lane, fv = 1.0f + lane * 1e-6f;
+    for (int st = 0; st < steps; ++st) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[tt], bv[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < IVALU; ++k) asm volatile("v_xor_b32 %0, 0x55, %0" : "+v"(iv));
+#pragma unroll
+                for (int k = 0; k < EXPS; ++k) asm volatile("v_exp_f32 %0, %0" : "+v"(ev));
+#pragma unroll
+                for (int k = 0; k < FMAS; ++k) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(fv) : "v"(ev));
+            }
+    }
+    float sum = ev + fv + iv;
+    for (int cb = 0; cb < 4; ++cb)
+        for (int i = 0; i < 16; ++i) sum += acc[cb][i];
+    out[blockIdx.x * 256 + threadIdx.x] = sum;
+}
+
 template <typename F>
 static double time_ms(F &&launch) {
     hipEvent_t a, b;
@@ -148,6 +185,17 @@ static void run32(const char *what, double *buf, int cus) {
     }
 }
 
+template <int IVALU, int EXPS, int FMAS>
+static void run_bf16(const char *what, double *buf, int cus) {
+    const int steps = 8000;
+    for (int wps = 1; wps <= 2; ++wps) {
+        const int blocks = cus * wps;
+        const double ms = time_ms([&] { hipLaunchKernelGGL((k_loop_bf16<IVALU, EXPS, FMAS>), dim3(blocks), dim3(256), 0, 0, reinterpret_cast<float *>(buf), steps); });
+        const double flop = 2.0 * 32 * 32 * 16 * 16.0 * steps * (double) blocks * 4;
+        printf("%-64s %d wave/SIMD: %7.1f TFLOP/s\n", what, wps, flop / ms / 1e9);
+    }
+}
+
 int main() {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
@@ -174,5 +222,11 @@ int main() {
     run32<0, 1, 0>("f32 mfma + 1 v_exp_f32 per MFMA", buf, cus);
     run32<0, 1, 2>("f32 mfma + 1 v_exp_f32 + 2 v_fma_f32 per MFMA", buf, cus);
     run32<0, 0, 4>("f32 mfma + 4 v_fma_f32 per MFMA", buf, cus);
+    run_bf16<0, 0, 0>("bf16 mfma 32x32x16, operands in registers", buf, cus);
+    run_bf16<1, 0, 0>("bf16 mfma + 1 int VALU per MFMA", buf, cus);
+    run_bf16<2, 0, 0>("bf16 mfma + 2 int VALU per MFMA", buf, cus);
+    run_bf16<0, 1, 0>("bf16 mfma + 1 v_exp_f32 per MFMA", buf, cus);
+    run_bf16<0, 1, 2>("bf16 mfma + 1 v_exp_f32 + 2 v_fma_f32 per MFMA", buf, cus);
+    run_bf16<0, 0, 4>("bf16 mfma + 4 v_fma_f32 per MFMA", buf, cus);
     return 0;
 }
