@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c5", choices=sorted(WORKLOADS))
+    ap.add_argument("--gram-mode", type=int, default=None, choices=[0, 1],
+                    help="fp32 only: 1 = bf16x6 split on the bf16 matrix cores (library default), 0 = native v_mfma_f32 chains")
     ap.add_argument("--cpu-sample-rows", type=int, default=20480)  # 4 implicit matvecs of ~3 s each on 128 host cores: about 12 s of CPU work
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
@@ -110,6 +112,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.gram_mode is not None:
+        _capi.set_option("gram_mode", args.gram_mode)
     prob = backend.ResidentProblem(params, X, device=local_rank, rank=rank, world=world)
     prob.cg_begin(y, 1e-30)  # eps^2 underflows: the loop only stops early on delta == 0 (fixed iteration count)
     if args.warmup > 0:

@@ -142,6 +142,48 @@ __global__ __launch_bounds__(256, 2) void k_loop_bf16(float *out, int steps) {
     out[blockIdx.x * 256 + threadIdx.x] = sum;
 }
 
+// bf16 MFMAs fed from LDS the way the split tile kernel does: per k-step one ds_read_b128 per column block, feeding NPROD MFMAs each
+// (row planes in registers), B fragments double buffered; BAR: one s_barrier per 4 k-steps
+template <int NPROD, int BAR>
+__global__ __launch_bounds__(256, 2) void k_loop_bf16_lds(float *out, int steps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    for (int i = tid; i < 16384 / 4; i += 256) reinterpret_cast<float *>(smem)[i] = 1e-3f * (i & 63);
+    __syncthreads();
+    f32x16 acc[4];
+    for (int cb = 0; cb < 4; ++cb)
+        for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+    bf16x8 av[3][4];
+    for (int p = 0; p < 3; ++p)
+        for (int i = 0; i < 4; ++i)
+            for (int e = 0; e < 8; ++e) av[p][i][e] = static_cast<__bf16>(1.f + 1e-2f * ((lane + i + e + p) & 7));
+    int rd_off[4];
+    for (int mm = 0; mm < 4; ++mm) rd_off[mm] = r * 128 + (((2 * mm + h) ^ ((r >> 1) & 7)) << 4);
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 bcur[4];
+    for (int cb = 0; cb < 4; ++cb) bcur[cb] = *reinterpret_cast<const f32x4 *>(smem + cb * 4096 + rd_off[0]);
+    for (int st = 0; st < steps; ++st) {
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            f32x4 bnext[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) bnext[cb] = *reinterpret_cast<const f32x4 *>(smem + cb * 4096 + rd_off[(mm + 1) & 3]);
+            if (BAR && mm == 2) __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int q = 0; q < NPROD; ++q)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][mm], __builtin_bit_cast(bf16x8, bcur[cb]), acc[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) bcur[cb] = bnext[cb];
+        }
+    }
+    float sum = 0.f;
+    for (int cb = 0; cb < 4; ++cb)
+        for (int i = 0; i < 16; ++i) sum += acc[cb][i];
+    out[blockIdx.x * 256 + threadIdx.x] = sum;
+}
+
 template <typename F>
 static double time_ms(F &&launch) {
     hipEvent_t a, b;
@@ -196,6 +238,17 @@ static void run_bf16(const char *what, double *buf, int cus) {
     }
 }
 
+template <int NPROD, int BAR>
+static void run_bf16_lds(const char *what, double *buf, int cus) {
+    const int steps = 4000;
+    for (int wps = 1; wps <= 2; ++wps) {
+        const int blocks = cus * wps;
+        const double ms = time_ms([&] { hipLaunchKernelGGL((k_loop_bf16_lds<NPROD, BAR>), dim3(blocks), dim3(256), 16384, 0, reinterpret_cast<float *>(buf), steps); });
+        const double flop = 2.0 * 32 * 32 * 16 * (16.0 * NPROD) * steps * (double) blocks * 4;
+        printf("%-64s %d wave/SIMD: %7.1f TFLOP/s\n", what, wps, flop / ms / 1e9);
+    }
+}
+
 int main() {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
@@ -228,5 +281,10 @@ int main() {
     run_bf16<0, 1, 0>("bf16 mfma + 1 v_exp_f32 per MFMA", buf, cus);
     run_bf16<0, 1, 2>("bf16 mfma + 1 v_exp_f32 + 2 v_fma_f32 per MFMA", buf, cus);
     run_bf16<0, 0, 4>("bf16 mfma + 4 v_fma_f32 per MFMA", buf, cus);
+    run_bf16_lds<3, 0>("bf16 mfma from LDS, 3 products per B fragment", buf, cus);
+    run_bf16_lds<2, 0>("bf16 mfma from LDS, 2 products per B fragment", buf, cus);
+    run_bf16_lds<1, 0>("bf16 mfma from LDS, 1 product per B fragment", buf, cus);
+    run_bf16_lds<3, 1>("bf16 mfma from LDS, 3 products, barrier per 4 k-steps", buf, cus);
+    run_bf16_lds<1, 1>("bf16 mfma from LDS, 1 product, barrier per 4 k-steps", buf, cus);
     return 0;
 }

@@ -11,6 +11,10 @@ for wl in c2 c3 c4 c5; do
   st=10; [ $wl = c5 ] && st=5
   python3 bench.py --workload $wl --steps $st --warmup 2 > $O/${TAG}_bench_${wl}_n1.json 2> $O/${TAG}_bench_${wl}.err
 done
+# the native v_mfma_f32 path of the fp32 workloads, for reference (the library default is the bf16x6 split)
+for wl in c2 c5; do
+  python3 bench.py --workload $wl --steps 5 --warmup 2 --gram-mode 0 --no-cpu-baseline > $O/${TAG}_bench_${wl}_n1_native_f32_mfma.json 2> $O/${TAG}_bench_${wl}_native.err
+done
 for wl in c2 c4 c5; do
   rm -rf $O/prof_$wl
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -- python3 bench.py --workload $wl --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_$wl.log 2>&1
