@@ -67,6 +67,7 @@ def main():
                     help="fp32 only: 1 = bf16x6 split on the bf16 matrix cores (library default), 0 = native v_mfma_f32 chains")
     ap.add_argument("--cpu-sample-rows", type=int, default=20480)  # 4 implicit matvecs of ~3 s each on 128 host cores: about 12 s of CPU work
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-native-reference", action="store_true", help="skip the extra native v_mfma_f32 run reported beside a bf16x6 headline")
     ap.add_argument("--seed", type=int, default=42)
     args = ap.parse_args()
 
@@ -201,9 +202,33 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(X, y, wl["kernel"], args.cpu_sample_rows, 3)
+        if bf16x6 and world == 1 and not args.no_native_reference:
+            # the same workload on native v_mfma_f32 chains (option gram_mode = 0), reported beside the headline -- never as `value`
+            prob.close()
+            _capi.set_option("gram_mode", 0)
+            nat = backend.ResidentProblem(params, X, device=local_rank, rank=rank, world=world)
+            nat.cg_begin(y, 1e-30)
+            nat.cg_step(1)
+            nat.synchronize()
+            j0 = nat.info()
+            tn = time.perf_counter()
+            nat.cg_step(min(args.steps, 5))
+            nat.synchronize()
+            tn = time.perf_counter() - tn
+            j1 = nat.info()
+            nsteps = int(j1["iterations"] - j0["iterations"])
+            nl = int(j1["matvec_launches"] - j0["matvec_launches"])
+            nk_ms = (j1["matvec_kernel_ms"] * j1["matvec_launches"] - j0["matvec_kernel_ms"] * j0["matvec_launches"]) / max(nl, 1)
+            out["native_f32_path"] = {"ms_per_step": tn / max(nsteps, 1) * 1e3, "value": flop_step * nsteps / tn / 1e9, "unit": "GFLOP/s", "steps": nsteps,
+                                      "tile_kernel_ms": nk_ms, "useful_tflops": useful_launch / (nk_ms * 1e-3) / 1e12 if nk_ms > 0 else 0.0,
+                                      "frac_of_f32_mfma_peak": useful_launch / (nk_ms * 1e-3) / 1e12 / PEAK_TFLOPS["float32"] if nk_ms > 0 else 0.0}
+            nat.close()
+            _capi.set_option("gram_mode", 1)
+            prob = None
         print(json.dumps(out), flush=True)
 
-    prob.close()
+    if prob is not None:
+        prob.close()
     if dist is not None:
         backend.comm_destroy()
         dist.destroy_process_group()

@@ -56,6 +56,9 @@ def test_bench_json_contract_small_workload():
     assert 0.05 < r["frac"] <= r["executed_frac"] < 1.0 and r["symmetric"] in (True, False)
     # fp32 default: the Gram tiles run as six bf16 plane products per multiply-add; the roofline is the bf16 MFMA peak
     planes = 6.0 if r["gram_mode"] == "bf16x6" else 1.0
+    if r["gram_mode"] == "bf16x6":  # the native v_mfma_f32 path of the same workload is reported beside the headline
+        nat = j["native_f32_path"]
+        assert nat["ms_per_step"] > j["ms_per_step"] and 0.05 < nat["frac_of_f32_mfma_peak"] < 1.0
     assert r["gram_mode"] in ("bf16x6", "native") and abs(r["achieved"] - planes * r["fp32_equivalent"]) < 1e-9 * r["achieved"]
     assert r["effective_full_square"] >= r["fp32_equivalent"] and planes * r["full_square_flop_per_launch"] >= r["executed_flop_per_launch"] * 0.99
     c = j["cpu_baseline"]

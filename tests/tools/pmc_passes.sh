@@ -5,7 +5,7 @@
 WL=${1:-c2}; STEPS=${2:-5}; OUT=${3:-gpurun_out/pmc_$WL}
 export TMPDIR=/tmp
 mkdir -p "$OUT"
-run() { name=$1; shift; timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py --workload "$WL" --steps "$STEPS" --warmup 1 --no-cpu-baseline > "$OUT/$name.log" 2>&1; echo "$name rc=$?"; }
+run() { name=$1; shift; timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py --workload "$WL" --steps "$STEPS" --warmup 1 --no-cpu-baseline --no-native-reference > "$OUT/$name.log" 2>&1; echo "$name rc=$?"; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run sq1 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
