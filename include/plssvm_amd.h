@@ -197,7 +197,8 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
 
 /* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT):
  *   "rbf_form"      0 = norm expansion on the matrix cores (default), 1 = direct (x_i - x_j)^2 on the vector ALU
- *   "j_chunk_tiles" number of 128-column tiles per work item; 0 = automatic (default: 2 ... 16, about 4096 work items per device)
+ *   "j_chunk_tiles" number of 128-column tiles per work item; 0 = automatic (default: about 4096 work items per device, 2 ... 16 tiles each,
+ *                   up to 64 for the bf16x6 kernel)
  *   "symmetric"     1 = evaluate only the kernel-matrix tiles on/below the diagonal and mirror them (default; num_features <= 512 in fp32,
  *                   <= 256 in fp64; a negative polynomial degree always runs the full square),
  *                   0 = full square (row-owned sums, results independent of the GPU count)
