@@ -91,6 +91,30 @@ __device__ __forceinline__ double fast_exp_f64(double x) {
     return __builtin_ldexp(p, static_cast<int>(k));
 }
 
+/* 2^t in double for the rbf epilogue of the fp64 v2 kernel (the data carries sqrt(2 gamma log2(e)), so the MFMA chain leaves
+ * t = log2(K)): t = k + r, k = rint(t), |r| <= 1/2, 2^r by its degree-12 Taylor polynomial in r ln2 (truncation 1.7e-16), v_ldexp_f64
+ * for the scale (underflow to 0 included).  16 vector instructions instead of the 20 of fast_exp_f64(acc * 2 gamma): every one of
+ * them costs matrix-core time beside v_mfma_f64.  (A 64-entry table + degree-5 polynomial needs 13, but its per-lane LDS gathers
+ * serialise in the register-bound epilogue: measured 16 % SLOWER.) */
+__device__ __forceinline__ double exp2_f64(double t) {
+    const double k = __builtin_rint(t);
+    const double r = t - k;
+    double p = 2.5678435993488196e-11;
+    p = fma(p, r, 4.44553827187081e-10);
+    p = fma(p, r, 7.054911620801121e-09);
+    p = fma(p, r, 1.0178086009239696e-07);
+    p = fma(p, r, 1.3215486790144305e-06);
+    p = fma(p, r, 1.5252733804059838e-05);
+    p = fma(p, r, 0.00015403530393381606);
+    p = fma(p, r, 0.0013333558146428441);
+    p = fma(p, r, 0.009618129107628477);
+    p = fma(p, r, 0.055504108664821576);
+    p = fma(p, r, 0.2402265069591007);
+    p = fma(p, r, 0.6931471805599453);
+    p = fma(p, r, 1.0);
+    return __builtin_ldexp(p, static_cast<int>(k));
+}
+
 /* DEG: polynomial degree class resolved OUTSIDE the per-element loop (a uniform switch around the whole epilogue):
  * 3 = cube, 2 = square, 0 = generic integer power.  Ignored for the other kernels. */
 template <int KT, int DEG, typename T>

@@ -107,13 +107,16 @@ static void set_kernel_scalars(TileArgs<T> &a, const lssvm_params &p, bool rbf_d
 
 /* rbf, matrix-core form: the (centred) data is pre-scaled so that the MFMA chain directly produces the exponent:
  * fp32: x' = sqrt(2 gamma log2 e) (x - mean)  =>  x_i'.x_j' - (|x_i'|^2 + |x_j'|^2)/2 = -gamma log2(e) |x_i - x_j|^2 ; fp64: unscaled */
+/* rbf on the matrix cores: the data is scaled so that the MFMA chain leaves the exponent in the unit the epilogue wants:
+ * fp32: -gamma log2(e) |xi - xj|^2 (epilogue v_exp_f32); fp64 on the v2 kernel (`fp64_v2`): the same (epilogue exp2_f64);
+ * fp64 on the generic kernel: unscaled (epilogue fast_exp_f64(acc * 2 gamma)). */
 template <typename T>
-T rbf_prescale(const lssvm_params &p) {
+T rbf_prescale(const lssvm_params &p, bool fp64_v2) {
+    constexpr double log2e = 1.4426950408889634073599246810019;
     if constexpr (std::is_same_v<T, float>) {
-        constexpr double log2e = 1.4426950408889634073599246810019;
         return static_cast<T>(std::sqrt(2.0 * static_cast<double>(static_cast<T>(p.gamma)) * log2e));
     } else {
-        return T(1);
+        return fp64_v2 ? static_cast<T>(std::sqrt(2.0 * p.gamma * log2e)) : T(1);
     }
 }
 
@@ -267,7 +270,7 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
     }
     // rbf on the matrix cores: centre the data, then c_i = -|x_i|^2 / 2
     if (params_.kernel_type == LSSVM_KERNEL_RBF && !rbf_direct_) {
-        center_columns<T>(X_, nullptr, rbf_prescale<T>(params_), stream_);
+        center_columns<T>(X_, nullptr, rbf_prescale<T>(params_, v2_eligible_f64(X_.ldx)), stream_);
         half_neg_norms<T>(X_, c_, stream_);
     }
     // polynomial in fp64 on the v2 kernel: fold gamma into the data (x' = sqrt(gamma) x, after q was computed from the raw data), so
@@ -683,7 +686,7 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     P.upload(points, LSSVM_MEM_HOST, npoints, nfeat, 0, s);
     DevBuf<T> cS, cP;
     if (params.kernel_type == LSSVM_KERNEL_RBF) {
-        center_columns<T>(S, &P, rbf_prescale<T>(params), s);
+        center_columns<T>(S, &P, rbf_prescale<T>(params, v2_eligible_f64(S.ldx)), s);
         half_neg_norms<T>(S, cS, s);
         half_neg_norms<T>(P, cP, s);
     }

@@ -463,8 +463,10 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
                             if constexpr (v2_base_kt(KT) == KT_POLY) {
                                 // the data carries sqrt(gamma) (Problem<double> pre-scales it for this kernel) and coef0 was added above
                                 kv = poly_power<v2_degree_class(KT)>(acc[rb][cb][i], a.degree);
+                            } else if constexpr (KT == KT_RBF) {
+                                kv = exp2_f64(acc[rb][cb][i]);  // the data is pre-scaled: acc = log2(K)
                             } else {
-                                kv = apply_kernel_function<KT, 0>(acc[rb][cb][i], a);
+                                kv = acc[rb][cb][i];
                             }
                             if constexpr (KT == KT_POLY) {
                                 if (padcol[cb]) kv = 0.0;

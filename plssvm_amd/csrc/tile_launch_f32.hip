@@ -63,7 +63,7 @@ void launch_tile_kernel<float>(TileArgs<float> &a, int kernel_type, bool rbf_dir
         launch_split_tile_kernel(a, kernel_type, grid, s);
         return;
     }
-    if (a.dc != nullptr && v2_eligible(a.ldx, rbf_direct)) {
+    if (a.dc != nullptr) {  // the records exist only where the v2 kernel was chosen when the data was prepared (v2_eligible)
         if (a.items != nullptr) {  // symmetric variant: one block per listed work item
             const dim3 sgrid(static_cast<unsigned>(a.num_items));
             switch (kernel_type) {

@@ -41,7 +41,7 @@ void launch_tile_kernel<double>(TileArgs<double> &a, int kernel_type, bool /*rbf
         ensure_dynamic_lds(tile_matvec_f64<KT_RBF>, lds);
         configured = true;
     }
-    if (a.dc != nullptr && v2_eligible_f64(a.ldx)) {  // V2D_LDS_BYTES < 64 KiB: no opt-in needed
+    if (a.dc != nullptr) {  // the records exist only where the v2 kernel was chosen when the data was prepared; V2D_LDS_BYTES < 64 KiB
         if (a.items != nullptr) {
             const dim3 sgrid(static_cast<unsigned>(a.num_items));
             switch (kernel_type) {
