@@ -6,8 +6,17 @@
 
 A "step" is ONE CG iteration (one implicit kernel-matrix--vector product + the CG vector updates, plus the residual
 refresh every 50th iteration, src/plssvm/backends/OpenMP/csvm.cpp:125-166) on synthetic data that is already resident in
-HBM when the timed region starts.  With N > 1 the implicit matrix is row-block sharded over the ranks (one process per
-GPU) and every step contains one RCCL all-gather of the K*d slices; the problem size is fixed, i.e. STRONG scaling.
+HBM when the timed region starts.  With N > 1 the implicit matrix is row-block sharded over the GPUs and every step contains
+ONE exchange of the partial K*d vectors (default symmetric variant: an RCCL all-reduce of n reals; full-square variant: an
+all-gather of the slices); the problem size is fixed, i.e. STRONG scaling.
+
+Three ways to run N > 1:
+  * under torchrun (the driver's way): one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE from the environment;
+  * `python bench.py --gpus N` typed as is: the parent starts N child ranks (one process per GPU) BEFORE it touches the GPU
+    itself, waits for them and exits with their worst code; rank 0 prints the JSON line;
+  * `python bench.py --gpus N --single-process`: ONE process drives all N devices through lssvm_mi355_problem_create_multi
+    (the mode behind plssvm::csvm); `--devices 0,0` lists the ordinals explicitly (repeats allowed: shards share a device,
+    which is how the sharded path runs on a one-GPU box -- n_gpus then still reports the distinct devices).
 
 Prints ONE JSON line on rank 0.  `value` = effective K*d GFLOP/s = 2 * n^2 * d * K / t (n = N_points - 1; full square, no
 symmetry credit); `cg_iters_per_s` is the other half of BASELINE.json's metric.
@@ -16,8 +25,11 @@ symmetry credit); `cg_iters_per_s` is the other half of BASELINE.j
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,27 +46,107 @@ WORKLOADS = {
 # dense matrix-core peaks of the arithmetic type (MI355X_MICROARCH.md, Chip-level parameters / Matrix cores)
 PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6, "bf16": 16 * 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md (bf16 = 16 x the f32 MFMA rate, ~2.5 PF)
 
+# the sources that decide how many bytes the tile kernel moves: profiles/hbm_traffic.json carries their hash, a stale entry is dropped
+TRAFFIC_SOURCES = ["plssvm_amd/csrc/lssvm_tile_f32_split.hip.hpp", "plssvm_amd/csrc/lssvm_tile_f32.hip.hpp", "plssvm_amd/csrc/lssvm_tile_f64.hip.hpp",
+                   "plssvm_amd/csrc/lssvm_device_common.hip.hpp", "plssvm_amd/csrc/lssvm_problem.hip"]
+
+
+def kernel_source_hash() -> str:
+    h = hashlib.sha256()
+    for rel in TRAFFIC_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(key: str):
+    """HBM-side bytes per tile-kernel launch from the committed rocprofv3 PMC passes (tests/tools/profile_round.sh writes
+    profiles/hbm_traffic.json).  PMC counters cannot be read from inside an un-profiled run, so the number is taken from the
+    file -- but ONLY while the kernel sources still hash to what was profiled; otherwise `traffic` is null."""
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(tfile) as f:
+            table = json.load(f)
+    except Exception:
+        return None, "profiles/hbm_traffic.json missing"
+    entry = table.get(key)
+    if entry is None:
+        return None, f"no PMC pass committed for {key}"
+    if isinstance(entry, dict):
+        if entry.get("kernel_sha") != kernel_source_hash():
+            return None, f"stale: PMC pass was taken on kernel sources {entry.get('kernel_sha')}, these are {kernel_source_hash()}"
+        return entry.get("bytes"), f"{entry.get('profile', 'profiles/')} (kernel sources {entry.get('kernel_sha')})"
+    return None, "unstamped entry (taken before the kernel-source stamp existed)"
+
+
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
 
 def cpu_baseline(X, y, kernel, sample_rows, iters):
-    """The CPU oracle (or, where it was built, the reference's own OpenMP kernels) on a bounded sample of the workload."""
+    """The reference's own OpenMP kernels (where oracle/_ref was built), else the CPU oracle, on a bounded sample of the workload.
+    Line A = the reference's default build type (RelWithDebInfo: -O2, CMakeLists.txt:23); line B = its Release flags
+    (-O3 -ffast-math, CMakeLists.txt:100-104, with -march=x86-64-v3 standing in for -march=native: the library is built off-box)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
 
-    kind = "reference" if oracle_lib.have_ref() else "port"
-    impl = oracle_lib.ref() if kind == "reference" else oracle_lib.oracle()
     ns = min(sample_rows, X.shape[0])
     Xs, ys = X[:ns], y[:ns]
-    t0 = time.perf_counter()
-    _, _, info = impl.solve(kernel, Xs, ys, 1e-30, iters, gamma=1.0 / X.shape[1], degree=3, coef0=0.0, cost=1.0)
-    wall = time.perf_counter() - t0
-    its = int(info["iterations"])
-    # the solve runs its + 1 implicit matvecs (one for the initial residual); price an iteration as wall / (its + 1)
-    t_iter = wall / (its + 1)
-    flop = 2.0 * (ns - 1) ** 2 * X.shape[1]
-    return {"value": flop / t_iter / 1e9, "unit": "GFLOP/s", "cores": oracle_lib.oracle().num_threads(), "kind": kind,
-            "sample": f"first {ns} rows of the workload, {its} CG iterations + initial residual ({its + 1} implicit matvecs), "
-                      f"{t_iter * 1e3:.1f} ms per matvec; effective GFLOP/s = 2*n^2*d / t is size independent",
-            "ms_per_step_at_sample": t_iter * 1e3}
+    cores = os.cpu_count() if oracle_lib.have_ref() else oracle_lib.oracle().num_threads()
+
+    def run(impl, kind, flags):
+        t0 = time.perf_counter()
+        _, _, info = impl.solve(kernel, Xs, ys, 1e-30, iters, gamma=1.0 / X.shape[1], degree=3, coef0=0.0, cost=1.0)
+        wall = time.perf_counter() - t0
+        its = int(info["iterations"])
+        # the solve runs its + 1 implicit matvecs (one for the initial residual); price an iteration as wall / (its + 1)
+        t_iter = wall / (its + 1)
+        flop = 2.0 * (ns - 1) ** 2 * X.shape[1]
+        return {"value": flop / t_iter / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": kind, "cpu_model": cpu_model(), "build_flags": flags,
+                "sample": f"first {ns} rows of the workload, {its} CG iterations + initial residual ({its + 1} implicit matvecs), "
+                          f"{t_iter * 1e3:.1f} ms per matvec; effective GFLOP/s = 2*n^2*d / t is size independent",
+                "ms_per_step_at_sample": t_iter * 1e3}
+
+    if oracle_lib.have_ref():
+        a = run(oracle_lib.ref(), "reference", "-O2 -fopenmp (the reference's default build type RelWithDebInfo, CMakeLists.txt:23)")
+    else:
+        a = run(oracle_lib.oracle(), "port", "-O2 -fopenmp -ffp-contract=off (oracle/Makefile)")
+    b = None
+    if oracle_lib.have_ref_release():
+        b = run(oracle_lib.ref_release(), "reference", "-O3 -ffast-math -march=x86-64-v3 -fopenmp (the reference's Release flags, CMakeLists.txt:100-104; "
+                                                       "x86-64-v3 instead of -march=native because the library is built off-box)")
+    return a, b
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N child ranks, one process per GPU.  Nothing in THIS process has touched
+    the GPU (no HIP call, no torch.cuda call), and no process is ever replaced by another: the children are ordinary child
+    processes and the parent only waits.  Rank 0 inherits stdout and prints the JSON line."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst = 0
+    for p in procs:
+        rc = p.wait()
+        worst = worst or rc
+    return worst
 
 
 def main():
@@ -63,20 +155,27 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c5", choices=sorted(WORKLOADS))
+    ap.add_argument("--single-process", action="store_true", help="N > 1: ONE process drives all devices (lssvm_mi355_problem_create_multi) instead of one process per GPU")
+    ap.add_argument("--devices", default=None, help="--single-process: comma separated HIP ordinals (repeats allowed), default 0..N-1")
+    ap.add_argument("--exchange", type=int, default=None, choices=[0, 1, 2], help="--single-process: 0 automatic, 1 RCCL, 2 peer kernels over xGMI")
     ap.add_argument("--gram-mode", type=int, default=None, choices=[0, 1],
                     help="fp32 only: 1 = bf16x6 split on the bf16 matrix cores (library default), 0 = native v_mfma_f32 chains")
-    ap.add_argument("--cpu-sample-rows", type=int, default=20480)  # 4 implicit matvecs of ~3 s each on 128 host cores: about 12 s of CPU work
+    ap.add_argument("--cpu-sample-rows", type=int, default=20480)  # 4 implicit matvecs of ~3 s each on 128 host cores: about 12 s of CPU work per line
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-native-reference", action="store_true", help="skip the extra native v_mfma_f32 run reported beside a bf16x6 headline")
     ap.add_argument("--seed", type=int, default=42)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+    launched = "WORLD_SIZE" in os.environ
+    if args.devices is not None:
+        args.single_process = True
+    if args.gpus > 1 and not launched and not args.single_process:
+        sys.exit(spawn_ranks(args.gpus))
+
+    rank = int(os.environ.get("RANK", "0")) if not args.single_process else 0
+    world = int(os.environ.get("WORLD_SIZE", "1")) if not args.single_process else 1
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if not args.single_process else 0
+    if not args.single_process and world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
     import numpy as np
@@ -89,6 +188,12 @@ def main():
     from plssvm_amd import _capi, backend
     from plssvm_amd.datagen import make_blobs_pm1
     from plssvm_amd.parameter import Parameter
+
+    devices = None
+    if args.single_process:
+        devices = [int(t) for t in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    shards = len(devices) if devices is not None else world
+    n_gpus = len(set(devices)) if devices is not None else world
 
     dist = None
     if world > 1:
@@ -107,15 +212,27 @@ def main():
     X, y = make_blobs_pm1(N, d, seed=args.seed, dtype=dt)  # identical on every rank (seeded)
     params = Parameter(kernel_type=wl["kernel"], degree=3, gamma=None, coef0=0.0, cost=1.0)
 
+    def device_sync():
+        if devices is not None:
+            for dev in sorted(set(devices)):
+                torch.cuda.synchronize(dev)
+        else:
+            torch.cuda.synchronize()
+
     def barrier():
-        torch.cuda.synchronize()
+        device_sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     if args.gram_mode is not None:
         _capi.set_option("gram_mode", args.gram_mode)
-    prob = backend.ResidentProblem(params, X, device=local_rank, rank=rank, world=world)
+    if args.exchange is not None:
+        _capi.set_option("exchange", args.exchange)
+    if devices is not None:
+        prob = backend.ResidentProblem(params, X, devices=devices)
+    else:
+        prob = backend.ResidentProblem(params, X, device=local_rank, rank=rank, world=world)
     prob.cg_begin(y, 1e-30)  # eps^2 underflows: the loop only stops early on delta == 0 (fixed iteration count)
     if args.warmup > 0:
         prob.cg_step(args.warmup)
@@ -140,27 +257,29 @@ def main():
     flop_step = 2.0 * n * n * d
     value = flop_step * steps_done / elapsed / 1e9
 
-    # roofline of the dominant kernel (the tile kernel of the implicit matvec), from HIP events on the solver stream
+    # roofline of the dominant kernel (the tile kernel of the implicit matvec), from HIP events on the solver stream(s); a process
+    # that drives several shards reports the slowest shard's average launch
     launches = int(i1["matvec_launches"] - i0["matvec_launches"])
     kern_ms_total = i1["matvec_kernel_ms"] * i1["matvec_launches"] - i0["matvec_kernel_ms"] * i0["matvec_launches"]
     kern_ms = kern_ms_total / max(launches, 1)
     from plssvm_amd.sharding import triangle_share, work_share
 
-    # Three flop counts of one tile-kernel launch on this rank:
+    # Three flop counts of one tile-kernel launch of one shard:
     #   square   = its share of the full n x n square, 2 n^2 d in total: the convention of `value` ("no symmetry credit")
     #   executed = what the matrix cores really do (symmetric variant: tiles on/below the diagonal, whole tiles incl. padding)
     #   useful   = the algorithm's own count: the full square for the full-square variant; entries j <= i for the symmetric one
     #              (the reference's count, svm_kernel.cpp:36-39).  `roofline.achieved` = useful / kernel time, so frac <= 1.
+    # The shares are dealt by equal area, so every shard's counts agree within a row block; priced here for shard `rank` (0 for one process).
     symmetric = bool(i1.get("symmetric", 0))
-    sq_mac, exe_mac = work_share(n, world, rank, symmetric)
-    use_mac = triangle_share(n, world, rank) if symmetric else sq_mac
+    sq_mac, exe_mac = work_share(n, shards, rank, symmetric)
+    use_mac = triangle_share(n, shards, rank) if symmetric else sq_mac
     kern_s = kern_ms * 1e-3
     square_launch, exec_launch, useful_launch = 2.0 * sq_mac * d, 2.0 * exe_mac * d, 2.0 * use_mac * d
     achieved = useful_launch / kern_s / 1e12 if kern_ms > 0 else 0.0
     executed = exec_launch / kern_s / 1e12 if kern_ms > 0 else 0.0
     effective = square_launch / kern_s / 1e12 if kern_ms > 0 else 0.0
     peak = PEAK_TFLOPS[wl["dtype"]]
-    # fp32 default "bf16x6": every fp32 multiply-add runs as SIX bf16 plane products on v_mfma_f32_32x32x16_bf16 (exact 3-way split of
+    # fp32 default "bf16x6": every fp32 multiply-add runs as SIX bf16 plane products on the bf16 MFMA (exact 3-way split of
     # the operands, fp32 accumulation, fp32-equivalent accuracy: DESIGN.md 4.1).  The roofline of that kernel is the dense bf16 MFMA
     # peak (16 x the f32 MFMA rate, MI355X_MICROARCH.md "Matrix cores"), and the algorithm's own flop count is 6 x the fp32 count.
     bf16x6 = bool(i1.get("gram_mode", 0))
@@ -170,29 +289,30 @@ def main():
         peak = PEAK_TFLOPS["bf16"]
         achieved *= plane_products
         executed *= plane_products
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.isfile(tfile):
-        try:
-            with open(tfile) as f:
-                traffic = json.load(f).get(f"{args.workload}_n{world}")
-        except Exception:
-            traffic = None
+    traffic, traffic_source = measured_traffic(f"{args.workload}_n{shards}")
 
     if rank == 0:
+        exchange_names = {0: "none", 1: "RCCL all-reduce" if symmetric else "RCCL all-gather", 2: "peer kernels over xGMI (fixed-order sum)"}
+        if shards == 1:
+            parallelism = "single GPU"
+        elif devices is not None:
+            parallelism = f"row-block sharding x{shards}, one process driving devices {devices}"
+        else:
+            parallelism = f"row-block sharding x{world}, one process per GPU"
         out = {
             "metric": "effective K*d GFLOP/s of the CG iteration (2*n^2*d per iteration / time), RBF fp32 N x d" if wl["kernel"] == "rbf" and wl["dtype"] == "float32"
             else f"effective K*d GFLOP/s of the CG iteration, {wl['kernel']} {wl['dtype']}",
             "value": value, "unit": "GFLOP/s", "cg_iters_per_s": steps_done / elapsed,
-            "n_gpus": world, "steps": steps_done, "warmup": args.warmup, "ms_per_step": elapsed / max(steps_done, 1) * 1e3,
+            "n_gpus": n_gpus, "steps": steps_done, "warmup": args.warmup, "ms_per_step": elapsed / max(steps_done, 1) * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if wl["dtype"] == "float32" else "f64", "data": "synthetic",
             "arithmetic": ("fp32 operands split exactly into 3 bf16 planes, 6 plane products per multiply-add accumulated in fp32 on the bf16 matrix cores"
                            if bf16x6 else "native " + wl["dtype"] + " matrix-core fma chains"),
             "config": {"workload": wl["desc"], "num_points": N, "num_features": d, "kernel": wl["kernel"], "gamma": 1.0 / d, "cost": 1.0,
-                       "seed": args.seed, "parallelism": f"row-block sharding x{world}" if world > 1 else "single GPU",
+                       "seed": args.seed, "parallelism": parallelism, "shards": shards, "exchange": exchange_names.get(int(i1.get("exchange", 0)), "?"),
                        "residuum_after_timed_steps": i1["residuum"]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "kernel": "lssvm::tile_matvec (implicit K*d tile kernel)", "launches": launches, "avg_launch_ms": kern_ms,
                          "algorithmic_flop_per_launch": useful_launch * plane_products, "symmetric": symmetric,
                          "executed_flop_per_launch": exec_launch * plane_products, "executed": executed, "executed_frac": executed / peak,
@@ -200,9 +320,12 @@ def main():
                          # the same launch priced with the full-square convention of `value` (can exceed the peak when symmetric)
                          "full_square_flop_per_launch": square_launch, "effective_full_square": effective},
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(X, y, wl["kernel"], args.cpu_sample_rows, 3)
-        if bf16x6 and world == 1 and not args.no_native_reference:
+        if not args.no_cpu_baseline and shards == 1:
+            line_a, line_b = cpu_baseline(X, y, wl["kernel"], args.cpu_sample_rows, 3)
+            out["cpu_baseline"] = line_a
+            if line_b is not None:
+                out["cpu_baseline_release"] = line_b
+        if bf16x6 and shards == 1 and not args.no_native_reference:
             # the same workload on native v_mfma_f32 chains (option gram_mode = 0), reported beside the headline -- never as `value`
             prob.close()
             _capi.set_option("gram_mode", 0)

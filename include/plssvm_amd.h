@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PLSSVM_AMD_ABI_VERSION 1
+#define PLSSVM_AMD_ABI_VERSION 2 /* 2: multi-device entry points (_multi), lssvm_cg_info grew local_devices / exchange */
 
 typedef enum lssvm_status {
     LSSVM_SUCCESS = 0,
@@ -75,6 +75,8 @@ typedef struct lssvm_cg_info {
     int32_t converged;       /* 1 if the stop test delta <= eps^2 * delta0 fired */
     int32_t symmetric;       /* 1 if the implicit matvec evaluated only the tiles on/below the diagonal (half the multiply-adds) */
     int32_t gram_mode;       /* fp32: 1 if the Gram tiles ran as the exact 3-way bf16 split on the bf16 matrix cores ("bf16x6"), else 0 */
+    int32_t local_devices;   /* devices driven by THIS process (1 for a single GPU and for one process per GPU) */
+    int32_t exchange;        /* how the partial K*v vectors were combined per matvec: 0 none, 1 RCCL (all-reduce / all-gather), 2 peer kernels over xGMI */
 } lssvm_cg_info;
 
 /* ------------------------------------------------------------------------------------------------------------------ */
@@ -98,6 +100,22 @@ int lssvm_mi355_solve_f32(const lssvm_params *params, const float *X, size_t num
                           float eps, uint64_t max_iter, float *alpha_out, float *rho_out, lssvm_cg_info *info);
 int lssvm_mi355_solve_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, const double *y,
                           double eps, uint64_t max_iter, double *alpha_out, double *rho_out, lssvm_cg_info *info);
+
+/* The same solve on SEVERAL devices of the calling process -- what a plssvm::csvm backend needs, since the reference drives all
+ * its devices from one process behind csvm::fit (gpu_csvm.hpp:283-299 device split, :574-593 per-device launches, :449-475
+ * device_reduction).  The implicit matrix is row-block sharded over the devices (the data matrix is replicated), one stream per
+ * device is driven by the calling thread, and the partial K*v vectors are combined once per matvec with an RCCL all-reduce
+ * (ncclCommInitAll) or, option "exchange" = 2, by peer kernels over xGMI.
+ *   num_devices == 0: automatic = every visible device, but at least 4096 points per device; devices must then be NULL;
+ *   num_devices >= 1: devices[0..num_devices) are HIP device ordinals, or NULL for 0 .. num_devices-1.  The same ordinal may be
+ *   listed several times (shards then share that device; the exchange falls back to peer kernels): how the sharded path is
+ *   exercised on a single-GPU machine. */
+int lssvm_mi355_solve_multi_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, const float *y,
+                                float eps, uint64_t max_iter, float *alpha_out, float *rho_out, lssvm_cg_info *info,
+                                const int *devices, int num_devices);
+int lssvm_mi355_solve_multi_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, const double *y,
+                                double eps, uint64_t max_iter, double *alpha_out, double *rho_out, lssvm_cg_info *info,
+                                const int *devices, int num_devices);
 
 /* csvm::predict_values (csvm.hpp:204, :208; recipe: backends/OpenMP/csvm.cpp:188-227, HIP/predict_kernel.hip.hpp:34-117).
  * w_inout has num_features entries; *w_valid != 0 on entry means it already holds w (linear kernel only), on exit it is
@@ -151,6 +169,12 @@ typedef struct lssvm_shard {
     int32_t world;
 } lssvm_shard;
 
+/* Host only, no device needed: the 128-row blocks [*block_begin, *block_end) of the implicit matrix that shard `rank` of `world`
+ * evaluates for a data set of `num_points` points.  symmetric != 0: only tiles on/below the diagonal are evaluated, blocks are
+ * dealt by equal AREA (boundary r = round(blocks * sqrt(r / world))); else equal contiguous runs.  The partition every
+ * Problem uses (plssvm_amd/sharding.py restates it for the flop accounting of bench.py). */
+int lssvm_mi355_shard_blocks(size_t num_points, int world, int rank, int symmetric, int64_t *block_begin, int64_t *block_end);
+
 /* RCCL bootstrap: rank 0 obtains a 128-byte unique id and hands it to the other ranks out of band
  * (bench.py / the Python launcher broadcast it with torch.distributed); every rank then calls comm_init.
  * One communicator per process.  Replaces the reference's host-staged device_reduction (gpu_csvm.hpp:449-475). */
@@ -162,12 +186,17 @@ int lssvm_mi355_comm_destroy(void);
 /* upload X (N x d row-major, dtype per `dtype`), compute q, QA_cost and the per-row norms on `device`. */
 int lssvm_mi355_problem_create(lssvm_mi355_problem **out, const lssvm_params *params, int dtype, const void *X, int mem_kind,
                                size_t num_points, size_t num_features, int device, const lssvm_shard *shard /* NULL = single GPU */);
+/* the same on several devices of this process (see lssvm_mi355_solve_multi_*); mem_kind LSSVM_MEM_DEVICE: X may live on any of them.
+ * Every lssvm_mi355_problem_* / lssvm_mi355_cg_* call below accepts the handle. */
+int lssvm_mi355_problem_create_multi(lssvm_mi355_problem **out, const lssvm_params *params, int dtype, const void *X, int mem_kind,
+                                     size_t num_points, size_t num_features, const int *devices, int num_devices);
 int lssvm_mi355_problem_destroy(lssvm_mi355_problem *p);
 
 /* read back q (N-1 entries, dtype of the problem) and QA_cost */
 int lssvm_mi355_problem_get_q(lssvm_mi355_problem *p, void *q_out, double *QA_cost_out);
 
-/* ret[0..N-1) += add * Abar * d (host vectors of the problem's dtype).  With sharding every rank returns the full vector. */
+/* ret[0..N-1) += add * Abar * d (host vectors of the problem's dtype, N-1 entries EACH: the library reads and writes exactly
+ * num_points - 1 elements of both).  With sharding every rank returns the full vector. */
 int lssvm_mi355_problem_matvec(lssvm_mi355_problem *p, const void *d, void *ret_inout, double add);
 
 /* CG, csvm.cpp:89-111: b = y[0..n) - y[n], x = 1, r = b - A x, delta0, d = r */
@@ -195,7 +224,8 @@ int lssvm_mi355_libsvm_fill_f32(lssvm_mi355_libsvm_file *file, float *X, uint64_
 int lssvm_mi355_libsvm_fill_f64(lssvm_mi355_libsvm_file *file, double *X, uint64_t ldx, double *labels);
 int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
 
-/* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT):
+/* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT).  set_option changes the process-wide DEFAULTS;
+ * every problem / solve takes a snapshot of them when it is created, so later changes never affect a live problem:
  *   "rbf_form"      0 = norm expansion on the matrix cores (default), 1 = direct (x_i - x_j)^2 on the vector ALU
  *   "j_chunk_tiles" number of 128-column tiles per work item; 0 = automatic (default: about 4096 work items per device, 2 ... 16 tiles each,
  *                   up to 64 for the bf16x6 kernel)
@@ -213,6 +243,10 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *                   different summation order; 0 = Gram tiles on v_mfma_f32_32x32x2_f32 (exact fmaf chains)
  *   "colslab_limit_mb" the symmetric variant needs n_tiles^2 / 2 column records of 128 reals (15.6 GB at 1M points in fp32, divided
  *                   by the number of ranks); above this many MiB per device the full square is evaluated instead (default 98304)
+ *   "exchange"      several devices in one process (the _multi entry points): 0 = automatic (RCCL when the listed devices are distinct, peer
+ *                   kernels otherwise; default), 1 = RCCL all-reduce / all-gather, 2 = peer kernels: every device adds the partial vectors of all
+ *                   devices through its xGMI peer mappings in rank order (bit-equal on all devices, deterministic)
+ *   "check_shards"  1 = cg_finish verifies that the CG scalars of all local shards are bit-equal (default), 0 = skip the check
  *   "force_collective" 1 = run the per-matvec RCCL collective even with a world of 1 (testing aid; default 0)
  *   "skip_collective"  1 = problems created with world > 1 need no communicator and do NOT exchange their partial K*v (testing aid:
  *                      lets one GPU evaluate every rank's share in turn; default 0)

@@ -27,7 +27,9 @@
 #include <algorithm>
 #include <cstddef>
 #include <cstdint>
+#include <iostream>
 #include <memory>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -100,6 +102,89 @@ struct parameter {
 }  // namespace detail
 using parameter = detail::parameter<double>;  // parameter.hpp:328
 
+/* ------------------------------------------------------------ named arguments (parameter.hpp:35-51, :209-262) ------------------------------------------------------------ */
+/* The reference builds its named parameters with the un-vendored `igor` library: `plssvm::kernel_type = ..., plssvm::gamma = ...`.
+ * The same call syntax, restated in ~40 lines: a name is an empty tag object whose operator= wraps the value. */
+namespace named {
+template <typename Tag, typename V>
+struct argument {
+    V value;
+};
+template <typename Tag>
+struct name {
+    template <typename V>
+    constexpr argument<Tag, std::decay_t<V>> operator=(V &&v) const {
+        return { std::forward<V>(v) };
+    }
+};
+struct kernel_type_tag {};
+struct gamma_tag {};
+struct degree_tag {};
+struct coef0_tag {};
+struct cost_tag {};
+struct num_devices_tag {};  // mi355 backend only: devices used by one solve (0 = automatic)
+
+template <typename T>
+struct is_argument : std::false_type {};
+template <typename Tag, typename V>
+struct is_argument<argument<Tag, V>> : std::true_type {};
+template <typename T, typename Tag>
+struct has_tag : std::false_type {};
+template <typename Tag, typename V>
+struct has_tag<argument<Tag, V>, Tag> : std::true_type {};
+template <typename Tag, typename... Args>
+constexpr int count_tag = (0 + ... + (has_tag<std::decay_t<Args>, Tag>::value ? 1 : 0));
+/* "Can only use named parameter!" / "Can only use each named parameter once!" (parameter.hpp:219-222) */
+template <typename... Args>
+constexpr bool only_named_v = (true && ... && is_argument<std::decay_t<Args>>::value);
+template <typename... Args>
+constexpr bool no_duplicates_v = count_tag<kernel_type_tag, Args...> <= 1 && count_tag<gamma_tag, Args...> <= 1 && count_tag<degree_tag, Args...> <= 1
+                                 && count_tag<coef0_tag, Args...> <= 1 && count_tag<cost_tag, Args...> <= 1 && count_tag<num_devices_tag, Args...> <= 1;
+}  // namespace named
+inline constexpr named::name<named::kernel_type_tag> kernel_type{};
+inline constexpr named::name<named::gamma_tag> gamma{};
+inline constexpr named::name<named::degree_tag> degree{};
+inline constexpr named::name<named::coef0_tag> coef0{};
+inline constexpr named::name<named::cost_tag> cost{};
+inline constexpr named::name<named::num_devices_tag> num_devices{};
+
+namespace detail {
+inline const char *kernel_name(kernel_function_type k) { return k == kernel_function_type::linear ? "linear" : (k == kernel_function_type::polynomial ? "polynomial" : "rbf"); }
+/* parameter<T>::set_named_arguments (parameter.hpp:216-262): kernel_type first, then the values, with the reference's warnings for
+ * values the chosen kernel ignores */
+template <typename... Args>
+inline void set_named_arguments(::plssvm_amd::parameter &p, int *num_devices_out, const Args &...args) {
+    static_assert(named::only_named_v<Args...>, "Can only use named parameter!");
+    static_assert(named::no_duplicates_v<Args...>, "Can only use each named parameter once!");
+    const auto warn = [&](const char *what) {
+        std::clog << what << " parameter provided, which is not used in the " << kernel_name(p.kernel_type) << " kernel!" << std::endl;
+    };
+    const auto first = [&](const auto &a) {
+        using A = std::decay_t<decltype(a)>;
+        if constexpr (named::has_tag<A, named::kernel_type_tag>::value) p.kernel_type = static_cast<kernel_function_type>(a.value);
+    };
+    const auto second = [&](const auto &a) {
+        using A = std::decay_t<decltype(a)>;
+        if constexpr (named::has_tag<A, named::gamma_tag>::value) {
+            p.set_gamma(static_cast<double>(a.value));
+            if (p.kernel_type == kernel_function_type::linear) warn("gamma");
+        } else if constexpr (named::has_tag<A, named::degree_tag>::value) {
+            p.degree = static_cast<int>(a.value);
+            if (p.kernel_type != kernel_function_type::polynomial) warn("degree");
+        } else if constexpr (named::has_tag<A, named::coef0_tag>::value) {
+            p.coef0 = static_cast<double>(a.value);
+            if (p.kernel_type != kernel_function_type::polynomial) warn("coef0");
+        } else if constexpr (named::has_tag<A, named::cost_tag>::value) {
+            p.cost = static_cast<double>(a.value);
+        } else if constexpr (named::has_tag<A, named::num_devices_tag>::value) {
+            if (num_devices_out != nullptr) *num_devices_out = static_cast<int>(a.value);
+        }
+    };
+    (first(args), ...);
+    (second(args), ...);
+}
+}  // namespace detail
+
 /* ------------------------------------------------------------ model (model.hpp, the members fit/predict touch) ------------------------------------------------------------ */
 template <typename T>
 struct model {
@@ -116,6 +201,12 @@ struct model {
 class csvm {
   public:
     explicit csvm(parameter params = {}) : params_{ params } { sanity_check_parameter(); }
+    /* csvm::csvm(Args &&...named_args) (csvm.hpp:77-83) */
+    template <typename... Args, std::enable_if_t<(sizeof...(Args) > 0) && named::only_named_v<Args...>, bool> = true>
+    explicit csvm(Args &&...named_args) {
+        detail::set_named_arguments(params_, nullptr, named_args...);
+        sanity_check_parameter();
+    }
     csvm(const csvm &) = delete;
     csvm(csvm &&) noexcept = default;
     csvm &operator=(const csvm &) = delete;
@@ -228,19 +319,59 @@ class csvm : public ::plssvm_amd::csvm {
   public:
     explicit csvm(parameter params = {}) : csvm{ target_platform::automatic, params } {}
     explicit csvm(target_platform target, parameter params = {}) : ::plssvm_amd::csvm{ params } { init(target); }
+    /* hip::csvm(Args &&...named_args) / (target, Args &&...named_args) (HIP/csvm.hpp:82-99), e.g.
+     *   mi355::csvm svm{ plssvm_amd::kernel_type = kernel_function_type::rbf, plssvm_amd::gamma = 0.01, plssvm_amd::num_devices = 8 }; */
+    template <typename... Args, std::enable_if_t<(sizeof...(Args) > 0) && named::only_named_v<Args...>, bool> = true>
+    explicit csvm(Args &&...named_args) : csvm{ target_platform::automatic, std::forward<Args>(named_args)... } {}
+    template <typename... Args, std::enable_if_t<(sizeof...(Args) > 0) && named::only_named_v<Args...>, bool> = true>
+    explicit csvm(const target_platform target, Args &&...named_args) : ::plssvm_amd::csvm{} {
+        parameter p{};
+        ::plssvm_amd::detail::set_named_arguments(p, &use_devices_, named_args...);
+        set_params(p);
+        init(target);
+        set_num_devices(use_devices_);
+    }
 
-    /* cg tracking values of the last solve (what the reference logs, csvm.cpp:167-176) */
+    /* cg tracking values of the last solve (what the reference logs, csvm.cpp:167-176).  The info block is written by the const
+     * solve virtuals, like the reference's performance tracker it is not synchronised: one solve at a time per csvm object. */
     [[nodiscard]] const lssvm_cg_info &last_cg_info() const noexcept { return info_; }
     [[nodiscard]] int num_available_devices() const noexcept { return num_devices_; }
+    /* devices one solve is sharded over: 0 = automatic (every visible device, at least 4096 points each -- the reference's backends
+     * also take every device they find, csvm.hip.cpp:66-75), 1 = device 0 only, k = devices 0 .. k-1 */
+    void set_num_devices(int n) {
+        if (n < 0 || n > num_devices_) throw backend_exception{ "Requested " + std::to_string(n) + " devices, but only " + std::to_string(num_devices_) + " are available!" };
+        use_devices_ = n;
+    }
+    [[nodiscard]] int get_num_devices() const noexcept { return use_devices_; }
+
+    /* the tracking entries of the last solve in the layout of the reference's performance tracker (performance_tracker.cpp:139-190):
+     * one YAML document with the groups `backend` (csvm.hip.cpp:59-60) and `cg` (csvm.cpp:167-174, csvm.hpp:318-320) */
+    void write_tracking_yaml(std::ostream &out) const {
+        out << "---\n"
+            << "backend:\n"
+            << "  backend: mi355\n"
+            << "  target_platform: gpu_amd\n"
+            << "  num_devices: " << info_.devices_used << "\n"
+            << "\n"
+            << "cg:\n"
+            << "  iterations: " << info_.iterations << "\n"
+            << "  max_iterations: " << info_.max_iterations << "\n"
+            << "  residuum: " << info_.residuum << "\n"
+            << "  target_residuum: " << info_.target_residuum << "\n"
+            << "  avg_iteration_time: " << info_.avg_iteration_ms << "ms\n"
+            << "  epsilon: " << info_.epsilon << "\n"
+            << "  total_runtime: " << info_.total_ms << "ms\n"
+            << "\n";
+    }
 
   protected:
     [[nodiscard]] std::pair<std::vector<float>, float> solve_system_of_linear_equations(const ::plssvm_amd::detail::parameter<float> &params, const std::vector<std::vector<float>> &A,
                                                                                         std::vector<float> b, float eps, unsigned long long max_iter) const override {
-        return solve_impl<float>(params, A, b, eps, max_iter, &lssvm_mi355_solve_f32);
+        return solve_impl<float>(params, A, b, eps, max_iter, &lssvm_mi355_solve_multi_f32);
     }
     [[nodiscard]] std::pair<std::vector<double>, double> solve_system_of_linear_equations(const ::plssvm_amd::detail::parameter<double> &params, const std::vector<std::vector<double>> &A,
                                                                                           std::vector<double> b, double eps, unsigned long long max_iter) const override {
-        return solve_impl<double>(params, A, b, eps, max_iter, &lssvm_mi355_solve_f64);
+        return solve_impl<double>(params, A, b, eps, max_iter, &lssvm_mi355_solve_multi_f64);
     }
     [[nodiscard]] std::vector<float> predict_values(const ::plssvm_amd::detail::parameter<float> &params, const std::vector<std::vector<float>> &support_vectors, const std::vector<float> &alpha,
                                                     float rho, std::vector<float> &w, const std::vector<std::vector<float>> &predict_points) const override {
@@ -272,7 +403,8 @@ class csvm : public ::plssvm_amd::csvm {
         const lssvm_params p = detail::to_c(params);
         std::vector<T> alpha(A.size());
         T rho{};
-        detail::check(fn(&p, flat.data(), A.size(), A.front().size(), b.data(), eps, static_cast<uint64_t>(max_iter), alpha.data(), &rho, &info_));
+        // all devices of this process behind ONE call, like gpu_csvm::solve_system_of_linear_equations_impl (gpu_csvm.hpp:477-654)
+        detail::check(fn(&p, flat.data(), A.size(), A.front().size(), b.data(), eps, static_cast<uint64_t>(max_iter), alpha.data(), &rho, &info_, nullptr, use_devices_));
         return std::make_pair(std::move(alpha), rho);
     }
 
@@ -303,7 +435,8 @@ class csvm : public ::plssvm_amd::csvm {
         return out;
     }
 
-    int num_devices_{ 0 };
+    int num_devices_{ 0 };  // visible devices
+    int use_devices_{ 0 };  // devices per solve (0 = automatic)
     mutable lssvm_cg_info info_{};
 };
 

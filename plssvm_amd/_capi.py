@@ -28,11 +28,11 @@ STATUS_NAMES = {0: "LSSVM_SUCCESS", -1: "LSSVM_ERR_INVALID_ARGUMENT", -2: "LSSVM
 # every symbol include/plssvm_amd.h declares (tests/test_capi_symbols.py checks the built library against this list AND the header)
 EXPORTED_SYMBOLS = [
     "lssvm_mi355_abi_version", "lssvm_mi355_device_count", "lssvm_mi355_device_name", "lssvm_mi355_last_error",
-    "lssvm_mi355_solve_f32", "lssvm_mi355_solve_f64", "lssvm_mi355_predict_values_f32", "lssvm_mi355_predict_values_f64",
+    "lssvm_mi355_solve_f32", "lssvm_mi355_solve_f64", "lssvm_mi355_solve_multi_f32", "lssvm_mi355_solve_multi_f64", "lssvm_mi355_predict_values_f32", "lssvm_mi355_predict_values_f64",
     "lssvm_mi355_generate_q_f32", "lssvm_mi355_generate_q_f64", "lssvm_mi355_run_device_kernel_f32", "lssvm_mi355_run_device_kernel_f64",
     "lssvm_mi355_calculate_w_f32", "lssvm_mi355_calculate_w_f64",
-    "lssvm_mi355_comm_get_unique_id", "lssvm_mi355_comm_init", "lssvm_mi355_comm_destroy",
-    "lssvm_mi355_problem_create", "lssvm_mi355_problem_destroy", "lssvm_mi355_problem_get_q", "lssvm_mi355_problem_matvec",
+    "lssvm_mi355_shard_blocks", "lssvm_mi355_comm_get_unique_id", "lssvm_mi355_comm_init", "lssvm_mi355_comm_destroy",
+    "lssvm_mi355_problem_create", "lssvm_mi355_problem_create_multi", "lssvm_mi355_problem_destroy", "lssvm_mi355_problem_get_q", "lssvm_mi355_problem_matvec",
     "lssvm_mi355_cg_begin", "lssvm_mi355_cg_step", "lssvm_mi355_cg_finish", "lssvm_mi355_problem_synchronize", "lssvm_mi355_problem_info",
     "lssvm_mi355_set_option", "lssvm_mi355_get_option",
     "lssvm_mi355_libsvm_open", "lssvm_mi355_libsvm_fill_f32", "lssvm_mi355_libsvm_fill_f64", "lssvm_mi355_libsvm_close",
@@ -48,7 +48,7 @@ class LssvmCgInfo(C.Structure):
     _fields_ = [("iterations", C.c_uint64), ("max_iterations", C.c_uint64), ("residuum", C.c_double), ("initial_residuum", C.c_double),
                 ("target_residuum", C.c_double), ("epsilon", C.c_double), ("avg_iteration_ms", C.c_double), ("total_ms", C.c_double),
                 ("setup_ms", C.c_double), ("matvec_kernel_ms", C.c_double), ("matvec_launches", C.c_uint64), ("devices_used", C.c_int32),
-                ("converged", C.c_int32), ("symmetric", C.c_int32), ("gram_mode", C.c_int32)]
+                ("converged", C.c_int32), ("symmetric", C.c_int32), ("gram_mode", C.c_int32), ("local_devices", C.c_int32), ("exchange", C.c_int32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -116,6 +116,27 @@ def device_name(device: int = 0) -> str:
     buf = C.create_string_buffer(256)
     check(lib.lssvm_mi355_device_name(C.c_int(device), buf, C.c_size_t(256)))
     return buf.value.decode()
+
+
+ABI_VERSION = 2
+# every tuning knob of lssvm_mi355_set_option (include/plssvm_amd.h)
+OPTION_NAMES = ["rbf_form", "j_chunk_tiles", "symmetric", "tile_kernel", "xcd_map", "lds_extra_kb", "debug_ablate", "item_order", "gram_mode",
+                "colslab_limit_mb", "force_collective", "skip_collective", "exchange", "check_shards"]
+
+
+def int_array(values):
+    """A C ``int[]`` (or NULL for None) for the device lists of the ``_multi`` entry points."""
+    if values is None:
+        return None, 0
+    values = [int(v) for v in values]
+    return (C.c_int * len(values))(*values), len(values)
+
+
+def shard_blocks(num_points: int, world: int, rank: int, symmetric: bool):
+    """The library's own row-block partition (host only): ``(block_begin, block_end)`` of shard ``rank``."""
+    b, e = C.c_int64(0), C.c_int64(0)
+    check(lib.lssvm_mi355_shard_blocks(C.c_size_t(num_points), C.c_int(world), C.c_int(rank), C.c_int(1 if symmetric else 0), C.byref(b), C.byref(e)))
+    return int(b.value), int(e.value)
 
 
 def set_option(name: str, value: int) -> None:

@@ -42,8 +42,11 @@ def _as_matrix(A, dtype=None) -> np.ndarray:
     return A
 
 
-def solve_system_of_linear_equations(params: Parameter, A, b, eps: float, max_iter: int):
-    """Returns ``(alpha[N], rho, info)`` -- ``csvm::solve_system_of_linear_equations`` (csvm.hpp:188-192)."""
+def solve_system_of_linear_equations(params: Parameter, A, b, eps: float, max_iter: int, devices=None, num_devices: int | None = None):
+    """Returns ``(alpha[N], rho, info)`` -- ``csvm::solve_system_of_linear_equations`` (csvm.hpp:188-192).
+
+    ``devices`` (a list of HIP ordinals; the same ordinal may repeat) or ``num_devices`` (0 = every visible device) select the
+    single-process multi-device solve ``lssvm_mi355_solve_multi_*``; with neither the solve runs on device 0."""
     A = _as_matrix(A)
     N, d = A.shape
     b = np.ascontiguousarray(b, dtype=A.dtype)
@@ -53,10 +56,19 @@ def solve_system_of_linear_equations(params: Parameter, A, b, eps: float, max_it
     alpha = np.zeros(N, dtype=A.dtype)
     rho = ct(0)
     info = LssvmCgInfo()
-    fn = getattr(lib, f"lssvm_mi355_solve_{suffix_of(A.dtype)}")
-    fn.restype = C.c_int
     ps = _params_struct(params, d)
-    check(fn(C.byref(ps), ptr(A), C.c_size_t(N), C.c_size_t(d), ptr(b), ct(eps), C.c_uint64(int(max_iter)), ptr(alpha), C.byref(rho), C.byref(info)))
+    if devices is None and num_devices is None:
+        fn = getattr(lib, f"lssvm_mi355_solve_{suffix_of(A.dtype)}")
+        fn.restype = C.c_int
+        check(fn(C.byref(ps), ptr(A), C.c_size_t(N), C.c_size_t(d), ptr(b), ct(eps), C.c_uint64(int(max_iter)), ptr(alpha), C.byref(rho), C.byref(info)))
+    else:
+        fn = getattr(lib, f"lssvm_mi355_solve_multi_{suffix_of(A.dtype)}")
+        fn.restype = C.c_int
+        dev_arr, ndev = _capi.int_array(devices)
+        if devices is None:
+            ndev = int(num_devices)
+        check(fn(C.byref(ps), ptr(A), C.c_size_t(N), C.c_size_t(d), ptr(b), ct(eps), C.c_uint64(int(max_iter)), ptr(alpha), C.byref(rho), C.byref(info),
+                 dev_arr, C.c_int(ndev)))
     return alpha, A.dtype.type(rho.value), info.as_dict()
 
 
@@ -146,7 +158,10 @@ def comm_destroy() -> None:
 class ResidentProblem:
     """A data matrix resident in HBM plus the CG state on it (``lssvm_mi355_problem_*`` / ``lssvm_mi355_cg_*``)."""
 
-    def __init__(self, params: Parameter, X, device: int = 0, rank: int = 0, world: int = 1, device_ptr: int | None = None, shape=None, dtype=None):
+    def __init__(self, params: Parameter, X, device: int = 0, rank: int = 0, world: int = 1, device_ptr: int | None = None, shape=None, dtype=None,
+                 devices=None):
+        """``devices``: a list of HIP ordinals -> ONE process drives all of them (``lssvm_mi355_problem_create_multi``; an empty list = every
+        visible device); otherwise ``device`` holds rank ``rank`` of a world of processes (one process per GPU, or a single GPU)."""
         self._h = C.c_void_p(None)
         if device_ptr is not None:
             N, d = shape
@@ -164,10 +179,18 @@ class ResidentProblem:
         self.num_points, self.num_features = int(N), int(d)
         self.params = params.resolved(d)
         ps = _params_struct(params, d)
-        shard = LssvmShard(rank, world)
-        lib.lssvm_mi355_problem_create.restype = C.c_int
-        check(lib.lssvm_mi355_problem_create(C.byref(self._h), C.byref(ps), C.c_int(_capi.dtype_code(self.dtype)), src, C.c_int(kind), C.c_size_t(N), C.c_size_t(d),
-                                             C.c_int(device), C.byref(shard)))
+        if devices is not None:
+            if (rank, world) != (0, 1):
+                raise InvalidParameterError("a device list (one process, several GPUs) and rank/world (one process per GPU) exclude each other")
+            dev_arr, ndev = _capi.int_array(list(devices) or None)
+            lib.lssvm_mi355_problem_create_multi.restype = C.c_int
+            check(lib.lssvm_mi355_problem_create_multi(C.byref(self._h), C.byref(ps), C.c_int(_capi.dtype_code(self.dtype)), src, C.c_int(kind), C.c_size_t(N),
+                                                       C.c_size_t(d), dev_arr, C.c_int(ndev)))
+        else:
+            shard = LssvmShard(rank, world)
+            lib.lssvm_mi355_problem_create.restype = C.c_int
+            check(lib.lssvm_mi355_problem_create(C.byref(self._h), C.byref(ps), C.c_int(_capi.dtype_code(self.dtype)), src, C.c_int(kind), C.c_size_t(N), C.c_size_t(d),
+                                                 C.c_int(device), C.byref(shard)))
         self._keep = None  # the library copied the data
 
     def close(self):
@@ -196,6 +219,8 @@ class ResidentProblem:
     def matvec(self, d, ret, add: float = 1.0):
         d = np.ascontiguousarray(d, dtype=self.dtype)
         out = np.array(ret, dtype=self.dtype, copy=True)
+        if not (d.ndim == out.ndim == 1 and d.size == out.size == self.num_points - 1):  # the library reads / writes exactly N - 1 elements of both
+            raise InvalidParameterError(f"Sizes mismatch!: {d.size} / {out.size} != {self.num_points - 1}")
         check(lib.lssvm_mi355_problem_matvec(self._h, ptr(d), ptr(out), C.c_double(add)))
         return out
 

@@ -44,7 +44,8 @@ lssvm::ProblemBase *impl_of(lssvm_mi355_problem *p) {
 }
 
 template <typename T>
-void solve_one_shot(const lssvm_params *params, const T *X, size_t N, size_t d, const T *y, T eps, uint64_t max_iter, T *alpha_out, T *rho_out, lssvm_cg_info *info) {
+void solve_one_shot(const lssvm_params *params, const T *X, size_t N, size_t d, const T *y, T eps, uint64_t max_iter, T *alpha_out, T *rho_out, lssvm_cg_info *info,
+                    const int *devices, int num_devices) {
     lssvm::check_params(params);
     LSSVM_REQUIRE(X != nullptr && N > 0, "The data must not be empty!");                                                                  // csvm.cpp:73
     LSSVM_REQUIRE(d > 0, "The data points must contain at least one feature!");                                                           // csvm.cpp:74
@@ -52,7 +53,7 @@ void solve_one_shot(const lssvm_params *params, const T *X, size_t N, size_t d, 
     LSSVM_REQUIRE(eps > T(0), "The stopping criterion in the CG algorithm must be greater than 0.0, but is " + std::to_string(eps) + "!");  // csvm.cpp:77
     LSSVM_REQUIRE(max_iter > 0, "The number of CG iterations must be greater than 0!");                                                   // csvm.cpp:78
     LSSVM_REQUIRE(alpha_out != nullptr && rho_out != nullptr, "alpha_out / rho_out must not be NULL");
-    lssvm::Problem<T> prob(*params, X, LSSVM_MEM_HOST, N, d, 0, nullptr);
+    lssvm::Solver<T> prob(*params, X, LSSVM_MEM_HOST, N, d, lssvm::resolve_devices(devices, num_devices, N), nullptr);
     prob.cg_begin(y, static_cast<double>(eps));
     prob.cg_step(max_iter, nullptr);
     double rho = 0.0;
@@ -67,7 +68,7 @@ template <typename T>
 void generate_q_one_shot(const lssvm_params *params, const T *X, size_t N, size_t d, T *q_out) {
     lssvm::check_params(params);
     LSSVM_REQUIRE(q_out != nullptr, "q_out must not be NULL");
-    lssvm::Problem<T> prob(*params, X, LSSVM_MEM_HOST, N, d, 0, nullptr);
+    lssvm::Solver<T> prob(*params, X, LSSVM_MEM_HOST, N, d, { 0 }, nullptr);
     prob.get_q(q_out, nullptr);
 }
 
@@ -103,11 +104,21 @@ int lssvm_mi355_device_name(int device, char *buf, size_t buf_len) {
 
 int lssvm_mi355_solve_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, const float *y, float eps, uint64_t max_iter,
                           float *alpha_out, float *rho_out, lssvm_cg_info *info) {
-    return guarded([&] { solve_one_shot<float>(params, X, num_points, num_features, y, eps, max_iter, alpha_out, rho_out, info); });
+    static const int device0 = 0;
+    return guarded([&] { solve_one_shot<float>(params, X, num_points, num_features, y, eps, max_iter, alpha_out, rho_out, info, &device0, 1); });
+}
+int lssvm_mi355_solve_multi_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, const float *y, float eps, uint64_t max_iter,
+                                float *alpha_out, float *rho_out, lssvm_cg_info *info, const int *devices, int num_devices) {
+    return guarded([&] { solve_one_shot<float>(params, X, num_points, num_features, y, eps, max_iter, alpha_out, rho_out, info, devices, num_devices); });
 }
 int lssvm_mi355_solve_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, const double *y, double eps, uint64_t max_iter,
                           double *alpha_out, double *rho_out, lssvm_cg_info *info) {
-    return guarded([&] { solve_one_shot<double>(params, X, num_points, num_features, y, eps, max_iter, alpha_out, rho_out, info); });
+    static const int device0 = 0;
+    return guarded([&] { solve_one_shot<double>(params, X, num_points, num_features, y, eps, max_iter, alpha_out, rho_out, info, &device0, 1); });
+}
+int lssvm_mi355_solve_multi_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, const double *y, double eps, uint64_t max_iter,
+                                double *alpha_out, double *rho_out, lssvm_cg_info *info, const int *devices, int num_devices) {
+    return guarded([&] { solve_one_shot<double>(params, X, num_points, num_features, y, eps, max_iter, alpha_out, rho_out, info, devices, num_devices); });
 }
 
 int lssvm_mi355_predict_values_f32(const lssvm_params *params, const float *sv, size_t nsv, size_t nfeat, const float *alpha, float rho, float *w_inout,
@@ -138,7 +149,7 @@ int lssvm_mi355_run_device_kernel_f32(const lssvm_params *params, const float *X
         lssvm::check_params(params);
         LSSVM_REQUIRE(q != nullptr, "The q array may not be empty!");  // csvm.cpp:284
         (void) QA_cost;  // q and QA_cost are functions of (X, params); they are recomputed on the device and must agree with the caller's
-        lssvm::Problem<float> prob(*params, X, LSSVM_MEM_HOST, num_points, num_features, 0, nullptr);
+        lssvm::Solver<float> prob(*params, X, LSSVM_MEM_HOST, num_points, num_features, { 0 }, nullptr);
         prob.matvec(d, ret_inout, static_cast<double>(add));
     });
 }
@@ -148,7 +159,7 @@ int lssvm_mi355_run_device_kernel_f64(const lssvm_params *params, const double *
         lssvm::check_params(params);
         LSSVM_REQUIRE(q != nullptr, "The q array may not be empty!");
         (void) QA_cost;
-        lssvm::Problem<double> prob(*params, X, LSSVM_MEM_HOST, num_points, num_features, 0, nullptr);
+        lssvm::Solver<double> prob(*params, X, LSSVM_MEM_HOST, num_points, num_features, { 0 }, nullptr);
         prob.matvec(d, ret_inout, add);
     });
 }
@@ -158,6 +169,18 @@ int lssvm_mi355_calculate_w_f32(const float *sv, size_t nsv, size_t nfeat, const
 }
 int lssvm_mi355_calculate_w_f64(const double *sv, size_t nsv, size_t nfeat, const double *alpha, double *w_out) {
     return guarded([&] { lssvm::calculate_w<double>(sv, nsv, nfeat, alpha, w_out); });
+}
+
+int lssvm_mi355_shard_blocks(size_t num_points, int world, int rank, int symmetric, int64_t *block_begin, int64_t *block_end) {
+    return guarded([&] {
+        LSSVM_REQUIRE(block_begin != nullptr && block_end != nullptr, "output pointers must not be NULL");
+        LSSVM_REQUIRE(num_points >= 2 && num_points < (size_t(1) << 31) - 4 * lssvm::TILE, "invalid number of data points");
+        LSSVM_REQUIRE(world >= 1 && rank >= 0 && rank < world, "invalid shard descriptor");
+        int b = 0, e = 0;
+        lssvm::shard_blocks(static_cast<int>((num_points - 1 + lssvm::TILE - 1) / lssvm::TILE), world, rank, symmetric != 0, b, e);
+        *block_begin = b;
+        *block_end = e;
+    });
 }
 
 /* ---- communicator ---- */
@@ -213,10 +236,29 @@ int lssvm_mi355_problem_create(lssvm_mi355_problem **out, const lssvm_params *pa
         lssvm::check_params(params);
         LSSVM_REQUIRE(dtype == LSSVM_DTYPE_F32 || dtype == LSSVM_DTYPE_F64, "dtype must be LSSVM_DTYPE_F32 or LSSVM_DTYPE_F64");
         auto h = std::make_unique<Handle>();
+        lssvm::select_device_checked(device);
         if (dtype == LSSVM_DTYPE_F32) {
-            h->impl = std::make_unique<lssvm::Problem<float>>(*params, X, mem_kind, num_points, num_features, device, shard);
+            h->impl = std::make_unique<lssvm::Solver<float>>(*params, X, mem_kind, num_points, num_features, std::vector<int>{ device }, shard);
         } else {
-            h->impl = std::make_unique<lssvm::Problem<double>>(*params, X, mem_kind, num_points, num_features, device, shard);
+            h->impl = std::make_unique<lssvm::Solver<double>>(*params, X, mem_kind, num_points, num_features, std::vector<int>{ device }, shard);
+        }
+        *out = reinterpret_cast<lssvm_mi355_problem *>(h.release());
+    });
+}
+int lssvm_mi355_problem_create_multi(lssvm_mi355_problem **out, const lssvm_params *params, int dtype, const void *X, int mem_kind, size_t num_points,
+                                     size_t num_features, const int *devices, int num_devices) {
+    return guarded([&] {
+        LSSVM_REQUIRE(out != nullptr, "out must not be NULL");
+        *out = nullptr;
+        lssvm::check_params(params);
+        LSSVM_REQUIRE(dtype == LSSVM_DTYPE_F32 || dtype == LSSVM_DTYPE_F64, "dtype must be LSSVM_DTYPE_F32 or LSSVM_DTYPE_F64");
+        LSSVM_REQUIRE(num_points >= 2, "The data must contain at least two data points!");
+        const std::vector<int> devs = lssvm::resolve_devices(devices, num_devices, num_points);
+        auto h = std::make_unique<Handle>();
+        if (dtype == LSSVM_DTYPE_F32) {
+            h->impl = std::make_unique<lssvm::Solver<float>>(*params, X, mem_kind, num_points, num_features, devs, nullptr);
+        } else {
+            h->impl = std::make_unique<lssvm::Solver<double>>(*params, X, mem_kind, num_points, num_features, devs, nullptr);
         }
         *out = reinterpret_cast<lssvm_mi355_problem *>(h.release());
     });
@@ -281,6 +323,11 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
             lssvm::options().colslab_limit_mb = value;
         } else if (n == "skip_collective") {
             lssvm::options().skip_collective = value != 0 ? 1 : 0;
+        } else if (n == "exchange") {
+            LSSVM_REQUIRE(value >= 0 && value <= 2, "exchange must be 0 (automatic), 1 (RCCL) or 2 (peer kernels)");
+            lssvm::options().exchange = value;
+        } else if (n == "check_shards") {
+            lssvm::options().check_shards = value != 0 ? 1 : 0;
         } else if (n == "item_order") {
             LSSVM_REQUIRE(value >= 0 && value <= 2, "item_order must be 0, 1 or 2");
             lssvm::options().item_order = value;
@@ -315,6 +362,10 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             *value_out = lssvm::options().colslab_limit_mb;
         } else if (n == "skip_collective") {
             *value_out = lssvm::options().skip_collective;
+        } else if (n == "exchange") {
+            *value_out = lssvm::options().exchange;
+        } else if (n == "check_shards") {
+            *value_out = lssvm::options().check_shards;
         } else if (n == "item_order") {
             *value_out = lssvm::options().item_order;
         } else {

@@ -1,6 +1,6 @@
 /*
- * lssvm_problem.hip -- implementation of the device-resident LS-SVM problem and its CG driver (see lssvm_problem.hip.hpp).
- * Compiled for gfx950 only.
+ * lssvm_problem.hip -- implementation of the device-resident LS-SVM problem (one shard per device) and its CG driver (see
+ * lssvm_problem.hip.hpp).  Compiled for gfx950 only.
  */
 #include "lssvm_problem.hip.hpp"
 
@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <mutex>
 
 namespace lssvm {
 
@@ -23,24 +24,61 @@ Comm &comm() {
 }
 
 void comm_load() {
+    static std::mutex m;
+    const std::lock_guard<std::mutex> lock(m);
     Comm &c = comm();
     if (c.lib != nullptr) return;
     // if the process already carries an RCCL (e.g. PyTorch's), reuse it; otherwise load the system one
     const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    void *lib = nullptr;
     for (const char *name : names) {
-        c.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (c.lib != nullptr) break;
+        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (lib != nullptr) break;
     }
-    if (c.lib == nullptr) throw Error(LSSVM_ERR_COMM, std::string("could not load RCCL: ") + dlerror());
-    c.pGetUniqueId = reinterpret_cast<decltype(c.pGetUniqueId)>(dlsym(c.lib, "ncclGetUniqueId"));
-    c.pCommInitRank = reinterpret_cast<decltype(c.pCommInitRank)>(dlsym(c.lib, "ncclCommInitRank"));
-    c.pCommDestroy = reinterpret_cast<decltype(c.pCommDestroy)>(dlsym(c.lib, "ncclCommDestroy"));
-    c.pAllGather = reinterpret_cast<decltype(c.pAllGather)>(dlsym(c.lib, "ncclAllGather"));
-    c.pAllReduce = reinterpret_cast<decltype(c.pAllReduce)>(dlsym(c.lib, "ncclAllReduce"));
-    c.pGetErrorString = reinterpret_cast<decltype(c.pGetErrorString)>(dlsym(c.lib, "ncclGetErrorString"));
-    if (!c.pGetUniqueId || !c.pCommInitRank || !c.pCommDestroy || !c.pAllGather || !c.pAllReduce || !c.pGetErrorString) {
+    if (lib == nullptr) throw Error(LSSVM_ERR_COMM, std::string("could not load RCCL: ") + dlerror());
+    c.pGetUniqueId = reinterpret_cast<decltype(c.pGetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    c.pCommInitRank = reinterpret_cast<decltype(c.pCommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    c.pCommInitAll = reinterpret_cast<decltype(c.pCommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+    c.pCommDestroy = reinterpret_cast<decltype(c.pCommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    c.pAllGather = reinterpret_cast<decltype(c.pAllGather)>(dlsym(lib, "ncclAllGather"));
+    c.pAllReduce = reinterpret_cast<decltype(c.pAllReduce)>(dlsym(lib, "ncclAllReduce"));
+    c.pGroupStart = reinterpret_cast<decltype(c.pGroupStart)>(dlsym(lib, "ncclGroupStart"));
+    c.pGroupEnd = reinterpret_cast<decltype(c.pGroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+    c.pGetErrorString = reinterpret_cast<decltype(c.pGetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!c.pGetUniqueId || !c.pCommInitRank || !c.pCommInitAll || !c.pCommDestroy || !c.pAllGather || !c.pAllReduce || !c.pGroupStart || !c.pGroupEnd || !c.pGetErrorString) {
         throw Error(LSSVM_ERR_COMM, "the loaded RCCL library lacks a required symbol");
     }
+    c.lib = lib;
+}
+
+static void nccl_check(ncclResult_t rc, const char *what) {
+    if (rc != ncclSuccess) throw Error(LSSVM_ERR_COMM, std::string(what) + " failed: " + comm().pGetErrorString(rc));
+}
+
+LocalComms::~LocalComms() {
+    for (size_t r = 0; r < comms.size(); ++r) {
+        if (comms[r] != nullptr) {
+            (void) hipSetDevice(devices[r]);
+            (void) comm().pCommDestroy(comms[r]);
+        }
+    }
+}
+
+/* the communicators of one device list are created once and re-used by later solves (ncclCommInitAll costs ~0.1 s per device);
+ * the cache itself is never destroyed: tearing RCCL down from a static destructor races with the HIP runtime's own exit */
+static std::shared_ptr<LocalComms> local_comms_for(const std::vector<int> &devices) {
+    static std::mutex m;
+    static auto *cached = new std::shared_ptr<LocalComms>();
+    const std::lock_guard<std::mutex> lock(m);
+    if (*cached && (*cached)->devices == devices) return *cached;
+    comm_load();
+    cached->reset();  // communicators of another device list: destroyed here unless a live solver still holds them
+    auto lc = std::make_shared<LocalComms>();
+    lc->devices = devices;
+    lc->comms.assign(devices.size(), nullptr);
+    nccl_check(comm().pCommInitAll(lc->comms.data(), static_cast<int>(devices.size()), devices.data()), "ncclCommInitAll");
+    *cached = lc;
+    return lc;
 }
 
 void check_params(const lssvm_params *params) {
@@ -53,16 +91,44 @@ void check_params(const lssvm_params *params) {
     LSSVM_REQUIRE(params->cost != 0.0 && std::isfinite(1.0 / params->cost), "cost must not be 0.0 since it is 1 / plssvm::cost!");  // svm_kernel.cpp:27
 }
 
-int select_device_checked(int device) {
+static int device_count_checked() {
     int count = 0;
     const hipError_t err = hipGetDeviceCount(&count);
     if (err != hipSuccess || count <= 0) {
         (void) hipGetLastError();
         throw Error(LSSVM_ERR_NO_DEVICE, "HIP backend selected but no HIP capable devices were found!");  // csvm.hip.cpp:70-72
     }
+    return count;
+}
+
+int select_device_checked(int device) {
+    const int count = device_count_checked();
     LSSVM_REQUIRE(device >= 0 && device < count, "Invalid device " + std::to_string(device) + " (" + std::to_string(count) + " available)!");
     LSSVM_HIP_CHECK(hipSetDevice(device));
     return count;
+}
+
+constexpr int MAX_LOCAL_DEVICES = 16;
+
+std::vector<int> resolve_devices(const int *devices, int num_devices, size_t num_points) {
+    const int count = device_count_checked();
+    LSSVM_REQUIRE(num_devices >= 0 && num_devices <= MAX_LOCAL_DEVICES, "num_devices must be between 0 (automatic) and " + std::to_string(MAX_LOCAL_DEVICES) + "!");
+    std::vector<int> out;
+    if (num_devices == 0) {
+        // automatic: every visible device, as the reference's backends do (csvm.hip.cpp:66-75), but never fewer than 32 row blocks
+        // (4096 points) per device -- below that the exchange and the launch latencies outweigh the split
+        LSSVM_REQUIRE(devices == nullptr, "a device list needs its length (num_devices > 0)");
+        const long tiles = (static_cast<long>(num_points) - 1 + TILE - 1) / TILE;
+        const int use = static_cast<int>(std::max<long>(1, std::min<long>(std::min(count, MAX_LOCAL_DEVICES), tiles / 32)));
+        for (int r = 0; r < use; ++r) out.push_back(r);
+        return out;
+    }
+    for (int r = 0; r < num_devices; ++r) {
+        const int dev = devices != nullptr ? devices[r] : r;
+        LSSVM_REQUIRE(dev >= 0 && dev < count, "Invalid device " + std::to_string(dev) + " (" + std::to_string(count) + " available)!");
+        out.push_back(dev);
+    }
+    return out;
 }
 
 /* ------------------------------------------------------------------ tile kernel selection ------------------------------------------------------------------ */
@@ -70,14 +136,13 @@ int select_device_checked(int device) {
 static bool v2_chunk_count_ok(int kchunks) {
     return kchunks <= 8 || (kchunks <= 16 && kchunks % 2 == 0);
 }
-bool v2_eligible(int ldx, bool rbf_direct) {
-    return !rbf_direct && v2_chunk_count_ok(ldx / F32_KC) && options().tile_kernel != 1;
+bool v2_eligible(const Options &o, int ldx, bool rbf_direct) {
+    return !rbf_direct && v2_chunk_count_ok(ldx / F32_KC) && o.tile_kernel != 1;
 }
-bool v2_eligible_f64(int ldx) {
-    return v2_chunk_count_ok(ldx / F64_KC) && options().tile_kernel != 1;
+bool v2_eligible_f64(const Options &o, int ldx) {
+    return v2_chunk_count_ok(ldx / F64_KC) && o.tile_kernel != 1;
 }
 
-/* kernel-function specific scalars of TileArgs */
 /* first row block of rank r when the lower triangle is dealt by equal area: round(tiles * sqrt(r / world)) */
 int sym_block_boundary(int num_tiles, int r, int world) {
     if (r <= 0) return 0;
@@ -86,6 +151,20 @@ int sym_block_boundary(int num_tiles, int r, int world) {
     return std::min(std::max(b, 0), num_tiles);
 }
 
+/* the row blocks [begin, end) of rank `rank`: equal AREAS of the lower triangle (symmetric variant: block ib costs ib + 1 tiles),
+ * equal contiguous runs otherwise (every row costs the same) */
+void shard_blocks(int num_tiles, int world, int rank, bool symmetric, int &begin, int &end) {
+    if (symmetric) {
+        begin = sym_block_boundary(num_tiles, rank, world);
+        end = sym_block_boundary(num_tiles, rank + 1, world);
+    } else {
+        const int per_rank = (num_tiles + world - 1) / world;
+        begin = std::min(rank * per_rank, num_tiles);
+        end = std::min(begin + per_rank, num_tiles);
+    }
+}
+
+/* kernel-function specific scalars of TileArgs */
 template <typename T>
 static void set_kernel_scalars(TileArgs<T> &a, const lssvm_params &p, bool rbf_direct) {
     a.degree = p.degree;
@@ -105,11 +184,17 @@ static void set_kernel_scalars(TileArgs<T> &a, const lssvm_params &p, bool rbf_d
     }
 }
 
-/* rbf, matrix-core form: the (centred) data is pre-scaled so that the MFMA chain directly produces the exponent:
- * fp32: x' = sqrt(2 gamma log2 e) (x - mean)  =>  x_i'.x_j' - (|x_i'|^2 + |x_j'|^2)/2 = -gamma log2(e) |x_i - x_j|^2 ; fp64: unscaled */
+/* the launch-related knobs travel inside TileArgs: the launchers never read the process-wide defaults */
+template <typename T>
+static void set_launch_options(TileArgs<T> &a, const Options &o) {
+    a.dbg = static_cast<int>(o.debug_ablate);
+    a.map_mode = o.xcd_map != 0 ? 1 : 0;
+    a.lds_extra_kb = static_cast<int>(o.lds_extra_kb);
+}
+
 /* rbf on the matrix cores: the data is scaled so that the MFMA chain leaves the exponent in the unit the epilogue wants:
- * fp32: -gamma log2(e) |xi - xj|^2 (epilogue v_exp_f32); fp64 on the v2 kernel (`fp64_v2`): the same (epilogue exp2_f64);
- * fp64 on the generic kernel: unscaled (epilogue fast_exp_f64(acc * 2 gamma)). */
+ * fp32: x' = sqrt(2 gamma log2 e) (x - mean)  =>  x_i'.x_j' - (|x_i'|^2 + |x_j'|^2)/2 = -gamma log2(e) |x_i - x_j|^2 (epilogue v_exp_f32);
+ * fp64 on the v2 kernel (`fp64_v2`): the same (epilogue exp2_f64); fp64 on the generic kernel: unscaled (epilogue fast_exp_f64(acc * 2 gamma)). */
 template <typename T>
 T rbf_prescale(const lssvm_params &p, bool fp64_v2) {
     constexpr double log2e = 1.4426950408889634073599246810019;
@@ -172,30 +257,21 @@ static T host_self_kernel(const lssvm_params &p, const std::vector<T> &x) {
     return std::pow(std::fma(static_cast<T>(p.gamma), val, static_cast<T>(p.coef0)), static_cast<T>(p.degree));
 }
 
-/* ------------------------------------------------------------------ Problem ------------------------------------------------------------------ */
+/* ------------------------------------------------------------------ Problem: one device's shard ------------------------------------------------------------------ */
 template <typename T>
-Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, size_t num_points, size_t num_features, int device, const lssvm_shard *shard) :
-    params_(params), device_(device) {
-    dtype = std::is_same_v<T, float> ? LSSVM_DTYPE_F32 : LSSVM_DTYPE_F64;
+Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *X, int mem_kind, size_t num_points, size_t num_features, int device, int rank, int world) :
+    opt_(opt), params_(params), device_(device), rank_(rank), world_(world) {
     check_params(&params_);
     LSSVM_REQUIRE(X != nullptr, "The data must not be empty!");                                           // csvm.cpp:73
     LSSVM_REQUIRE(num_points >= 2, "The data must contain at least two data points!");
     LSSVM_REQUIRE(num_features >= 1, "The data points must contain at least one feature!");               // csvm.cpp:74
     LSSVM_REQUIRE(num_points < (size_t(1) << 31) - 4 * TILE && num_features < (size_t(1) << 24), "problem too large for 32-bit tile indices");
     LSSVM_REQUIRE(mem_kind == LSSVM_MEM_HOST || mem_kind == LSSVM_MEM_DEVICE, "invalid mem_kind");
-    if (shard != nullptr) {
-        LSSVM_REQUIRE(shard->world >= 1 && shard->rank >= 0 && shard->rank < shard->world, "invalid shard descriptor");
-        rank_ = shard->rank;
-        world_ = shard->world;
-        if (world_ > 1 && options().skip_collective == 0) {
-            LSSVM_REQUIRE(comm().comm != nullptr && comm().world == world_ && comm().rank == rank_,
-                          "row-block sharding requested but lssvm_mi355_comm_init was not called with the same rank/world");
-            LSSVM_REQUIRE(comm().device == device, "the communicator was created for another device");
-        }
-    }
+    LSSVM_REQUIRE(world_ >= 1 && rank_ >= 0 && rank_ < world_, "invalid shard descriptor");
     select_device_checked(device_);
     const double t0 = now_ms();
-    LSSVM_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    stream_.create();
+    hipStream_t st = stream_.s;
 
     N_ = num_points;
     n_ = static_cast<int>(num_points - 1);
@@ -204,25 +280,22 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
     nvec_ = ib_per_rank_ * world_ * TILE;
     // symmetric variant: v2 kernels only; a negative polynomial degree can give inf on zero-padded rows -> full square
     const int ldx_probe = padded_features<T>(num_features);
-    const bool v2_ok = std::is_same_v<T, float> ? (options().rbf_form == 0 && v2_eligible(ldx_probe, false)) : v2_eligible_f64(ldx_probe);
-    sym_ = options().symmetric != 0 && v2_ok && !(params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree < 0);
+    const bool v2_ok = std::is_same_v<T, float> ? (opt_.rbf_form == 0 && v2_eligible(opt_, ldx_probe, false)) : v2_eligible_f64(opt_, ldx_probe);
+    sym_ = opt_.symmetric != 0 && v2_ok && !(params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree < 0);
     if (sym_) {
         // the symmetric variant keeps one 128-entry record per evaluated off-diagonal tile (15.6 GB for 1M points in fp32, spread
         // over the ranks by area).  Beyond the budget fall back to the full square -- a rule in n, world and sizeof(T) only, so
         // that every rank of a sharded solve takes the same decision.
         const double slab_bytes = 0.5 * static_cast<double>(num_tiles_) * static_cast<double>(num_tiles_) * TILE * sizeof(T) / static_cast<double>(world_);
-        if (slab_bytes > static_cast<double>(options().colslab_limit_mb) * 1048576.0) sym_ = false;
+        if (slab_bytes > static_cast<double>(opt_.colslab_limit_mb) * 1048576.0) sym_ = false;
     }
-    if (sym_) {
-        // the work of row block ib is proportional to ib + 1 (tiles on or below the diagonal): equal AREAS per rank
-        ib_begin_ = sym_block_boundary(num_tiles_, rank_, world_);
-        num_ib_ = sym_block_boundary(num_tiles_, rank_ + 1, world_) - ib_begin_;
-    } else {
-        ib_begin_ = std::min(rank_ * ib_per_rank_, num_tiles_);
-        num_ib_ = std::min(ib_begin_ + ib_per_rank_, num_tiles_) - ib_begin_;
+    {
+        int ib_end = 0;
+        shard_blocks(num_tiles_, world_, rank_, sym_, ib_begin_, ib_end);
+        num_ib_ = ib_end - ib_begin_;
     }
-    if (options().j_chunk_tiles > 0) {
-        jc_tiles_ = static_cast<int>(options().j_chunk_tiles);
+    if (opt_.j_chunk_tiles > 0) {
+        jc_tiles_ = static_cast<int>(opt_.j_chunk_tiles);
     } else {
         // automatic: long chunks amortise a work item's prologue (row panel load) and keep its row sums in registers, but the grid
         // must fill 256 CUs x 2 workgroups several times over.  Measured optimum (tests/tools/gpu_probe.py --small, 3 000 ... 50 000
@@ -231,30 +304,31 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
         const long area = sym_ ? (ib_end * (ib_end + 1) - static_cast<long>(ib_begin_) * (ib_begin_ + 1)) / 2 : static_cast<long>(num_ib_) * num_tiles_;
         // the bf16x6 kernel has the costlier work-item prologue (three planes of the row panel) and the faster tiles: longer chunks
         // (measured 16 -> 64 tiles: +1.5 % at 100 000 points, +2 % at 300 000; the native kernels are flat or lose beyond 16)
-        const bool split = std::is_same_v<T, float> && options().gram_mode == 1 && options().rbf_form == 0 && v2_eligible(ldx_probe, false)
+        const bool split = std::is_same_v<T, float> && opt_.gram_mode == 1 && opt_.rbf_form == 0 && v2_eligible(opt_, ldx_probe, false)
                            && round_up(static_cast<long>(num_features), 64) <= 256;
         jc_tiles_ = static_cast<int>(std::min<long>(split ? 64 : 16, std::max<long>(2, (area + 2048) / 4096)));
     }
     num_jc_ = (num_tiles_ + jc_tiles_ - 1) / jc_tiles_;
-    rbf_direct_ = (params_.kernel_type == LSSVM_KERNEL_RBF) && (options().rbf_form == 1) && std::is_same_v<T, float>;
+    rbf_direct_ = (params_.kernel_type == LSSVM_KERNEL_RBF) && (opt_.rbf_form == 1) && std::is_same_v<T, float>;
     inv_cost_ = static_cast<double>(T(1) / static_cast<T>(params_.cost));  // "1 / params.cost" in real_type, csvm.cpp:297
 
     // data matrix: all N points (the last one is row n; it takes part in q and QA_cost only)
-    X_.upload(X, mem_kind, num_points, num_features, static_cast<size_t>(nvec_), stream_);
+    X_.upload(X, mem_kind, num_points, num_features, static_cast<size_t>(nvec_), st);
 
     // QA_cost = k(x_last, x_last) + 1/C, evaluated on the host in the real type (csvm.cpp:86)
     std::vector<T> last(num_features);
-    LSSVM_HIP_CHECK(hipMemcpyAsync(last.data(), X_.data.p + static_cast<size_t>(n_) * X_.ldx, num_features * sizeof(T), hipMemcpyDeviceToHost, stream_));
-    LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));
+    LSSVM_HIP_CHECK(hipMemcpyAsync(last.data(), X_.data.p + static_cast<size_t>(n_) * X_.ldx, num_features * sizeof(T), hipMemcpyDeviceToHost, st));
+    LSSVM_HIP_CHECK(hipStreamSynchronize(st));
     QA_cost_ = static_cast<double>(host_self_kernel<T>(params_, last) + T(1) / static_cast<T>(params_.cost));
 
     // vectors (zero padded to nvec_)
-    for (DevBuf<T> *v : { &q_, &b_, &x_, &r_, &d_, &Ad_, &Kv_, &tmp_ }) v->alloc_zero(nvec_, stream_);
-    ylast_.alloc_zero(num_points, stream_);
-    part_.alloc_zero(static_cast<size_t>(RED_BLOCKS) * 2, stream_);
-    sc_.alloc_zero(SC_COUNT, stream_);
-    partial_.alloc_zero(static_cast<size_t>(std::max(num_jc_, 1)) * std::max(num_ib_, 1) * TILE, stream_);
-    LSSVM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&host_sc_), SC_COUNT * sizeof(double), hipHostMallocDefault));
+    for (DevBuf<T> *v : { &q_, &b_, &x_, &r_, &d_, &Ad_, &Kv_, &tmp_ }) v->alloc_zero(nvec_, st);
+    Kres_ = Kv_.p;
+    ylast_.alloc_zero(num_points, st);
+    part_.alloc_zero(static_cast<size_t>(RED_BLOCKS) * 2, st);
+    sc_.alloc_zero(SC_COUNT, st);
+    partial_.alloc_zero(static_cast<size_t>(std::max(num_jc_, 1)) * std::max(num_ib_, 1) * TILE, st);
+    host_sc_.alloc(SC_COUNT);
 
     // q from the raw (un-centred) data: bit-compatible fma chains (q_kernel.cpp:18-55)
     {
@@ -262,48 +336,48 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
         const dim3 grid((n_ + 127) / 128), block(128);
         const T g = static_cast<T>(params_.gamma), c0 = static_cast<T>(params_.coef0);
         switch (params_.kernel_type) {
-            case LSSVM_KERNEL_LINEAR: hipLaunchKernelGGL((k_q<KT_LINEAR, T>), grid, block, 0, stream_, X_.data.p, X_.ldx, X_.dfeat, n_, xlast, params_.degree, g, c0, q_.p); break;
-            case LSSVM_KERNEL_POLYNOMIAL: hipLaunchKernelGGL((k_q<KT_POLY, T>), grid, block, 0, stream_, X_.data.p, X_.ldx, X_.dfeat, n_, xlast, params_.degree, g, c0, q_.p); break;
-            default: hipLaunchKernelGGL((k_q<KT_RBF, T>), grid, block, 0, stream_, X_.data.p, X_.ldx, X_.dfeat, n_, xlast, params_.degree, g, c0, q_.p); break;
+            case LSSVM_KERNEL_LINEAR: hipLaunchKernelGGL((k_q<KT_LINEAR, T>), grid, block, 0, st, X_.data.p, X_.ldx, X_.dfeat, n_, xlast, params_.degree, g, c0, q_.p); break;
+            case LSSVM_KERNEL_POLYNOMIAL: hipLaunchKernelGGL((k_q<KT_POLY, T>), grid, block, 0, st, X_.data.p, X_.ldx, X_.dfeat, n_, xlast, params_.degree, g, c0, q_.p); break;
+            default: hipLaunchKernelGGL((k_q<KT_RBF, T>), grid, block, 0, st, X_.data.p, X_.ldx, X_.dfeat, n_, xlast, params_.degree, g, c0, q_.p); break;
         }
         LSSVM_HIP_CHECK(hipGetLastError());
     }
     // rbf on the matrix cores: centre the data, then c_i = -|x_i|^2 / 2
     if (params_.kernel_type == LSSVM_KERNEL_RBF && !rbf_direct_) {
-        center_columns<T>(X_, nullptr, rbf_prescale<T>(params_, v2_eligible_f64(X_.ldx)), stream_);
-        half_neg_norms<T>(X_, c_, stream_);
+        center_columns<T>(X_, nullptr, rbf_prescale<T>(params_, v2_eligible_f64(opt_, X_.ldx)), st);
+        half_neg_norms<T>(X_, c_, st);
     }
     // polynomial in fp64 on the v2 kernel: fold gamma into the data (x' = sqrt(gamma) x, after q was computed from the raw data), so
     // that the MFMA chain leaves gamma * <x_i, x_j> and the epilogue is the bare integer power -- every vector ALU instruction
     // beside v_mfma_f64 costs matrix-core time (gamma > 0 is a precondition of the kernel, parameter.hpp / csvm.cpp:77)
     if constexpr (std::is_same_v<T, double>) {
-        if (params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && v2_eligible_f64(X_.ldx) && params_.gamma > 0.0) {
-            hipLaunchKernelGGL(k_center<T>, dim3((X_.dfeat + 255) / 256, X_.rows), dim3(256), 0, stream_, X_.data.p, X_.ldx, X_.dfeat, X_.rows,
+        if (params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && v2_eligible_f64(opt_, X_.ldx) && params_.gamma > 0.0) {
+            hipLaunchKernelGGL(k_center<T>, dim3((X_.dfeat + 255) / 256, X_.rows), dim3(256), 0, st, X_.data.p, X_.ldx, X_.dfeat, X_.rows,
                                static_cast<const T *>(nullptr), static_cast<T>(std::sqrt(params_.gamma)));
             LSSVM_HIP_CHECK(hipGetLastError());
             poly_prescaled_ = true;
         }
     }
     if constexpr (std::is_same_v<T, float>) {
-        // option gram_mode = 1: the (centred, scaled) data once more as three bf16 planes, features in natural order
+        // gram_mode = 1 (default): the (centred, scaled) data once more as three bf16 planes, features in natural order
         const int ldx16 = round_up(static_cast<long>(num_features), 64);
-        if (options().gram_mode == 1 && !rbf_direct_ && v2_eligible(X_.ldx, false) && ldx16 <= 256) {
+        if (opt_.gram_mode == 1 && !rbf_direct_ && v2_eligible(opt_, X_.ldx, false) && ldx16 <= 256) {
             ldx16_ = ldx16;
             const size_t plane_stride = static_cast<size_t>(X_.rows_alloc) * ldx16;
-            planes_.alloc_zero(3 * plane_stride, stream_);
-            split_bf16_planes(X_.data.p, X_.ldx, X_.dfeat, static_cast<size_t>(X_.rows_alloc), ldx16, planes_.p, plane_stride, stream_);
+            planes_.alloc_zero(3 * plane_stride, st);
+            split_bf16_planes(X_.data.p, X_.ldx, X_.dfeat, static_cast<size_t>(X_.rows_alloc), ldx16, planes_.p, plane_stride, st);
         }
     }
-    interleave_features<T>(X_, stream_);
-    if ((std::is_same_v<T, float> && v2_eligible(X_.ldx, rbf_direct_)) || (std::is_same_v<T, double> && v2_eligible_f64(X_.ldx))) {
-        dc_.alloc_zero(static_cast<size_t>(std::max(num_tiles_, 1)) * 256, stream_);  // (d_j | c_j) records: 256 reals per 128 columns
+    interleave_features<T>(X_, st);
+    if ((std::is_same_v<T, float> && v2_eligible(opt_, X_.ldx, rbf_direct_)) || (std::is_same_v<T, double> && v2_eligible_f64(opt_, X_.ldx))) {
+        dc_.alloc_zero(static_cast<size_t>(std::max(num_tiles_, 1)) * 256, st);  // (d_j | c_j) records: 256 reals per 128 columns
     }
     if (sym_) {
         // work items = the non-empty (row block, column chunk) pairs, column chunk major (concurrent workgroups share the chunk)
         // (the hardware dispatches workgroups in item order as CU slots free up).  item_order >= 1: the items cut short by the
         // diagonal go last, longest first, so the final dispatch round is made of the shortest items.
         std::vector<int2> items, cut;
-        const int order = static_cast<int>(options().item_order);
+        const int order = static_cast<int>(opt_.item_order);
         for (int jc = 0; jc < num_jc_; ++jc) {
             for (int k = 0; k < num_ib_; ++k) {
                 const int ibl = order == 2 ? num_ib_ - 1 - k : k;
@@ -318,33 +392,30 @@ Problem<T>::Problem(const lssvm_params &params, const void *X, int mem_kind, siz
         });
         items.insert(items.end(), cut.begin(), cut.end());
         num_items_ = static_cast<int>(items.size());
-        items_.alloc_zero(std::max<size_t>(items.size(), 1), stream_);
-        if (!items.empty()) LSSVM_HIP_CHECK(hipMemcpyAsync(items_.p, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice, stream_));
+        items_.alloc_zero(std::max<size_t>(items.size(), 1), st);
+        if (!items.empty()) LSSVM_HIP_CHECK(hipMemcpyAsync(items_.p, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice, st));
         const long ib_end = ib_begin_ + num_ib_;
         pair_origin_ = static_cast<long>(ib_begin_) * (ib_begin_ - 1) / 2;
         const long records = ib_end * (ib_end - 1) / 2 - pair_origin_;
-        colslab_.alloc_zero(static_cast<size_t>(std::max<long>(records, 1)) * TILE, stream_);
-        LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));  // `items` goes out of scope
+        colslab_.alloc_zero(static_cast<size_t>(std::max<long>(records, 1)) * TILE, st);
+        LSSVM_HIP_CHECK(hipStreamSynchronize(st));  // `items` goes out of scope
     }
     events_.resize(4);
     for (EvPair &e : events_) {
-        LSSVM_HIP_CHECK(hipEventCreate(&e.a));
-        LSSVM_HIP_CHECK(hipEventCreate(&e.b));
+        e.a.create(true);
+        e.b.create(true);
     }
-    LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));
+    ev_ready_.create(false);
+    ev_consumed_.create(false);
+    LSSVM_HIP_CHECK(hipStreamSynchronize(st));
     setup_ms_ = now_ms() - t0;
 }
 
 template <typename T>
 Problem<T>::~Problem() {
     (void) hipSetDevice(device_);
-    if (stream_ != nullptr) (void) hipStreamSynchronize(stream_);
-    for (EvPair &e : events_) {
-        if (e.a) (void) hipEventDestroy(e.a);
-        if (e.b) (void) hipEventDestroy(e.b);
-    }
-    if (host_sc_ != nullptr) (void) hipHostFree(host_sc_);
-    if (stream_ != nullptr) (void) hipStreamDestroy(stream_);
+    if (stream_.s != nullptr) (void) hipStreamSynchronize(stream_.s);
+    // members release themselves (events, pinned words, device buffers, then the stream)
 }
 
 template <typename T>
@@ -375,15 +446,16 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     a.ncols_valid = n_;
     set_kernel_scalars(a, params_, rbf_direct_);
     if (poly_prescaled_) a.gamma = T(1);
+    set_launch_options(a, opt_);
     return a;
 }
 
 template <typename T>
 void Problem<T>::drain_events() {
     for (EvPair &e : events_) {
-        if (e.pending && hipEventQuery(e.b) == hipSuccess) {
+        if (e.pending && hipEventQuery(e.b.e) == hipSuccess) {
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            if (hipEventElapsedTime(&ms, e.a.e, e.b.e) == hipSuccess) {
                 matvec_ms_ += ms;
                 ++matvec_launches_;
             }
@@ -393,222 +465,418 @@ void Problem<T>::drain_events() {
 }
 
 template <typename T>
-void Problem<T>::apply_K(const T *v_dev) {
-    // the implicit K * v: tile kernel over this device's row blocks, slabs added in a fixed order, slices exchanged
+void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
+    // this shard's part of the implicit K * v: tile kernel over its row blocks, slabs added in a fixed order
+    hipStream_t st = stream_.s;
     EvPair *ev = nullptr;
-    for (EvPair &e : events_) {
-        if (!e.pending) {
-            ev = &e;
-            break;
-        }
-    }
-    if (ev == nullptr) {
-        drain_events();
+    for (int attempt = 0; attempt < 2 && ev == nullptr; ++attempt) {
         for (EvPair &e : events_) {
             if (!e.pending) {
                 ev = &e;
                 break;
             }
         }
+        if (ev == nullptr) drain_events();
     }
-    const bool skip = world_ > 1 && options().skip_collective != 0;  // testing aid: this rank's share only
-    const bool collective = !skip && (world_ > 1 || (options().force_collective != 0 && comm().comm != nullptr && comm().world == 1));
-    if ((sym_ && collective) || skip) {
-        // every rank adds row sums of its blocks and column sums into all earlier rows: start from zero, all-reduce at the end
-        LSSVM_HIP_CHECK(hipMemsetAsync(Kv_.p, 0, static_cast<size_t>(nvec_) * sizeof(T), stream_));
+    if (zero_first) {
+        // symmetric variant, sharded: every rank adds row sums of its blocks and column sums into all earlier rows: start from zero
+        LSSVM_HIP_CHECK(hipMemsetAsync(Kv_.p, 0, static_cast<size_t>(nvec_) * sizeof(T), st));
     }
-    if (num_ib_ > 0) {
-        TileArgs<T> a = tile_args(v_dev);
-        if (dc_.p != nullptr) {  // v2 kernels: pack (d_j | c_j) records for the LDS-DMA
-            const int ncols = num_tiles_ * TILE;
+    if (num_ib_ <= 0) return;
+    TileArgs<T> a = tile_args(v_dev);
+    if (dc_.p != nullptr) {  // v2 kernels: pack (d_j | c_j) records for the LDS-DMA
+        const int ncols = num_tiles_ * TILE;
+        if constexpr (std::is_same_v<T, float>) {
+            hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, st, v_dev, c_.p, ncols, dc_.p);
+        } else {
+            hipLaunchKernelGGL(k_pack_dc_f64, dim3((ncols + 255) / 256), dim3(256), 0, st, v_dev, c_.p, ncols, dc_.p);
+        }
+    }
+    if (ev != nullptr) LSSVM_HIP_CHECK(hipEventRecord(ev->a.e, st));
+    launch_tile_kernel<T>(a, params_.kernel_type, rbf_direct_, num_jc_, st);
+    if (ev != nullptr) {
+        LSSVM_HIP_CHECK(hipEventRecord(ev->b.e, st));
+        ev->pending = true;
+    }
+    const int nrows = num_ib_ * TILE;
+    if (sym_) {
+        // rows of this device's blocks (slabs of the chunks that exist for each block), then the mirrored column sums
+        hipLaunchKernelGGL(k_reduce_partials_sym<T>, dim3((nrows + 255) / 256), dim3(256), 0, st, partial_.p, a.part_stride, jc_tiles_, ib_begin_, nrows, Kv_.p, 0);
+        const int ib_end = ib_begin_ + num_ib_;
+        if (ib_end > 1) {
             if constexpr (std::is_same_v<T, float>) {
-                hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, stream_, v_dev, c_.p, ncols, dc_.p);
-            } else {
-                hipLaunchKernelGGL(k_pack_dc_f64, dim3((ncols + 255) / 256), dim3(256), 0, stream_, v_dev, c_.p, ncols, dc_.p);
+                hipLaunchKernelGGL((k_reduce_colslab<T, 128>), dim3(ib_end - 1), dim3(1024), 0, st, colslab_.p, pair_origin_, ib_begin_, ib_end, Kv_.p);
+            } else {  // fp64: records per 64-column sub-tile
+                hipLaunchKernelGGL((k_reduce_colslab<T, 64>), dim3(2 * (ib_end - 1)), dim3(1024), 0, st, colslab_.p, pair_origin_, ib_begin_, ib_end, Kv_.p);
             }
         }
-        if (ev != nullptr) LSSVM_HIP_CHECK(hipEventRecord(ev->a, stream_));
-        launch_tile_kernel<T>(a, params_.kernel_type, rbf_direct_, num_jc_, stream_);
-        if (ev != nullptr) {
-            LSSVM_HIP_CHECK(hipEventRecord(ev->b, stream_));
-            ev->pending = true;
+    } else {
+        hipLaunchKernelGGL(k_reduce_partials<T>, dim3((nrows + 255) / 256), dim3(256), 0, st, partial_.p, a.part_stride, num_jc_, ib_begin_ * TILE, nrows, Kv_.p);
+    }
+    LSSVM_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void Problem<T>::enqueue_sum_and_qdot(const T *v_dev, int slot_sum, int slot_q) {
+    hipLaunchKernelGGL(k_sum_and_qdot<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_.s, v_dev, q_.p, n_, part_.p);
+    hipLaunchKernelGGL(k_finish2, dim3(1), dim3(RED_THREADS), 0, stream_.s, part_.p, sc_.p, slot_sum, slot_q);
+    LSSVM_HIP_CHECK(hipGetLastError());
+}
+
+template class Problem<float>;
+template class Problem<double>;
+
+/* ------------------------------------------------------------------ Solver: CG over the shards of this process ------------------------------------------------------------------ */
+/* peer exchange: every device reads the partial vectors of ALL shards through its peer mappings (xGMI) and adds them in rank
+ * order -- the same order on every device, so the exchanged vectors are bit-equal -- or, for the full-square variant, picks every
+ * entry from the shard that owns its row */
+struct PeerPtrs {
+    const void *p[MAX_LOCAL_DEVICES];
+};
+template <typename T>
+__global__ void k_peer_sum(PeerPtrs src, int world, int n, T *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    T s = static_cast<const T *>(src.p[0])[i];
+    for (int r = 1; r < world; ++r) s += static_cast<const T *>(src.p[r])[i];
+    out[i] = s;
+}
+template <typename T>
+__global__ void k_peer_gather(PeerPtrs src, int slice, int n, T *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = static_cast<const T *>(src.p[i / slice])[i];
+}
+
+template <typename T>
+Solver<T>::Solver(const lssvm_params &params, const void *X, int mem_kind, size_t num_points, size_t num_features, const std::vector<int> &devices, const lssvm_shard *shard) :
+    opt_(options()) {
+    dtype = std::is_same_v<T, float> ? LSSVM_DTYPE_F32 : LSSVM_DTYPE_F64;
+    const double t0 = now_ms();
+    LSSVM_REQUIRE(!devices.empty() && devices.size() <= static_cast<size_t>(MAX_LOCAL_DEVICES), "invalid number of devices");
+    int rank0 = 0;
+    world_ = static_cast<int>(devices.size());
+    if (shard != nullptr && (shard->world != 1 || shard->rank != 0)) {
+        // one process per GPU: this process holds rank `rank` of `world`
+        LSSVM_REQUIRE(devices.size() == 1, "a shard descriptor (one process per GPU) and a device list (one process, several GPUs) exclude each other");
+        LSSVM_REQUIRE(shard->world >= 1 && shard->rank >= 0 && shard->rank < shard->world, "invalid shard descriptor");
+        rank0 = shard->rank;
+        world_ = shard->world;
+        if (opt_.skip_collective == 0) {
+            LSSVM_REQUIRE(comm().comm != nullptr && comm().world == world_ && comm().rank == rank0,
+                          "row-block sharding requested but lssvm_mi355_comm_init was not called with the same rank/world");
+            LSSVM_REQUIRE(comm().device == devices[0], "the communicator was created for another device");
+            exchange_ = Exchange::process_rccl;
         }
-        const int nrows = num_ib_ * TILE;
-        if (sym_) {
-            // rows of this device's blocks (slabs of the chunks that exist for each block), then the mirrored column sums
-            hipLaunchKernelGGL(k_reduce_partials_sym<T>, dim3((nrows + 255) / 256), dim3(256), 0, stream_, partial_.p, a.part_stride, jc_tiles_, ib_begin_, nrows, Kv_.p, 0);
-            const int ib_end = ib_begin_ + num_ib_;
-            if (ib_end > 1) {
-                if constexpr (std::is_same_v<T, float>) {
-                    hipLaunchKernelGGL((k_reduce_colslab<T, 128>), dim3(ib_end - 1), dim3(1024), 0, stream_, colslab_.p, pair_origin_, ib_begin_, ib_end, Kv_.p);
-                } else {  // fp64: records per 64-column sub-tile
-                    hipLaunchKernelGGL((k_reduce_colslab<T, 64>), dim3(2 * (ib_end - 1)), dim3(1024), 0, stream_, colslab_.p, pair_origin_, ib_begin_, ib_end, Kv_.p);
+    } else if (devices.size() == 1) {
+        if (opt_.force_collective != 0 && comm().comm != nullptr && comm().world == 1) exchange_ = Exchange::process_rccl;
+    } else {
+        std::vector<int> sorted(devices);
+        std::sort(sorted.begin(), sorted.end());
+        const bool distinct = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
+        LSSVM_REQUIRE(opt_.exchange != 1 || distinct, "RCCL needs distinct devices (option exchange = 1)");
+        exchange_ = (opt_.exchange == 1 || (opt_.exchange == 0 && distinct)) ? Exchange::local_rccl : Exchange::peer;
+        if (opt_.skip_collective != 0) exchange_ = Exchange::none;
+    }
+    for (size_t r = 0; r < devices.size(); ++r) {
+        shards_.push_back(std::make_unique<Problem<T>>(opt_, params, X, mem_kind, num_points, num_features, devices[r], rank0 + static_cast<int>(r), world_));
+    }
+    if (exchange_ == Exchange::local_rccl) local_comms_ = local_comms_for(devices);
+    if (exchange_ == Exchange::peer) {
+        for (auto &p : shards_) {
+            p->activate();
+            for (auto &o : shards_) {
+                if (o->device_ == p->device_) continue;
+                int can = 0;
+                LSSVM_HIP_CHECK(hipDeviceCanAccessPeer(&can, p->device_, o->device_));
+                if (can == 0) throw Error(LSSVM_ERR_COMM, "device " + std::to_string(p->device_) + " cannot map the memory of device " + std::to_string(o->device_) + " (use option exchange = 1)");
+                const hipError_t e = hipDeviceEnablePeerAccess(o->device_, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) LSSVM_HIP_CHECK(e);
+                (void) hipGetLastError();
+            }
+            p->Ksum_.alloc_zero(p->nvec_, p->stream());
+            p->Kres_ = p->Ksum_.p;
+        }
+    }
+    sync_all();
+    setup_ms_ = now_ms() - t0;
+}
+
+template <typename T>
+Solver<T>::~Solver() {
+    for (auto &p : shards_) {
+        (void) hipSetDevice(p->device_);
+        (void) hipStreamSynchronize(p->stream());
+    }
+}
+
+template <typename T>
+void Solver<T>::sync_all() {
+    for (auto &p : shards_) {
+        p->activate();
+        LSSVM_HIP_CHECK(hipStreamSynchronize(p->stream()));
+        p->drain_events();
+    }
+}
+
+template <typename T>
+void Solver<T>::exchange() {
+    Comm &c = comm();
+    const ncclDataType_t dt = std::is_same_v<T, float> ? ncclFloat32 : ncclFloat64;
+    const bool sym = shards_[0]->sym_;
+    const size_t count = static_cast<size_t>(shards_[0]->num_tiles_) * TILE;
+    const size_t slice = static_cast<size_t>(shards_[0]->ib_per_rank_) * TILE;
+    switch (exchange_) {
+        case Exchange::none: break;
+        case Exchange::process_rccl: {
+            // one collective per implicit matvec.  Symmetric variant: every rank holds partial sums for all rows up to its last
+            // block -> sum (in place); full square: every rank contributes its contiguous slice of K*v (in place)
+            Problem<T> &p = *shards_[0];
+            p.activate();
+            if (sym) {
+                nccl_check(c.pAllReduce(p.Kv_.p, p.Kv_.p, count, dt, ncclSum, c.comm, p.stream()), "ncclAllReduce");
+            } else {
+                nccl_check(c.pAllGather(p.Kv_.p + static_cast<size_t>(p.rank_) * slice, p.Kv_.p, slice, dt, c.comm, p.stream()), "ncclAllGather");
+            }
+            break;
+        }
+        case Exchange::local_rccl: {
+            nccl_check(c.pGroupStart(), "ncclGroupStart");
+            for (size_t r = 0; r < shards_.size(); ++r) {
+                Problem<T> &p = *shards_[r];
+                if (sym) {
+                    nccl_check(c.pAllReduce(p.Kv_.p, p.Kv_.p, count, dt, ncclSum, local_comms_->comms[r], p.stream()), "ncclAllReduce");
+                } else {
+                    nccl_check(c.pAllGather(p.Kv_.p + r * slice, p.Kv_.p, slice, dt, local_comms_->comms[r], p.stream()), "ncclAllGather");
                 }
             }
-        } else {
-            hipLaunchKernelGGL(k_reduce_partials<T>, dim3((nrows + 255) / 256), dim3(256), 0, stream_, partial_.p, a.part_stride, num_jc_, ib_begin_ * TILE, nrows, Kv_.p);
+            nccl_check(c.pGroupEnd(), "ncclGroupEnd");
+            break;
         }
-        LSSVM_HIP_CHECK(hipGetLastError());
-    }
-    if (collective) {
-        // one collective per implicit matvec
-        Comm &c = comm();
-        const ncclDataType_t dt = std::is_same_v<T, float> ? ncclFloat32 : ncclFloat64;
-        if (sym_) {
-            // symmetric variant: every rank holds partial sums for all rows up to its last block -> sum (in place)
-            const ncclResult_t rc = c.pAllReduce(Kv_.p, Kv_.p, static_cast<size_t>(num_tiles_) * TILE, dt, ncclSum, c.comm, stream_);
-            if (rc != ncclSuccess) throw Error(LSSVM_ERR_COMM, std::string("ncclAllReduce failed: ") + c.pGetErrorString(rc));
-        } else {
-            // full square: every rank contributes its contiguous slice of K*v (in place)
-            const size_t slice = static_cast<size_t>(ib_per_rank_) * TILE;
-            const ncclResult_t rc = c.pAllGather(Kv_.p + static_cast<size_t>(rank_) * slice, Kv_.p, slice, dt, c.comm, stream_);
-            if (rc != ncclSuccess) throw Error(LSSVM_ERR_COMM, std::string("ncclAllGather failed: ") + c.pGetErrorString(rc));
+        case Exchange::peer: {
+            PeerPtrs src{};
+            for (size_t r = 0; r < shards_.size(); ++r) src.p[r] = shards_[r]->Kv_.p;
+            for (auto &p : shards_) {
+                p->activate();
+                LSSVM_HIP_CHECK(hipEventRecord(p->ev_ready_.e, p->stream()));
+            }
+            const int n = static_cast<int>(count);
+            for (auto &p : shards_) {
+                p->activate();
+                for (auto &o : shards_) {
+                    if (o.get() != p.get()) LSSVM_HIP_CHECK(hipStreamWaitEvent(p->stream(), o->ev_ready_.e, 0));
+                }
+                if (sym) {
+                    hipLaunchKernelGGL(k_peer_sum<T>, dim3((n + 255) / 256), dim3(256), 0, p->stream(), src, static_cast<int>(shards_.size()), n, p->Ksum_.p);
+                } else {
+                    hipLaunchKernelGGL(k_peer_gather<T>, dim3((n + 255) / 256), dim3(256), 0, p->stream(), src, static_cast<int>(slice), n, p->Ksum_.p);
+                }
+                LSSVM_HIP_CHECK(hipGetLastError());
+                LSSVM_HIP_CHECK(hipEventRecord(p->ev_consumed_.e, p->stream()));
+            }
+            // a shard's partial vector may be overwritten (next matvec) only after every device has read it
+            for (auto &p : shards_) {
+                p->activate();
+                for (auto &o : shards_) {
+                    if (o.get() != p.get()) LSSVM_HIP_CHECK(hipStreamWaitEvent(p->stream(), o->ev_consumed_.e, 0));
+                }
+            }
+            break;
         }
     }
 }
 
 template <typename T>
-void Problem<T>::sum_and_qdot(const T *v_dev, int slot_sum, int slot_q) {
-    hipLaunchKernelGGL(k_sum_and_qdot<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_, v_dev, q_.p, n_, part_.p);
-    hipLaunchKernelGGL(k_finish2, dim3(1), dim3(RED_THREADS), 0, stream_, part_.p, sc_.p, slot_sum, slot_q);
-    LSSVM_HIP_CHECK(hipGetLastError());
+void Solver<T>::apply_K(Vec which) {
+    const bool skip = world_ > 1 && opt_.skip_collective != 0;  // testing aid: this rank's share only
+    const bool collective = exchange_ != Exchange::none;
+    for (auto &p : shards_) {
+        p->activate();
+        p->enqueue_apply_K_local(vec_of(*p, which), (p->sym_ && collective) || skip);
+    }
+    if (collective) exchange();
 }
 
 template <typename T>
-void Problem<T>::get_q(void *q_out, double *QA_cost_out) {
-    LSSVM_HIP_CHECK(hipSetDevice(device_));
+void Solver<T>::get_q(void *q_out, double *QA_cost_out) {
+    Problem<T> &p = *shards_[0];
+    p.activate();
     if (q_out != nullptr) {
-        LSSVM_HIP_CHECK(hipMemcpyAsync(q_out, q_.p, static_cast<size_t>(n_) * sizeof(T), hipMemcpyDeviceToHost, stream_));
-        LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));
+        LSSVM_HIP_CHECK(hipMemcpyAsync(q_out, p.q_.p, static_cast<size_t>(p.n_) * sizeof(T), hipMemcpyDeviceToHost, p.stream()));
+        LSSVM_HIP_CHECK(hipStreamSynchronize(p.stream()));
     }
-    if (QA_cost_out != nullptr) *QA_cost_out = QA_cost_;
+    if (QA_cost_out != nullptr) *QA_cost_out = p.QA_cost_;
 }
 
 template <typename T>
-void Problem<T>::matvec(const void *d, void *ret_inout, double add) {
+void Solver<T>::matvec(const void *d, void *ret_inout, double add) {
     LSSVM_REQUIRE(d != nullptr && ret_inout != nullptr, "The d / ret arrays may not be empty!");              // csvm.cpp:284-286
     LSSVM_REQUIRE(add == 1.0 || add == -1.0, "add must either be -1.0 or 1.0, but is " + std::to_string(add) + "!");  // svm_kernel.cpp:28
-    LSSVM_HIP_CHECK(hipSetDevice(device_));
-    const size_t bytes = static_cast<size_t>(n_) * sizeof(T);
-    // tmp_ <- d (zero padded), Ad_ <- ret
-    LSSVM_HIP_CHECK(hipMemcpyAsync(tmp_.p, d, bytes, hipMemcpyHostToDevice, stream_));
-    LSSVM_HIP_CHECK(hipMemcpyAsync(Ad_.p, ret_inout, bytes, hipMemcpyHostToDevice, stream_));
-    sum_and_qdot(tmp_.p, SC_S, SC_QD);
-    apply_K(tmp_.p);
-    hipLaunchKernelGGL(k_apply_ret<T>, dim3((n_ + 255) / 256), dim3(256), 0, stream_, Kv_.p, tmp_.p, q_.p, sc_.p, n_, inv_cost_, QA_cost_, add, Ad_.p);
-    LSSVM_HIP_CHECK(hipGetLastError());
-    LSSVM_HIP_CHECK(hipMemcpyAsync(ret_inout, Ad_.p, bytes, hipMemcpyDeviceToHost, stream_));
-    LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));
-    drain_events();
+    const size_t bytes = static_cast<size_t>(shards_[0]->n_) * sizeof(T);
+    for (auto &p : shards_) {
+        p->activate();
+        // tmp_ <- d (zero padded), Ad_ <- ret
+        LSSVM_HIP_CHECK(hipMemcpyAsync(p->tmp_.p, d, bytes, hipMemcpyHostToDevice, p->stream()));
+        LSSVM_HIP_CHECK(hipMemcpyAsync(p->Ad_.p, ret_inout, bytes, hipMemcpyHostToDevice, p->stream()));
+        p->enqueue_sum_and_qdot(p->tmp_.p, SC_S, SC_QD);
+    }
+    apply_K(Vec::tmp);
+    for (auto &p : shards_) {
+        p->activate();
+        hipLaunchKernelGGL(k_apply_ret<T>, dim3((p->n_ + 255) / 256), dim3(256), 0, p->stream(), p->Kres_, p->tmp_.p, p->q_.p, p->sc_.p, p->n_, p->inv_cost_, p->QA_cost_, add, p->Ad_.p);
+        LSSVM_HIP_CHECK(hipGetLastError());
+    }
+    Problem<T> &p0 = *shards_[0];
+    p0.activate();
+    LSSVM_HIP_CHECK(hipMemcpyAsync(ret_inout, p0.Ad_.p, bytes, hipMemcpyDeviceToHost, p0.stream()));
+    sync_all();
 }
 
 template <typename T>
-void Problem<T>::cg_begin(const void *y, double eps) {
+void Solver<T>::cg_begin(const void *y, double eps) {
     LSSVM_REQUIRE(y != nullptr, "The right hand side vector must not be empty!");
     LSSVM_REQUIRE(static_cast<T>(eps) > T(0), "The stopping criterion in the CG algorithm must be greater than 0.0, but is " + std::to_string(eps) + "!");  // csvm.cpp:77
-    LSSVM_HIP_CHECK(hipSetDevice(device_));
-    cg_t0_ = now_ms();
+    const double t0 = now_ms();
     eps_ = eps;
     iter_ = 0;
     converged_ = false;
-    matvec_ms_ = 0.0;
-    matvec_launches_ = 0;
     cg_wall_ms_ = 0.0;
-
-    y_last_ = static_cast<double>(static_cast<const T *>(y)[N_ - 1]);
-    LSSVM_HIP_CHECK(hipMemcpyAsync(ylast_.p, y, N_ * sizeof(T), hipMemcpyHostToDevice, stream_));
-    const dim3 gn((n_ + 255) / 256), bn(256);
-    hipLaunchKernelGGL(k_make_b<T>, gn, bn, 0, stream_, ylast_.p, n_, b_.p);        // csvm.cpp:89-91
-    hipLaunchKernelGGL(k_fill<T>, gn, bn, 0, stream_, x_.p, n_, T(1));              // csvm.cpp:95
+    const size_t N = shards_[0]->N_;
+    y_last_ = static_cast<double>(static_cast<const T *>(y)[N - 1]);
+    for (auto &p : shards_) {
+        p->activate();
+        p->matvec_ms_ = 0.0;
+        p->matvec_launches_ = 0;
+        hipStream_t st = p->stream();
+        LSSVM_HIP_CHECK(hipMemcpyAsync(p->ylast_.p, y, N * sizeof(T), hipMemcpyHostToDevice, st));
+        const dim3 gn((p->n_ + 255) / 256), bn(256);
+        hipLaunchKernelGGL(k_make_b<T>, gn, bn, 0, st, p->ylast_.p, p->n_, p->b_.p);        // csvm.cpp:89-91
+        hipLaunchKernelGGL(k_fill<T>, gn, bn, 0, st, p->x_.p, p->n_, T(1));                // csvm.cpp:95
+        p->enqueue_sum_and_qdot(p->x_.p, SC_SUMX, SC_QX);
+    }
     // r = b - A x   (csvm.cpp:101-104)
-    sum_and_qdot(x_.p, SC_SUMX, SC_QX);
-    apply_K(x_.p);
-    hipLaunchKernelGGL(k_residual<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_, Kv_.p, x_.p, q_.p, b_.p, sc_.p, n_, inv_cost_, QA_cost_, r_.p, part_.p);
-    hipLaunchKernelGGL(k_finish_delta, dim3(1), dim3(RED_THREADS), 0, stream_, part_.p, sc_.p, sc_.p + SC_COUNT - 1, 1);  // csvm.cpp:107-108
-    // d = r   (csvm.cpp:111), and the sums the next matvec needs
-    hipLaunchKernelGGL(k_update_d<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_, d_.p, r_.p, q_.p, sc_.p, n_, 1, part_.p);
-    hipLaunchKernelGGL(k_finish2, dim3(1), dim3(RED_THREADS), 0, stream_, part_.p, sc_.p, static_cast<int>(SC_S), static_cast<int>(SC_QD));
-    LSSVM_HIP_CHECK(hipGetLastError());
-    LSSVM_HIP_CHECK(hipMemcpyAsync(host_sc_, sc_.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));
-    drain_events();
-    delta0_ = static_cast<double>(static_cast<T>(host_sc_[SC_DELTA0]));
+    apply_K(Vec::x);
+    for (auto &p : shards_) {
+        p->activate();
+        hipStream_t st = p->stream();
+        hipLaunchKernelGGL(k_residual<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->Kres_, p->x_.p, p->q_.p, p->b_.p, p->sc_.p, p->n_, p->inv_cost_, p->QA_cost_, p->r_.p, p->part_.p);
+        hipLaunchKernelGGL(k_finish_delta, dim3(1), dim3(RED_THREADS), 0, st, p->part_.p, p->sc_.p, p->sc_.p + SC_COUNT - 1, 1);  // csvm.cpp:107-108
+        // d = r   (csvm.cpp:111), and the sums the next matvec needs
+        hipLaunchKernelGGL(k_update_d<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->d_.p, p->r_.p, p->q_.p, p->sc_.p, p->n_, 1, p->part_.p);
+        hipLaunchKernelGGL(k_finish2, dim3(1), dim3(RED_THREADS), 0, st, p->part_.p, p->sc_.p, static_cast<int>(SC_S), static_cast<int>(SC_QD));
+        LSSVM_HIP_CHECK(hipGetLastError());
+    }
+    Problem<T> &p0 = *shards_[0];
+    p0.activate();
+    LSSVM_HIP_CHECK(hipMemcpyAsync(p0.host_sc_.p, p0.sc_.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, p0.stream()));
+    sync_all();
+    delta0_ = static_cast<double>(static_cast<T>(p0.host_sc_.p[SC_DELTA0]));
     delta_ = delta0_;
     begun_ = true;
-    cg_wall_ms_ += now_ms() - cg_t0_;
+    cg_wall_ms_ += now_ms() - t0;
 }
 
 template <typename T>
-void Problem<T>::cg_step(uint64_t iterations, int *done_out) {
+void Solver<T>::cg_step(uint64_t iterations, int *done_out) {
     LSSVM_REQUIRE(begun_, "cg_step called before cg_begin");
-    LSSVM_HIP_CHECK(hipSetDevice(device_));
     const double t0 = now_ms();
     // target residuum in the real type, exactly as the reference evaluates "eps * eps * delta0" (csvm.cpp:155)
     const T target = static_cast<T>(eps_) * static_cast<T>(eps_) * static_cast<T>(delta0_);
+    Problem<T> &p0 = *shards_[0];
     for (uint64_t k = 0; k < iterations && !converged_; ++k) {
         // Ad = A d   (csvm.cpp:131-132)
-        apply_K(d_.p);
-        hipLaunchKernelGGL(k_Ad_and_dAd<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_, Kv_.p, d_.p, q_.p, sc_.p, n_, inv_cost_, QA_cost_, Ad_.p, part_.p);
-        hipLaunchKernelGGL(k_finish_alpha, dim3(1), dim3(RED_THREADS), 0, stream_, part_.p, sc_.p);  // csvm.cpp:135
-        if (iter_ % 50 == 49) {
-            // x += alpha d ; r = b - A x   (csvm.cpp:138-145)
-            hipLaunchKernelGGL(k_update_x_r<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_, x_.p, r_.p, d_.p, Ad_.p, sc_.p, n_, 0, part_.p);
-            sum_and_qdot(x_.p, SC_SUMX, SC_QX);
-            apply_K(x_.p);
-            hipLaunchKernelGGL(k_residual<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_, Kv_.p, x_.p, q_.p, b_.p, sc_.p, n_, inv_cost_, QA_cost_, r_.p, part_.p);
-        } else {
-            // x += alpha d ; r -= alpha Ad   (csvm.cpp:138, :148)
-            hipLaunchKernelGGL(k_update_x_r<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_, x_.p, r_.p, d_.p, Ad_.p, sc_.p, n_, 1, part_.p);
+        apply_K(Vec::d);
+        const bool refresh = iter_ % 50 == 49;
+        for (auto &p : shards_) {
+            p->activate();
+            hipStream_t st = p->stream();
+            hipLaunchKernelGGL(k_Ad_and_dAd<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->Kres_, p->d_.p, p->q_.p, p->sc_.p, p->n_, p->inv_cost_, p->QA_cost_, p->Ad_.p, p->part_.p);
+            hipLaunchKernelGGL(k_finish_alpha, dim3(1), dim3(RED_THREADS), 0, st, p->part_.p, p->sc_.p);  // csvm.cpp:135
+            // x += alpha d ; r -= alpha Ad   (csvm.cpp:138, :148) -- or, every 50th iteration, x only and r = b - A x below (csvm.cpp:140-145)
+            hipLaunchKernelGGL(k_update_x_r<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->x_.p, p->r_.p, p->d_.p, p->Ad_.p, p->sc_.p, p->n_, refresh ? 0 : 1, p->part_.p);
+            if (refresh) p->enqueue_sum_and_qdot(p->x_.p, SC_SUMX, SC_QX);
+            LSSVM_HIP_CHECK(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_finish_delta, dim3(1), dim3(RED_THREADS), 0, stream_, part_.p, sc_.p, sc_.p + SC_COUNT - 1, 0);  // csvm.cpp:152-153
-        LSSVM_HIP_CHECK(hipGetLastError());
-        LSSVM_HIP_CHECK(hipMemcpyAsync(host_sc_ + SC_DELTA, sc_.p + SC_DELTA, sizeof(double), hipMemcpyDeviceToHost, stream_));
-        LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));
-        drain_events();
+        if (refresh) {
+            apply_K(Vec::x);
+            for (auto &p : shards_) {
+                p->activate();
+                hipLaunchKernelGGL(k_residual<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, p->stream(), p->Kres_, p->x_.p, p->q_.p, p->b_.p, p->sc_.p, p->n_, p->inv_cost_, p->QA_cost_, p->r_.p, p->part_.p);
+            }
+        }
+        for (auto &p : shards_) {
+            p->activate();
+            hipLaunchKernelGGL(k_finish_delta, dim3(1), dim3(RED_THREADS), 0, p->stream(), p->part_.p, p->sc_.p, p->sc_.p + SC_COUNT - 1, 0);  // csvm.cpp:152-153
+            LSSVM_HIP_CHECK(hipGetLastError());
+        }
+        // the stop test needs delta on the host: 8 bytes from shard 0 (all shards hold the same bits)
+        p0.activate();
+        LSSVM_HIP_CHECK(hipMemcpyAsync(p0.host_sc_.p + SC_DELTA, p0.sc_.p + SC_DELTA, sizeof(double), hipMemcpyDeviceToHost, p0.stream()));
+        LSSVM_HIP_CHECK(hipStreamSynchronize(p0.stream()));
+        for (auto &p : shards_) p->drain_events();
         ++iter_;
-        delta_ = static_cast<double>(static_cast<T>(host_sc_[SC_DELTA]));
+        delta_ = static_cast<double>(static_cast<T>(p0.host_sc_.p[SC_DELTA]));
         if (static_cast<T>(delta_) <= target) {  // csvm.cpp:155-158: tested BEFORE the direction update
             converged_ = true;
             break;
         }
         // d = beta d + r   (csvm.cpp:161-163)
-        hipLaunchKernelGGL(k_update_d<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_, d_.p, r_.p, q_.p, sc_.p, n_, 0, part_.p);
-        hipLaunchKernelGGL(k_finish2, dim3(1), dim3(RED_THREADS), 0, stream_, part_.p, sc_.p, static_cast<int>(SC_S), static_cast<int>(SC_QD));
-        LSSVM_HIP_CHECK(hipGetLastError());
+        for (auto &p : shards_) {
+            p->activate();
+            hipStream_t st = p->stream();
+            hipLaunchKernelGGL(k_update_d<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->d_.p, p->r_.p, p->q_.p, p->sc_.p, p->n_, 0, p->part_.p);
+            hipLaunchKernelGGL(k_finish2, dim3(1), dim3(RED_THREADS), 0, st, p->part_.p, p->sc_.p, static_cast<int>(SC_S), static_cast<int>(SC_QD));
+            LSSVM_HIP_CHECK(hipGetLastError());
+        }
     }
     cg_wall_ms_ += now_ms() - t0;
     if (done_out != nullptr) *done_out = converged_ ? 1 : 0;
 }
 
 template <typename T>
-void Problem<T>::cg_finish(void *alpha_out, double *rho_out, lssvm_cg_info *info) {
+void Solver<T>::cg_finish(void *alpha_out, double *rho_out, lssvm_cg_info *info) {
     LSSVM_REQUIRE(begun_, "cg_finish called before cg_begin");
     LSSVM_REQUIRE(alpha_out != nullptr && rho_out != nullptr, "alpha_out / rho_out must not be NULL");
-    LSSVM_HIP_CHECK(hipSetDevice(device_));
     const double t0 = now_ms();
     // bias = y_last + QA_cost * sum(x) - q^T x ; alpha_N = -sum(x) ; rho = -bias   (csvm.cpp:179-182)
-    sum_and_qdot(x_.p, SC_SUMX, SC_QX);
-    LSSVM_HIP_CHECK(hipMemcpyAsync(host_sc_, sc_.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    LSSVM_HIP_CHECK(hipMemcpyAsync(alpha_out, x_.p, static_cast<size_t>(n_) * sizeof(T), hipMemcpyDeviceToHost, stream_));
-    LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));
-    const T sum_x = static_cast<T>(host_sc_[SC_SUMX]);
-    const T bias = static_cast<T>(y_last_ + QA_cost_ * host_sc_[SC_SUMX] - host_sc_[SC_QX]);
-    static_cast<T *>(alpha_out)[n_] = -sum_x;
+    const bool check = shards_.size() > 1 && opt_.check_shards != 0 && exchange_ != Exchange::none;
+    for (auto &p : shards_) {
+        if (p.get() != shards_[0].get() && !check) continue;
+        p->activate();
+        p->enqueue_sum_and_qdot(p->x_.p, SC_SUMX, SC_QX);
+        LSSVM_HIP_CHECK(hipMemcpyAsync(p->host_sc_.p, p->sc_.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, p->stream()));
+    }
+    Problem<T> &p0 = *shards_[0];
+    p0.activate();
+    LSSVM_HIP_CHECK(hipMemcpyAsync(alpha_out, p0.x_.p, static_cast<size_t>(p0.n_) * sizeof(T), hipMemcpyDeviceToHost, p0.stream()));
+    sync_all();
+    if (check) {
+        // every shard ran the same O(n) kernels on the same exchanged vectors: their scalars must agree to the bit
+        for (auto &p : shards_) {
+            for (int slot : { static_cast<int>(SC_DELTA), static_cast<int>(SC_SUMX), static_cast<int>(SC_QX) }) {
+                if (std::memcmp(&p->host_sc_.p[slot], &p0.host_sc_.p[slot], sizeof(double)) != 0) {
+                    throw Error(LSSVM_ERR_INTERNAL, "the shards of the solve diverged: device " + std::to_string(p->device_) + " holds another CG scalar than device "
+                                                        + std::to_string(p0.device_));
+                }
+            }
+        }
+    }
+    const T sum_x = static_cast<T>(p0.host_sc_.p[SC_SUMX]);
+    const T bias = static_cast<T>(y_last_ + p0.QA_cost_ * p0.host_sc_.p[SC_SUMX] - p0.host_sc_.p[SC_QX]);
+    static_cast<T *>(alpha_out)[p0.n_] = -sum_x;
     *rho_out = static_cast<double>(-bias);
     cg_wall_ms_ += now_ms() - t0;
     if (info != nullptr) fill_info(info);
 }
 
 template <typename T>
-void Problem<T>::synchronize() {
-    LSSVM_HIP_CHECK(hipSetDevice(device_));
-    LSSVM_HIP_CHECK(hipStreamSynchronize(stream_));
-    drain_events();
+void Solver<T>::synchronize() {
+    sync_all();
 }
 
 template <typename T>
-void Problem<T>::fill_info(lssvm_cg_info *info) {
+void Solver<T>::fill_info(lssvm_cg_info *info) {
     std::memset(info, 0, sizeof(*info));
+    const Problem<T> &p0 = *shards_[0];
     info->iterations = iter_;
     info->max_iterations = 0;
     info->residuum = delta_;
@@ -618,16 +886,22 @@ void Problem<T>::fill_info(lssvm_cg_info *info) {
     info->avg_iteration_ms = iter_ > 0 ? cg_wall_ms_ / static_cast<double>(iter_) : 0.0;
     info->total_ms = cg_wall_ms_;
     info->setup_ms = setup_ms_;
-    info->matvec_kernel_ms = matvec_launches_ > 0 ? matvec_ms_ / static_cast<double>(matvec_launches_) : 0.0;
-    info->matvec_launches = matvec_launches_;
+    // the tile kernel of the slowest shard sets the pace of a sharded matvec
+    for (const auto &p : shards_) {
+        const double avg = p->matvec_launches_ > 0 ? p->matvec_ms_ / static_cast<double>(p->matvec_launches_) : 0.0;
+        info->matvec_kernel_ms = std::max(info->matvec_kernel_ms, avg);
+    }
+    info->matvec_launches = p0.matvec_launches_;
     info->devices_used = world_;
     info->converged = converged_ ? 1 : 0;
-    info->symmetric = sym_ ? 1 : 0;
-    info->gram_mode = planes_.p != nullptr ? 1 : 0;
+    info->symmetric = p0.sym_ ? 1 : 0;
+    info->gram_mode = p0.planes_.p != nullptr ? 1 : 0;
+    info->local_devices = static_cast<int32_t>(shards_.size());
+    info->exchange = exchange_ == Exchange::none ? 0 : (exchange_ == Exchange::peer ? 2 : 1);
 }
 
-template class Problem<float>;
-template class Problem<double>;
+template class Solver<float>;
+template class Solver<double>;
 
 /* ------------------------------------------------------------------ predict path ------------------------------------------------------------------ */
 template <typename T>
@@ -660,6 +934,7 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     LSSVM_REQUIRE(out != nullptr && w_valid != nullptr, "out / w_valid must not be NULL");
     select_device_checked(0);
     hipStream_t s = nullptr;
+    const Options opt = options();
 
     if (params.kernel_type == LSSVM_KERNEL_LINEAR) {
         LSSVM_REQUIRE(w_inout != nullptr, "w must have num_features entries for the linear kernel");
@@ -686,11 +961,11 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     P.upload(points, LSSVM_MEM_HOST, npoints, nfeat, 0, s);
     DevBuf<T> cS, cP;
     if (params.kernel_type == LSSVM_KERNEL_RBF) {
-        center_columns<T>(S, &P, rbf_prescale<T>(params, v2_eligible_f64(S.ldx)), s);
+        center_columns<T>(S, &P, rbf_prescale<T>(params, v2_eligible_f64(opt, S.ldx)), s);
         half_neg_norms<T>(S, cS, s);
         half_neg_norms<T>(P, cP, s);
     }
-    const bool v2 = std::is_same_v<T, float> ? v2_eligible(S.ldx, false) : v2_eligible_f64(S.ldx);
+    const bool v2 = std::is_same_v<T, float> ? v2_eligible(opt, S.ldx, false) : v2_eligible_f64(opt, S.ldx);
     bool poly_prescaled = false;
     if constexpr (std::is_same_v<T, double>) {
         // the fp64 v2 kernel evaluates the polynomial on data that carries sqrt(gamma) (see Problem<T>'s constructor)
@@ -707,8 +982,8 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     const int num_jt = S.rows_alloc / TILE;
     const int num_ib = P.rows_alloc / TILE;
     // column tiles per work item: the option, or automatically about 4096 work items (see Problem<T>'s constructor)
-    const int jc_tiles = options().j_chunk_tiles > 0
-                             ? static_cast<int>(options().j_chunk_tiles)
+    const int jc_tiles = opt.j_chunk_tiles > 0
+                             ? static_cast<int>(opt.j_chunk_tiles)
                              : static_cast<int>(std::min<long>(16, std::max<long>(2, (static_cast<long>(num_ib) * num_jt + 2048) / 4096)));
     const int num_jc = (num_jt + jc_tiles - 1) / jc_tiles;
     DevBuf<T> a, partial, Kv, o;
@@ -749,6 +1024,7 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     ta.ncols_valid = S.rows;
     set_kernel_scalars(ta, params, false);
     if (poly_prescaled) ta.gamma = T(1);
+    set_launch_options(ta, opt);
     launch_tile_kernel<T>(ta, params.kernel_type, false, num_jc, s);
     hipLaunchKernelGGL(k_reduce_partials<T>, dim3((P.rows_alloc + 255) / 256), dim3(256), 0, s, partial.p, ta.part_stride, num_jc, 0, P.rows_alloc, Kv.p);
     hipLaunchKernelGGL(k_sub_rho<T>, dim3((P.rows + 255) / 256), dim3(256), 0, s, Kv.p, P.rows, rho, o.p);

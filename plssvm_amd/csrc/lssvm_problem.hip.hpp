@@ -5,7 +5,7 @@
  *   gpu_csvm::setup_data_on_device        include/plssvm/backends/gpu_csvm.hpp:302-346   (SoA + 96 pad rows  -> row-major, k-chunk padded)
  *   gpu_csvm::generate_q                  gpu_csvm.hpp:349-384
  *   gpu_csvm::run_device_kernel           gpu_csvm.hpp:431-447
- *   gpu_csvm::device_reduction            gpu_csvm.hpp:449-475                           (host-staged sum -> RCCL all-gather over xGMI)
+ *   gpu_csvm::device_reduction            gpu_csvm.hpp:449-475                           (host-staged sum -> RCCL all-reduce / peer kernels over xGMI)
  *   gpu_csvm::solve_system_of_linear_equations_impl   gpu_csvm.hpp:477-654               (host BLAS-1 + 3 PCIe copies / iteration
  *                                                                                          -> everything device resident, one 8-byte read-back)
  * with the CG recipe of src/plssvm/backends/OpenMP/csvm.cpp:71-183 (x0 = 1, residual refresh every 50 iterations,
@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -64,21 +65,28 @@ struct Options {
     int64_t item_order = 1;        // symmetric variant, order of the work items: 0 column-chunk major, 1 = 0 with the short (diagonal) items moved to the end, longest first
     int64_t gram_mode = 1;         // fp32, <= 256 features: 1 = exact 3-way bf16 split of the operands, six plane products on the bf16 MFMA (default), 0 = v_mfma_f32
     int64_t colslab_limit_mb = 98304;  // symmetric variant only while its column slab (per device) stays below this many MiB (96 GiB of the 288 GB)
-    int64_t force_collective = 0;
-    int64_t skip_collective = 0;   // testing aid: sharded problems (world > 1) need no communicator and leave their PARTIAL K*v un-exchanged  // testing aid: run the all-gather even for world == 1 (needs lssvm_mi355_comm_init(.., 0, 1, ..))
+    int64_t force_collective = 0;  // testing aid: run the per-matvec collective even for a world of one (needs lssvm_mi355_comm_init(.., 0, 1, ..))
+    int64_t skip_collective = 0;   // testing aid: sharded problems (world > 1) need no communicator and leave their PARTIAL K*v un-exchanged
+    int64_t exchange = 0;          // several devices in ONE process: 0 = automatic (RCCL when the devices are distinct, else peer kernels), 1 = RCCL all-reduce / all-gather
+                                   // (ncclCommInitAll), 2 = peer kernels: every device sums the partial vectors of all devices over xGMI in rank order
+    int64_t check_shards = 1;      // several devices in ONE process: cg_finish verifies that the CG scalars of all shards are bit-equal
 };
+/* process-wide DEFAULTS (lssvm_mi355_set_option); every problem takes a snapshot when it is created */
 Options &options();
 
 /* ------------------------------------------------------------------ RCCL (lazy) ------------------------------------------------------------------ */
-struct Comm {
+struct Comm {  // the RCCL entry points (dlopen'ed once) + the communicator of a one-process-per-GPU launch
     void *lib = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
     decltype(&ncclGetUniqueId) pGetUniqueId = nullptr;
     decltype(&ncclCommInitRank) pCommInitRank = nullptr;
+    decltype(&ncclCommInitAll) pCommInitAll = nullptr;
     decltype(&ncclCommDestroy) pCommDestroy = nullptr;
     decltype(&ncclAllGather) pAllGather = nullptr;
     decltype(&ncclAllReduce) pAllReduce = nullptr;
+    decltype(&ncclGroupStart) pGroupStart = nullptr;
+    decltype(&ncclGroupEnd) pGroupEnd = nullptr;
     decltype(&ncclGetErrorString) pGetErrorString = nullptr;
 };
 Comm &comm();
@@ -144,8 +152,42 @@ struct DeviceMatrix {
         rows_alloc = std::max(round_up(static_cast<long>(nrows), TILE), round_up(static_cast<long>(min_rows_alloc), TILE));
         data.alloc_zero(static_cast<size_t>(rows_alloc) * ldx, s);
         LSSVM_HIP_CHECK(hipMemcpy2DAsync(data.p, static_cast<size_t>(ldx) * sizeof(T), src, nfeat * sizeof(T), nfeat * sizeof(T), nrows,
-                                         mem_kind == LSSVM_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+                                         mem_kind == LSSVM_MEM_DEVICE ? hipMemcpyDefault : hipMemcpyHostToDevice, s));  // (a device source may live on another device of the process)
     }
+};
+
+/* ------------------------------------------------------------------ more RAII: stream, events, pinned host words ------------------------------------------------------------------ */
+struct Stream {
+    hipStream_t s = nullptr;
+    Stream() = default;
+    Stream(const Stream &) = delete;
+    Stream &operator=(const Stream &) = delete;
+    ~Stream() {
+        if (s != nullptr) (void) hipStreamDestroy(s);
+    }
+    void create() { LSSVM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); }
+};
+struct Event {
+    hipEvent_t e = nullptr;
+    Event() = default;
+    Event(const Event &) = delete;
+    Event &operator=(const Event &) = delete;
+    Event(Event &&o) noexcept : e(o.e) { o.e = nullptr; }
+    ~Event() {
+        if (e != nullptr) (void) hipEventDestroy(e);
+    }
+    void create(bool timing) { LSSVM_HIP_CHECK(hipEventCreateWithFlags(&e, timing ? hipEventDefault : hipEventDisableTiming)); }
+};
+template <typename U>
+struct PinnedBuf {
+    U *p = nullptr;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf() {
+        if (p != nullptr) (void) hipHostFree(p);
+    }
+    void alloc(size_t n) { LSSVM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p), n * sizeof(U), hipHostMallocDefault)); }
 };
 
 /* ------------------------------------------------------------------ tile kernel launch ------------------------------------------------------------------ */
@@ -163,12 +205,85 @@ template <typename T>
 void half_neg_norms(const DeviceMatrix<T> &M, DevBuf<T> &c, hipStream_t s);
 template <typename T>
 void interleave_features(DeviceMatrix<T> &M, hipStream_t s);
-bool v2_eligible(int ldx, bool rbf_direct);
+bool v2_eligible(const Options &o, int ldx, bool rbf_direct);
 void split_bf16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, uint16_t *planes, size_t plane_stride, hipStream_t s);  // tile_launch_f32s.hip
-bool v2_eligible_f64(int ldx);
+bool v2_eligible_f64(const Options &o, int ldx);
 int sym_block_boundary(int num_tiles, int r, int world);
+void shard_blocks(int num_tiles, int world, int rank, bool symmetric, int &begin, int &end);
 
-/* ------------------------------------------------------------------ the resident problem ------------------------------------------------------------------ */
+/* ------------------------------------------------------------------ one device's share of the problem ------------------------------------------------------------------ */
+/* Problem<T>: the data matrix resident on ONE device plus the CG vectors, and the row blocks `rank` of `world` of the implicit
+ * matrix.  Every method only ENQUEUES work on the shard's stream (set-up excepted); the CG recipe and the exchange between
+ * shards are driven by Solver<T>.  Replaces gpu_csvm::setup_data_on_device / generate_q / run_device_kernel (gpu_csvm.hpp:302-447). */
+template <typename T>
+class Solver;
+
+template <typename T>
+class Problem {
+  public:
+    Problem(const Options &opt, const lssvm_params &params, const void *X, int mem_kind, size_t num_points, size_t num_features, int device, int rank, int world);
+    ~Problem();
+    Problem(const Problem &) = delete;
+    Problem &operator=(const Problem &) = delete;
+
+    void activate() const { LSSVM_HIP_CHECK(hipSetDevice(device_)); }
+    /* Kv_ <- this shard's part of K * v (complete for a world of one): tile kernel + fixed-order reductions */
+    void enqueue_apply_K_local(const T *v_dev, bool zero_first);
+    void enqueue_sum_and_qdot(const T *v_dev, int slot_sum, int slot_q);
+    void drain_events();
+    hipStream_t stream() const { return stream_.s; }
+
+  private:
+    friend class Solver<T>;
+    TileArgs<T> tile_args(const T *v_dev) const;
+
+    Options opt_{};
+    lssvm_params params_{};
+    int device_ = 0;
+    int rank_ = 0, world_ = 1;
+    Stream stream_;
+
+    size_t N_ = 0;  // data points
+    int n_ = 0;     // N - 1
+    int num_tiles_ = 0;  // ceil(n / TILE): row blocks == column tiles
+    int ib_begin_ = 0, num_ib_ = 0, ib_per_rank_ = 0;
+    int jc_tiles_ = 16, num_jc_ = 1;
+    int nvec_ = 0;  // allocated vector length (multiple of TILE * world)
+    bool rbf_direct_ = false;
+    bool poly_prescaled_ = false;  // fp64 polynomial on the v2 kernel: X_ carries sqrt(gamma), the kernel sees gamma = 1
+    DevBuf<uint16_t> planes_;      // gram_mode 1: X as three bf16 planes [3][rows_alloc][ldx16]
+    int ldx16_ = 0;
+
+    DeviceMatrix<T> X_;
+    DevBuf<T> c_;  // -0.5 |x|^2 (rbf, centred data)
+    DevBuf<T> q_, b_, x_, r_, d_, Ad_, Kv_, Ksum_, tmp_, ylast_;
+    T *Kres_ = nullptr;  // the exchanged K * v the O(n) kernels read: Kv_ itself, or Ksum_ when peer kernels do the exchange
+    DevBuf<T> partial_;
+    DevBuf<T> dc_;  // v2 kernels: packed (d_j | c_j) records
+    // symmetric variant
+    bool sym_ = false;
+    DevBuf<int2> items_;
+    int num_items_ = 0;
+    DevBuf<T> colslab_;
+    long pair_origin_ = 0;
+    DevBuf<double> part_, sc_;
+    PinnedBuf<double> host_sc_;  // SC_COUNT doubles
+    double QA_cost_ = 0.0;
+    double inv_cost_ = 1.0;
+    double setup_ms_ = 0.0;
+
+    // statistics: HIP events around the tile kernel
+    double matvec_ms_ = 0.0;
+    uint64_t matvec_launches_ = 0;
+    struct EvPair {
+        Event a, b;
+        bool pending = false;
+    };
+    std::vector<EvPair> events_;
+    Event ev_ready_, ev_consumed_;  // peer exchange: partial vector written / all partial vectors read
+};
+
+/* ------------------------------------------------------------------ the resident problem (what a C handle points to) ------------------------------------------------------------------ */
 struct ProblemBase {
     int dtype = 0;
     virtual ~ProblemBase() = default;
@@ -181,11 +296,26 @@ struct ProblemBase {
     virtual void fill_info(lssvm_cg_info *info) = 0;
 };
 
+/* communicators of the devices of ONE process (ncclCommInitAll); cached per device list, destroyed at exit */
+struct LocalComms {
+    std::vector<int> devices;
+    std::vector<ncclComm_t> comms;
+    ~LocalComms();
+};
+
+/* Solver<T>: the CG driver (csvm.cpp:71-183 / gpu_csvm.hpp:477-654) over the shards that live in THIS process:
+ *   - one shard, world 1: single GPU;
+ *   - one shard, rank r of a world of processes: one process per GPU (torchrun), exchange = the process communicator (RCCL);
+ *   - D shards on D devices: single process, one stream per device driven by the calling thread, exchange = RCCL (ncclCommInitAll,
+ *     group calls) or peer kernels over xGMI.  This is the mode behind plssvm::csvm (the reference drives all its devices from one
+ *     process too, gpu_csvm.hpp:283-299, :574-593).
+ * Every shard runs the identical O(n) kernels on the identical exchanged vector, so all CG scalars are bit-equal on all shards and
+ * the host reads the stop criterion from shard 0 only. */
 template <typename T>
-class Problem final : public ProblemBase {
+class Solver final : public ProblemBase {
   public:
-    Problem(const lssvm_params &params, const void *X, int mem_kind, size_t num_points, size_t num_features, int device, const lssvm_shard *shard);
-    ~Problem() override;
+    Solver(const lssvm_params &params, const void *X, int mem_kind, size_t num_points, size_t num_features, const std::vector<int> &devices, const lssvm_shard *shard);
+    ~Solver() override;
 
     void get_q(void *q_out, double *QA_cost_out) override;
     void matvec(const void *d, void *ret_inout, double add) override;
@@ -196,60 +326,27 @@ class Problem final : public ProblemBase {
     void fill_info(lssvm_cg_info *info) override;
 
   private:
-    void apply_K(const T *v_dev);  // Kv_ <- K * v  (all rows, after the all-gather)
-    void sum_and_qdot(const T *v_dev, int slot_sum, int slot_q);
-    void drain_events();
-    TileArgs<T> tile_args(const T *v_dev) const;
+    enum class Exchange { none, process_rccl, local_rccl, peer };
+    enum class Vec { d, x, tmp };
+    void apply_K(Vec which);  // every shard: Kres_ <- K * v (all rows)
+    void exchange();
+    void sync_all();
+    T *vec_of(Problem<T> &p, Vec which) const { return which == Vec::d ? p.d_.p : (which == Vec::x ? p.x_.p : p.tmp_.p); }
 
-    lssvm_params params_{};
-    int device_ = 0;
-    int rank_ = 0, world_ = 1;
-    hipStream_t stream_ = nullptr;
+    Options opt_{};
+    std::vector<std::unique_ptr<Problem<T>>> shards_;
+    Exchange exchange_ = Exchange::none;
+    std::shared_ptr<LocalComms> local_comms_;
+    int world_ = 1;  // shards of the problem in total (all processes)
 
-    size_t N_ = 0;  // data points
-    int n_ = 0;     // N - 1
-    int num_tiles_ = 0;  // ceil(n / TILE): row blocks == column tiles
-    int ib_begin_ = 0, num_ib_ = 0, ib_per_rank_ = 0;
-    int jc_tiles_ = 16, num_jc_ = 1;
-    int nvec_ = 0;  // allocated vector length (multiple of TILE * world)
-    bool rbf_direct_ = false;
-    bool poly_prescaled_ = false;
-    DevBuf<uint16_t> planes_;      // gram_mode 1: X as three bf16 planes [3][rows_alloc][ldx16]
-    int ldx16_ = 0;  // fp64 polynomial on the v2 kernel: X_ carries sqrt(gamma), the kernel sees gamma = 1
-
-    DeviceMatrix<T> X_;
-    DevBuf<T> c_;  // -0.5 |x|^2 (rbf, centred data)
-    DevBuf<T> q_, b_, x_, r_, d_, Ad_, Kv_, tmp_, ylast_;
-    DevBuf<T> partial_;
-    DevBuf<T> dc_;  // fp32 v2 kernel: packed (d_j | c_j) records
-    // symmetric variant
-    bool sym_ = false;
-    DevBuf<int2> items_;
-    int num_items_ = 0;
-    DevBuf<T> colslab_;
-    long pair_origin_ = 0;
-    DevBuf<double> part_, sc_;
-    double *host_sc_ = nullptr;  // pinned, SC_COUNT doubles
-    double QA_cost_ = 0.0;
-    double inv_cost_ = 1.0;
-    double y_last_ = 0.0;
-
-    // CG state
+    // CG state (host side)
     double eps_ = 0.0;
     double delta0_ = 0.0, delta_ = 0.0;
-    uint64_t iter_ = 0;        // iterations done
+    double y_last_ = 0.0;
+    uint64_t iter_ = 0;  // iterations done
     bool converged_ = false;
     bool begun_ = false;
-
-    // statistics
-    double setup_ms_ = 0.0, cg_wall_ms_ = 0.0, cg_t0_ = 0.0;
-    double matvec_ms_ = 0.0;
-    uint64_t matvec_launches_ = 0;
-    struct EvPair {
-        hipEvent_t a = nullptr, b = nullptr;
-        bool pending = false;
-    };
-    std::vector<EvPair> events_;
+    double setup_ms_ = 0.0, cg_wall_ms_ = 0.0;
 };
 
 /* one-shot helpers used by the C ABI */
@@ -261,5 +358,7 @@ void calculate_w(const T *sv, size_t nsv, size_t nfeat, const T *alpha, T *w_out
 
 void check_params(const lssvm_params *params);
 int select_device_checked(int device);
+/* `num_devices` == 0: automatic (all visible devices, but at least 32 row blocks per device); `devices` may be NULL (0 .. num_devices-1) */
+std::vector<int> resolve_devices(const int *devices, int num_devices, size_t num_points);
 
 }  // namespace lssvm

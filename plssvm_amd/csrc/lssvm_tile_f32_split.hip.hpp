@@ -1,5 +1,5 @@
 /*
- * lssvm_tile_f32_split.hip.hpp -- fp32 tile kernel on the bf16 matrix cores ("bf16x6", option gram_mode = 1, OPT-IN).
+ * lssvm_tile_f32_split.hip.hpp -- fp32 tile kernel on the bf16 matrix cores ("bf16x6", option gram_mode = 1: the DEFAULT for <= 256 features).
  *
  * Every fp32 operand is split EXACTLY into three bf16 planes, x = hi + mid + lo (8 + 8 + 8 mantissa bits), once at set-up
  * (k_split_bf16x3).  The Gram tile is accumulated in fp32 from the six plane products of significance >= 2^-16,

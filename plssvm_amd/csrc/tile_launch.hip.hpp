@@ -6,20 +6,34 @@
 
 #include "lssvm_problem.hip.hpp"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace lssvm {
 
+/* dynamic LDS above 64 KiB must be opted into once per kernel AND per device; the note is taken only after the call succeeded */
+inline void ensure_dynamic_lds_impl(const void *kernel, size_t bytes) {
+    static std::mutex m;
+    static std::map<std::pair<int, const void *>, size_t> done;
+    int device = 0;
+    LSSVM_HIP_CHECK(hipGetDevice(&device));
+    const std::lock_guard<std::mutex> lock(m);
+    const auto key = std::make_pair(device, kernel);
+    const auto it = done.find(key);
+    if (it != done.end() && it->second == bytes) return;
+    LSSVM_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+    done[key] = bytes;
+}
 template <typename K>
 static void ensure_dynamic_lds(K kernel, size_t bytes) {
-    // dynamic LDS above 64 KiB must be opted into once per kernel
-    LSSVM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+    ensure_dynamic_lds_impl(reinterpret_cast<const void *>(kernel), bytes);
 }
 
 /* fills the block -> work item mapping fields and returns the grid size */
 template <typename T>
 static unsigned finish_mapping(TileArgs<T> &a, int num_jc) {
-    a.num_jc = num_jc;
-    a.dbg = static_cast<int>(options().debug_ablate);
-    a.map_mode = options().xcd_map != 0 ? 1 : 0;
+    a.num_jc = num_jc;  // (dbg, map_mode and lds_extra_kb were filled in by the caller from ITS options: set_launch_options)
     a.super_i = (a.num_ib + 7) / 8;
     if (a.map_mode == 0) return static_cast<unsigned>(a.num_ib) * static_cast<unsigned>(num_jc);
     const long supers = static_cast<long>(a.super_i) * ((num_jc + 7) / 8);

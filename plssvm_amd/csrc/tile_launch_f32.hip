@@ -12,38 +12,18 @@ namespace lssvm {
 template <int KT, bool SYM>
 static void launch_v2_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
     const dim3 block(TILE_THREADS);
-    const size_t V2_LDS_BYTES = lssvm::V2_LDS_BYTES + static_cast<size_t>(options().lds_extra_kb) * 1024;  // experiment knob: limits workgroups per CU
-    static size_t configured_for = 0;
-    if (configured_for != V2_LDS_BYTES) {
-        configured_for = V2_LDS_BYTES;
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 1, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 2, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 3, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 4, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 5, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 6, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 7, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 8, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 10, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 12, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 14, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_v2<KT, 16, SYM>, V2_LDS_BYTES);
-    }
+    const size_t V2_LDS_BYTES = lssvm::V2_LDS_BYTES + static_cast<size_t>(a.lds_extra_kb) * 1024;  // experiment knob: limits workgroups per CU
+#define LSSVM_V2_CASE(N)                                                                                  \
+    case N:                                                                                               \
+        ensure_dynamic_lds(tile_matvec_f32_v2<KT, N, SYM>, V2_LDS_BYTES);                                 \
+        hipLaunchKernelGGL((tile_matvec_f32_v2<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);            \
+        break;
     switch (a.kchunks) {
-        case 1: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 1, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 2: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 2, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 3: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 3, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 4: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 4, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 5: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 5, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 6: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 6, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 7: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 7, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 8: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 8, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 10: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 10, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 12: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 12, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 14: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 14, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 16: hipLaunchKernelGGL((tile_matvec_f32_v2<KT, 16, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
+        LSSVM_V2_CASE(1) LSSVM_V2_CASE(2) LSSVM_V2_CASE(3) LSSVM_V2_CASE(4) LSSVM_V2_CASE(5) LSSVM_V2_CASE(6) LSSVM_V2_CASE(7) LSSVM_V2_CASE(8)
+        LSSVM_V2_CASE(10) LSSVM_V2_CASE(12) LSSVM_V2_CASE(14) LSSVM_V2_CASE(16)
         default: throw Error(LSSVM_ERR_INTERNAL, "no v2 tile kernel for this number of k-chunks");
     }
+#undef LSSVM_V2_CASE
 }
 
 template <>
@@ -52,13 +32,6 @@ void launch_tile_kernel<float>(TileArgs<float> &a, int kernel_type, bool rbf_dir
     const dim3 block(TILE_THREADS);
     if (grid.x == 0) return;
     constexpr size_t lds = static_cast<size_t>(4) * TILE * F32_LS * sizeof(float) + TILE * sizeof(float);  // staging ring + c_i of the row block
-    static bool configured = false;
-    if (!configured) {
-        ensure_dynamic_lds(tile_matvec_f32<KT_LINEAR>, lds);
-        ensure_dynamic_lds(tile_matvec_f32<KT_POLY>, lds);
-        ensure_dynamic_lds(tile_matvec_f32<KT_RBF>, lds);
-        configured = true;
-    }
     if (a.dc != nullptr && a.Xc16 != nullptr) {  // option gram_mode = 1: the three-plane bf16 data exists
         launch_split_tile_kernel(a, kernel_type, grid, s);
         return;
@@ -98,12 +71,19 @@ void launch_tile_kernel<float>(TileArgs<float> &a, int kernel_type, bool rbf_dir
         return;
     }
     switch (kernel_type) {
-        case KT_LINEAR: hipLaunchKernelGGL(tile_matvec_f32<KT_LINEAR>, grid, block, lds, s, a); break;
-        case KT_POLY: hipLaunchKernelGGL(tile_matvec_f32<KT_POLY>, grid, block, lds, s, a); break;
+        case KT_LINEAR:
+            ensure_dynamic_lds(tile_matvec_f32<KT_LINEAR>, lds);
+            hipLaunchKernelGGL(tile_matvec_f32<KT_LINEAR>, grid, block, lds, s, a);
+            break;
+        case KT_POLY:
+            ensure_dynamic_lds(tile_matvec_f32<KT_POLY>, lds);
+            hipLaunchKernelGGL(tile_matvec_f32<KT_POLY>, grid, block, lds, s, a);
+            break;
         default:
             if (rbf_direct) {
                 hipLaunchKernelGGL(tile_matvec_rbf_direct_f32, grid, block, 0, s, a);
             } else {
+                ensure_dynamic_lds(tile_matvec_f32<KT_RBF>, lds);
                 hipLaunchKernelGGL(tile_matvec_f32<KT_RBF>, grid, block, lds, s, a);
             }
             break;

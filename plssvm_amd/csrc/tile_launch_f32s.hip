@@ -11,21 +11,16 @@ namespace lssvm {
 template <int KT, bool SYM>
 static void launch_s6_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
     const dim3 block(TILE_THREADS);
-    static bool configured = false;
-    if (!configured) {
-        configured = true;
-        ensure_dynamic_lds(tile_matvec_f32_s6<KT, 1, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_s6<KT, 2, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_s6<KT, 3, SYM>, V2_LDS_BYTES);
-        ensure_dynamic_lds(tile_matvec_f32_s6<KT, 4, SYM>, V2_LDS_BYTES);
-    }
+#define LSSVM_S6_CASE(N)                                                                                  \
+    case N:                                                                                               \
+        ensure_dynamic_lds(tile_matvec_f32_s6<KT, N, SYM>, V2_LDS_BYTES);                                 \
+        hipLaunchKernelGGL((tile_matvec_f32_s6<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);            \
+        break;
     switch (a.ldx16 / 64) {
-        case 1: hipLaunchKernelGGL((tile_matvec_f32_s6<KT, 1, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 2: hipLaunchKernelGGL((tile_matvec_f32_s6<KT, 2, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 3: hipLaunchKernelGGL((tile_matvec_f32_s6<KT, 3, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
-        case 4: hipLaunchKernelGGL((tile_matvec_f32_s6<KT, 4, SYM>), grid, block, V2_LDS_BYTES, s, a); break;
+        LSSVM_S6_CASE(1) LSSVM_S6_CASE(2) LSSVM_S6_CASE(3) LSSVM_S6_CASE(4)
         default: throw Error(LSSVM_ERR_INTERNAL, "no split tile kernel for this number of features");
     }
+#undef LSSVM_S6_CASE
 }
 
 template <bool SYM>

@@ -34,13 +34,6 @@ void launch_tile_kernel<double>(TileArgs<double> &a, int kernel_type, bool /*rbf
     const dim3 block(TILE_THREADS);
     if (grid.x == 0) return;
     constexpr size_t lds = static_cast<size_t>(4) * TILE * F64_LS * sizeof(double);
-    static bool configured = false;
-    if (!configured) {
-        ensure_dynamic_lds(tile_matvec_f64<KT_LINEAR>, lds);
-        ensure_dynamic_lds(tile_matvec_f64<KT_POLY>, lds);
-        ensure_dynamic_lds(tile_matvec_f64<KT_RBF>, lds);
-        configured = true;
-    }
     if (a.dc != nullptr) {  // the records exist only where the v2 kernel was chosen when the data was prepared; V2D_LDS_BYTES < 64 KiB
         if (a.items != nullptr) {
             const dim3 sgrid(static_cast<unsigned>(a.num_items));
@@ -76,9 +69,18 @@ void launch_tile_kernel<double>(TileArgs<double> &a, int kernel_type, bool /*rbf
         return;
     }
     switch (kernel_type) {
-        case KT_LINEAR: hipLaunchKernelGGL(tile_matvec_f64<KT_LINEAR>, grid, block, lds, s, a); break;
-        case KT_POLY: hipLaunchKernelGGL(tile_matvec_f64<KT_POLY>, grid, block, lds, s, a); break;
-        default: hipLaunchKernelGGL(tile_matvec_f64<KT_RBF>, grid, block, lds, s, a); break;
+        case KT_LINEAR:
+            ensure_dynamic_lds(tile_matvec_f64<KT_LINEAR>, lds);
+            hipLaunchKernelGGL(tile_matvec_f64<KT_LINEAR>, grid, block, lds, s, a);
+            break;
+        case KT_POLY:
+            ensure_dynamic_lds(tile_matvec_f64<KT_POLY>, lds);
+            hipLaunchKernelGGL(tile_matvec_f64<KT_POLY>, grid, block, lds, s, a);
+            break;
+        default:
+            ensure_dynamic_lds(tile_matvec_f64<KT_RBF>, lds);
+            hipLaunchKernelGGL(tile_matvec_f64<KT_RBF>, grid, block, lds, s, a);
+            break;
     }
     LSSVM_HIP_CHECK(hipGetLastError());
 }

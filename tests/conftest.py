@@ -40,6 +40,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _library_options_are_restored():
+    """A test may change the library's process-wide option defaults; whatever it leaves behind is put back, so that no later test
+    silently runs a non-default kernel (round 1: a test left gram_mode at 0 for everything after it)."""
+    from plssvm_amd import _capi
+
+    before = {name: _capi.get_option(name) for name in _capi.OPTION_NAMES}
+    yield
+    for name, value in before.items():
+        if _capi.get_option(name) != value:
+            _capi.set_option(name, value)
+
+
 @pytest.fixture(scope="session")
 def golden():
     return np.load(os.path.join(HERE, "golden", "golden.npz"))

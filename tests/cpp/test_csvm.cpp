@@ -12,6 +12,7 @@
 #include <cstring>
 #include <limits>
 #include <random>
+#include <sstream>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -144,6 +145,68 @@ static void test_fit_predict_score(pa::kernel_function_type kernel) {
     EXPECT_TRUE(labels.size() == N && (labels[0] == T(1) || labels[0] == T(-1)));
 }
 
+static void test_named_arguments_and_tracking(bool have_gpu) {
+    // the named-parameter constructors (HIP/csvm.hpp:82-99, tests/backends/HIP/hip_csvm.cpp "construct_target_and_named_args")
+    if (!have_gpu) {
+        EXPECT_THROW_WHAT((pa::mi355::csvm{ pa::kernel_type = pa::kernel_function_type::rbf, pa::gamma = 0.25 }), pa::mi355::backend_exception, "no HIP capable devices were found");
+        EXPECT_THROW_WHAT((pa::mi355::csvm{ pa::kernel_type = pa::kernel_function_type::rbf, pa::gamma = -0.25 }), pa::invalid_parameter_exception, "gamma must be greater than 0.0");
+        return;
+    }
+    const pa::mi355::csvm svm{ pa::target_platform::gpu_amd, pa::kernel_type = pa::kernel_function_type::polynomial, pa::degree = 2, pa::gamma = 0.25, pa::coef0 = 1.5, pa::cost = 4.0,
+                               pa::num_devices = 1 };
+    const pa::parameter p = svm.get_params();
+    EXPECT_TRUE(p.kernel_type == pa::kernel_function_type::polynomial && p.degree == 2 && p.gamma == 0.25 && !p.gamma_is_default && p.coef0 == 1.5 && p.cost == 4.0);
+    EXPECT_TRUE(svm.get_num_devices() == 1);
+    const auto via_factory = pa::make_csvm(pa::backend_type::mi355, pa::kernel_type = pa::kernel_function_type::rbf, pa::cost = 2.0);
+    EXPECT_TRUE(via_factory->get_params().kernel_type == pa::kernel_function_type::rbf && via_factory->get_params().gamma_is_default && via_factory->get_params().cost == 2.0);
+    EXPECT_THROW_WHAT((pa::mi355::csvm{ pa::num_devices = 4096 }), pa::mi355::backend_exception, "devices, but only");
+    EXPECT_THROW_WHAT((pa::mi355::csvm{ pa::target_platform::gpu_nvidia, pa::cost = 2.0 }), pa::mi355::backend_exception, "Invalid target platform");
+    // tracking entries of a solve in the reference's YAML layout (performance_tracker.cpp:139-190)
+    const std::vector<std::vector<double>> X = { { 1, 2 }, { 3, 4 }, { 5, 7 }, { -1, 0 } };
+    const std::vector<double> y = { 1, -1, 1, -1 };
+    pa::mi355::csvm lin{ pa::kernel_type = pa::kernel_function_type::linear };
+    (void) lin.fit(X, y, 1e-8);
+    std::ostringstream yaml;
+    lin.write_tracking_yaml(yaml);
+    const std::string t = yaml.str();
+    EXPECT_TRUE(t.rfind("---\n", 0) == 0 && t.find("backend:\n  backend: mi355\n") != std::string::npos && t.find("cg:\n  iterations: ") != std::string::npos
+                && t.find("  target_residuum: ") != std::string::npos && t.find("  epsilon: 1e-08\n") != std::string::npos);
+}
+
+template <typename T>
+static void test_multi_device_shards(pa::kernel_function_type kernel) {
+    // the sharded solve behind ONE call (lssvm_mi355_solve_multi_*): three shards on device 0 against the plain single-device solve
+    std::mt19937 gen(11);
+    std::uniform_real_distribution<T> u(T(-1), T(1));
+    const std::size_t N = 700, d = 24;
+    std::vector<T> X(N * d), y(N);
+    for (auto &v : X) v = u(gen);
+    for (std::size_t i = 0; i < N; ++i) y[i] = (i % 2 == 0) ? T(1) : T(-1);
+    const lssvm_params prm{ static_cast<int32_t>(kernel), 3, 1.0 / d, 0.0, 1.0 };
+    std::vector<T> a1(N), a3(N);
+    T rho1{}, rho3{};
+    lssvm_cg_info i1{}, i3{};
+    const int devs[3] = { 0, 0, 0 };
+    int rc1, rc3;
+    if constexpr (std::is_same_v<T, float>) {
+        rc1 = lssvm_mi355_solve_f32(&prm, X.data(), N, d, y.data(), T(1e-5), 60, a1.data(), &rho1, &i1);
+        rc3 = lssvm_mi355_solve_multi_f32(&prm, X.data(), N, d, y.data(), T(1e-5), 60, a3.data(), &rho3, &i3, devs, 3);
+    } else {
+        rc1 = lssvm_mi355_solve_f64(&prm, X.data(), N, d, y.data(), T(1e-9), 60, a1.data(), &rho1, &i1);
+        rc3 = lssvm_mi355_solve_multi_f64(&prm, X.data(), N, d, y.data(), T(1e-9), 60, a3.data(), &rho3, &i3, devs, 3);
+    }
+    EXPECT_TRUE(rc1 == 0 && rc3 == 0);
+    if (rc3 != 0) std::printf("  %s\n", lssvm_mi355_last_error());
+    EXPECT_TRUE(i1.devices_used == 1 && i3.devices_used == 3 && i3.local_devices == 3 && i3.exchange == 2);
+    T err = 0, scale = 0;
+    for (std::size_t i = 0; i < N; ++i) {
+        err = std::max(err, std::abs(a1[i] - a3[i]));
+        scale = std::max(scale, std::abs(a1[i]));
+    }
+    EXPECT_TRUE(err <= (std::is_same_v<T, float> ? T(2e-3) : T(1e-8)) * scale);
+    EXPECT_TRUE(std::abs(rho1 - rho3) <= (std::is_same_v<T, float> ? T(2e-3) : T(1e-8)) * std::max(T(1), std::abs(rho1)));
+}
+
 static void test_factory_and_exceptions(bool have_gpu) {
     // tests/csvm_factory.cpp:61-212
     EXPECT_THROW_WHAT((void) pa::make_csvm(pa::backend_type::cuda), pa::unsupported_backend_exception, "No cuda backend available!");
@@ -181,6 +244,7 @@ int main(int argc, char **argv) {
     const bool have_gpu = lssvm_mi355_device_count() > 0;
     if (no_gpu && have_gpu) std::printf("note: --no-gpu given but a device is visible; running the no-GPU subset anyway\n");
     test_factory_and_exceptions(have_gpu && !no_gpu);
+    test_named_arguments_and_tracking(have_gpu && !no_gpu);
     if (!no_gpu) {
         if (!have_gpu) {
             std::printf("no HIP device visible: run with --no-gpu for the CPU-only subset\n");
@@ -195,6 +259,8 @@ int main(int argc, char **argv) {
         for (const auto k : { pa::kernel_function_type::linear, pa::kernel_function_type::polynomial, pa::kernel_function_type::rbf }) {
             test_fit_predict_score<float>(k);
             test_fit_predict_score<double>(k);
+            test_multi_device_shards<float>(k);
+            test_multi_device_shards<double>(k);
         }
     }
     std::printf("%d checks, %d failed\n", g_checks, g_failed);

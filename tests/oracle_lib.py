@@ -13,6 +13,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "liblssvm_oracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "liblssvm_ref.so")
+REF_RELEASE_SO = os.path.join(ROOT, "oracle", "_ref", "liblssvm_ref_release.so")  # the reference's Release flags: timing baseline only
 
 KERNELS = {"linear": 0, "polynomial": 1, "rbf": 2}
 
@@ -177,6 +178,16 @@ def ref() -> CpuPath:
     if "ref" not in _cache:
         _cache["ref"] = CpuPath(REF_SO, "ref")
     return _cache["ref"]
+
+
+def have_ref_release() -> bool:
+    return os.path.isfile(REF_RELEASE_SO)
+
+
+def ref_release() -> CpuPath:
+    if "ref_release" not in _cache:
+        _cache["ref_release"] = CpuPath(REF_RELEASE_SO, "ref")
+    return _cache["ref_release"]
 
 
 def float_near(a, b, factor=128.0):

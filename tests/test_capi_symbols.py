@@ -49,10 +49,10 @@ def test_no_oracle_or_torch_in_the_product_library():
 
 
 def test_abi_version_and_struct_layout():
-    assert _capi.lib.lssvm_mi355_abi_version() == 1
+    assert _capi.lib.lssvm_mi355_abi_version() == _capi.ABI_VERSION
     assert C.sizeof(_capi.LssvmParams) == 32
     assert C.sizeof(_capi.LssvmShard) == 8
-    assert C.sizeof(_capi.LssvmCgInfo) == 104
+    assert C.sizeof(_capi.LssvmCgInfo) == 112
 
 
 has_gpu = _capi.device_count() > 0

@@ -147,3 +147,40 @@ def test_symmetric_partition_is_a_balanced_cover(n, world):
     if tiles >= 64 * world:  # enough blocks: every rank's area is within a few percent of the mean
         mean = sum(executed) / world
         assert max(abs(e - mean) for e in executed) < 0.05 * mean
+
+
+@pytest.mark.parametrize("n", [1, 127, 128, 129, 390, 4095, 49_999, 999_999])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_the_librarys_own_partition_equals_the_python_restatement(n, world):
+    """lssvm_mi355_shard_blocks is the function Problem<T> partitions with (plssvm_amd/csrc/lssvm_problem.hip: shard_blocks); the Python
+    copy in plssvm_amd/sharding.py (used for bench.py's flop accounting and by the gloo tests above) must agree with it block for block."""
+    from plssvm_amd import _capi
+
+    sym = sharding.sym_block_partition(n, world)
+    rows = sharding.row_block_partition(n, world)
+    tiles = (n + sharding.TILE - 1) // sharding.TILE
+    covered = 0
+    for r in range(world):
+        assert _capi.shard_blocks(n + 1, world, r, True) == sym[r]
+        b0, b1 = _capi.shard_blocks(n + 1, world, r, False)
+        assert (min(b0 * sharding.TILE, n), min(b1 * sharding.TILE, n)) == rows[r]
+        covered += sym[r][1] - sym[r][0]
+    assert covered == tiles and sym[0][0] == 0 and sym[-1][1] == tiles
+
+
+def test_bench_spawns_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` typed as is must start two child ranks itself (no torchrun).  Without a GPU every child stops at the
+    loud "needs an MI355X" check -- which proves the parent spawned them with RANK / WORLD_SIZE set and returned their exit code."""
+    import subprocess
+    import sys
+
+    from plssvm_amd import _capi
+
+    if _capi.device_count() > 0:
+        pytest.skip("on a GPU box this would run the full benchmark; the spawn path is exercised by bench.py itself there")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "c2"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0
+    assert out.stderr.count("bench.py needs an MI355X") == 2, out.stderr

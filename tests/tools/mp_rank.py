@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""One rank of a one-process-per-GPU run THROUGH THE LIBRARY (tests/test_gpu_multi_device.py starts two of these as fresh child
+processes; it also runs under torchrun).  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment.  The RCCL unique id is
+handed over through a gloo process group (CPU), so the only RCCL user in the process is libplssvm_amd.so itself.  Rank r runs
+ResidentProblem(rank=r, world=W): one implicit matvec and a few CG iterations; rank 0 also runs the single-GPU problem and writes
+the distances.  Every rank writes a hash of its alpha: all ranks must hold the same bits."""
+
+import argparse
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--symmetric", type=int, default=1)
+    ap.add_argument("--points", type=int, default=6000)
+    ap.add_argument("--features", type=int, default=128)
+    ap.add_argument("--out", required=True)
+    args = ap.parse_args()
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
+
+    import numpy as np
+    import torch.distributed as dist
+
+    from plssvm_amd import _capi, backend
+    from plssvm_amd.datagen import make_blobs_pm1
+    from plssvm_amd.parameter import Parameter
+    from plssvm_amd.sharding import exchange_unique_id
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        uid = exchange_unique_id(dist, backend.comm_get_unique_id, device=None)
+        backend.comm_init(local, rank, world, uid)
+        _capi.set_option("symmetric", args.symmetric)
+        X, y = make_blobs_pm1(args.points, args.features, seed=5, dtype=np.float32)
+        p = Parameter(kernel_type="rbf")
+        n = args.points - 1
+        v = np.random.default_rng(9).uniform(-1, 1, size=n).astype(np.float32)
+        zero = np.zeros(n, np.float32)
+        with backend.ResidentProblem(p, X, device=local, rank=rank, world=world) as prob:
+            got = prob.matvec(v, zero, 1.0)
+            prob.cg_begin(y, 1e-30)
+            prob.cg_step(12)
+            alpha, rho, info = prob.cg_finish()
+        out = {"rank": rank, "alpha_sha": hashlib.sha256(alpha.tobytes()).hexdigest(), "rho": float(rho), "devices_used": int(info["devices_used"]),
+               "exchange": int(info["exchange"]), "symmetric": int(info["symmetric"])}
+        if rank == 0:
+            with backend.ResidentProblem(p, X, device=local) as single:
+                want = single.matvec(v, zero, 1.0)
+                single.cg_begin(y, 1e-30)
+                single.cg_step(12)
+                a1, rho1, _ = single.cg_finish()
+            out["matvec_err"] = float(np.max(np.abs(got - want)) / np.max(np.abs(want)))
+            out["alpha_err"] = float(np.max(np.abs(alpha - a1)) / np.max(np.abs(a1)))
+        dist.barrier()
+        backend.comm_destroy()
+        with open(args.out, "w") as f:
+            json.dump(out, f)
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
