@@ -318,6 +318,9 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
         } else if (n == "gram_mode") {
             LSSVM_REQUIRE(value == 0 || value == 1, "gram_mode must be 0 or 1");
             lssvm::options().gram_mode = value;
+        } else if (n == "mfma_shape") {
+            LSSVM_REQUIRE(value == 0 || value == 1, "mfma_shape must be 0 (32x32x16) or 1 (16x16x32)");
+            lssvm::options().mfma_shape = value;
         } else if (n == "colslab_limit_mb") {
             LSSVM_REQUIRE(value >= 0, "colslab_limit_mb must not be negative");
             lssvm::options().colslab_limit_mb = value;
@@ -358,6 +361,8 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             *value_out = lssvm::options().force_collective;
         } else if (n == "gram_mode") {
             *value_out = lssvm::options().gram_mode;
+        } else if (n == "mfma_shape") {
+            *value_out = lssvm::options().mfma_shape;
         } else if (n == "colslab_limit_mb") {
             *value_out = lssvm::options().colslab_limit_mb;
         } else if (n == "skip_collective") {

@@ -190,6 +190,7 @@ static void set_launch_options(TileArgs<T> &a, const Options &o) {
     a.dbg = static_cast<int>(o.debug_ablate);
     a.map_mode = o.xcd_map != 0 ? 1 : 0;
     a.lds_extra_kb = static_cast<int>(o.lds_extra_kb);
+    a.mfma_shape = static_cast<int>(o.mfma_shape);
 }
 
 /* rbf on the matrix cores: the data is scaled so that the MFMA chain leaves the exponent in the unit the epilogue wants:

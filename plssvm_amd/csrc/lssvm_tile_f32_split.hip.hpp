@@ -353,6 +353,326 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
     }
 }
 
+/*
+ * The same kernel on v_mfma_f32_16x16x32_bf16 (option mfma_shape = 1).  Same data movement (LDS-DMA ring, swizzled 128-byte rows, records,
+ * hand-over), same number of matrix-core cycles; what changes is the instruction shape: a wave's 32 rows x 128 columns are 2 x 8 blocks of
+ * 16 x 16 (64 accumulator registers, as before), one B fragment (16 columns x 32 features, one ds_read_b128) feeds up to 6 MFMAs (2 row
+ * blocks x up to 3 row planes) instead of 3.  Why: in the power-bound regime this kernel runs in, MI355X holds a higher clock on the 16x16x32
+ * shape (MI355X_MICROARCH.md "DVFS give-back" (7): 1.12-1.15 x the FLOP/s of the 32x32x16 loop at equal cycles per FLOP, on random data).
+ * Operand maps (cdna_hip_programming.md section 3): lane l holds A[row l & 15][k = 8 (l >> 4) + j] and B[k = 8 (l >> 4) + j][col l & 15], j = 0..7;
+ * the result has col = l & 15, row = 4 (l >> 4) + reg.
+ * A step (= one plane of one 64-feature chunk) is processed in four groups mm = (k32 step kk = mm >> 1, column half cbh = mm & 1) of four column
+ * blocks each, so that the B fragments stay double buffered in 2 x 16 registers and the hand-over sits in the middle of a step as before.
+ */
+template <int KT, int NK64, bool SYM>
+__global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec_f32_s6w(const TileArgs<float> a) {
+    constexpr int NKC = 3 * NK64;  // plane-chunks (steps) per tile: for every 64-feature chunk the planes hi, mid, lo
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char *ring = smem_raw;                                                          // [V2_RING][128 rows][128 B]
+    char *dcs = smem_raw + V2_RING * V2_SLOT_BYTES;                                 // [V2_DC_SLOTS][256 floats]
+    float *cis = reinterpret_cast<float *>(dcs + V2_DC_SLOTS * 1024);               // [128] c_i of the row panel (rbf)
+    float *dis = cis + TILE;                                                        // [128] d_i of the row panel (SYM)
+    float *colred = dis + TILE;                                                     // [2][4 waves][128] column sums of a tile (SYM)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15;  // row of an A block / column of a B block
+    const int g = lane >> 4;  // k group (operands), row group (results)
+
+    int ibl, jc;
+    if constexpr (SYM) {
+        const int2 it = a.items[blockIdx.x];
+        ibl = __builtin_amdgcn_readfirstlane(it.x);
+        jc = __builtin_amdgcn_readfirstlane(it.y);
+    } else {
+        if (!decode_work_item(a, ibl, jc)) return;
+    }
+    const int ib = a.ib_begin + ibl;
+    const int row0 = ib * TILE;
+    const int jt_begin = jc * a.jc_tiles;
+    const int jt_end = SYM ? min(jt_begin + a.jc_tiles, ib + 1) : min(jt_begin + a.jc_tiles, a.num_jt);
+    const int ntiles = jt_end - jt_begin;
+    if (ntiles <= 0) return;
+    const int nsteps = ntiles * NKC;
+    const long rec0 = SYM ? (static_cast<long>(ib) * (ib - 1) / 2 - a.pair_origin) : 0;
+
+    // ---- the row panel: A fragments of this wave's 32 rows (two blocks of 16), all features, all three planes: lane (r, g) holds features
+    // 32 kk + 8 g .. + 7 of row 16 rb + r for k32 step kk ----
+    bf16x8 afrag[3][2 * NK64][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const uint16_t *xr = a.Xr16 + p * a.plane_stride + static_cast<size_t>(row0 + wave * 32 + 16 * rb + r) * a.ldx16 + 8 * g;
+#pragma unroll
+            for (int kk = 0; kk < 2 * NK64; ++kk) afrag[p][kk][rb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(xr + 32 * kk));
+        }
+    }
+    if constexpr (KT == KT_RBF) {
+        if (tid < TILE) cis[tid] = a.cr[row0 + tid];
+    }
+    if constexpr (SYM) {
+        if (tid < TILE) dis[tid] = a.dvec[row0 + tid];
+    }
+    // make the compiler retire these ordinary loads HERE, before any LDS-DMA is in flight
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int kk = 0; kk < 2 * NK64; ++kk)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) asm volatile("" : "+v"(afrag[p][kk][rb]));
+
+    // ---- LDS-DMA addressing: identical to tile_matvec_f32_s6 (the LDS image does not depend on the MFMA shape) ----
+    unsigned dma_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * (4 * wave + i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        dma_off[i] = 2u * static_cast<unsigned>(row * a.ldx16 + 8 * c);
+    }
+    auto issue_chunk = [&](int step) {
+        const int t = step / NKC;
+        const int kc = step - t * NKC;
+        const char *base = sgpr_ptr(a.Xc16 + (kc % 3) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (kc / 3) * 64);
+        char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + lane_off(dma_off[i])), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_chunk_part = [&](int step, int i) {
+        const int t = step / NKC;
+        const int kc = step - t * NKC;
+        const char *base = sgpr_ptr(a.Xc16 + (kc % 3) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (kc / 3) * 64);
+        char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES + wave * 4096;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + lane_off(dma_off[i])), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
+    };
+    auto issue_dc = [&](int t) {
+        if (lane < 16) {
+            const char *src = sgpr_ptr(a.dc + static_cast<size_t>(jt_begin + t) * 256) + __builtin_amdgcn_readfirstlane(wave * 256);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (src + 16u * (lane_off(threadIdx.x) & 15u)), (lds_ptr_t) (dcs + (t % V2_DC_SLOTS) * 1024 + wave * 256), 16, 0, 0);
+        }
+    };
+
+    // ---- read addressing: lane (r, g) reads the 16-B logical slot 4 kk + g of row 16 cb + r; the swizzle (row >> 1) & 7 depends on r only, the
+    // column block is an immediate offset.  Conflict free for ds_read_b128 (its 16-lane groups see eight distinct XOR values twice, on both
+    // halves of the 256-byte bank line) ----
+    int rd_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) rd_off[kk] = r * 128 + (((4 * kk + g) ^ ((r >> 1) & 7)) << 4);
+
+    float rowpart[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rowpart[i] = 0.0f;
+    f32x4 acc[2][8];
+    float dj[8], cj[8];
+    bool padcol[8] = { false, false, false, false, false, false, false, false };
+
+    // ---- prologue: chunks 0, 1, 2 (each preceded by the record of the tile that starts with it) ----
+    issue_dc(0);
+    issue_chunk(0);
+#pragma unroll
+    for (int pre = 1; pre <= 2; ++pre) {
+        if (pre < nsteps) {
+            if (pre % NKC == 0) issue_dc(pre / NKC);
+            issue_chunk(pre);
+        }
+    }
+    if (nsteps >= 3) {
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    } else if (nsteps == 2) {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    f32x4 bcur[4];  // B fragments of the group about to be multiplied (double buffered against bnext in the loop)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bcur[c] = *reinterpret_cast<const f32x4 *>(ring + c * 2048 + rd_off[0]);
+
+    auto handover = [&](int step, int kc_plus3_mod, auto checked) {
+        constexpr bool CHECKED = decltype(checked)::value;
+        if constexpr (!CHECKED) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kc_plus3_mod == 0) issue_dc((step + 3) / NKC);
+        } else {
+            if (step + 1 < nsteps) {
+                if (step + 2 < nsteps) {
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (step + 3 < nsteps) {
+                    if (kc_plus3_mod == 0) issue_dc((step + 3) / NKC);
+                    issue_chunk(step + 3);
+                }
+            }
+        }
+    };
+
+    auto flush_cols = [&](int t) {
+        if (tid < TILE) {
+            const float *cr_ = colred + (t & 1) * 512;
+            const float sum = (cr_[tid] + cr_[128 + tid]) + (cr_[256 + tid] + cr_[384 + tid]);
+            float *rec = a.colslab + (rec0 + jt_begin + t) * TILE;
+            rec[static_cast<unsigned>(tid)] = sum;
+        }
+    };
+
+    auto tile_body = [&](int t, auto checked) {
+        const int s0 = t * NKC;
+        const bool tile_sym = SYM && (jt_begin + t < ib);  // strictly below the diagonal
+        {
+            const float *dcr = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                dj[cb] = dcr[cb * 16 + r];
+                if constexpr (KT == KT_RBF) cj[cb] = dcr[128 + cb * 16 + r];
+                if constexpr (KT == KT_POLY) padcol[cb] = (a.degree < 0) && ((jt_begin + t) * TILE + cb * 16 + r >= a.ncols_valid);
+            }
+            if constexpr (KT == KT_RBF) {  // the accumulators start at c_i + c_j
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    const f32x4 civ = *reinterpret_cast<const f32x4 *>(cis + wave * 32 + 16 * rb + 4 * g);
+#pragma unroll
+                    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[rb][cb][e] = civ[e] + cj[cb];
+                }
+            }
+        }
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            const int step = s0 + kc;
+            const char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES;
+            const char *slot_next = ring + ((step + 1) % V2_RING) * V2_SLOT_BYTES;
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+                const int kk = mm >> 1, cbh = mm & 1;
+                f32x4 bnext[4];
+                if (mm < 3) {  // next group of this chunk: (kk', cbh') = ((mm + 1) >> 1, (mm + 1) & 1)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) bnext[c] = *reinterpret_cast<const f32x4 *>(slot + (4 * ((mm + 1) & 1) + c) * 2048 + rd_off[(mm + 1) >> 1]);
+                }
+                if (mm == 2) {
+                    if constexpr (SYM) {
+                        if (kc == 0 && t > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    handover(step, (kc + 3) % NKC, checked);
+                    if constexpr (SYM) {
+                        if (kc == 0 && t > 0) flush_cols(t - 1);
+                    }
+                }
+                if (mm == 3) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) bnext[c] = *reinterpret_cast<const f32x4 *>(slot_next + c * 2048 + rd_off[0]);
+                }
+                const int chunk = kc / 3, plane = kc % 3;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if (q + plane > 2) continue;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int cb = 4 * cbh + c;
+                        const bf16x8 bv = __builtin_bit_cast(bf16x8, bcur[c]);
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb) {
+                            const bf16x8 av = afrag[q][2 * chunk + kk][rb];
+                            if (KT != KT_RBF && kc == 0 && kk == 0 && q == 0) {
+                                const f32x4 zero = { 0.f, 0.f, 0.f, 0.f };
+                                acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, zero, 0, 0, 0);
+                            } else {
+                                acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[rb][cb], 0, 0, 0);
+                            }
+                        }
+                        if constexpr (!decltype(checked)::value) {
+                            if (q == 0 && mm >= 2 && (c & 1) == 0) issue_chunk_part(step + 3, (mm - 2) * 2 + (c >> 1));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) bcur[c] = bnext[c];
+            }
+        }
+        {
+            auto epilogue = [&](auto with_cols) {
+                constexpr bool COLS = decltype(with_cols)::value;
+                f32x4 di[2];
+                float colacc[8] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+                if constexpr (COLS) {
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) di[rb] = *reinterpret_cast<const f32x4 *>(dis + wave * 32 + 16 * rb + 4 * g);
+                }
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float kv = apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(acc[rb][cb][e], a);
+                            if constexpr (KT == KT_POLY) {
+                                if (padcol[cb]) kv = 0.0f;
+                            }
+                            rowpart[4 * rb + e] = fmaf(kv, dj[cb], rowpart[4 * rb + e]);
+                            if constexpr (COLS) colacc[cb] = fmaf(kv, di[rb][e], colacc[cb]);
+                        }
+                if constexpr (COLS) {
+                    float *cw = colred + (t & 1) * 512 + wave * 128;
+#pragma unroll
+                    for (int cb = 0; cb < 8; ++cb) {
+                        float v = colacc[cb];  // the four lane groups hold different rows of the same column
+                        v += __shfl_xor(v, 16);
+                        v += __shfl_xor(v, 32);
+                        if (g == 0) cw[cb * 16 + r] = v;
+                    }
+                }
+            };
+            if (tile_sym) {
+                epilogue(std::true_type{});
+            } else {
+                epilogue(std::false_type{});
+            }
+        }
+    };
+
+    constexpr int TAIL_TILES = (3 + NKC - 1) / NKC;
+    const int nmain = ntiles > TAIL_TILES ? ntiles - TAIL_TILES : 0;
+    int t = 0;
+    for (; t < nmain; ++t) tile_body(t, std::false_type{});
+    for (; t < ntiles; ++t) tile_body(t, std::true_type{});
+    if constexpr (SYM) {
+        if (jt_begin + ntiles - 1 < ib) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            flush_cols(ntiles - 1);
+        }
+    }
+
+    // every lane group owns its rows: reduce over the 16 columns of the group and store
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float v = rowpart[i];
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 1);
+        rowpart[i] = v;
+    }
+    if (r == 0) {
+        float *dst = a.partial + static_cast<size_t>(jc) * a.part_stride + ibl * TILE + wave * 32 + 4 * g;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[16 * (i >> 2) + (i & 3)] = rowpart[i];
+    }
+}
+
 /* x = hi + mid + lo, each rounded to nearest-even bf16 of the remainder (exact: the remainders are representable in fp32).
  * X: [rows][ldx] fp32, features in natural order; planes: [3][rows][ldx16] bf16, zero padded. */
 __global__ void k_split_bf16x3(const float *__restrict__ X, int ldx, int dfeat, size_t rows, int ldx16, uint16_t *__restrict__ planes, size_t plane_stride) {

@@ -13,8 +13,13 @@ static void launch_s6_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
     const dim3 block(TILE_THREADS);
 #define LSSVM_S6_CASE(N)                                                                                  \
     case N:                                                                                               \
-        ensure_dynamic_lds(tile_matvec_f32_s6<KT, N, SYM>, V2_LDS_BYTES);                                 \
-        hipLaunchKernelGGL((tile_matvec_f32_s6<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);            \
+        if (a.mfma_shape == 1) {                                                                          \
+            ensure_dynamic_lds(tile_matvec_f32_s6w<KT, N, SYM>, V2_LDS_BYTES);                            \
+            hipLaunchKernelGGL((tile_matvec_f32_s6w<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);       \
+        } else {                                                                                          \
+            ensure_dynamic_lds(tile_matvec_f32_s6<KT, N, SYM>, V2_LDS_BYTES);                             \
+            hipLaunchKernelGGL((tile_matvec_f32_s6<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);        \
+        }                                                                                                 \
         break;
     switch (a.ldx16 / 64) {
         LSSVM_S6_CASE(1) LSSVM_S6_CASE(2) LSSVM_S6_CASE(3) LSSVM_S6_CASE(4)

@@ -188,6 +188,10 @@ static void test_multi_device_shards(pa::kernel_function_type kernel) {
     lssvm_cg_info i1{}, i3{};
     const int devs[3] = { 0, 0, 0 };
     int rc1, rc3;
+    // the yardstick of an fp32 CG trajectory is its distance to the float64 solve (rounding noise is amplified from iteration to iteration)
+    std::vector<double> Xd(X.begin(), X.end()), yd(y.begin(), y.end()), a64(N);
+    double rho64{};
+    const int rc64 = lssvm_mi355_solve_f64(&prm, Xd.data(), N, d, yd.data(), 1e-9, 60, a64.data(), &rho64, nullptr);
     if constexpr (std::is_same_v<T, float>) {
         rc1 = lssvm_mi355_solve_f32(&prm, X.data(), N, d, y.data(), T(1e-5), 60, a1.data(), &rho1, &i1);
         rc3 = lssvm_mi355_solve_multi_f32(&prm, X.data(), N, d, y.data(), T(1e-5), 60, a3.data(), &rho3, &i3, devs, 3);
@@ -195,16 +199,19 @@ static void test_multi_device_shards(pa::kernel_function_type kernel) {
         rc1 = lssvm_mi355_solve_f64(&prm, X.data(), N, d, y.data(), T(1e-9), 60, a1.data(), &rho1, &i1);
         rc3 = lssvm_mi355_solve_multi_f64(&prm, X.data(), N, d, y.data(), T(1e-9), 60, a3.data(), &rho3, &i3, devs, 3);
     }
-    EXPECT_TRUE(rc1 == 0 && rc3 == 0);
+    EXPECT_TRUE(rc1 == 0 && rc3 == 0 && rc64 == 0);
     if (rc3 != 0) std::printf("  %s\n", lssvm_mi355_last_error());
     EXPECT_TRUE(i1.devices_used == 1 && i3.devices_used == 3 && i3.local_devices == 3 && i3.exchange == 2);
-    T err = 0, scale = 0;
+    double err1 = 0, err3 = 0, scale = 0;
     for (std::size_t i = 0; i < N; ++i) {
-        err = std::max(err, std::abs(a1[i] - a3[i]));
-        scale = std::max(scale, std::abs(a1[i]));
+        err1 = std::max(err1, std::abs(static_cast<double>(a1[i]) - a64[i]));
+        err3 = std::max(err3, std::abs(static_cast<double>(a3[i]) - a64[i]));
+        scale = std::max(scale, std::abs(a64[i]));
     }
-    EXPECT_TRUE(err <= (std::is_same_v<T, float> ? T(2e-3) : T(1e-8)) * scale);
-    EXPECT_TRUE(std::abs(rho1 - rho3) <= (std::is_same_v<T, float> ? T(2e-3) : T(1e-8)) * std::max(T(1), std::abs(rho1)));
+    // both solves are converged to the stop criterion (eps = 1e-5 / 1e-9): they agree at that accuracy, not at rounding accuracy
+    const double tol = std::is_same_v<T, float> ? 1e-3 : 1e-6;
+    EXPECT_TRUE(err3 <= 2 * err1 + tol * scale);
+    EXPECT_TRUE(std::abs(static_cast<double>(rho3) - rho64) <= 2 * std::abs(static_cast<double>(rho1) - rho64) + 10 * tol * std::max(1.0, std::abs(rho64)));  // rho = -(y_N + QA_cost sum(x) - q.x) cancels
 }
 
 static void test_factory_and_exceptions(bool have_gpu) {

@@ -55,8 +55,13 @@ def main():
                 single.cg_begin(y, 1e-30)
                 single.cg_step(12)
                 a1, rho1, _ = single.cg_finish()
+            with backend.ResidentProblem(p, X.astype(np.float64), device=local) as truth:  # the same iterations in float64: the yardstick
+                truth.cg_begin(y.astype(np.float64), 1e-30)
+                truth.cg_step(12)
+                a64, _, _ = truth.cg_finish()
             out["matvec_err"] = float(np.max(np.abs(got - want)) / np.max(np.abs(want)))
-            out["alpha_err"] = float(np.max(np.abs(alpha - a1)) / np.max(np.abs(a1)))
+            out["alpha_err64"] = float(np.max(np.abs(alpha - a64)) / np.max(np.abs(a64)))
+            out["single_err64"] = float(np.max(np.abs(a1 - a64)) / np.max(np.abs(a64)))
         dist.barrier()
         backend.comm_destroy()
         with open(args.out, "w") as f:
