@@ -57,12 +57,14 @@ def train_main(argv=None) -> int:
     ap.add_argument("-c", "--cost", type=float, default=1.0, help="set the parameter C")
     ap.add_argument("-e", "--epsilon", type=float, default=0.001, help="set the tolerance of termination criterion")
     ap.add_argument("-i", "--max_iter", type=int, default=None, help="set the maximum number of CG iterations (default: num_features)")
+    ap.add_argument("--performance_tracking", default=None, metavar="FILE",
+                    help="the output YAML file where the performance tracking results are written to (appended); '-' dumps them to stderr")  # parser_train.cpp
     _common(ap)
     ap.add_argument("input", nargs="?", help="training_set_file")
     ap.add_argument("model", nargs="?", help="model_file")
     args = ap.parse_args(argv)
     if args.version:
-        print("plssvm_amd (MI355X-native LS-SVM CG backend), C ABI version 1")
+        print("plssvm_amd (MI355X-native LS-SVM CG backend), C ABI version 2")
         return 0
     if args.input is None:
         print("Error missing input file!", file=sys.stderr)
@@ -89,8 +91,26 @@ def train_main(argv=None) -> int:
                                       f"(target: {info['target_residuum']}) and an average iteration time of {info['avg_iteration_ms']:.3f}ms.")
         _log(verb, ("full", "libsvm"), f"optimization finished, #iter = {info['iterations']}")  # csvm.cpp:175-176
         _log(verb, ("full", "timing"), f"Solved minimization problem (r = b - Ax) using the Conjugate Gradient (CG) methode in {info['total_runtime_ms']:.0f}ms.\n")
+        t_w = time.perf_counter()
         model.save(model_file)
+        t_w = time.perf_counter() - t_w
         _log(verb, ("full", "timing"), f"Write {model.num_support_vectors()} support vectors with {model.num_features()} features to the libsvm model file '{model_file}'.")
+        if args.performance_tracking is not None:
+            from .performance_tracker import PerformanceTracker
+
+            tr = PerformanceTracker()
+            tr.add_parameter(params, np.dtype(real_type).name)
+            tr.add_backend(info.get("devices_used", 1))
+            tr.add_cg_info(info)
+            tr.add("data_set_read", "num_data_points", data.num_data_points())
+            tr.add("data_set_read", "num_features", data.num_features())
+            tr.add("data_set_read", "filename", args.input)
+            tr.add("model_write", "num_support_vectors", model.num_support_vectors())
+            tr.add("model_write", "rho", float(model.rho))  # model.hpp:221
+            tr.add("model_write", "filename", model_file)
+            tr.add("model_write", "time", f"{t_w * 1e3:.0f}ms")
+            tr.add("", "total_time", f"{(time.perf_counter() - t0) * 1e3:.0f}ms")  # main_train.cpp:57
+            tr.save(None if args.performance_tracking == "-" else args.performance_tracking)
         _log(verb, ("full",), f"\nTotal runtime: {(time.perf_counter() - t0) * 1e3:.0f}ms")
     except PlssvmError as e:
         print(f"{e}\nException type: {type(e).__name__}", file=sys.stderr)
@@ -106,7 +126,7 @@ def predict_main(argv=None) -> int:
     ap.add_argument("output", nargs="?", help="output_file")
     args = ap.parse_args(argv)
     if args.version:
-        print("plssvm_amd (MI355X-native LS-SVM CG backend), C ABI version 1")
+        print("plssvm_amd (MI355X-native LS-SVM CG backend), C ABI version 2")
         return 0
     if args.test is None:
         print("Error missing test file!", file=sys.stderr)

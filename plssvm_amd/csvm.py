@@ -113,7 +113,9 @@ class CSVM:
 class MI355CSVM(CSVM):
     """The MI355X backend (counterpart of plssvm::hip::csvm, HIP/csvm.hpp:39-99, csvm.hip.cpp:47-85)."""
 
-    def __init__(self, target=TargetPlatform.AUTOMATIC, params: Parameter | None = None, **kwargs):
+    def __init__(self, target=TargetPlatform.AUTOMATIC, params: Parameter | None = None, num_devices: int = 0, **kwargs):
+        """``num_devices``: devices ONE solve is sharded over -- 0 = automatic (every visible device, at least 4096 points each; the reference's
+        backends take every device they find, csvm.hip.cpp:66-75), 1 = device 0 only, k = devices 0 .. k-1 (gpu_csvm.hpp:283-299)."""
         if isinstance(target, Parameter):
             target, params = TargetPlatform.AUTOMATIC, target
         super().__init__(params, **kwargs)
@@ -123,9 +125,13 @@ class MI355CSVM(CSVM):
         self.num_devices = _capi.device_count()
         if self.num_devices <= 0:
             raise BackendError("MI355 backend selected but no HIP capable devices were found!")
+        if not 0 <= int(num_devices) <= self.num_devices:
+            raise BackendError(f"Requested {num_devices} devices, but only {self.num_devices} are available!")
+        self.use_devices = int(num_devices)
 
     def solve_system_of_linear_equations(self, params, A, b, eps, max_iter):
-        return backend.solve_system_of_linear_equations(params, A, b, eps, max_iter)
+        # all devices of this process behind ONE call (gpu_csvm::solve_system_of_linear_equations_impl, gpu_csvm.hpp:477-654)
+        return backend.solve_system_of_linear_equations(params, A, b, eps, max_iter, num_devices=self.use_devices)
 
     def predict_values(self, params, support_vectors, alpha, rho, w, predict_points):
         return backend.predict_values(params, support_vectors, alpha, rho, w, predict_points)

@@ -46,18 +46,45 @@ PARAM_SETS = {
 KERNELS = ["linear", "polynomial", "rbf"]
 
 
+def independent_parse(filename, num_features):
+    """A second, deliberately naive reading of a LIBSVM file (str.split + float), independent of plssvm_amd.io_libsvm: the fixtures
+    must not depend on the package's own parser being right (circular for row f1)."""
+    rows, labels = [], []
+    for line in open(filename):
+        line = line.strip()
+        if not line or line.startswith("#"):
+            continue
+        tok = line.split()
+        labels.append(float(tok[0]))
+        row = [0.0] * num_features
+        for t in tok[1:]:
+            idx, val = t.split(":")
+            row[int(idx) - 1] = float(val)
+        rows.append(row)
+    return np.array(rows, dtype=np.float64), np.array(labels, dtype=np.float64)
+
+
 def load_inputs():
     sets = {}
     X, y = parse_libsvm_data(os.path.join(REF_DATA, "5x4.libsvm"), dtype=np.float64)
     sets["5x4"] = (X, np.asarray(y, dtype=np.float64))
     X, y = parse_libsvm_data(os.path.join(REF_DATA, "500x200.libsvm"), dtype=np.float64)
     sets["500x200"] = (X, np.asarray(y, dtype=np.float64))
+    for name, fname in (("5x4", "5x4.libsvm"), ("500x200", "500x200.libsvm")):
+        Xi, yi = independent_parse(os.path.join(REF_DATA, fname), sets[name][0].shape[1])
+        assert np.array_equal(Xi, sets[name][0]) and np.array_equal(yi, sets[name][1]), f"{fname}: the two parsers disagree"
     X, y = make_blobs_pm1(263, 37, seed=7, dtype=np.float64)
     sets["blobs263x37"] = (X, y.astype(np.float64))
     return sets
 
 
 def main():
+    if "--verify-inputs" in sys.argv:  # the committed inputs.npz against both parsers, without regenerating anything
+        committed = np.load(os.path.join(HERE, "inputs.npz"))
+        for k, (X, y) in load_inputs().items():
+            assert np.array_equal(committed[f"{k}_X"], X) and np.array_equal(committed[f"{k}_y"], y), k
+        print("inputs.npz verified against the package parser AND the independent parser")
+        return
     if not oracle_lib.have_ref():
         raise SystemExit("oracle/_ref/liblssvm_ref.so missing: run `make -C oracle ref` first")
     ref = oracle_lib.ref()
