@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--exchange", type=int, default=None, choices=[0, 1, 2], help="--single-process: 0 automatic, 1 RCCL, 2 peer kernels over xGMI")
     ap.add_argument("--gram-mode", type=int, default=None, choices=[0, 1],
                     help="fp32 only: 1 = bf16x6 split on the bf16 matrix cores (library default), 0 = native v_mfma_f32 chains")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="set a library tuning knob (lssvm_mi355_set_option) before the problem is created; repeatable")
     ap.add_argument("--cpu-sample-rows", type=int, default=20480)  # 4 implicit matvecs of ~3 s each on 128 host cores: about 12 s of CPU work per line
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-native-reference", action="store_true", help="skip the extra native v_mfma_f32 run reported beside a bf16x6 headline")
@@ -229,6 +230,9 @@ def main():
         _capi.set_option("gram_mode", args.gram_mode)
     if args.exchange is not None:
         _capi.set_option("exchange", args.exchange)
+    for kv in args.option:
+        name, value = kv.split("=", 1)
+        _capi.set_option(name.strip(), int(value))
     if devices is not None:
         prob = backend.ResidentProblem(params, X, devices=devices)
     else:
@@ -309,7 +313,7 @@ def main():
             "arithmetic": ("fp32 operands split exactly into 3 bf16 planes, 6 plane products per multiply-add accumulated in fp32 on the bf16 matrix cores"
                            if bf16x6 else "native " + wl["dtype"] + " matrix-core fma chains"),
             "config": {"workload": wl["desc"], "num_points": N, "num_features": d, "kernel": wl["kernel"], "gamma": 1.0 / d, "cost": 1.0,
-                       "seed": args.seed, "parallelism": parallelism, "shards": shards, "exchange": exchange_names.get(int(i1.get("exchange", 0)), "?"),
+                       "seed": args.seed, "library_options": args.option, "parallelism": parallelism, "shards": shards, "exchange": exchange_names.get(int(i1.get("exchange", 0)), "?"),
                        "residuum_after_timed_steps": i1["residuum"]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_source": traffic_source,

@@ -225,7 +225,8 @@ int lssvm_mi355_libsvm_fill_f64(lssvm_mi355_libsvm_file *file, double *X, uint64
 int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
 
 /* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT).  set_option changes the process-wide DEFAULTS;
- * every problem / solve takes a snapshot of them when it is created, so later changes never affect a live problem:
+ * every problem / solve takes a snapshot of them when it is created, so later changes never affect a live problem.  The defaults can
+ * be preset from the environment: LSSVM_MI355_OPTIONS="name=value,name=value" (read once when the library is loaded):
  *   "rbf_form"      0 = norm expansion on the matrix cores (default), 1 = direct (x_i - x_j)^2 on the vector ALU
  *   "j_chunk_tiles" number of 128-column tiles per work item; 0 = automatic (default: about 4096 work items per device, 2 ... 16 tiles each,
  *                   up to 64 for the bf16x6 kernel)
@@ -241,6 +242,9 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *   "gram_mode"     fp32, num_features <= 256: 1 = "bf16x6" (default): every operand is split EXACTLY into three bf16 planes and the
  *                   six significant plane products are accumulated in fp32 on v_mfma_f32_32x32x16_bf16 -- fp32-equivalent accuracy,
  *                   different summation order; 0 = Gram tiles on v_mfma_f32_32x32x2_f32 (exact fmaf chains)
+ *   "mfma_shape"    bf16x6 kernel: 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16 (same matrix-core cycles; the chip holds a higher
+ *                   clock under the second shape, MI355X_MICROARCH.md "DVFS give-back"), 2 = 1 with hand-scheduled MFMA groups (B fragments in
+ *                   registers the compiler does not own, counted LDS waits) for num_features <= 128; default 2
  *   "colslab_limit_mb" the symmetric variant needs n_tiles^2 / 2 column records of 128 reals (15.6 GB at 1M points in fp32, divided
  *                   by the number of ranks); above this many MiB per device the full square is evaluated instead (default 98304)
  *   "exchange"      several devices in one process (the _multi entry points): 0 = automatic (RCCL when the listed devices are distinct, peer

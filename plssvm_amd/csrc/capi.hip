@@ -7,6 +7,7 @@
 
 #include "libsvm_reader.hpp"
 
+#include <cstdlib>
 #include <memory>
 #include <new>
 
@@ -319,7 +320,7 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
             LSSVM_REQUIRE(value == 0 || value == 1, "gram_mode must be 0 or 1");
             lssvm::options().gram_mode = value;
         } else if (n == "mfma_shape") {
-            LSSVM_REQUIRE(value == 0 || value == 1, "mfma_shape must be 0 (32x32x16) or 1 (16x16x32)");
+            LSSVM_REQUIRE(value >= 0 && value <= 2, "mfma_shape must be 0 (32x32x16), 1 (16x16x32) or 2 (16x16x32, hand-scheduled groups)");
             lssvm::options().mfma_shape = value;
         } else if (n == "colslab_limit_mb") {
             LSSVM_REQUIRE(value >= 0, "colslab_limit_mb must not be negative");
@@ -378,6 +379,33 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
         }
     });
 }
+
+/* The process-wide option defaults can be preset from the environment, LSSVM_MI355_OPTIONS="name=value,name=value" (applied once when the
+ * library is loaded; unknown names or bad values are reported on stderr and ignored): lets a whole test suite or an unmodified host
+ * program run against another kernel selection. */
+namespace {
+struct EnvOptions {
+    EnvOptions() {
+        const char *env = std::getenv("LSSVM_MI355_OPTIONS");
+        if (env == nullptr) return;
+        std::string all(env);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            const size_t end = std::min(all.find(',', pos), all.size());
+            const std::string item = all.substr(pos, end - pos);
+            pos = end + 1;
+            const size_t eq = item.find('=');
+            if (eq == std::string::npos) continue;
+            char *stop = nullptr;
+            const long long value = std::strtoll(item.c_str() + eq + 1, &stop, 10);
+            if (lssvm_mi355_set_option(item.substr(0, eq).c_str(), value) != LSSVM_SUCCESS) {
+                std::fprintf(stderr, "libplssvm_amd: LSSVM_MI355_OPTIONS: %s\n", lssvm_mi355_last_error());
+            }
+        }
+    }
+};
+const EnvOptions g_env_options;
+}  // namespace
 
 /* ---- LIBSVM data files: fast reader for well-formed files (libsvm_reader.hpp) ---- */
 struct lssvm_mi355_libsvm_file {

@@ -187,6 +187,31 @@ __device__ __forceinline__ unsigned lane_off(unsigned v) {
     return v;
 }
 
+/* compile-time loop: f(std::integral_constant<int, I>{}) for I = BEGIN .. END-1 (indices usable as template arguments / asm immediates) */
+template <int BEGIN, int END, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (BEGIN < END) {
+        f(std::integral_constant<int, BEGIN>{});
+        static_for<BEGIN + 1, END>(f);
+    }
+}
+
+/* Hand-issued LDS read + counted wait.  The compiler waits for its own LDS reads with s_waitcnt lgkmcnt(0) when a group of reads and their
+ * first use meet in one block, which exposes the full LDS latency in front of every MFMA group although the fragments needed were
+ * requested a whole group earlier.  These reads are invisible to its counter logic: the code that uses them states the wait itself
+ * (LDS operations return in order, so "all but the N newest" is exact as long as N later reads were issued, whatever else the compiler adds
+ * in between only makes the wait longer).  The wait takes the registers as in/out operands so that no consumer can be scheduled above it. */
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_read_b128(unsigned lds_addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "i"(OFF));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait4(f32x4 &b0, f32x4 &b1, f32x4 &b2, f32x4 &b3) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : "i"(N));
+}
+
 /* The v2 kernels take the polynomial degree class as part of their kernel-type template parameter, so every instantiation
  * carries ONE epilogue (the three-way runtime switch of with_degree_class made the register allocator budget for the generic
  * integer-power path and spill in the cube path). */

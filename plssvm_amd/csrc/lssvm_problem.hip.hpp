@@ -64,7 +64,8 @@ struct Options {
     int64_t debug_ablate = 0;      // diagnostic timing ablations of the fp32 tile kernel (results are wrong when != 0)
     int64_t item_order = 1;        // symmetric variant, order of the work items: 0 column-chunk major, 1 = 0 with the short (diagonal) items moved to the end, longest first
     int64_t gram_mode = 1;         // fp32, <= 256 features: 1 = exact 3-way bf16 split of the operands, six plane products on the bf16 MFMA (default), 0 = v_mfma_f32
-    int64_t mfma_shape = 0;        // bf16x6 kernel: 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16 (same cycles, other clock under load)
+    int64_t mfma_shape = 2;        // bf16x6 kernel: 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16 (same matrix-core cycles, the chip holds a higher
+                                   // clock under it), 2 = 1 with hand-scheduled MFMA groups for <= 128 features (default; more features run as 1)
     int64_t colslab_limit_mb = 98304;  // symmetric variant only while its column slab (per device) stays below this many MiB (96 GiB of the 288 GB)
     int64_t force_collective = 0;  // testing aid: run the per-matvec collective even for a world of one (needs lssvm_mi355_comm_init(.., 0, 1, ..))
     int64_t skip_collective = 0;   // testing aid: sharded problems (world > 1) need no communicator and leave their PARTIAL K*v un-exchanged

@@ -16,7 +16,15 @@
 
 #include "lssvm_device_common.hip.hpp"
 
+#ifdef LSSVM_USE_SCHED_BARRIER
+#define LSSVM_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define LSSVM_SCHED_BARRIER() ((void) 0)
+#endif
+
 namespace lssvm {
+
+#include "lssvm_s6w_groups.inc"
 
 template <int KT, int NK64, bool SYM>
 __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec_f32_s6(const TileArgs<float> a) {
@@ -124,7 +132,6 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
 #pragma unroll
     for (int i = 0; i < 16; ++i) rowpart[i] = 0.0f;
     f32x16 acc[4];
-    float dj[4], cj[4];
     bool padcol[4] = { false, false, false, false };
 
     // ---- prologue: chunks 0, 1, 2 (each preceded by the record of the tile that starts with it) ----
@@ -201,17 +208,20 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
         const int s0 = t * NKC;
         const bool tile_sym = SYM && (jt_begin + t < ib);  // strictly below the diagonal
         {
-            // tile_init: per-lane column data + accumulator start values (the record became visible at the last hand-over)
+            // tile_init: accumulator start values (the record became visible at the last hand-over).  d_j is read from the record in the
+            // epilogue and c_j only here, so that neither lives in registers across the MFMA steps (a spill reloaded inside the loop is a
+            // vector-memory operation: its vmcnt(0) drains the LDS-DMA queue)
             const float *dcr = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);
+            if constexpr (KT == KT_POLY) {
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                dj[cb] = dcr[cb * 32 + r];
-                if constexpr (KT == KT_RBF) cj[cb] = dcr[128 + cb * 32 + r];
-                if constexpr (KT == KT_POLY) padcol[cb] = (a.degree < 0) && ((jt_begin + t) * TILE + cb * 32 + r >= a.ncols_valid);
+                for (int cb = 0; cb < 4; ++cb) padcol[cb] = (a.degree < 0) && ((jt_begin + t) * TILE + cb * 32 + r >= a.ncols_valid);
             }
             // rbf: the accumulators start at c_i + c_j (vector adds; producing the sum with one extra MFMA per accumulator --
             // A = (c_i, 1), B = (1, c_j) -- was measured 0.8 % slower at c5: the adds overlap with the other workgroup's MFMAs)
             if constexpr (KT == KT_RBF) {
+                float cj[4];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) cj[cb] = dcr[128 + cb * 32 + r];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const f32x4 civ = *reinterpret_cast<const f32x4 *>(cis + wave * 32 + 8 * g4 + 4 * h);
@@ -292,17 +302,20 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
                         for (int e = 0; e < 4; ++e) di[4 * g4 + e] = dv[e];
                     }
                 }
+                const float *dcr = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);  // the record stays valid until tile t + 4 is announced
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
+                for (int cb = 0; cb < 4; ++cb) {
+                    const float djv = dcr[cb * 32 + r];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         float kv = apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(acc[cb][i], a);
                         if constexpr (KT == KT_POLY) {
                             if (padcol[cb]) kv = 0.0f;
                         }
-                        rowpart[i] = fmaf(kv, dj[cb], rowpart[i]);
+                        rowpart[i] = fmaf(kv, djv, rowpart[i]);
                         if constexpr (COLS) colacc[cb] = fmaf(kv, di[i], colacc[cb]);
                     }
+                }
                 if constexpr (COLS) {
                     float *cw = colred + (t & 1) * 512 + wave * 128;
 #pragma unroll
@@ -364,8 +377,8 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
  * A step (= one plane of one 64-feature chunk) is processed in four groups mm = (k32 step kk = mm >> 1, column half cbh = mm & 1) of four column
  * blocks each, so that the B fragments stay double buffered in 2 x 16 registers and the hand-over sits in the middle of a step as before.
  */
-template <int KT, int NK64, bool SYM>
-__global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec_f32_s6w(const TileArgs<float> a) {
+template <int KT, int NK64, bool SYM, bool HAND>
+__device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
     constexpr int NKC = 3 * NK64;  // plane-chunks (steps) per tile: for every 64-feature chunk the planes hi, mid, lo
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char *ring = smem_raw;                                                          // [V2_RING][128 rows][128 B]
@@ -432,8 +445,9 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
         dma_off[i] = 2u * static_cast<unsigned>(row * a.ldx16 + 8 * c);
     }
     auto issue_chunk = [&](int step) {
-        const int t = step / NKC;
-        const int kc = step - t * NKC;
+        if (LSSVM_DBG(a, 16) && step > 3) return;  // ablation: no DMA after the prologue
+        const int t = LSSVM_DBG(a, 1) ? 0 : step / NKC;  // ablation bit 1: always the same (L2-resident) tile
+        const int kc = LSSVM_DBG(a, 1) ? 0 : step - t * NKC;
         const char *base = sgpr_ptr(a.Xc16 + (kc % 3) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (kc / 3) * 64);
         char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES + wave * 4096;
 #pragma unroll
@@ -442,10 +456,28 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
         }
     };
     auto issue_chunk_part = [&](int step, int i) {
+        if (LSSVM_DBG(a, 16)) return;
+        if (LSSVM_DBG(a, 64) && i != 0) return;   // bit 64: a quarter of the DMA instructions (timing only)
+        if (LSSVM_DBG(a, 128) && wave != 0) return;  // bit 128: only wave 0 issues DMA
         const int t = step / NKC;
         const int kc = step - t * NKC;
         const char *base = sgpr_ptr(a.Xc16 + (kc % 3) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (kc / 3) * 64);
         char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES + wave * 4096;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + lane_off(dma_off[i])), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
+    };
+    // steady state: the chunk (tile t or t + 1, plane-chunk KC known at compile time) costs two scalar adds per DMA instead of the divisions and
+    // 64-bit multiplies of the generic form; `xc_tile` = first byte of column tile t in plane 0 (uniform), advanced once per tile
+    const size_t tile_bytes = static_cast<size_t>(TILE) * a.ldx16 * 2;
+    const size_t plane_bytes = a.plane_stride * 2;
+    const char *xc_tile = reinterpret_cast<const char *>(a.Xc16) + static_cast<size_t>(jt_begin) * tile_bytes;
+    auto issue_part_static = [&](auto kc3_c, unsigned slot_idx, int i) {  // kc3 = kc + 3 of the issuing step, slot_idx = (step + 3) % V2_RING
+        constexpr int KC3 = decltype(kc3_c)::value;
+        constexpr int KC = KC3 % NKC;
+        if (LSSVM_DBG(a, 16)) return;
+        if (LSSVM_DBG(a, 64) && i != 0) return;   // bit 64: a quarter of the DMA instructions (timing only)
+        if (LSSVM_DBG(a, 128) && wave != 0) return;  // bit 128: only wave 0 issues DMA
+        const char *base = xc_tile + (KC3 >= NKC ? tile_bytes : size_t(0)) + (KC % 3) * plane_bytes + (KC / 3) * 128;
+        char *slot = ring + slot_idx * V2_SLOT_BYTES + wave * 4096;
         __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + lane_off(dma_off[i])), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
     };
     auto issue_dc = [&](int t) {
@@ -466,7 +498,6 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
 #pragma unroll
     for (int i = 0; i < 8; ++i) rowpart[i] = 0.0f;
     f32x4 acc[2][8];
-    float dj[8], cj[8];
     bool padcol[8] = { false, false, false, false, false, false, false, false };
 
     // ---- prologue: chunks 0, 1, 2 (each preceded by the record of the tile that starts with it) ----
@@ -489,17 +520,32 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    f32x4 bcur[4];  // B fragments of the group about to be multiplied (double buffered against bnext in the loop)
+    // B fragments: two buffers used alternately by the groups (group mm multiplies bbuf[mm & 1] while the reads into bbuf[(mm + 1) & 1] are
+    // in flight).  The reads are ordinary loads: the compiler's own waits guard them.  (Hand-issued ds_read_b128 + counted s_waitcnt were
+    // tried and are WRONG here: the register allocator copies a destination register at a block boundary before the wait, i.e. before the
+    // data has landed -- measured as NaNs.)  What the hand-written form was after is obtained with a scheduling barrier instead: it keeps
+    // all four reads of the next group at the head of the current group, so that the lgkmcnt(0) the compiler puts in front of the next
+    // group's first MFMA waits for requests that are a whole group old, not for ones it sank to that very spot.
+    // HAND (num_features <= 128, two waves per SIMD): the B fragments live in v[224:255], which the compiler does not own (the kernel is
+    // compiled with amdgpu_num_vgpr(224)); the groups are the hand-scheduled blocks of lssvm_s6w_groups.inc -- reads of the next group's
+    // fragments, a COUNTED wait, the MFMAs.  Nothing can copy an in-flight register, because nothing else knows these registers.
+    f32x4 bbuf[2][4];
+    const unsigned ring_lds = static_cast<unsigned>(reinterpret_cast<size_t>(ring));  // the low half of a generic LDS address is the LDS address
+    const unsigned rdl[2] = { ring_lds + static_cast<unsigned>(rd_off[0]), ring_lds + static_cast<unsigned>(rd_off[1]) };
+    if constexpr (HAND) {
+        s6w_fill_b0<0, 2048, 4096, 6144>(rdl[0]);
+    } else {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) bcur[c] = *reinterpret_cast<const f32x4 *>(ring + c * 2048 + rd_off[0]);
+        for (int c = 0; c < 4; ++c) bbuf[0][c] = *reinterpret_cast<const f32x4 *>(ring + c * 2048 + rd_off[0]);
+    }
 
-    auto handover = [&](int step, int kc_plus3_mod, auto checked) {
+    auto handover = [&](int step, int kc_plus3_mod, int tile_of_step_plus3, auto checked) {
         constexpr bool CHECKED = decltype(checked)::value;
         if constexpr (!CHECKED) {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (!LSSVM_DBG(a, 16) && !LSSVM_DBG(a, 32)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // bit 32: DMA issued but never waited for
+            if (!LSSVM_DBG(a, 8)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kc_plus3_mod == 0) issue_dc((step + 3) / NKC);
+            if (kc_plus3_mod == 0) issue_dc(tile_of_step_plus3);
         } else {
             if (step + 1 < nsteps) {
                 if (step + 2 < nsteps) {
@@ -510,7 +556,7 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 if (step + 3 < nsteps) {
-                    if (kc_plus3_mod == 0) issue_dc((step + 3) / NKC);
+                    if (kc_plus3_mod == 0) issue_dc(tile_of_step_plus3);
                     issue_chunk(step + 3);
                 }
             }
@@ -521,8 +567,9 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
         if (tid < TILE) {
             const float *cr_ = colred + (t & 1) * 512;
             const float sum = (cr_[tid] + cr_[128 + tid]) + (cr_[256 + tid] + cr_[384 + tid]);
-            float *rec = a.colslab + (rec0 + jt_begin + t) * TILE;
-            rec[static_cast<unsigned>(tid)] = sum;
+            // uniform base in SGPRs + 32-bit lane offset (a 64-bit per-lane pointer would be hoisted out of the tile loop and spilled)
+            float *rec = const_cast<float *>(reinterpret_cast<const float *>(sgpr_ptr(a.colslab + (rec0 + jt_begin + t) * TILE)));
+            rec[lane_off(static_cast<unsigned>(tid))] = sum;
         }
     };
 
@@ -530,51 +577,144 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
         const int s0 = t * NKC;
         const bool tile_sym = SYM && (jt_begin + t < ib);  // strictly below the diagonal
         {
+            // (d_j is read from the record in the epilogue, c_j only here: neither lives in registers across the MFMA steps -- this kernel
+            // has no register to spare, and a scratch reload in the loop drains the LDS-DMA queue with its vmcnt(0))
             const float *dcr = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);
+            if constexpr (KT == KT_POLY) {
 #pragma unroll
-            for (int cb = 0; cb < 8; ++cb) {
-                dj[cb] = dcr[cb * 16 + r];
-                if constexpr (KT == KT_RBF) cj[cb] = dcr[128 + cb * 16 + r];
-                if constexpr (KT == KT_POLY) padcol[cb] = (a.degree < 0) && ((jt_begin + t) * TILE + cb * 16 + r >= a.ncols_valid);
+                for (int cb = 0; cb < 8; ++cb) padcol[cb] = (a.degree < 0) && ((jt_begin + t) * TILE + cb * 16 + r >= a.ncols_valid);
             }
             if constexpr (KT == KT_RBF) {  // the accumulators start at c_i + c_j
+                f32x4 civ[2];
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    const f32x4 civ = *reinterpret_cast<const f32x4 *>(cis + wave * 32 + 16 * rb + 4 * g);
+                for (int rb = 0; rb < 2; ++rb) civ[rb] = *reinterpret_cast<const f32x4 *>(cis + wave * 32 + 16 * rb + 4 * g);
 #pragma unroll
-                    for (int cb = 0; cb < 8; ++cb)
+                for (int cb = 0; cb < 8; ++cb) {
+                    const float cjv = dcr[128 + cb * 16 + r];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[rb][cb][e] = civ[e] + cj[cb];
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[rb][cb][e] = civ[rb][e] + cjv;
                 }
             }
         }
-#pragma unroll
-        for (int kc = 0; kc < NKC; ++kc) {
+        const unsigned phase = static_cast<unsigned>(s0) & (V2_RING - 1);  // ring slot of the tile's first step (uniform)
+        static_for<0, NKC>([&](auto kc_c) {
+            constexpr int kc = decltype(kc_c)::value;
+            constexpr int chunk = kc / 3, plane = kc % 3;
             const int step = s0 + kc;
-            const char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES;
-            const char *slot_next = ring + ((step + 1) % V2_RING) * V2_SLOT_BYTES;
-#pragma unroll
-            for (int mm = 0; mm < 4; ++mm) {
-                const int kk = mm >> 1, cbh = mm & 1;
-                f32x4 bnext[4];
-                if (mm < 3) {  // next group of this chunk: (kk', cbh') = ((mm + 1) >> 1, (mm + 1) & 1)
+            const unsigned slot_off = ((phase + kc) & (V2_RING - 1)) * V2_SLOT_BYTES;
+            const unsigned slot_next_off = ((phase + kc + 1) & (V2_RING - 1)) * V2_SLOT_BYTES;
+            const char *slot = ring + slot_off;
+            const char *slot_next = ring + slot_next_off;
+            static_for<0, 4>([&](auto mm_c) {
+                constexpr int mm = decltype(mm_c)::value;
+                constexpr int kk = mm >> 1, cbh = mm & 1;
+                // is there a group after this one?  (steady state: always; last tiles of the work item: not after the very last group)
+                const bool more = !decltype(checked)::value || mm < 3 || step + 1 < nsteps;
+                if constexpr (HAND) {
+                    constexpr int NQ = 3 - plane;
+                    constexpr bool ZC = (KT != KT_RBF) && kc == 0 && kk == 0;  // first MFMA of every accumulator of this column half starts from 0
+                    constexpr int CUR = mm & 1;
+                    if constexpr (mm == 2) {
+                        if constexpr (SYM) {
+                            if (kc == 0 && t > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        }
+                        handover(step, (kc + 3) % NKC, t + (kc + 3) / NKC, checked);
+                        if constexpr (SYM) {
+                            if (kc == 0 && t > 0) flush_cols(t - 1);
+                        }
+                    }
+                    // where the NEXT group's fragments come from: this chunk (mm < 3) or the first group of the next chunk (mm == 3)
+                    constexpr int NKK = (mm + 1) >> 1, NH = (mm + 1) & 1;
+                    const unsigned paddr = mm < 3 ? rdl[NKK & 1] + slot_off : rdl[0] + slot_next_off;
+                    constexpr int PO = mm < 3 ? 4 * NH * 2048 : 0;
+                    f32x4 &c0 = acc[0][4 * cbh + 0], &c1 = acc[1][4 * cbh + 0], &c2 = acc[0][4 * cbh + 1], &c3 = acc[1][4 * cbh + 1];
+                    f32x4 &c4 = acc[0][4 * cbh + 2], &c5 = acc[1][4 * cbh + 2], &c6 = acc[0][4 * cbh + 3], &c7 = acc[1][4 * cbh + 3];
+                    const bf16x8 &a00 = afrag[0][2 * chunk + kk][0], &a01 = afrag[0][2 * chunk + kk][1];
+#define LSSVM_S6W_CALL(FN, ...)                                                              \
+    do {                                                                                     \
+        if (more) {                                                                          \
+            FN##_p1_##__VA_ARGS__;                                                           \
+        } else {                                                                             \
+            FN##_p0_##__VA_ARGS__;                                                           \
+        }                                                                                    \
+    } while (0)
+                    if constexpr (NQ == 3) {
+                        const bf16x8 &a10 = afrag[1][2 * chunk + kk][0], &a11 = afrag[1][2 * chunk + kk][1];
+                        const bf16x8 &a20 = afrag[2][2 * chunk + kk][0], &a21 = afrag[2][2 * chunk + kk][1];
+                        if constexpr (ZC) {
+                            if constexpr (CUR == 0) {
+                                if (more) s6w_group_q3_b0_p1_z1<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
+                                else s6w_group_q3_b0_p0_z1<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
+                            } else {
+                                if (more) s6w_group_q3_b1_p1_z1<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
+                                else s6w_group_q3_b1_p0_z1<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
+                            }
+                        } else {
+                            if constexpr (CUR == 0) {
+                                if (more) s6w_group_q3_b0_p1_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
+                                else s6w_group_q3_b0_p0_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
+                            } else {
+                                if (more) s6w_group_q3_b1_p1_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
+                                else s6w_group_q3_b1_p0_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
+                            }
+                        }
+                    } else if constexpr (NQ == 2) {
+                        const bf16x8 &a10 = afrag[1][2 * chunk + kk][0], &a11 = afrag[1][2 * chunk + kk][1];
+                        if constexpr (CUR == 0) {
+                            if (more) s6w_group_q2_b0_p1_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, paddr);
+                            else s6w_group_q2_b0_p0_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, paddr);
+                        } else {
+                            if (more) s6w_group_q2_b1_p1_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, paddr);
+                            else s6w_group_q2_b1_p0_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, paddr);
+                        }
+                    } else {
+                        if constexpr (CUR == 0) {
+                            if (more) s6w_group_q1_b0_p1_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, paddr);
+                            else s6w_group_q1_b0_p0_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, paddr);
+                        } else {
+                            if (more) s6w_group_q1_b1_p1_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, paddr);
+                            else s6w_group_q1_b1_p0_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, paddr);
+                        }
+                    }
+#undef LSSVM_S6W_CALL
+                    // the LDS-DMA of chunk step + 3 goes between the groups of the step's second half (two instructions behind each)
+                    if constexpr (!decltype(checked)::value && mm >= 2) {
+                        issue_part_static(std::integral_constant<int, kc + 3>{}, (phase + kc + 3) & (V2_RING - 1), (mm - 2) * 2 + 0);
+                        issue_part_static(std::integral_constant<int, kc + 3>{}, (phase + kc + 3) & (V2_RING - 1), (mm - 2) * 2 + 1);
+                    }
+                    if constexpr (kc == NKC - 1 && mm == 3) {
+                        // the epilogue's vector ALU instructions read what the last MFMAs write: the compiler cannot see inside the groups,
+                        // so the wait states an XDL write needs before a VALU read (8 passes: 11) are spent here, once per tile
+                        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+                    }
+                } else {
+                f32x4(&bcur)[4] = bbuf[mm & 1];
+
+                f32x4(&bnext)[4] = bbuf[(mm + 1) & 1];
+                if constexpr (mm < 3) {  // next group of this chunk: (kk', cbh') = ((mm + 1) >> 1, (mm + 1) & 1)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) bnext[c] = *reinterpret_cast<const f32x4 *>(slot + (4 * ((mm + 1) & 1) + c) * 2048 + rd_off[(mm + 1) >> 1]);
+                    if constexpr (mm != 2) LSSVM_SCHED_BARRIER();
                 }
-                if (mm == 2) {
+                if constexpr (mm == 2) {
                     if constexpr (SYM) {
                         if (kc == 0 && t > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     }
-                    handover(step, (kc + 3) % NKC, checked);
+                    handover(step, (kc + 3) % NKC, t + (kc + 3) / NKC, checked);
                     if constexpr (SYM) {
                         if (kc == 0 && t > 0) flush_cols(t - 1);
                     }
+                    LSSVM_SCHED_BARRIER();
                 }
-                if (mm == 3) {
+                if constexpr (mm == 3) {  // first group of the next chunk: visible since this step's hand-over
+                    if (more) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) bnext[c] = *reinterpret_cast<const f32x4 *>(slot_next + c * 2048 + rd_off[0]);
+                        for (int c = 0; c < 4; ++c) bnext[c] = *reinterpret_cast<const f32x4 *>(slot_next + c * 2048 + rd_off[0]);
+                    }
+                    LSSVM_SCHED_BARRIER();
                 }
-                const int chunk = kc / 3, plane = kc % 3;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     if (q + plane > 2) continue;
@@ -593,15 +733,17 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
                             }
                         }
                         if constexpr (!decltype(checked)::value) {
-                            if (q == 0 && mm >= 2 && (c & 1) == 0) issue_chunk_part(step + 3, (mm - 2) * 2 + (c >> 1));
+                            if (q == 0 && mm >= 2 && (c & 1) == 0) {
+                                issue_part_static(std::integral_constant<int, kc + 3>{}, (phase + kc + 3) & (V2_RING - 1), (mm - 2) * 2 + (c >> 1));
+                            }
                         }
                     }
                 }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) bcur[c] = bnext[c];
-            }
-        }
-        {
+                }  // !HAND
+            });
+        });
+        xc_tile += tile_bytes;
+        if (!LSSVM_DBG(a, 4)) {
             auto epilogue = [&](auto with_cols) {
                 constexpr bool COLS = decltype(with_cols)::value;
                 f32x4 di[2];
@@ -610,8 +752,10 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb) di[rb] = *reinterpret_cast<const f32x4 *>(dis + wave * 32 + 16 * rb + 4 * g);
                 }
+                const float *dcr = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);  // the record stays valid until tile t + 4 is announced
 #pragma unroll
-                for (int cb = 0; cb < 8; ++cb)
+                for (int cb = 0; cb < 8; ++cb) {
+                    const float djv = dcr[cb * 16 + r];
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -620,9 +764,10 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
                             if constexpr (KT == KT_POLY) {
                                 if (padcol[cb]) kv = 0.0f;
                             }
-                            rowpart[4 * rb + e] = fmaf(kv, dj[cb], rowpart[4 * rb + e]);
+                            rowpart[4 * rb + e] = fmaf(kv, djv, rowpart[4 * rb + e]);
                             if constexpr (COLS) colacc[cb] = fmaf(kv, di[rb][e], colacc[cb]);
                         }
+                }
                 if constexpr (COLS) {
                     float *cw = colred + (t & 1) * 512 + wave * 128;
 #pragma unroll
@@ -671,6 +816,18 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
 #pragma unroll
         for (int i = 0; i < 8; ++i) dst[16 * (i >> 2) + (i & 3)] = rowpart[i];
     }
+}
+
+/* the two kernels around s6w_body: compiler-scheduled groups (any supported feature count), and hand-scheduled groups for the
+ * two-waves-per-SIMD instantiations, where the compiler is confined to v0..v223 so that v[224:255] can hold the B fragments */
+template <int KT, int NK64, bool SYM>
+__global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec_f32_s6w(const TileArgs<float> a) {
+    s6w_body<KT, NK64, SYM, false>(a);
+}
+template <int KT, int NK64, bool SYM>
+__global__ __launch_bounds__(TILE_THREADS, 2) __attribute__((amdgpu_num_vgpr(224))) void tile_matvec_f32_s6h(const TileArgs<float> a) {
+    static_assert(NK64 <= 2, "the hand-scheduled groups assume the 256-register budget of two waves per SIMD");
+    s6w_body<KT, NK64, SYM, true>(a);
 }
 
 /* x = hi + mid + lo, each rounded to nearest-even bf16 of the remainder (exact: the remainders are representable in fp32).

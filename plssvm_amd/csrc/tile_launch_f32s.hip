@@ -13,7 +13,14 @@ static void launch_s6_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
     const dim3 block(TILE_THREADS);
 #define LSSVM_S6_CASE(N)                                                                                  \
     case N:                                                                                               \
-        if (a.mfma_shape == 1) {                                                                          \
+        if (a.mfma_shape == 2) {                                                                          \
+            if constexpr (N <= 2) {                                                                       \
+                ensure_dynamic_lds(tile_matvec_f32_s6h<KT, N, SYM>, V2_LDS_BYTES);                        \
+                hipLaunchKernelGGL((tile_matvec_f32_s6h<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);   \
+                break;                                                                                    \
+            }                                                                                             \
+        }                                                                                                 \
+        if (a.mfma_shape >= 1) {                                                                          \
             ensure_dynamic_lds(tile_matvec_f32_s6w<KT, N, SYM>, V2_LDS_BYTES);                            \
             hipLaunchKernelGGL((tile_matvec_f32_s6w<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);       \
         } else {                                                                                          \

@@ -450,7 +450,10 @@ def test_baseline_config0_500x4_linear_fp64_through_the_libsvm_files(tmp_path):
         assert np.max(np.abs(model.alpha[:-1] - g[:-1])) < tol * np.max(np.abs(g))
         assert abs(model.alpha[-1] - g[-1]) < tol_sum and abs(model.alpha.sum()) < 1e-12
         assert abs(float(model.rho) - float(fx[f"{tag}/rho"])) < tol_sum
-        assert abs(float(info["residuum"]) - float(fx[f"{tag}/delta"])) <= 1e-6 * float(fx[f"{tag}/delta"]) + 1e-20
+        if tag == "default":
+            assert abs(float(info["residuum"]) - float(fx[f"{tag}/delta"])) <= 1e-6 * float(fx[f"{tag}/delta"])
+        else:  # at delta / delta0 ~ 1e-22 the last residual is rounding noise: it only has to meet the stop criterion, as the reference's does
+            assert float(info["residuum"]) <= float(info["target_residuum"]) and float(fx[f"{tag}/delta"]) <= float(info["target_residuum"])
     mf = tmp_path / "500x4.model"
     model.save(mf)
     m2 = Model.load(mf, real_type=np.float64)
