@@ -69,7 +69,7 @@ typedef struct lssvm_cg_info {
     double avg_iteration_ms; /* host wall clock per CG iteration */
     double total_ms;         /* host wall clock of begin + all steps + finish */
     double setup_ms;         /* host->device transfer of the data matrix, q vector, norms */
-    double matvec_kernel_ms; /* average device time of ONE implicit matvec tile-kernel launch (HIP events on the solver stream) */
+    double matvec_kernel_ms; /* average device time of the tile-kernel launches of ONE implicit matvec (HIP events on the solver stream) */
     uint64_t matvec_launches;
     int32_t devices_used;    /* world size of the row-block sharding (1 = single GPU) */
     int32_t converged;       /* 1 if the stop test delta <= eps^2 * delta0 fired */
@@ -77,6 +77,8 @@ typedef struct lssvm_cg_info {
     int32_t gram_mode;       /* fp32: 1 if the Gram tiles ran as the exact 3-way bf16 split on the bf16 matrix cores ("bf16x6"), else 0 */
     int32_t local_devices;   /* devices driven by THIS process (1 for a single GPU and for one process per GPU) */
     int32_t exchange;        /* how the partial K*v vectors were combined per matvec: 0 none, 1 RCCL (all-reduce / all-gather), 2 peer kernels over xGMI */
+    int32_t tile_launches_per_matvec; /* row-block bands per implicit matvec (option colslab_band_mb); matvec_kernel_ms is their SUM */
+    int32_t reserved_;
 } lssvm_cg_info;
 
 /* ------------------------------------------------------------------------------------------------------------------ */
@@ -245,8 +247,10 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *   "mfma_shape"    bf16x6 kernel: 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16 (same matrix-core cycles; the chip holds a higher
  *                   clock under the second shape, MI355X_MICROARCH.md "DVFS give-back"), 2 = 1 with hand-scheduled MFMA groups (B fragments in
  *                   registers the compiler does not own, counted LDS waits) for num_features <= 128; default 2
- *   "colslab_limit_mb" the symmetric variant needs n_tiles^2 / 2 column records of 128 reals (15.6 GB at 1M points in fp32, divided
- *                   by the number of ranks); above this many MiB per device the full square is evaluated instead (default 98304)
+ *   "colslab_band_mb" the symmetric variant leaves one record of 128 column sums per evaluated off-diagonal tile; the device's row blocks are
+ *                   cut into bands of equal area whose records fit this many MiB (default 2048), the tile kernel runs band by band into one
+ *                   slab and every band is folded into K*v before the next (1M points in fp32: 15.6 GB of records -> 8 bands, 2 GiB)
+ *   "colslab_limit_mb" upper bound of the band slab (default 98304); 0 switches the symmetric variant off (full square)
  *   "exchange"      several devices in one process (the _multi entry points): 0 = automatic (RCCL when the listed devices are distinct, peer
  *                   kernels otherwise; default), 1 = RCCL all-reduce / all-gather, 2 = peer kernels: every device adds the partial vectors of all
  *                   devices through its xGMI peer mappings in rank order (bit-equal on all devices, deterministic)

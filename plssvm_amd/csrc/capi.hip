@@ -322,6 +322,9 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
         } else if (n == "mfma_shape") {
             LSSVM_REQUIRE(value >= 0 && value <= 2, "mfma_shape must be 0 (32x32x16), 1 (16x16x32) or 2 (16x16x32, hand-scheduled groups)");
             lssvm::options().mfma_shape = value;
+        } else if (n == "colslab_band_mb") {
+            LSSVM_REQUIRE(value >= 1, "colslab_band_mb must be positive");
+            lssvm::options().colslab_band_mb = value;
         } else if (n == "colslab_limit_mb") {
             LSSVM_REQUIRE(value >= 0, "colslab_limit_mb must not be negative");
             lssvm::options().colslab_limit_mb = value;
@@ -364,6 +367,8 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             *value_out = lssvm::options().gram_mode;
         } else if (n == "mfma_shape") {
             *value_out = lssvm::options().mfma_shape;
+        } else if (n == "colslab_band_mb") {
+            *value_out = lssvm::options().colslab_band_mb;
         } else if (n == "colslab_limit_mb") {
             *value_out = lssvm::options().colslab_limit_mb;
         } else if (n == "skip_collective") {

@@ -283,13 +283,9 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     const int ldx_probe = padded_features<T>(num_features);
     const bool v2_ok = std::is_same_v<T, float> ? (opt_.rbf_form == 0 && v2_eligible(opt_, ldx_probe, false)) : v2_eligible_f64(opt_, ldx_probe);
     sym_ = opt_.symmetric != 0 && v2_ok && !(params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree < 0);
-    if (sym_) {
-        // the symmetric variant keeps one 128-entry record per evaluated off-diagonal tile (15.6 GB for 1M points in fp32, spread
-        // over the ranks by area).  Beyond the budget fall back to the full square -- a rule in n, world and sizeof(T) only, so
-        // that every rank of a sharded solve takes the same decision.
-        const double slab_bytes = 0.5 * static_cast<double>(num_tiles_) * static_cast<double>(num_tiles_) * TILE * sizeof(T) / static_cast<double>(world_);
-        if (slab_bytes > static_cast<double>(opt_.colslab_limit_mb) * 1048576.0) sym_ = false;
-    }
+    // the symmetric variant keeps one 128-entry record per evaluated off-diagonal tile of the row-block BAND in flight (see the bands
+    // below); colslab_limit_mb = 0 switches the variant off (a rule in the options only, so every rank of a sharded solve decides alike)
+    if (sym_ && opt_.colslab_limit_mb == 0) sym_ = false;
     {
         int ib_end = 0;
         shard_blocks(num_tiles_, world_, rank_, sym_, ib_begin_, ib_end);
@@ -374,34 +370,62 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         dc_.alloc_zero(static_cast<size_t>(std::max(num_tiles_, 1)) * 256, st);  // (d_j | c_j) records: 256 reals per 128 columns
     }
     if (sym_) {
-        // work items = the non-empty (row block, column chunk) pairs, column chunk major (concurrent workgroups share the chunk)
-        // (the hardware dispatches workgroups in item order as CU slots free up).  item_order >= 1: the items cut short by the
-        // diagonal go last, longest first, so the final dispatch round is made of the shortest items.
-        std::vector<int2> items, cut;
-        const int order = static_cast<int>(opt_.item_order);
-        for (int jc = 0; jc < num_jc_; ++jc) {
-            for (int k = 0; k < num_ib_; ++k) {
-                const int ibl = order == 2 ? num_ib_ - 1 - k : k;
-                const int ib = ib_begin_ + ibl;
-                if (jc * jc_tiles_ > ib) continue;
-                const bool is_cut = (jc + 1) * jc_tiles_ > ib + 1;  // fewer than jc_tiles tiles
-                (order >= 1 && is_cut ? cut : items).push_back(make_int2(ibl, jc));
-            }
+        // Row-block BANDS.  Every evaluated off-diagonal tile leaves a 128-entry record of column sums (no atomics: one writer per record,
+        // k_reduce_colslab adds the records of a column in a fixed order).  All records of the triangle would be n_tiles^2 / 2 * 512 bytes
+        // (15.6 GB at 1M points in fp32); instead the device's row blocks are cut into bands of equal AREA whose records fit
+        // colslab_band_mb, the tile kernel runs band by band into the SAME slab and the band's records are folded into K*v before the
+        // next band overwrites them.  One band for up to ~360 000 points per device at the default 2 GiB.
+        const long ib_end_all = ib_begin_ + num_ib_;
+        const auto pairs_below = [](long b) { return b * (b - 1) / 2; };
+        const double rec_bytes = static_cast<double>(TILE) * sizeof(T);
+        const double total_bytes = static_cast<double>(pairs_below(ib_end_all) - pairs_below(ib_begin_)) * rec_bytes;
+        const double band_bytes = static_cast<double>(std::min(std::max<int64_t>(opt_.colslab_band_mb, 1), opt_.colslab_limit_mb)) * 1048576.0;
+        const int nbands = static_cast<int>(std::min<double>(std::max(1.0, std::ceil(total_bytes / band_bytes)), std::max(num_ib_, 1)));
+        // equal areas: band k of this device ends where the triangle area reaches (k + 1) / nbands of the device's share
+        const double a0 = static_cast<double>(ib_begin_) * ib_begin_, a1 = static_cast<double>(ib_end_all) * ib_end_all;
+        std::vector<int> edge(nbands + 1, ib_begin_);
+        for (int k = 1; k < nbands; ++k) {
+            const int e = static_cast<int>(std::llround(std::sqrt(a0 + (a1 - a0) * static_cast<double>(k) / nbands)));
+            edge[k] = std::min<int>(std::max(e, edge[k - 1]), static_cast<int>(ib_end_all));
         }
-        std::stable_sort(cut.begin(), cut.end(), [&](const int2 &x, const int2 &y) {
-            return (ib_begin_ + x.x + 1 - x.y * jc_tiles_) > (ib_begin_ + y.x + 1 - y.y * jc_tiles_);
-        });
-        items.insert(items.end(), cut.begin(), cut.end());
+        edge[nbands] = static_cast<int>(ib_end_all);
+        // work items = the non-empty (row block, column chunk) pairs, band by band, column chunk major inside a band (concurrent
+        // workgroups share the chunk; the hardware dispatches workgroups in item order as CU slots free up).  item_order >= 1: the
+        // items cut short by the diagonal go last in their band, longest first, so that the final dispatch round is made of the shortest items.
+        std::vector<int2> items;
+        const int order = static_cast<int>(opt_.item_order);
+        long max_records = 1;
+        for (int k = 0; k < nbands; ++k) {
+            Band band{};
+            band.ib_begin = edge[k];
+            band.ib_end = edge[k + 1];
+            band.item_begin = static_cast<int>(items.size());
+            band.pair_origin = pairs_below(band.ib_begin);
+            std::vector<int2> full, cut;
+            for (int jc = 0; jc < num_jc_; ++jc) {
+                for (int kk = band.ib_begin; kk < band.ib_end; ++kk) {
+                    const int ib = order == 2 ? band.ib_end - 1 - (kk - band.ib_begin) : kk;
+                    if (jc * jc_tiles_ > ib) continue;
+                    const bool is_cut = (jc + 1) * jc_tiles_ > ib + 1;  // fewer than jc_tiles tiles
+                    (order >= 1 && is_cut ? cut : full).push_back(make_int2(ib - ib_begin_, jc));
+                }
+            }
+            std::stable_sort(cut.begin(), cut.end(), [&](const int2 &x, const int2 &y) {
+                return (ib_begin_ + x.x + 1 - x.y * jc_tiles_) > (ib_begin_ + y.x + 1 - y.y * jc_tiles_);
+            });
+            items.insert(items.end(), full.begin(), full.end());
+            items.insert(items.end(), cut.begin(), cut.end());
+            band.item_count = static_cast<int>(items.size()) - band.item_begin;
+            max_records = std::max(max_records, pairs_below(band.ib_end) - band.pair_origin);
+            if (band.ib_end > band.ib_begin) bands_.push_back(band);
+        }
         num_items_ = static_cast<int>(items.size());
         items_.alloc_zero(std::max<size_t>(items.size(), 1), st);
         if (!items.empty()) LSSVM_HIP_CHECK(hipMemcpyAsync(items_.p, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice, st));
-        const long ib_end = ib_begin_ + num_ib_;
-        pair_origin_ = static_cast<long>(ib_begin_) * (ib_begin_ - 1) / 2;
-        const long records = ib_end * (ib_end - 1) / 2 - pair_origin_;
-        colslab_.alloc_zero(static_cast<size_t>(std::max<long>(records, 1)) * TILE, st);
+        colslab_.alloc_zero(static_cast<size_t>(max_records) * TILE, st);
         LSSVM_HIP_CHECK(hipStreamSynchronize(st));  // `items` goes out of scope
     }
-    events_.resize(4);
+    events_.resize(4 * std::max<size_t>(bands_.size(), 1));
     for (EvPair &e : events_) {
         e.a.create(true);
         e.b.create(true);
@@ -432,10 +456,10 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     a.Xc16 = planes_.p;
     a.plane_stride = static_cast<size_t>(X_.rows_alloc) * ldx16_;
     a.ldx16 = ldx16_;
-    a.items = sym_ ? items_.p : nullptr;
+    a.items = sym_ ? items_.p : nullptr;  // (the symmetric variant launches band by band: enqueue_apply_K_local offsets these two)
     a.num_items = num_items_;
     a.colslab = colslab_.p;
-    a.pair_origin = pair_origin_;
+    a.pair_origin = 0;
     a.partial = partial_.p;
     a.part_stride = static_cast<long>(std::max(num_ib_, 1)) * TILE;
     a.ldx = X_.ldx;
@@ -457,8 +481,8 @@ void Problem<T>::drain_events() {
         if (e.pending && hipEventQuery(e.b.e) == hipSuccess) {
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, e.a.e, e.b.e) == hipSuccess) {
-                matvec_ms_ += ms;
-                ++matvec_launches_;
+                matvec_ms_ += ms;  // the band launches of one matvec add up; the matvec is counted once
+                if (e.first_of_matvec) ++matvec_launches_;
             }
             e.pending = false;
         }
@@ -467,20 +491,20 @@ void Problem<T>::drain_events() {
 
 template <typename T>
 void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
-    // this shard's part of the implicit K * v: tile kernel over its row blocks, slabs added in a fixed order
+    // this shard's part of the implicit K * v: tile kernel over its row blocks (band by band), slabs added in a fixed order
     hipStream_t st = stream_.s;
-    EvPair *ev = nullptr;
-    for (int attempt = 0; attempt < 2 && ev == nullptr; ++attempt) {
-        for (EvPair &e : events_) {
-            if (!e.pending) {
-                ev = &e;
-                break;
+    auto free_event = [&]() -> EvPair * {
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            for (EvPair &e : events_) {
+                if (!e.pending) return &e;
             }
+            drain_events();
         }
-        if (ev == nullptr) drain_events();
-    }
-    if (zero_first) {
-        // symmetric variant, sharded: every rank adds row sums of its blocks and column sums into all earlier rows: start from zero
+        return nullptr;
+    };
+    if (zero_first || sym_) {
+        // symmetric variant: row sums of the device's blocks and the mirrored column sums of every band are ADDED into K*v (and, sharded,
+        // every rank adds into all earlier rows): start from zero
         LSSVM_HIP_CHECK(hipMemsetAsync(Kv_.p, 0, static_cast<size_t>(nvec_) * sizeof(T), st));
     }
     if (num_ib_ <= 0) return;
@@ -493,25 +517,43 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
             hipLaunchKernelGGL(k_pack_dc_f64, dim3((ncols + 255) / 256), dim3(256), 0, st, v_dev, c_.p, ncols, dc_.p);
         }
     }
-    if (ev != nullptr) LSSVM_HIP_CHECK(hipEventRecord(ev->a.e, st));
-    launch_tile_kernel<T>(a, params_.kernel_type, rbf_direct_, num_jc_, st);
-    if (ev != nullptr) {
-        LSSVM_HIP_CHECK(hipEventRecord(ev->b.e, st));
-        ev->pending = true;
-    }
     const int nrows = num_ib_ * TILE;
     if (sym_) {
-        // rows of this device's blocks (slabs of the chunks that exist for each block), then the mirrored column sums
-        hipLaunchKernelGGL(k_reduce_partials_sym<T>, dim3((nrows + 255) / 256), dim3(256), 0, st, partial_.p, a.part_stride, jc_tiles_, ib_begin_, nrows, Kv_.p, 0);
-        const int ib_end = ib_begin_ + num_ib_;
-        if (ib_end > 1) {
-            if constexpr (std::is_same_v<T, float>) {
-                hipLaunchKernelGGL((k_reduce_colslab<T, 128>), dim3(ib_end - 1), dim3(1024), 0, st, colslab_.p, pair_origin_, ib_begin_, ib_end, Kv_.p);
-            } else {  // fp64: records per 64-column sub-tile
-                hipLaunchKernelGGL((k_reduce_colslab<T, 64>), dim3(2 * (ib_end - 1)), dim3(1024), 0, st, colslab_.p, pair_origin_, ib_begin_, ib_end, Kv_.p);
+        bool first = true;
+        for (const Band &band : bands_) {
+            TileArgs<T> ab = a;
+            ab.items = items_.p + band.item_begin;
+            ab.num_items = band.item_count;
+            ab.pair_origin = band.pair_origin;
+            EvPair *ev = free_event();
+            if (ev != nullptr) LSSVM_HIP_CHECK(hipEventRecord(ev->a.e, st));
+            launch_tile_kernel<T>(ab, params_.kernel_type, rbf_direct_, num_jc_, st);
+            if (ev != nullptr) {
+                LSSVM_HIP_CHECK(hipEventRecord(ev->b.e, st));
+                ev->pending = true;
+                ev->first_of_matvec = first;
+            }
+            first = false;
+            // fold the band's mirrored column sums into K*v before the next band re-uses the slab
+            if (band.ib_end > 1) {
+                if constexpr (std::is_same_v<T, float>) {
+                    hipLaunchKernelGGL((k_reduce_colslab<T, 128>), dim3(band.ib_end - 1), dim3(1024), 0, st, colslab_.p, band.pair_origin, band.ib_begin, band.ib_end, Kv_.p);
+                } else {  // fp64: records per 64-column sub-tile
+                    hipLaunchKernelGGL((k_reduce_colslab<T, 64>), dim3(2 * (band.ib_end - 1)), dim3(1024), 0, st, colslab_.p, band.pair_origin, band.ib_begin, band.ib_end, Kv_.p);
+                }
             }
         }
+        // rows of this device's blocks: the slabs of the column chunks that exist for each block, added on top
+        hipLaunchKernelGGL(k_reduce_partials_sym<T>, dim3((nrows + 255) / 256), dim3(256), 0, st, partial_.p, a.part_stride, jc_tiles_, ib_begin_, nrows, Kv_.p, 1);
     } else {
+        EvPair *ev = free_event();
+        if (ev != nullptr) LSSVM_HIP_CHECK(hipEventRecord(ev->a.e, st));
+        launch_tile_kernel<T>(a, params_.kernel_type, rbf_direct_, num_jc_, st);
+        if (ev != nullptr) {
+            LSSVM_HIP_CHECK(hipEventRecord(ev->b.e, st));
+            ev->pending = true;
+            ev->first_of_matvec = true;
+        }
         hipLaunchKernelGGL(k_reduce_partials<T>, dim3((nrows + 255) / 256), dim3(256), 0, st, partial_.p, a.part_stride, num_jc_, ib_begin_ * TILE, nrows, Kv_.p);
     }
     LSSVM_HIP_CHECK(hipGetLastError());
@@ -898,6 +940,7 @@ void Solver<T>::fill_info(lssvm_cg_info *info) {
     info->symmetric = p0.sym_ ? 1 : 0;
     info->gram_mode = p0.planes_.p != nullptr ? 1 : 0;
     info->local_devices = static_cast<int32_t>(shards_.size());
+    info->tile_launches_per_matvec = static_cast<int32_t>(std::max<size_t>(p0.bands_.size(), 1));
     info->exchange = exchange_ == Exchange::none ? 0 : (exchange_ == Exchange::peer ? 2 : 1);
 }
 

@@ -66,6 +66,7 @@ struct Options {
     int64_t gram_mode = 1;         // fp32, <= 256 features: 1 = exact 3-way bf16 split of the operands, six plane products on the bf16 MFMA (default), 0 = v_mfma_f32
     int64_t mfma_shape = 2;        // bf16x6 kernel: 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16 (same matrix-core cycles, the chip holds a higher
                                    // clock under it), 2 = 1 with hand-scheduled MFMA groups for <= 128 features (default; more features run as 1)
+    int64_t colslab_band_mb = 2048;    // symmetric variant: the column-sum records of ONE row-block band may take this many MiB; the tile kernel runs band by band
     int64_t colslab_limit_mb = 98304;  // symmetric variant only while its column slab (per device) stays below this many MiB (96 GiB of the 288 GB)
     int64_t force_collective = 0;  // testing aid: run the per-matvec collective even for a world of one (needs lssvm_mi355_comm_init(.., 0, 1, ..))
     int64_t skip_collective = 0;   // testing aid: sharded problems (world > 1) need no communicator and leave their PARTIAL K*v un-exchanged
@@ -266,8 +267,13 @@ class Problem {
     bool sym_ = false;
     DevBuf<int2> items_;
     int num_items_ = 0;
-    DevBuf<T> colslab_;
-    long pair_origin_ = 0;
+    DevBuf<T> colslab_;  // the records of the band in flight
+    struct Band {
+        int ib_begin, ib_end;       // row blocks [begin, end) of the band (global block indices)
+        int item_begin, item_count; // its work items in items_
+        long pair_origin;           // record index of (ib_begin, 0) in the packed triangle: ib_begin (ib_begin - 1) / 2
+    };
+    std::vector<Band> bands_;
     DevBuf<double> part_, sc_;
     PinnedBuf<double> host_sc_;  // SC_COUNT doubles
     double QA_cost_ = 0.0;
@@ -280,6 +286,7 @@ class Problem {
     struct EvPair {
         Event a, b;
         bool pending = false;
+        bool first_of_matvec = true;
     };
     std::vector<EvPair> events_;
     Event ev_ready_, ev_consumed_;  // peer exchange: partial vector written / all partial vectors read

@@ -579,9 +579,39 @@ def test_every_ranks_share_on_one_gpu(kernel, dtype, N, d, sym, world):
     assert all(s > 0 for s in shares[: min(world, (n + 127) // 128)])
 
 
+@pytest.mark.parametrize("kernel, dtype", [("rbf", np.float32), ("polynomial", np.float64), ("linear", np.float32)])
+def test_row_block_bands_of_the_column_slab(oracle, kernel, dtype):
+    """The column-sum records of the symmetric variant are produced band by band into one slab (option colslab_band_mb; 1M points in fp32
+    would otherwise need 15.6 GB of records): with 1 MiB bands a 20 000-point problem runs its tile kernel 5-7 times per matvec, and the
+    result must equal the single-band result within the kernel-level bar (the bands only re-associate the fixed-order sums), also sharded."""
+    N, d = 20_000, 24
+    X, y = make_blobs_pm1(N, d, seed=17, dtype=dtype)
+    p = Parameter(kernel_type=kernel)
+    v = np.random.default_rng(2).uniform(-1, 1, size=N - 1).astype(dtype)
+    zero = np.zeros(N - 1, dtype)
+    with backend.ResidentProblem(p, X) as prob:
+        assert prob.info()["tile_launches_per_matvec"] == 1
+        one = prob.matvec(v, zero, 1.0)
+    _capi.set_option("colslab_band_mb", 1)
+    with backend.ResidentProblem(p, X) as prob:
+        bands = prob.info()["tile_launches_per_matvec"]
+        many = prob.matvec(v, zero, 1.0)
+        err, _, _ = _sampled_rows_vs_oracle(oracle, prob, kernel, X, np.array([0, 1, 127, 128, 5000, 12345, N - 2]))
+        assert err < 16 * np.finfo(dtype).eps
+        prob.cg_begin(y, 1e-30)
+        prob.cg_step(2)
+        assert prob.info()["matvec_launches"] == 3  # a matvec counts once however many bands it takes
+    with backend.ResidentProblem(p, X, devices=[0, 0, 0]) as prob:
+        sharded = prob.matvec(v, zero, 1.0)
+    rec_mib = (157 * 156 / 2) * 128 * np.dtype(dtype).itemsize / 2**20
+    assert bands == int(np.ceil(rec_mib)) and bands > 1
+    scale = np.max(np.abs(one))
+    eps = np.finfo(dtype).eps
+    assert np.max(np.abs(many - one)) < 64 * eps * scale and np.max(np.abs(sharded - one)) < 64 * eps * scale
+
+
 def test_column_slab_budget_falls_back_to_the_full_square():
-    """Above the column-slab budget (option colslab_limit_mb; the default 96 GiB is reached near 2.5M points in fp32) the solver
-    evaluates the full square instead of failing to allocate."""
+    """Option colslab_limit_mb = 0 switches the symmetric variant off: the solver evaluates the full square (row-owned sums)."""
     X, y = make_blobs_pm1(3000, 16, seed=4, dtype=np.float32)
     p = Parameter(kernel_type="rbf")
     with backend.ResidentProblem(p, X) as prob:
