@@ -78,7 +78,8 @@ typedef struct lssvm_cg_info {
     int32_t local_devices;   /* devices driven by THIS process (1 for a single GPU and for one process per GPU) */
     int32_t exchange;        /* how the partial K*v vectors were combined per matvec: 0 none, 1 RCCL (all-reduce / all-gather), 2 peer kernels over xGMI */
     int32_t tile_launches_per_matvec; /* row-block bands per implicit matvec (option colslab_band_mb); matvec_kernel_ms is their SUM */
-    int32_t reserved_;
+    int32_t rbf_direct;      /* fp32 rbf: 1 if the formula-exact (x_i - x_j)^2 kernel ran instead of the matrix-core norm expansion (option rbf_form) */
+    double rbf_exponent_scale; /* fp32 rbf, rbf_form 0: 2 gamma log2(e) max|x - mean|^2, the quantity compared with rbf_direct_above */
 } lssvm_cg_info;
 
 /* ------------------------------------------------------------------------------------------------------------------ */
@@ -229,7 +230,11 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
 /* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT).  set_option changes the process-wide DEFAULTS;
  * every problem / solve takes a snapshot of them when it is created, so later changes never affect a live problem.  The defaults can
  * be preset from the environment: LSSVM_MI355_OPTIONS="name=value,name=value" (read once when the library is loaded):
- *   "rbf_form"      0 = norm expansion on the matrix cores (default), 1 = direct (x_i - x_j)^2 on the vector ALU
+ *   "rbf_form"      fp32 rbf: 0 = automatic (default): the norm expansion c_i + c_j + x_i'.x_j' on the matrix cores, unless
+ *                   R2 = 2 gamma log2(e) max|x - mean|^2 exceeds "rbf_direct_above" -- the expansion's exponent carries an absolute error of
+ *                   ~2^-24 R2 whatever the distance of the pair, which nearby pairs (K ~ 1) see as a relative error of K; then, and with
+ *                   1 = always, the formula-exact (x_i - x_j)^2 kernel on the vector ALU runs (5x slower); 2 = always the matrix cores
+ *   "rbf_direct_above" threshold of rbf_form 0 (default 32: [-1,1]-scaled data with gamma = 1 / num_features has R2 <= 3)
  *   "j_chunk_tiles" number of 128-column tiles per work item; 0 = automatic (default: about 4096 work items per device, 2 ... 16 tiles each,
  *                   up to 64 for the bf16x6 kernel)
  *   "symmetric"     1 = evaluate only the kernel-matrix tiles on/below the diagonal and mirror them (default; num_features <= 512 in fp32,

@@ -48,7 +48,7 @@ class LssvmCgInfo(C.Structure):
     _fields_ = [("iterations", C.c_uint64), ("max_iterations", C.c_uint64), ("residuum", C.c_double), ("initial_residuum", C.c_double),
                 ("target_residuum", C.c_double), ("epsilon", C.c_double), ("avg_iteration_ms", C.c_double), ("total_ms", C.c_double),
                 ("setup_ms", C.c_double), ("matvec_kernel_ms", C.c_double), ("matvec_launches", C.c_uint64), ("devices_used", C.c_int32),
-                ("converged", C.c_int32), ("symmetric", C.c_int32), ("gram_mode", C.c_int32), ("local_devices", C.c_int32), ("exchange", C.c_int32), ("tile_launches_per_matvec", C.c_int32), ("reserved_", C.c_int32)]
+                ("converged", C.c_int32), ("symmetric", C.c_int32), ("gram_mode", C.c_int32), ("local_devices", C.c_int32), ("exchange", C.c_int32), ("tile_launches_per_matvec", C.c_int32), ("rbf_direct", C.c_int32), ("rbf_exponent_scale", C.c_double)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -120,7 +120,7 @@ def device_name(device: int = 0) -> str:
 
 ABI_VERSION = 2
 # every tuning knob of lssvm_mi355_set_option (include/plssvm_amd.h)
-OPTION_NAMES = ["rbf_form", "j_chunk_tiles", "symmetric", "tile_kernel", "xcd_map", "lds_extra_kb", "debug_ablate", "item_order", "gram_mode", "mfma_shape",
+OPTION_NAMES = ["rbf_form", "rbf_direct_above", "j_chunk_tiles", "symmetric", "tile_kernel", "xcd_map", "lds_extra_kb", "debug_ablate", "item_order", "gram_mode", "mfma_shape",
                 "colslab_band_mb", "colslab_limit_mb", "force_collective", "skip_collective", "exchange", "check_shards"]
 
 

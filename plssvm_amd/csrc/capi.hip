@@ -297,8 +297,11 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
         LSSVM_REQUIRE(name != nullptr, "name must not be NULL");
         const std::string n(name);
         if (n == "rbf_form") {
-            LSSVM_REQUIRE(value == 0 || value == 1, "rbf_form must be 0 or 1");
+            LSSVM_REQUIRE(value >= 0 && value <= 2, "rbf_form must be 0 (automatic), 1 (direct) or 2 (matrix cores)");
             lssvm::options().rbf_form = value;
+        } else if (n == "rbf_direct_above") {
+            LSSVM_REQUIRE(value >= 0, "rbf_direct_above must not be negative");
+            lssvm::options().rbf_direct_above = value;
         } else if (n == "j_chunk_tiles") {
             LSSVM_REQUIRE(value >= 0 && value <= (1 << 20), "j_chunk_tiles out of range");
             lssvm::options().j_chunk_tiles = value;
@@ -349,6 +352,8 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
         const std::string n(name);
         if (n == "rbf_form") {
             *value_out = lssvm::options().rbf_form;
+        } else if (n == "rbf_direct_above") {
+            *value_out = lssvm::options().rbf_direct_above;
         } else if (n == "j_chunk_tiles") {
             *value_out = lssvm::options().j_chunk_tiles;
         } else if (n == "symmetric") {

@@ -356,6 +356,23 @@ __global__ void k_center(T *__restrict__ X, int ldx, int dfeat, int nrows, const
     const int i = blockIdx.y;
     if (f < dfeat && i < nrows) X[static_cast<size_t>(i) * ldx + f] = (X[static_cast<size_t>(i) * ldx + f] - (mean != nullptr ? mean[f] : T(0))) * scale;
 }
+/* sq_i = |x_i - mean|^2 in double over the valid features (one wave per row, coalesced); the data is not modified */
+template <typename T>
+__global__ void k_centred_sqnorm(const T *__restrict__ X, int ldx, int dfeat, int nrows, const T *__restrict__ mean, double *__restrict__ sq) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const T *x = X + static_cast<size_t>(row) * ldx;
+    double s = 0.0;
+    for (int f = lane; f < dfeat; f += 64) {
+        const double dlt = static_cast<double>(x[f]) - static_cast<double>(mean[f]);
+        s += dlt * dlt;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) sq[row] = s;
+}
+
 /* c_i = -0.5 * |x_i|^2 (one wave per row, coalesced) */
 template <typename T>
 __global__ void k_half_neg_norms(const T *__restrict__ X, int ldx, int nrows_total, T *__restrict__ c) {

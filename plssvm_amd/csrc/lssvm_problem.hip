@@ -206,23 +206,65 @@ T rbf_prescale(const lssvm_params &p, bool fp64_v2) {
     }
 }
 
+/* column means of M's valid rows, in double, deterministic two-stage sum */
 template <typename T>
-void center_columns(DeviceMatrix<T> &M, DeviceMatrix<T> *M2, T scale, hipStream_t s) {
+static void column_means(const DeviceMatrix<T> &M, DevBuf<T> &mean, hipStream_t s) {
     const int rows_per_block = 256;
     const int nblocks = (M.rows + rows_per_block - 1) / rows_per_block;
     DevBuf<double> part;
     part.alloc_zero(static_cast<size_t>(nblocks) * M.ldx, s);
-    DevBuf<T> mean;
     mean.alloc_zero(M.ldx, s);
     const dim3 g1(nblocks, (M.ldx + 255) / 256);
     hipLaunchKernelGGL(k_colsum_stage1<T>, g1, dim3(256), 0, s, M.data.p, M.ldx, M.rows, rows_per_block, part.p);
     hipLaunchKernelGGL(k_colsum_stage2<T>, dim3((M.ldx + 255) / 256), dim3(256), 0, s, part.p, nblocks, M.ldx, M.rows, mean.p);
+    LSSVM_HIP_CHECK(hipGetLastError());
+    LSSVM_HIP_CHECK(hipStreamSynchronize(s));  // part is released on return
+}
+
+/* max_i |x_i - mean|^2 over the valid rows of M (the data is NOT modified) */
+template <typename T>
+static double max_centred_sqnorm(const DeviceMatrix<T> &M, const DevBuf<T> &mean, hipStream_t s) {
+    DevBuf<double> sq;
+    sq.alloc_zero(static_cast<size_t>(M.rows), s);
+    hipLaunchKernelGGL(k_centred_sqnorm<T>, dim3((M.rows + 3) / 4), dim3(256), 0, s, M.data.p, M.ldx, M.dfeat, M.rows, mean.p, sq.p);
+    LSSVM_HIP_CHECK(hipGetLastError());
+    std::vector<double> host(static_cast<size_t>(M.rows));
+    LSSVM_HIP_CHECK(hipMemcpyAsync(host.data(), sq.p, host.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    LSSVM_HIP_CHECK(hipStreamSynchronize(s));
+    return host.empty() ? 0.0 : *std::max_element(host.begin(), host.end());
+}
+
+template <typename T>
+void center_columns(DeviceMatrix<T> &M, DeviceMatrix<T> *M2, T scale, hipStream_t s) {
+    DevBuf<T> mean;
+    column_means<T>(M, mean, s);
     hipLaunchKernelGGL(k_center<T>, dim3((M.dfeat + 255) / 256, M.rows), dim3(256), 0, s, M.data.p, M.ldx, M.dfeat, M.rows, mean.p, scale);
     if (M2 != nullptr) {
         hipLaunchKernelGGL(k_center<T>, dim3((M2->dfeat + 255) / 256, M2->rows), dim3(256), 0, s, M2->data.p, M2->ldx, M2->dfeat, M2->rows, mean.p, scale);
     }
     LSSVM_HIP_CHECK(hipGetLastError());
-    LSSVM_HIP_CHECK(hipStreamSynchronize(s));  // part / mean are released on return
+    LSSVM_HIP_CHECK(hipStreamSynchronize(s));  // mean is released on return
+}
+
+/* fp32 rbf, option rbf_form = 0 (automatic): the matrix-core form evaluates the exponent as c_i + c_j + x_i'.x_j' on data scaled by
+ * sqrt(2 gamma log2 e), so its ABSOLUTE error is about 2^-24 times the size of the terms that cancel, R2 = 2 gamma log2(e) max |x - mean|^2,
+ * whatever the distance of the pair -- for nearby points (K close to 1) that is a relative error of K of ~R2 * 2^-24, where the reference's
+ * direct (x_i - x_j)^2 chain keeps all its digits.  [-1, 1]-scaled data with gamma = 1 / num_features has R2 <= 3; gamma = 1 at 128
+ * features has R2 ~ 100.  Above `rbf_direct_above` the formula-exact vector-ALU kernel is used instead (5x slower, same accuracy class as
+ * the reference).  Returns true for the direct form.  `M2` (predict: the points beside the support vectors) may be NULL. */
+template <typename T>
+static bool rbf_wants_direct_form(const Options &o, const lssvm_params &p, const DeviceMatrix<T> &M, const DeviceMatrix<T> *M2, hipStream_t s, double *r2_out) {
+    if (r2_out != nullptr) *r2_out = 0.0;
+    if (!std::is_same_v<T, float> || p.kernel_type != LSSVM_KERNEL_RBF) return false;
+    if (o.rbf_form == 1) return true;
+    if (o.rbf_form == 2) return false;
+    DevBuf<T> mean;
+    column_means<T>(M, mean, s);
+    double sq = max_centred_sqnorm<T>(M, mean, s);
+    if (M2 != nullptr) sq = std::max(sq, max_centred_sqnorm<T>(*M2, mean, s));
+    const double r2 = 2.0 * static_cast<double>(static_cast<T>(p.gamma)) * 1.4426950408889634 * sq;
+    if (r2_out != nullptr) *r2_out = r2;
+    return r2 > static_cast<double>(o.rbf_direct_above);
 }
 
 /* fp32: reorder the features of every group of 8 to 0,2,4,6,1,3,5,7 (the operand order of the MFMA kernels); fp64: nothing */
@@ -279,9 +321,13 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     num_tiles_ = (n_ + TILE - 1) / TILE;
     ib_per_rank_ = (num_tiles_ + world_ - 1) / world_;
     nvec_ = ib_per_rank_ * world_ * TILE;
+    // data matrix: all N points (the last one is row n; it takes part in q and QA_cost only)
+    X_.upload(X, mem_kind, num_points, num_features, static_cast<size_t>(nvec_), st);
+    // fp32 rbf: matrix cores (norm expansion) or the formula-exact vector-ALU kernel?  (every shard sees the same data: same decision)
+    rbf_direct_ = rbf_wants_direct_form<T>(opt_, params_, X_, nullptr, st, &rbf_r2_);
     // symmetric variant: v2 kernels only; a negative polynomial degree can give inf on zero-padded rows -> full square
     const int ldx_probe = padded_features<T>(num_features);
-    const bool v2_ok = std::is_same_v<T, float> ? (opt_.rbf_form == 0 && v2_eligible(opt_, ldx_probe, false)) : v2_eligible_f64(opt_, ldx_probe);
+    const bool v2_ok = std::is_same_v<T, float> ? v2_eligible(opt_, ldx_probe, rbf_direct_) : v2_eligible_f64(opt_, ldx_probe);
     sym_ = opt_.symmetric != 0 && v2_ok && !(params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree < 0);
     // the symmetric variant keeps one 128-entry record per evaluated off-diagonal tile of the row-block BAND in flight (see the bands
     // below); colslab_limit_mb = 0 switches the variant off (a rule in the options only, so every rank of a sharded solve decides alike)
@@ -301,16 +347,12 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         const long area = sym_ ? (ib_end * (ib_end + 1) - static_cast<long>(ib_begin_) * (ib_begin_ + 1)) / 2 : static_cast<long>(num_ib_) * num_tiles_;
         // the bf16x6 kernel has the costlier work-item prologue (three planes of the row panel) and the faster tiles: longer chunks
         // (measured 16 -> 64 tiles: +1.5 % at 100 000 points, +2 % at 300 000; the native kernels are flat or lose beyond 16)
-        const bool split = std::is_same_v<T, float> && opt_.gram_mode == 1 && opt_.rbf_form == 0 && v2_eligible(opt_, ldx_probe, false)
+        const bool split = std::is_same_v<T, float> && opt_.gram_mode == 1 && v2_eligible(opt_, ldx_probe, rbf_direct_)
                            && round_up(static_cast<long>(num_features), 64) <= 256;
         jc_tiles_ = static_cast<int>(std::min<long>(split ? 64 : 16, std::max<long>(2, (area + 2048) / 4096)));
     }
     num_jc_ = (num_tiles_ + jc_tiles_ - 1) / jc_tiles_;
-    rbf_direct_ = (params_.kernel_type == LSSVM_KERNEL_RBF) && (opt_.rbf_form == 1) && std::is_same_v<T, float>;
     inv_cost_ = static_cast<double>(T(1) / static_cast<T>(params_.cost));  // "1 / params.cost" in real_type, csvm.cpp:297
-
-    // data matrix: all N points (the last one is row n; it takes part in q and QA_cost only)
-    X_.upload(X, mem_kind, num_points, num_features, static_cast<size_t>(nvec_), st);
 
     // QA_cost = k(x_last, x_last) + 1/C, evaluated on the host in the real type (csvm.cpp:86)
     std::vector<T> last(num_features);
@@ -940,6 +982,8 @@ void Solver<T>::fill_info(lssvm_cg_info *info) {
     info->symmetric = p0.sym_ ? 1 : 0;
     info->gram_mode = p0.planes_.p != nullptr ? 1 : 0;
     info->local_devices = static_cast<int32_t>(shards_.size());
+    info->rbf_direct = p0.rbf_direct_ ? 1 : 0;
+    info->rbf_exponent_scale = p0.rbf_r2_;
     info->tile_launches_per_matvec = static_cast<int32_t>(std::max<size_t>(p0.bands_.size(), 1));
     info->exchange = exchange_ == Exchange::none ? 0 : (exchange_ == Exchange::peer ? 2 : 1);
 }
@@ -1004,12 +1048,13 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     S.upload(sv, LSSVM_MEM_HOST, nsv, nfeat, 0, s);
     P.upload(points, LSSVM_MEM_HOST, npoints, nfeat, 0, s);
     DevBuf<T> cS, cP;
-    if (params.kernel_type == LSSVM_KERNEL_RBF) {
+    const bool rbf_direct = rbf_wants_direct_form<T>(opt, params, S, &P, s, nullptr);  // same rule as the training matvec (Problem<T>)
+    if (params.kernel_type == LSSVM_KERNEL_RBF && !rbf_direct) {
         center_columns<T>(S, &P, rbf_prescale<T>(params, v2_eligible_f64(opt, S.ldx)), s);
         half_neg_norms<T>(S, cS, s);
         half_neg_norms<T>(P, cP, s);
     }
-    const bool v2 = std::is_same_v<T, float> ? v2_eligible(opt, S.ldx, false) : v2_eligible_f64(opt, S.ldx);
+    const bool v2 = std::is_same_v<T, float> ? v2_eligible(opt, S.ldx, rbf_direct) : v2_eligible_f64(opt, S.ldx);
     bool poly_prescaled = false;
     if constexpr (std::is_same_v<T, double>) {
         // the fp64 v2 kernel evaluates the polynomial on data that carries sqrt(gamma) (see Problem<T>'s constructor)
@@ -1066,10 +1111,10 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     ta.num_jt = num_jt;
     ta.jc_tiles = jc_tiles;
     ta.ncols_valid = S.rows;
-    set_kernel_scalars(ta, params, false);
+    set_kernel_scalars(ta, params, rbf_direct);
     if (poly_prescaled) ta.gamma = T(1);
     set_launch_options(ta, opt);
-    launch_tile_kernel<T>(ta, params.kernel_type, false, num_jc, s);
+    launch_tile_kernel<T>(ta, params.kernel_type, rbf_direct, num_jc, s);
     hipLaunchKernelGGL(k_reduce_partials<T>, dim3((P.rows_alloc + 255) / 256), dim3(256), 0, s, partial.p, ta.part_stride, num_jc, 0, P.rows_alloc, Kv.p);
     hipLaunchKernelGGL(k_sub_rho<T>, dim3((P.rows + 255) / 256), dim3(256), 0, s, Kv.p, P.rows, rho, o.p);
     LSSVM_HIP_CHECK(hipGetLastError());

@@ -52,7 +52,7 @@ def test_abi_version_and_struct_layout():
     assert _capi.lib.lssvm_mi355_abi_version() == _capi.ABI_VERSION
     assert C.sizeof(_capi.LssvmParams) == 32
     assert C.sizeof(_capi.LssvmShard) == 8
-    assert C.sizeof(_capi.LssvmCgInfo) == 120
+    assert C.sizeof(_capi.LssvmCgInfo) == 128
 
 
 has_gpu = _capi.device_count() > 0

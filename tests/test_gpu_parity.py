@@ -271,10 +271,67 @@ def test_rbf_direct_form_agrees_with_matrix_core_form(oracle):
     _capi.set_option("rbf_form", 1)
     try:
         b = backend.run_device_kernel(p, q, np.zeros(699, np.float32), rhs, X, 2.0, 1.0)
+        assert _capi.get_option("rbf_form") == 1
     finally:
         _capi.set_option("rbf_form", 0)
     eps = np.finfo(np.float32).eps
     assert ol.rel_inf(a, want) < 32 * eps and ol.rel_inf(b, want) < 32 * eps
+
+
+@pytest.mark.parametrize("case", ["gamma1", "gamma10", "unscaled"])
+def test_rbf_large_exponent_scale_switches_to_the_direct_kernel(oracle, case):
+    """the matrix-core rbf form evaluates the exponent as c_i + c_j + x_i'.x_j'; its absolute error is ~2^-24 R2 with
+    R2 = 2 gamma log2(e) max|x - mean|^2, which pairs of NEARBY points (K ~ 1) see as a relative error of K.  With rbf_form = 0 the
+    library measures R2 and runs the formula-exact (x_i - x_j)^2 kernel above rbf_direct_above (default 32).  Cases: gamma = 1 and 10 at
+    128 features on [-1,1]-scaled data (gamma = 1 lands just BELOW the threshold and stays on the matrix cores), and unscaled data (features of order 30) at gamma = 1/d.  Every data set carries near-duplicate
+    points, the pairs that lose digits.  Asserted against the float64 oracle on the scale of each row's summands: the automatic choice
+    stays below 16 eps; the forced matrix-core form (rbf_form = 2) is measurably worse by roughly R2 / 32 -- the reason for the switch --
+    yet bounded by 2^-22 R2.  predict_values follows the same rule."""
+    rng = np.random.default_rng(12)
+    N, d = 1500, 128
+    X, y = make_blobs_pm1(N, d, seed=3, dtype=np.float32)
+    if case == "unscaled":
+        X = (X * 30.0).astype(np.float32)
+        gamma = 1.0 / d
+    else:
+        gamma = 1.0 if case == "gamma1" else 10.0
+    X[1::2] = (X[0::2] + rng.normal(0, 1e-3, size=X[0::2].shape) * (30.0 if case == "unscaled" else 1.0)).astype(np.float32)  # near-duplicate pairs
+    p = Parameter(kernel_type="rbf", gamma=gamma)
+    n = N - 1
+    v = rng.uniform(-1, 1, size=n).astype(np.float32)
+    X64, v64 = X.astype(np.float64), v.astype(np.float64)
+    q64 = oracle.q("rbf", X64, gamma=gamma)
+    want = oracle.matvec("rbf", X64, q64, v64, np.zeros(n), 2.0, 1.0, 1.0, gamma=gamma)
+    sq = np.einsum("ij,ij->i", X64, X64)
+    K = np.exp(-gamma * np.maximum(sq[:n, None] + sq[None, :n] - 2.0 * (X64[:n] @ X64[:n].T), 0.0))
+    absv = np.abs(v64)
+    scale = K @ absv + (2.0 + np.abs(q64)) * absv.sum() + np.abs(q64) @ absv + absv
+    eps = np.finfo(np.float32).eps
+    errs = {}
+    for form in (0, 2):
+        _capi.set_option("rbf_form", form)
+        with backend.ResidentProblem(p, X) as prob:
+            info = prob.info()
+            got = prob.matvec(v, np.zeros(n, np.float32), 1.0)
+        if form == 0:
+            r2 = info["rbf_exponent_scale"]
+            direct = info["rbf_direct"]
+            assert direct == (1 if r2 > 32 else 0) and (case == "gamma1" or direct == 1)  # gamma = 1 sits just below the threshold (R2 ~ 26)
+        else:
+            assert info["rbf_direct"] == 0
+        # the GPU's own q (fp32) enters the rank-1 terms: compare K*v + rank-1 with the float64 product of the SAME fp32 data
+        errs[form] = float(np.max(np.abs(got - want) / scale))
+    assert errs[0] < (16 if direct else 32) * eps, (case, errs, r2)  # below the threshold the matrix-core form keeps 32 eps: the threshold's promise
+    assert errs[2] < 2.0 ** -22 * max(r2, 32.0), (case, errs, r2)
+    # predict_values takes the same decision
+    alpha = rng.uniform(-1, 1, size=N).astype(np.float32)
+    pts = X[:64] + np.float32(1e-3)
+    want_p, _ = oracle.predict_values("rbf", X64, alpha.astype(np.float64), 0.25, pts.astype(np.float64), gamma=gamma)
+    Kp = np.exp(-gamma * np.maximum(np.einsum("ij,ij->i", pts.astype(np.float64), pts.astype(np.float64))[:, None] + sq[None, :] - 2.0 * (pts.astype(np.float64) @ X64.T), 0.0))
+    scale_p = Kp @ np.abs(alpha.astype(np.float64)) + 0.25
+    _capi.set_option("rbf_form", 0)
+    got_p, _ = backend.predict_values(p, X, alpha, 0.25, None, pts)
+    assert np.max(np.abs(got_p - want_p) / scale_p) < (16 if direct else 32) * eps
 
 
 def test_rbf_uncentred_data_with_large_offset(oracle):
