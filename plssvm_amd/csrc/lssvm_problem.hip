@@ -109,6 +109,7 @@ int select_device_checked(int device) {
 }
 
 constexpr int MAX_LOCAL_DEVICES = 16;
+constexpr int SPLIT_MAX_FEATURES = 384;  // the bf16x6 kernels exist for 1 ... 6 chunks of 64 features (row panel = 3 planes in registers)
 
 std::vector<int> resolve_devices(const int *devices, int num_devices, size_t num_points) {
     const int count = device_count_checked();
@@ -348,7 +349,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         // the bf16x6 kernel has the costlier work-item prologue (three planes of the row panel) and the faster tiles: longer chunks
         // (measured 16 -> 64 tiles: +1.5 % at 100 000 points, +2 % at 300 000; the native kernels are flat or lose beyond 16)
         const bool split = std::is_same_v<T, float> && opt_.gram_mode == 1 && v2_eligible(opt_, ldx_probe, rbf_direct_)
-                           && round_up(static_cast<long>(num_features), 64) <= 256;
+                           && round_up(static_cast<long>(num_features), 64) <= SPLIT_MAX_FEATURES;
         jc_tiles_ = static_cast<int>(std::min<long>(split ? 64 : 16, std::max<long>(2, (area + 2048) / 4096)));
     }
     num_jc_ = (num_tiles_ + jc_tiles_ - 1) / jc_tiles_;
@@ -400,7 +401,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     if constexpr (std::is_same_v<T, float>) {
         // gram_mode = 1 (default): the (centred, scaled) data once more as three bf16 planes, features in natural order
         const int ldx16 = round_up(static_cast<long>(num_features), 64);
-        if (opt_.gram_mode == 1 && !rbf_direct_ && v2_eligible(opt_, X_.ldx, false) && ldx16 <= 256) {
+        if (opt_.gram_mode == 1 && !rbf_direct_ && v2_eligible(opt_, X_.ldx, false) && ldx16 <= SPLIT_MAX_FEATURES) {
             ldx16_ = ldx16;
             const size_t plane_stride = static_cast<size_t>(X_.rows_alloc) * ldx16;
             planes_.alloc_zero(3 * plane_stride, st);
@@ -497,6 +498,7 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     a.Xr16 = planes_.p;
     a.Xc16 = planes_.p;
     a.plane_stride = static_cast<size_t>(X_.rows_alloc) * ldx16_;
+    a.plane_stride_r = a.plane_stride;
     a.ldx16 = ldx16_;
     a.items = sym_ ? items_.p : nullptr;  // (the symmetric variant launches band by band: enqueue_apply_K_local offsets these two)
     a.num_items = num_items_;
@@ -1066,6 +1068,19 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
             poly_prescaled = true;
         }
     }
+    // fp32, gram_mode = 1: both sides once more as three bf16 planes (the bf16x6 kernels, full-square instance: rows = points, columns = support vectors)
+    DevBuf<uint16_t> planesS, planesP;
+    int ldx16 = 0;
+    if constexpr (std::is_same_v<T, float>) {
+        const int l16 = round_up(static_cast<long>(nfeat), 64);
+        if (opt.gram_mode == 1 && v2 && l16 <= SPLIT_MAX_FEATURES) {
+            ldx16 = l16;
+            planesS.alloc_zero(3 * static_cast<size_t>(S.rows_alloc) * ldx16, s);
+            planesP.alloc_zero(3 * static_cast<size_t>(P.rows_alloc) * ldx16, s);
+            split_bf16_planes(S.data.p, S.ldx, S.dfeat, static_cast<size_t>(S.rows_alloc), ldx16, planesS.p, static_cast<size_t>(S.rows_alloc) * ldx16, s);
+            split_bf16_planes(P.data.p, P.ldx, P.dfeat, static_cast<size_t>(P.rows_alloc), ldx16, planesP.p, static_cast<size_t>(P.rows_alloc) * ldx16, s);
+        }
+    }
     interleave_features<T>(S, s);
     interleave_features<T>(P, s);
     const int num_jt = S.rows_alloc / TILE;
@@ -1102,6 +1117,11 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
         LSSVM_HIP_CHECK(hipGetLastError());
     }
     ta.dc = dc.p;
+    ta.Xr16 = planesP.p;
+    ta.Xc16 = planesS.p;
+    ta.plane_stride = static_cast<size_t>(S.rows_alloc) * ldx16;
+    ta.plane_stride_r = static_cast<size_t>(P.rows_alloc) * ldx16;
+    ta.ldx16 = ldx16;
     ta.partial = partial.p;
     ta.part_stride = P.rows_alloc;
     ta.ldx = S.ldx;

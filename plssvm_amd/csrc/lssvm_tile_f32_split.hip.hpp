@@ -10,7 +10,7 @@
  * same 32-eps kernel-level bar).  Why: the bf16 MFMA moves 16x the multiply-adds per instruction (6 of them = 3/8 of the time of
  * the f32 MFMAs) AND, unlike the f32 MFMA, co-issues with the vector ALU (tests/tools/microbench_f64.hip), so the epilogue hides.
  * Structure: tile_matvec_f32_v2 with (64-feature chunk, plane) as the step -- same LDS-DMA ring, swizzle, hand-over, records,
- * epilogue and symmetric variant.  For num_features <= 256.
+ * epilogue and symmetric variant.  For num_features <= 384 (1 ... 6 chunks of 64 features; above 128 one workgroup per CU).
  */
 #pragma once
 
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
     bf16x8 afrag[3][4 * NK64];
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        const uint16_t *xr = a.Xr16 + p * a.plane_stride + static_cast<size_t>(row0 + wave * 32 + r) * a.ldx16 + 8 * h;
+        const uint16_t *xr = a.Xr16 + p * a.plane_stride_r + static_cast<size_t>(row0 + wave * 32 + r) * a.ldx16 + 8 * h;
 #pragma unroll
         for (int s = 0; s < 4 * NK64; ++s) afrag[p][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(xr + 16 * s));
     }
@@ -417,7 +417,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
     for (int p = 0; p < 3; ++p) {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-            const uint16_t *xr = a.Xr16 + p * a.plane_stride + static_cast<size_t>(row0 + wave * 32 + 16 * rb + r) * a.ldx16 + 8 * g;
+            const uint16_t *xr = a.Xr16 + p * a.plane_stride_r + static_cast<size_t>(row0 + wave * 32 + 16 * rb + r) * a.ldx16 + 8 * g;
 #pragma unroll
             for (int kk = 0; kk < 2 * NK64; ++kk) afrag[p][kk][rb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(xr + 32 * kk));
         }

@@ -39,7 +39,8 @@ struct TileArgs {
     const T *dc;      // fp32 v2 kernel: packed [num_jt][256] records (d_j | c_j) for LDS-DMA (k_pack_dc)
     const uint16_t *Xr16;  // fp32 split kernel: the row side as three bf16 planes [3][rows][ldx16] (hi, mid, lo: x = hi + mid + lo exactly)
     const uint16_t *Xc16;  // fp32 split kernel: the column side, same layout
-    size_t plane_stride;   // elements between the planes
+    size_t plane_stride;   // elements between the planes of the COLUMN side
+    size_t plane_stride_r; // elements between the planes of the ROW side (training: the same matrix; predict_values: the points to predict)
     int ldx16;             // padded features of the planes (multiple of 64)
     const int2 *items; // symmetric variant: list of the non-empty (local row block, column chunk) work items
     int num_items;    // symmetric variant: length of `items` = grid size

@@ -29,7 +29,7 @@ static void launch_s6_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
         }                                                                                                 \
         break;
     switch (a.ldx16 / 64) {
-        LSSVM_S6_CASE(1) LSSVM_S6_CASE(2) LSSVM_S6_CASE(3) LSSVM_S6_CASE(4)
+        LSSVM_S6_CASE(1) LSSVM_S6_CASE(2) LSSVM_S6_CASE(3) LSSVM_S6_CASE(4) LSSVM_S6_CASE(5) LSSVM_S6_CASE(6)
         default: throw Error(LSSVM_ERR_INTERNAL, "no split tile kernel for this number of features");
     }
 #undef LSSVM_S6_CASE

@@ -203,6 +203,37 @@ def test_predict_values_known_answer(dt):
     assert ol.float_near(out, np.array([0, 4], dtype=dt)) and w is None
 
 
+@pytest.mark.parametrize("kernel", ["polynomial", "rbf"])
+@pytest.mark.parametrize("nsv, npts, d", [(1300, 700, 128), (777, 130, 40), (520, 1025, 384), (300, 200, 500)])
+def test_predict_values_on_the_bf16_matrix_cores(oracle, kernel, nsv, npts, d):
+    """predict_values is the rectangular instance of the tile kernel (HIP/predict_kernel.hip.hpp:63-117: rows = points to predict,
+    columns = support vectors).  In fp32 with gram_mode = 1 it runs on the bf16x6 kernels for up to 384 features (500 features: the native
+    v_mfma_f32 kernel in both modes); both modes must match the float64 oracle on the scale of each point's summands."""
+    rng = np.random.default_rng(nsv + d)
+    sv = rng.uniform(-1, 1, size=(nsv, d)).astype(np.float32)
+    alpha = rng.uniform(-1, 1, size=nsv).astype(np.float32)
+    pts = rng.uniform(-1, 1, size=(npts, d)).astype(np.float32)
+    kw = dict(degree=3, gamma=1.0 / d, coef0=0.5)
+    p = Parameter(kernel_type=kernel, degree=3, gamma=1.0 / d, coef0=0.5)
+    want, _ = oracle.predict_values(kernel, sv.astype(np.float64), alpha.astype(np.float64), 0.125, pts.astype(np.float64), **kw)
+    G = pts.astype(np.float64) @ sv.astype(np.float64).T
+    if kernel == "rbf":
+        sq_s, sq_p = np.einsum("ij,ij->i", sv, sv, dtype=np.float64), np.einsum("ij,ij->i", pts, pts, dtype=np.float64)
+        K = np.exp(-(1.0 / d) * np.maximum(sq_p[:, None] + sq_s[None, :] - 2.0 * G, 0.0))
+    else:
+        K = (G / d + 0.5) ** 3
+    scale = np.abs(K) @ np.abs(alpha.astype(np.float64)) + 0.125
+    out = {}
+    for mode in (1, 0):
+        _capi.set_option("gram_mode", mode)
+        out[mode], _ = backend.predict_values(p, sv, alpha, 0.125, None, pts)
+        assert np.max(np.abs(out[mode] - want) / scale) < 16 * np.finfo(np.float32).eps, mode
+    if d <= 384:
+        assert not np.array_equal(out[0], out[1])  # two different kernels ran
+    else:
+        assert np.array_equal(out[0], out[1])      # above 384 features both modes are the native kernel
+
+
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_predict_values_and_calculate_w_vs_oracle(oracle, kernel, dt):
@@ -685,10 +716,10 @@ def test_column_slab_budget_falls_back_to_the_full_square():
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
-@pytest.mark.parametrize("N, d", [(300, 7), (1500, 64), (4097, 128), (2300, 200), (1100, 256)])
+@pytest.mark.parametrize("N, d", [(300, 7), (1500, 64), (4097, 128), (2300, 200), (1100, 256), (1300, 320), (900, 384)])
 @pytest.mark.parametrize("sym", [1, 0])
 def test_bf16_split_gram_mode_is_fp32_accurate(oracle, kernel, N, d, sym):
-    """gram_mode = 1 (the DEFAULT for up to 256 features): the fp32 operands are split exactly into three bf16 planes and the six
+    """gram_mode = 1 (the DEFAULT for up to 384 features): the fp32 operands are split exactly into three bf16 planes and the six
     significant plane products are accumulated in fp32 on the bf16 matrix cores; gram_mode = 0: native v_mfma_f32 chains.  Both must
     meet the same bar: no farther from the float64 product than 4x the fp32 CPU oracle (or 64 eps)."""
     X, y = make_blobs_pm1(N, d, seed=27, dtype=np.float32)
