@@ -294,6 +294,9 @@ def main():
         achieved *= plane_products
         executed *= plane_products
     traffic, traffic_source = measured_traffic(f"{args.workload}_n{shards}")
+    bands = int(i1.get("tile_launches_per_matvec", 1))
+    if traffic is not None:
+        traffic *= bands  # the PMC passes count per tile-kernel launch (= per row-block band); `achieved` is priced per matvec
 
     if rank == 0:
         exchange_names = {0: "none", 1: "RCCL all-reduce" if symmetric else "RCCL all-gather", 2: "peer kernels over xGMI (fixed-order sum)"}
@@ -318,6 +321,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_source": traffic_source,
                          "kernel": "lssvm::tile_matvec (implicit K*d tile kernel)", "launches": launches, "avg_launch_ms": kern_ms,
+                         "tile_launches_per_matvec": bands,
+                         "launch_note": "a 'launch' here is ONE implicit matvec = the sum of its row-block band launches of the tile kernel (rocprofv3 lists the bands one by one)",
                          "algorithmic_flop_per_launch": useful_launch * plane_products, "symmetric": symmetric,
                          "executed_flop_per_launch": exec_launch * plane_products, "executed": executed, "executed_frac": executed / peak,
                          "gram_mode": "bf16x6" if bf16x6 else "native", "fp32_equivalent": fp32_equivalent, "fp32_mfma_peak": PEAK_TFLOPS["float32"],

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("outdir")
     ap.add_argument("--json")
     ap.add_argument("--key")
+    ap.add_argument("--profile", default=None, help="name of the committed summary file the numbers come from")
     args = ap.parse_args()
     per, names = collect(args.outdir)
     if not per:
@@ -64,7 +65,11 @@ def main():
         if os.path.isfile(args.json):
             with open(args.json) as fh:
                 data = json.load(fh)
-        data[args.key] = rd + wr
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+        from bench import kernel_source_hash  # the stamp bench.py checks before it reports `traffic`
+
+        data[args.key] = {"bytes": rd + wr, "read_bytes": rd, "write_bytes": wr, "kernel_sha": kernel_source_hash(), "profile": args.profile or args.outdir,
+                          "launches_per_matvec_note": "bytes are per tile-kernel LAUNCH as rocprofv3 counts them; bench.py multiplies by tile_launches_per_matvec"}
         with open(args.json, "w") as fh:
             json.dump(data, fh, indent=1, sort_keys=True)
             fh.write("\n")

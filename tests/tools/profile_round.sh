@@ -26,7 +26,7 @@ done
 for wl in c2 c4 c5; do
   rm -rf $O/pmc_$wl
   bash tests/tools/pmc_passes.sh $wl 3 $O/pmc_$wl
-  python3 tests/tools/pmc_summarize.py $wl $O/pmc_$wl --json $O/${TAG}_hbm_traffic.json --key ${wl}_n1 >> $O/${TAG}_pmc_tile_matvec.txt 2>&1
+  python3 tests/tools/pmc_summarize.py $wl $O/pmc_$wl --json $O/${TAG}_hbm_traffic.json --key ${wl}_n1 --profile profiles/${TAG}_pmc_tile_matvec.txt >> $O/${TAG}_pmc_tile_matvec.txt 2>&1
   echo >> $O/${TAG}_pmc_tile_matvec.txt
   rm -rf $O/pmc_$wl   # raw per-dispatch CSVs are large; the summary is what is kept
 done
