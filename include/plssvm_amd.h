@@ -234,6 +234,9 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *                   R2 = 2 gamma log2(e) max|x - mean|^2 exceeds "rbf_direct_above" -- the expansion's exponent carries an absolute error of
  *                   ~2^-24 R2 whatever the distance of the pair, which nearby pairs (K ~ 1) see as a relative error of K; then, and with
  *                   1 = always, the formula-exact (x_i - x_j)^2 kernel on the vector ALU runs (5x slower); 2 = always the matrix cores
+ *   "rbf_fold"      fp32 rbf on the 16x16x32 bf16x6 kernels: 1 (default) = the column records carry (2^c_j d_j | 2^c_j) and the accumulators start
+ *                   from c_i as the C operand of their first MFMA -- no start-value instructions, K_ij = 2^acc 2^c_j (one more rounding than
+ *                   2^(acc + c_j); used while the exponent scale R2 <= 200 keeps both factors far inside the fp32 range); 0 = start values c_i + c_j
  *   "rbf_direct_above" threshold of rbf_form 0 (default 32: [-1,1]-scaled data with gamma = 1 / num_features has R2 <= 3)
  *   "j_chunk_tiles" number of 128-column tiles per work item; 0 = automatic (default: about 4096 work items per device, 2 ... 16 tiles each,
  *                   up to 64 for the bf16x6 kernel)

@@ -299,6 +299,8 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
         if (n == "rbf_form") {
             LSSVM_REQUIRE(value >= 0 && value <= 2, "rbf_form must be 0 (automatic), 1 (direct) or 2 (matrix cores)");
             lssvm::options().rbf_form = value;
+        } else if (n == "rbf_fold") {
+            lssvm::options().rbf_fold = value != 0 ? 1 : 0;
         } else if (n == "rbf_direct_above") {
             LSSVM_REQUIRE(value >= 0, "rbf_direct_above must not be negative");
             lssvm::options().rbf_direct_above = value;
@@ -352,6 +354,8 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
         const std::string n(name);
         if (n == "rbf_form") {
             *value_out = lssvm::options().rbf_form;
+        } else if (n == "rbf_fold") {
+            *value_out = lssvm::options().rbf_fold;
         } else if (n == "rbf_direct_above") {
             *value_out = lssvm::options().rbf_direct_above;
         } else if (n == "j_chunk_tiles") {

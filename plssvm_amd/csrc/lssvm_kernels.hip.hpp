@@ -21,12 +21,22 @@ namespace lssvm {
 
 
 /* dc[jt][0..127] = d of tile jt, dc[jt][128..255] = c (rbf: -|x_j|^2/2, else unused): one 1-KiB LDS-DMA record per tile */
-__global__ void k_pack_dc(const float *__restrict__ dvec, const float *__restrict__ cc, int ncols_padded, float *__restrict__ dc) {
+/* folded != 0 (rbf on the 16x16x32 bf16x6 kernels): dc[jt][0..127] = 2^c_j * d_j, dc[jt][128..255] = 2^c_j -- the tile kernel then starts its
+ * accumulators from c_i alone (as the C operand of the first MFMA) and evaluates K_ij d_j = 2^acc * (2^c_j d_j); used only while
+ * |c| <= 100, so neither factor leaves the fp32 range */
+__global__ void k_pack_dc(const float *__restrict__ dvec, const float *__restrict__ cc, int ncols_padded, float *__restrict__ dc, int folded) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ncols_padded) return;
     const int jt = j >> 7, l = j & 127;
-    dc[static_cast<size_t>(jt) * 256 + l] = dvec[j];
-    dc[static_cast<size_t>(jt) * 256 + 128 + l] = (cc != nullptr) ? cc[j] : 0.0f;
+    const float c = (cc != nullptr) ? cc[j] : 0.0f;
+    if (folded) {
+        const float e = __builtin_amdgcn_exp2f(c);
+        dc[static_cast<size_t>(jt) * 256 + l] = e * dvec[j];
+        dc[static_cast<size_t>(jt) * 256 + 128 + l] = e;
+    } else {
+        dc[static_cast<size_t>(jt) * 256 + l] = dvec[j];
+        dc[static_cast<size_t>(jt) * 256 + 128 + l] = c;
+    }
 }
 
 /* in place: the features of every aligned group of 8 are reordered to 0,2,4,6,1,3,5,7 (fp32 HBM layout, see above) */

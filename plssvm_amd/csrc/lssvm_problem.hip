@@ -109,6 +109,7 @@ int select_device_checked(int device) {
 }
 
 constexpr int MAX_LOCAL_DEVICES = 16;
+constexpr double FOLD_MAX_R2 = 200.0;    // folded rbf records (KT_RBFF) only while |c| = R2 / 2 <= 100: 2^c and 2^acc stay far inside the fp32 range
 constexpr int SPLIT_MAX_FEATURES = 384;  // the bf16x6 kernels exist for 1 ... 6 chunks of 64 features (row panel = 3 planes in registers)
 
 std::vector<int> resolve_devices(const int *devices, int num_devices, size_t num_points) {
@@ -258,13 +259,13 @@ static bool rbf_wants_direct_form(const Options &o, const lssvm_params &p, const
     if (r2_out != nullptr) *r2_out = 0.0;
     if (!std::is_same_v<T, float> || p.kernel_type != LSSVM_KERNEL_RBF) return false;
     if (o.rbf_form == 1) return true;
-    if (o.rbf_form == 2) return false;
     DevBuf<T> mean;
     column_means<T>(M, mean, s);
     double sq = max_centred_sqnorm<T>(M, mean, s);
     if (M2 != nullptr) sq = std::max(sq, max_centred_sqnorm<T>(*M2, mean, s));
     const double r2 = 2.0 * static_cast<double>(static_cast<T>(p.gamma)) * 1.4426950408889634 * sq;
     if (r2_out != nullptr) *r2_out = r2;
+    if (o.rbf_form == 2) return false;  // matrix cores whatever the scale (r2 is still reported: it decides the record form)
     return r2 > static_cast<double>(o.rbf_direct_above);
 }
 
@@ -406,6 +407,8 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
             const size_t plane_stride = static_cast<size_t>(X_.rows_alloc) * ldx16;
             planes_.alloc_zero(3 * plane_stride, st);
             split_bf16_planes(X_.data.p, X_.ldx, X_.dfeat, static_cast<size_t>(X_.rows_alloc), ldx16, planes_.p, plane_stride, st);
+            // rbf on the 16x16x32 kernels: folded records while the exponent terms stay small (rbf_r2_ = 2 max|c| in the exponent's unit)
+            dc_folded_ = params_.kernel_type == LSSVM_KERNEL_RBF && opt_.mfma_shape >= 1 && opt_.rbf_fold != 0 && rbf_r2_ <= FOLD_MAX_R2;
         }
     }
     interleave_features<T>(X_, st);
@@ -516,6 +519,7 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     set_kernel_scalars(a, params_, rbf_direct_);
     if (poly_prescaled_) a.gamma = T(1);
     set_launch_options(a, opt_);
+    a.dc_folded = dc_folded_ ? 1 : 0;
     return a;
 }
 
@@ -556,7 +560,7 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
     if (dc_.p != nullptr) {  // v2 kernels: pack (d_j | c_j) records for the LDS-DMA
         const int ncols = num_tiles_ * TILE;
         if constexpr (std::is_same_v<T, float>) {
-            hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, st, v_dev, c_.p, ncols, dc_.p);
+            hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, st, v_dev, c_.p, ncols, dc_.p, a.dc_folded);
         } else {
             hipLaunchKernelGGL(k_pack_dc_f64, dim3((ncols + 255) / 256), dim3(256), 0, st, v_dev, c_.p, ncols, dc_.p);
         }
@@ -1050,7 +1054,9 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     S.upload(sv, LSSVM_MEM_HOST, nsv, nfeat, 0, s);
     P.upload(points, LSSVM_MEM_HOST, npoints, nfeat, 0, s);
     DevBuf<T> cS, cP;
-    const bool rbf_direct = rbf_wants_direct_form<T>(opt, params, S, &P, s, nullptr);  // same rule as the training matvec (Problem<T>)
+    double rbf_r2 = 0.0;
+    const bool rbf_direct = rbf_wants_direct_form<T>(opt, params, S, &P, s, &rbf_r2);  // same rule as the training matvec (Problem<T>)
+    int dc_folded = 0;
     if (params.kernel_type == LSSVM_KERNEL_RBF && !rbf_direct) {
         center_columns<T>(S, &P, rbf_prescale<T>(params, v2_eligible_f64(opt, S.ldx)), s);
         half_neg_norms<T>(S, cS, s);
@@ -1079,6 +1085,7 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
             planesP.alloc_zero(3 * static_cast<size_t>(P.rows_alloc) * ldx16, s);
             split_bf16_planes(S.data.p, S.ldx, S.dfeat, static_cast<size_t>(S.rows_alloc), ldx16, planesS.p, static_cast<size_t>(S.rows_alloc) * ldx16, s);
             split_bf16_planes(P.data.p, P.ldx, P.dfeat, static_cast<size_t>(P.rows_alloc), ldx16, planesP.p, static_cast<size_t>(P.rows_alloc) * ldx16, s);
+            dc_folded = (params.kernel_type == LSSVM_KERNEL_RBF && opt.mfma_shape >= 1 && opt.rbf_fold != 0 && rbf_r2 <= FOLD_MAX_R2) ? 1 : 0;
         }
     }
     interleave_features<T>(S, s);
@@ -1110,13 +1117,14 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
         dc.alloc_zero(static_cast<size_t>(num_jt) * 256, s);
         const int ncols = num_jt * TILE;
         if constexpr (std::is_same_v<T, float>) {
-            hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, s, a.p, cS.p, ncols, dc.p);
+            hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, s, a.p, cS.p, ncols, dc.p, dc_folded);
         } else {
             hipLaunchKernelGGL(k_pack_dc_f64, dim3((ncols + 255) / 256), dim3(256), 0, s, a.p, cS.p, ncols, dc.p);
         }
         LSSVM_HIP_CHECK(hipGetLastError());
     }
     ta.dc = dc.p;
+    ta.dc_folded = dc_folded;
     ta.Xr16 = planesP.p;
     ta.Xc16 = planesS.p;
     ta.plane_stride = static_cast<size_t>(S.rows_alloc) * ldx16;

@@ -57,6 +57,8 @@ struct Error : std::runtime_error {
 struct Options {
     int64_t rbf_form = 0;        // fp32 rbf: 0 automatic (matrix cores unless the exponent scale of the data exceeds rbf_direct_above), 1 always the direct
                                  // (x_i - x_j)^2 kernel on the vector ALU, 2 always the norm expansion on the matrix cores
+    int64_t rbf_fold = 1;        // fp32 rbf on the 16x16x32 bf16x6 kernels: 1 = folded column records (2^c_j d_j | 2^c_j), accumulators start from c_i as the C
+                                 // operand of their first MFMA (default, while the exponent scale stays below 200); 0 = start values c_i + c_j by vector adds
     int64_t rbf_direct_above = 32;  // rbf_form 0: threshold on 2 gamma log2(e) max|x - mean|^2 (absolute error of the matrix-core exponent ~ 2^-24 x that)
     int64_t j_chunk_tiles = 0;   // 128-column tiles per work item; 0 = automatic (2 ... 16, about 4096 work items per device)
     int64_t symmetric = 1;         // 1: evaluate only the tiles on/below the diagonal and mirror them (fp32 v2 kernel), 0: full square
@@ -255,7 +257,8 @@ class Problem {
     int jc_tiles_ = 16, num_jc_ = 1;
     int nvec_ = 0;  // allocated vector length (multiple of TILE * world)
     bool rbf_direct_ = false;
-    double rbf_r2_ = 0.0;  // 2 gamma log2(e) max|x - mean|^2 (rbf_form 0 only)
+    double rbf_r2_ = 0.0;  // fp32 rbf: 2 gamma log2(e) max|x - mean|^2
+    bool dc_folded_ = false;  // the (d_j | c_j) records carry (2^c_j d_j | 2^c_j): rbf on the 16x16x32 bf16x6 kernels
     bool poly_prescaled_ = false;  // fp64 polynomial on the v2 kernel: X_ carries sqrt(gamma), the kernel sees gamma = 1
     DevBuf<uint16_t> planes_;      // gram_mode 1: X as three bf16 planes [3][rows_alloc][ldx16]
     int ldx16_ = 0;

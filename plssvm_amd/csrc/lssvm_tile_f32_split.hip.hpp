@@ -422,7 +422,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
             for (int kk = 0; kk < 2 * NK64; ++kk) afrag[p][kk][rb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(xr + 32 * kk));
         }
     }
-    if constexpr (KT == KT_RBF) {
+    if constexpr (KT == KT_RBF || KT == KT_RBFF) {
         if (tid < TILE) cis[tid] = a.cr[row0 + tid];
     }
     if constexpr (SYM) {
@@ -498,6 +498,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) rowpart[i] = 0.0f;
     f32x4 acc[2][8];
+    f32x4 civ0[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };  // KT_RBFF: c_i of the wave's two row blocks, the C operand of the first MFMAs
     bool padcol[8] = { false, false, false, false, false, false, false, false };
 
     // ---- prologue: chunks 0, 1, 2 (each preceded by the record of the tile that starts with it) ----
@@ -584,6 +585,13 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
 #pragma unroll
                 for (int cb = 0; cb < 8; ++cb) padcol[cb] = (a.degree < 0) && ((jt_begin + t) * TILE + cb * 16 + r >= a.ncols_valid);
             }
+            if constexpr (KT == KT_RBFF) {
+                // folded records: the accumulators start from c_i, which the FIRST MFMA of every accumulator takes as its C operand (the
+                // same four values for all eight column blocks of a row block): no start-value instruction at all.  c_j comes in as the
+                // factor 2^c_j of the record.
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) civ0[rb] = *reinterpret_cast<const f32x4 *>(cis + wave * 32 + 16 * rb + 4 * g);
+            }
             if constexpr (KT == KT_RBF) {  // the accumulators start at c_i + c_j
                 f32x4 civ[2];
 #pragma unroll
@@ -614,7 +622,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
                 const bool more = !decltype(checked)::value || mm < 3 || step + 1 < nsteps;
                 if constexpr (HAND) {
                     constexpr int NQ = 3 - plane;
-                    constexpr bool ZC = (KT != KT_RBF) && kc == 0 && kk == 0;  // first MFMA of every accumulator of this column half starts from 0
+                    constexpr bool ZC = (KT != KT_RBF) && kc == 0 && kk == 0;  // first MFMA of every accumulator of this column half: C = 0 (or c_i: KT_RBFF)
                     constexpr int CUR = mm & 1;
                     if constexpr (mm == 2) {
                         if constexpr (SYM) {
@@ -643,7 +651,15 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
                     if constexpr (NQ == 3) {
                         const bf16x8 &a10 = afrag[1][2 * chunk + kk][0], &a11 = afrag[1][2 * chunk + kk][1];
                         const bf16x8 &a20 = afrag[2][2 * chunk + kk][0], &a21 = afrag[2][2 * chunk + kk][1];
-                        if constexpr (ZC) {
+                        if constexpr (ZC && KT == KT_RBFF) {
+                            if constexpr (CUR == 0) {
+                                if (more) s6w_group_q3_b0_p1_z2<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, civ0[0], civ0[1], paddr);
+                                else s6w_group_q3_b0_p0_z2<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, civ0[0], civ0[1], paddr);
+                            } else {
+                                if (more) s6w_group_q3_b1_p1_z2<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, civ0[0], civ0[1], paddr);
+                                else s6w_group_q3_b1_p0_z2<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, civ0[0], civ0[1], paddr);
+                            }
+                        } else if constexpr (ZC) {
                             if constexpr (CUR == 0) {
                                 if (more) s6w_group_q3_b0_p1_z1<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
                                 else s6w_group_q3_b0_p0_z1<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
@@ -725,7 +741,9 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
 #pragma unroll
                         for (int rb = 0; rb < 2; ++rb) {
                             const bf16x8 av = afrag[q][2 * chunk + kk][rb];
-                            if (KT != KT_RBF && kc == 0 && kk == 0 && q == 0) {
+                            if (KT == KT_RBFF && kc == 0 && kk == 0 && q == 0) {
+                                acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, civ0[rb], 0, 0, 0);
+                            } else if (KT != KT_RBF && kc == 0 && kk == 0 && q == 0) {
                                 const f32x4 zero = { 0.f, 0.f, 0.f, 0.f };
                                 acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, zero, 0, 0, 0);
                             } else {
@@ -775,6 +793,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
                         float v = colacc[cb];  // the four lane groups hold different rows of the same column
                         v += __shfl_xor(v, 16);
                         v += __shfl_xor(v, 32);
+                        if constexpr (KT == KT_RBFF) v *= dcr[128 + cb * 16 + r];  // K_ij = 2^acc * 2^c_j: the column's factor once per column
                         if (g == 0) cw[cb * 16 + r] = v;
                     }
                 }

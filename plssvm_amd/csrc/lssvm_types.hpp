@@ -16,6 +16,8 @@ constexpr int KT_POLY = 1;
 constexpr int KT_RBF = 2;
 constexpr int KT_POLY2 = 3;  // v2 tile kernels only: polynomial with degree 2 / 3 (KT_POLY = any other integer degree)
 constexpr int KT_POLY3 = 4;
+constexpr int KT_RBFF = 5;   // bf16x6 16x16x32 kernels only: rbf with the FOLDED records (w_j = 2^c_j d_j | e_j = 2^c_j): the accumulators start from c_i as
+                             // the C operand of their first MFMA (no start-value adds), K_ij = 2^acc * e_j
 
 constexpr int TILE = 128;          // rows / columns of one workgroup tile of the implicit matrix
 constexpr int TILE_THREADS = 256;  // 4 wave64 arranged 2 x 2, each owning a 64 x 64 sub-tile
@@ -36,7 +38,8 @@ struct TileArgs {
     const T *cr;      // rbf: -0.5 * |x_i|^2 per row-side point
     const T *cc;      // rbf: -0.5 * |x_j|^2 per column-side point
     const T *dvec;    // [num_jt*TILE] vector multiplied from the right, EXACT zeros beyond the valid columns
-    const T *dc;      // fp32 v2 kernel: packed [num_jt][256] records (d_j | c_j) for LDS-DMA (k_pack_dc)
+    const T *dc;      // v2 kernels: packed [num_jt][256] records (d_j | c_j) for LDS-DMA (k_pack_dc); KT_RBFF: (2^c_j d_j | 2^c_j)
+    int dc_folded;    // host side only: 1 if the records carry the folded form (rbf on the 16x16x32 bf16x6 kernels while |c| stays small)
     const uint16_t *Xr16;  // fp32 split kernel: the row side as three bf16 planes [3][rows][ldx16] (hi, mid, lo: x = hi + mid + lo exactly)
     const uint16_t *Xc16;  // fp32 split kernel: the column side, same layout
     size_t plane_stride;   // elements between the planes of the COLUMN side

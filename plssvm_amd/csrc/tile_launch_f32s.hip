@@ -23,9 +23,11 @@ static void launch_s6_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
         if (a.mfma_shape >= 1) {                                                                          \
             ensure_dynamic_lds(tile_matvec_f32_s6w<KT, N, SYM>, V2_LDS_BYTES);                            \
             hipLaunchKernelGGL((tile_matvec_f32_s6w<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);       \
-        } else {                                                                                          \
+        } else if constexpr (KT != KT_RBFF) {                                                             \
             ensure_dynamic_lds(tile_matvec_f32_s6<KT, N, SYM>, V2_LDS_BYTES);                             \
             hipLaunchKernelGGL((tile_matvec_f32_s6<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);        \
+        } else {                                                                                          \
+            throw Error(LSSVM_ERR_INTERNAL, "folded rbf records need the 16x16x32 kernels");              \
         }                                                                                                 \
         break;
     switch (a.ldx16 / 64) {
@@ -48,7 +50,13 @@ static void launch_s6(const TileArgs<float> &a, int kernel_type, dim3 grid, hipS
                 launch_s6_kt<KT_POLY, SYM>(a, grid, s);
             }
             break;
-        default: launch_s6_kt<KT_RBF, SYM>(a, grid, s); break;
+        default:
+            if (a.dc_folded != 0) {
+                launch_s6_kt<KT_RBFF, SYM>(a, grid, s);  // only the 16x16x32 kernels understand the folded records (Problem sets the flag with mfma_shape >= 1)
+            } else {
+                launch_s6_kt<KT_RBF, SYM>(a, grid, s);
+            }
+            break;
     }
 }
 

@@ -3,6 +3,8 @@ pointer handed over the C ABI, and bench.py's JSON contract on a small workload.
 
 import json
 import os
+
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # single node: RCCL's bootstrap need not scan the interfaces (it took 100-600 s on some boxes)
 import subprocess
 import sys
 

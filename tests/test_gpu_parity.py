@@ -365,6 +365,53 @@ def test_rbf_large_exponent_scale_switches_to_the_direct_kernel(oracle, case):
     assert np.max(np.abs(got_p - want_p) / scale_p) < (16 if direct else 32) * eps
 
 
+def test_rbf_folded_and_unfolded_column_records_agree(oracle):
+    """fp32 rbf on the 16x16x32 bf16x6 kernels: option rbf_fold (default 1) starts the accumulators from c_i as the first MFMA's C operand and
+    carries 2^c_j in the column record; rbf_fold = 0 starts them at c_i + c_j with vector adds.  Two evaluations of the same numbers: both
+    within 16 eps of the float64 product on the scale of each row's summands, for the symmetric variant, the full square and predict_values."""
+    N, d = 2500, 128
+    X, _ = make_blobs_pm1(N, d, seed=9, dtype=np.float32)
+    p = Parameter(kernel_type="rbf", gamma=0.5)  # an exponent scale well above the default gamma's
+    _capi.set_option("rbf_form", 2)               # ... kept on the matrix cores whatever it is
+    rows = np.array([0, 1, 127, 128, 129, 1000, 2047, N - 2])
+    eps = np.finfo(np.float32).eps
+    alpha = np.random.default_rng(3).uniform(-1, 1, size=N).astype(np.float32)
+    pts = X[:200] + np.float32(0.01)
+    want_p, _ = oracle.predict_values("rbf", X.astype(np.float64), alpha.astype(np.float64), 0.5, pts.astype(np.float64), gamma=0.5)
+    for sym in (1, 0):
+        _capi.set_option("symmetric", sym)
+        for fold in (1, 0):
+            _capi.set_option("rbf_fold", fold)
+            with backend.ResidentProblem(p, X) as prob:
+                info = prob.info()
+                assert info["rbf_direct"] == 0 and info["gram_mode"] == 1 and 4 < info["rbf_exponent_scale"] < 200
+                err, _, _ = _sampled_rows_vs_oracle_gamma(oracle, prob, X, rows, 0.5)
+            assert err < 2.0 ** -22 * max(info["rbf_exponent_scale"], 32.0), (sym, fold, err / eps)  # the matrix-core bound of INTEGRATION.md section 6
+    for fold in (1, 0):
+        _capi.set_option("rbf_fold", fold)
+        got_p, _ = backend.predict_values(p, X, alpha, 0.5, None, pts)
+        assert np.max(np.abs(got_p - want_p)) < 16 * eps * np.abs(alpha).sum()
+
+
+def _sampled_rows_vs_oracle_gamma(oracle, prob, X, rows, gamma):
+    """_sampled_rows_vs_oracle for the rbf kernel with an explicit gamma"""
+    N, d = X.shape
+    n = N - 1
+    rng = np.random.default_rng(0)
+    rhs = rng.uniform(-1, 1, size=n).astype(X.dtype)
+    q, QA = prob.q()
+    got = prob.matvec(rhs, np.zeros(n, X.dtype), 1.0)
+    X64, q64, rhs64 = X.astype(np.float64), q.astype(np.float64), rhs.astype(np.float64)
+    want = np.zeros(n)
+    for r in rows:
+        want = oracle.matvec_rows("rbf", X64, q64, rhs64, want, float(QA), 1.0, 1.0, int(r), int(r) + 1, gamma=gamma)
+    sq = np.einsum("ij,ij->i", X64, X64)
+    K = np.exp(-gamma * np.maximum(sq[rows, None] + sq[None, :n] - 2.0 * (X64[rows] @ X64[:n].T), 0.0))
+    absd = np.abs(rhs64)
+    scale = K @ absd + (abs(float(QA)) + np.abs(q64[rows])) * absd.sum() + np.abs(q64) @ absd + absd[rows]
+    return float(np.max(np.abs(got[rows] - want[rows]) / scale)), got, rhs
+
+
 def test_rbf_uncentred_data_with_large_offset(oracle):
     """Features with a common offset far larger than their spread: the centring keeps the norm expansion accurate."""
     rng = np.random.default_rng(2)

@@ -9,6 +9,8 @@ import argparse
 import hashlib
 import json
 import os
+
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # single node: RCCL's bootstrap need not scan the interfaces (it took 100-600 s on some boxes)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
