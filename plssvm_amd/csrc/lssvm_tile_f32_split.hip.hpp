@@ -455,16 +455,6 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
             __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + lane_off(dma_off[i])), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
         }
     };
-    auto issue_chunk_part = [&](int step, int i) {
-        if (LSSVM_DBG(a, 16)) return;
-        if (LSSVM_DBG(a, 64) && i != 0) return;   // bit 64: a quarter of the DMA instructions (timing only)
-        if (LSSVM_DBG(a, 128) && wave != 0) return;  // bit 128: only wave 0 issues DMA
-        const int t = step / NKC;
-        const int kc = step - t * NKC;
-        const char *base = sgpr_ptr(a.Xc16 + (kc % 3) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (kc / 3) * 64);
-        char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES + wave * 4096;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + lane_off(dma_off[i])), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
-    };
     // steady state: the chunk (tile t or t + 1, plane-chunk KC known at compile time) costs two scalar adds per DMA instead of the divisions and
     // 64-bit multiplies of the generic form; `xc_tile` = first byte of column tile t in plane 0 (uniform), advanced once per tile
     const size_t tile_bytes = static_cast<size_t>(TILE) * a.ldx16 * 2;
@@ -640,14 +630,6 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
                     f32x4 &c0 = acc[0][4 * cbh + 0], &c1 = acc[1][4 * cbh + 0], &c2 = acc[0][4 * cbh + 1], &c3 = acc[1][4 * cbh + 1];
                     f32x4 &c4 = acc[0][4 * cbh + 2], &c5 = acc[1][4 * cbh + 2], &c6 = acc[0][4 * cbh + 3], &c7 = acc[1][4 * cbh + 3];
                     const bf16x8 &a00 = afrag[0][2 * chunk + kk][0], &a01 = afrag[0][2 * chunk + kk][1];
-#define LSSVM_S6W_CALL(FN, ...)                                                              \
-    do {                                                                                     \
-        if (more) {                                                                          \
-            FN##_p1_##__VA_ARGS__;                                                           \
-        } else {                                                                             \
-            FN##_p0_##__VA_ARGS__;                                                           \
-        }                                                                                    \
-    } while (0)
                     if constexpr (NQ == 3) {
                         const bf16x8 &a10 = afrag[1][2 * chunk + kk][0], &a11 = afrag[1][2 * chunk + kk][1];
                         const bf16x8 &a20 = afrag[2][2 * chunk + kk][0], &a21 = afrag[2][2 * chunk + kk][1];
@@ -694,7 +676,6 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
                             else s6w_group_q1_b1_p0_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, paddr);
                         }
                     }
-#undef LSSVM_S6W_CALL
                     // the LDS-DMA of chunk step + 3 goes between the groups of the step's second half (two instructions behind each)
                     if constexpr (!decltype(checked)::value && mm >= 2) {
                         issue_part_static(std::integral_constant<int, kc + 3>{}, (phase + kc + 3) & (V2_RING - 1), (mm - 2) * 2 + 0);

@@ -145,3 +145,35 @@ def test_fit_predict_score_and_cli_roundtrip(tmp_path, kernel, rt):
     assert out.returncode == 0 and "Accuracy = " in out.stdout, out.stdout + out.stderr
     pred = [float(v) for v in (tmp_path / "out.predict").read_text().split()]
     assert np.mean(np.array(pred) == y[test]) > 0.98
+
+
+def test_performance_tracker_yaml_layout(tmp_path):
+    """plssvm_amd/performance_tracker.py writes what performance_tracker::save writes (src/plssvm/detail/performance_tracker.cpp:139-190):
+    one YAML document per run -- '---', a meta_data block, then one block per category with two-space indented `name: value` lines, string
+    values quoted (:36-38), the ungrouped total_time last (main_train.cpp:57); appended to the file."""
+    import yaml
+
+    from plssvm_amd.performance_tracker import PerformanceTracker
+
+    info = dict(iterations=7, max_iterations=500, residuum=2.5e-12, target_residuum=1.0e-11, avg_iteration_ms=0.123456, epsilon=1e-10, total_runtime_ms=12.6,
+                devices_used=2)
+    out = tmp_path / "track.yaml"
+    for run in range(2):
+        tr = PerformanceTracker()
+        tr.add_parameter(Parameter(kernel_type="rbf", gamma=0.25, cost=2.0), "float32")
+        tr.add_backend(info["devices_used"])
+        tr.add_cg_info(info)
+        tr.add("data_set_read", "filename", "train.libsvm")
+        tr.add("", "total_time", "15ms")
+        tr.save(str(out))
+    text = out.read_text()
+    assert text.count("---\n") == 2 and text.startswith("---\nmeta_data:\n  date:")
+    docs = list(yaml.safe_load_all(text))
+    assert len(docs) == 2
+    doc = docs[1]
+    assert doc["parameter"] == {"kernel_type": "rbf", "degree": 3, "gamma": 0.25, "coef0": 0.0, "cost": 2.0, "real_type": "float"}
+    assert doc["backend"] == {"backend": "mi355", "target_platform": "gpu_amd", "num_devices": 2}
+    assert doc["cg"]["iterations"] == 7 and doc["cg"]["max_iterations"] == 500 and float(doc["cg"]["epsilon"]) == 1e-10  # ({} formatting like the reference: "1e-10", which YAML 1.1 reads as a string)
+    assert doc["cg"]["avg_iteration_time"] == "0.123456ms" and doc["cg"]["total_runtime"] == "13ms"
+    assert doc["data_set_read"]["filename"] == "train.libsvm" and doc["total_time"] == "15ms"
+    assert '  filename: "train.libsvm"\n' in text and "\ncg:\n  iterations: 7\n" in text
