@@ -212,6 +212,22 @@ __device__ __forceinline__ void lds_wait4(f32x4 &b0, f32x4 &b1, f32x4 &b2, f32x4
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : "i"(N));
 }
 
+/* v + (v of lane ^ 32) and v + (v of lane ^ 16) WITHOUT the LDS crossbar: gfx950's v_permlane32_swap / v_permlane16_swap exchange the upper
+ * half (odd 16-lane rows) of the first register with the lower half (even rows) of the second; fed with two copies of v the two results are
+ * [lo, lo] and [hi, hi], whose sum is the butterfly step.  (__shfl_xor compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt(0): an LDS round
+ * trip per step, which serialised the eight column blocks of the symmetric epilogue -- 24 LDS latencies per tile.  The builtin form of the
+ * swaps mis-compiles when both operands are the same value (ROCm 7.2: it adds the first result to itself), hence the asm.) */
+__device__ __forceinline__ float sum_with_lane_xor32(float v) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float sum_with_lane_xor16(float v) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 /* The v2 kernels take the polynomial degree class as part of their kernel-type template parameter, so every instantiation
  * carries ONE epilogue (the three-way runtime switch of with_degree_class made the register allocator budget for the generic
  * integer-power path and spill in the cube path). */

@@ -511,6 +511,10 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+    if constexpr (KT == KT_RBFF) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) civ0[rb] = *reinterpret_cast<const f32x4 *>(cis + wave * 32 + 16 * rb + 4 * g);
+    }
     // B fragments: two buffers used alternately by the groups (group mm multiplies bbuf[mm & 1] while the reads into bbuf[(mm + 1) & 1] are
     // in flight).  The reads are ordinary loads: the compiler's own waits guard them.  (Hand-issued ds_read_b128 + counted s_waitcnt were
     // tried and are WRONG here: the register allocator copies a destination register at a block boundary before the wait, i.e. before the
@@ -575,13 +579,9 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
 #pragma unroll
                 for (int cb = 0; cb < 8; ++cb) padcol[cb] = (a.degree < 0) && ((jt_begin + t) * TILE + cb * 16 + r >= a.ncols_valid);
             }
-            if constexpr (KT == KT_RBFF) {
-                // folded records: the accumulators start from c_i, which the FIRST MFMA of every accumulator takes as its C operand (the
-                // same four values for all eight column blocks of a row block): no start-value instruction at all.  c_j comes in as the
-                // factor 2^c_j of the record.
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) civ0[rb] = *reinterpret_cast<const f32x4 *>(cis + wave * 32 + 16 * rb + 4 * g);
-            }
+            // (KT_RBFF, folded records: the accumulators start from c_i, which the FIRST MFMA of every accumulator takes as its C operand -- the
+            // same four values for all eight column blocks of a row block, loaded once per work item into civ0: no start-value instruction and
+            // no LDS read at the head of a tile.  c_j comes in as the factor 2^c_j of the record.)
             if constexpr (KT == KT_RBF) {  // the accumulators start at c_i + c_j
                 f32x4 civ[2];
 #pragma unroll
@@ -759,23 +759,31 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
                     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float kv = apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(acc[rb][cb][e], a);
+                            float kv = LSSVM_DBG(a, 2) ? acc[rb][cb][e] : apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(acc[rb][cb][e], a);  // bit 2: no exp
                             if constexpr (KT == KT_POLY) {
                                 if (padcol[cb]) kv = 0.0f;
+                            }
+                            if (LSSVM_DBG(a, 256)) {  // bit 256: no fmas (one add keeps the value alive)
+                                rowpart[4 * rb + e] += kv;
+                                continue;
                             }
                             rowpart[4 * rb + e] = fmaf(kv, djv, rowpart[4 * rb + e]);
                             if constexpr (COLS) colacc[cb] = fmaf(kv, di[rb][e], colacc[cb]);
                         }
                 }
                 if constexpr (COLS) {
+                    // the four lane groups hold different rows of the same column: two butterfly steps on the vector ALU (no LDS round trips),
+                    // then ONE branch for the eight stores, so that the whole epilogue stays a single basic block the compiler can overlap
                     float *cw = colred + (t & 1) * 512 + wave * 128;
 #pragma unroll
                     for (int cb = 0; cb < 8; ++cb) {
-                        float v = colacc[cb];  // the four lane groups hold different rows of the same column
-                        v += __shfl_xor(v, 16);
-                        v += __shfl_xor(v, 32);
+                        float v = sum_with_lane_xor16(sum_with_lane_xor32(colacc[cb]));
                         if constexpr (KT == KT_RBFF) v *= dcr[128 + cb * 16 + r];  // K_ij = 2^acc * 2^c_j: the column's factor once per column
-                        if (g == 0) cw[cb * 16 + r] = v;
+                        colacc[cb] = v;
+                    }
+                    if (g == 0) {
+#pragma unroll
+                        for (int cb = 0; cb < 8; ++cb) cw[cb * 16 + r] = colacc[cb];
                     }
                 }
             };
