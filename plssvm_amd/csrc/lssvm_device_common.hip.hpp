@@ -228,6 +228,19 @@ __device__ __forceinline__ float sum_with_lane_xor16(float v) {
     return a + b;
 }
 
+__device__ __forceinline__ double sum_with_lane_xor32(double v) {
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+    unsigned alo = static_cast<unsigned>(bits), blo = alo, ahi = static_cast<unsigned>(bits >> 32), bhi = ahi;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3" : "+v"(alo), "+v"(blo), "+v"(ahi), "+v"(bhi));
+    return __builtin_bit_cast(double, (static_cast<unsigned long long>(ahi) << 32) | alo) + __builtin_bit_cast(double, (static_cast<unsigned long long>(bhi) << 32) | blo);
+}
+__device__ __forceinline__ double sum_with_lane_xor16(double v) {
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+    unsigned alo = static_cast<unsigned>(bits), blo = alo, ahi = static_cast<unsigned>(bits >> 32), bhi = ahi;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3" : "+v"(alo), "+v"(blo), "+v"(ahi), "+v"(bhi));
+    return __builtin_bit_cast(double, (static_cast<unsigned long long>(ahi) << 32) | alo) + __builtin_bit_cast(double, (static_cast<unsigned long long>(bhi) << 32) | blo);
+}
+
 /* The v2 kernels take the polynomial degree class as part of their kernel-type template parameter, so every instantiation
  * carries ONE epilogue (the three-way runtime switch of with_degree_class made the register allocator budget for the generic
  * integer-power path and spill in the cube path). */

@@ -319,9 +319,10 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
                 if constexpr (COLS) {
                     float *cw = colred + (t & 1) * 512 + wave * 128;
 #pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) {
-                        const float v = colacc[cb] + __shfl_xor(colacc[cb], 32);  // the two lane halves hold different rows
-                        if (h == 0) cw[cb * 32 + r] = v;
+                    for (int cb = 0; cb < 4; ++cb) colacc[cb] = sum_with_lane_xor32(colacc[cb]);  // the two lane halves hold different rows (no LDS round trip)
+                    if (h == 0) {
+#pragma unroll
+                        for (int cb = 0; cb < 4; ++cb) cw[cb * 32 + r] = colacc[cb];
                     }
                 }
             };

@@ -478,11 +478,12 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
                 if constexpr (COLS) {
                     double *cw = colred + (t & 1) * 256 + wave * 64;
 #pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) {
-                        double v = colacc[cb];
-                        v += __shfl_xor(v, 16);  // the four quarter-waves hold different rows of the same column
-                        v += __shfl_xor(v, 32);
-                        if (q == 0) cw[cb * 16 + r] = v;
+                    // the four quarter-waves hold different rows of the same column: butterfly on the vector ALU (v_permlane*_swap; __shfl_xor
+                    // is an LDS round trip per step and, with a store branch per column block, serialised them), then one store branch
+                    for (int cb = 0; cb < 4; ++cb) colacc[cb] = sum_with_lane_xor16(sum_with_lane_xor32(colacc[cb]));
+                    if (q == 0) {
+#pragma unroll
+                        for (int cb = 0; cb < 4; ++cb) cw[cb * 16 + r] = colacc[cb];
                     }
                 }
             };
