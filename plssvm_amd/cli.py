@@ -140,7 +140,7 @@ def predict_main(argv=None) -> int:
         t0 = time.perf_counter()
         real_type = np.float32 if args.use_float_as_real_type else np.float64
         label_type = str if args.use_strings_as_labels else float
-        data = DataSet(filename=args.test, real_type=real_type, label_type=label_type) if _has_two_labels(args.test, label_type) else _unlabeled(args.test, real_type)
+        data = DataSet(filename=args.test, real_type=real_type, label_type=label_type) if _has_two_labels(args.test, label_type) else _unlabeled(args.test, real_type, label_type)
         model = Model.load(args.model, real_type=real_type, label_type=label_type)
         svm = make_csvm(args.backend, TargetPlatform(args.target_platform))
         predicted = svm.predict(model, data)
@@ -174,10 +174,11 @@ class _Unlabeled(DataSet):
     pass
 
 
-def _unlabeled(filename, real_type):
-    """a test file without labels, or with a single class: usable for prediction only (labels kept for the accuracy line)"""
+def _unlabeled(filename, real_type, label_type=float):
+    """a test file without labels, or with a single class: usable for prediction only (labels kept for the accuracy line, parsed with the
+    label type the command line asked for: --use_strings_as_labels must not turn "cat" into a float conversion error)"""
     from .io_libsvm import parse_libsvm_data
-    X, labels = parse_libsvm_data(filename, dtype=real_type)
+    X, labels = parse_libsvm_data(filename, dtype=real_type, label_type=label_type)
     ds = DataSet(X, None, real_type=real_type)
     ds._labels = labels
     return ds
