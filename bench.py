@@ -158,7 +158,13 @@ def main():
     ap.add_argument("--workload", default="c5", choices=sorted(WORKLOADS))
     ap.add_argument("--single-process", action="store_true", help="N > 1: ONE process drives all devices (lssvm_mi355_problem_create_multi) instead of one process per GPU")
     ap.add_argument("--devices", default=None, help="--single-process: comma separated HIP ordinals (repeats allowed), default 0..N-1")
-    ap.add_argument("--exchange", type=int, default=None, choices=[0, 1, 2], help="--single-process: 0 automatic, 1 RCCL, 2 peer kernels over xGMI")
+    ap.add_argument("--exchange", type=int, default=None, choices=[0, 1, 2],
+                    help="how the partial K*v vectors meet.  --single-process: 0 automatic, 1 RCCL, 2 peer kernels over xGMI.  One process per GPU: 1 (default) the "
+                         "library's RCCL communicator, 2 HIP IPC + the peer kernel (no RCCL inside the library)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the ranks' barrier / id exchange (nccl = RCCL)")
+    ap.add_argument("--rank-devices", default=None,
+                    help="one process per GPU: comma separated HIP ordinal per local rank (default: the local rank).  Repeats put several ranks on one device "
+                         "-- a functional check of the rank path on a one-GPU box (needs --exchange 2 --dist-backend gloo: RCCL refuses two ranks on one device)")
     ap.add_argument("--gram-mode", type=int, default=None, choices=[0, 1],
                     help="fp32 only: 1 = bf16x6 split on the bf16 matrix cores (library default), 0 = native v_mfma_f32 chains")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="set a library tuning knob (lssvm_mi355_set_option) before the problem is created; repeatable")
@@ -185,6 +191,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (the HIP path has no CPU fallback)")
+    rank_devices = [int(t) for t in args.rank_devices.split(",")] if args.rank_devices else None
+    if rank_devices is not None and not args.single_process:
+        if len(rank_devices) != world:
+            raise SystemExit(f"--rank-devices lists {len(rank_devices)} devices for {world} ranks")
+        local_rank = rank_devices[local_rank]  # from here on: this rank's HIP ordinal
     torch.cuda.set_device(local_rank)
 
     from plssvm_amd import _capi, backend
@@ -195,18 +206,22 @@ def main():
     if args.single_process:
         devices = [int(t) for t in args.devices.split(",")] if args.devices else list(range(args.gpus))
     shards = len(devices) if devices is not None else world
-    n_gpus = len(set(devices)) if devices is not None else world
+    n_gpus = len(set(devices)) if devices is not None else (len(set(rank_devices)) if rank_devices is not None else world)
 
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        # hand rank 0's RCCL unique id to every rank, then build the library's own communicator (one per process)
-        from plssvm_amd.sharding import init_library_communicator
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        if args.exchange != 2:
+            # hand rank 0's RCCL unique id to every rank, then build the library's own communicator (one per process)
+            from plssvm_amd.sharding import init_library_communicator
 
-        init_library_communicator(dist, local_rank)
+            init_library_communicator(dist, local_rank, device="cuda" if args.dist_backend == "nccl" else None)
 
     wl = WORKLOADS[args.workload]
     N, d = wl["n"], wl["d"]
@@ -238,6 +253,10 @@ def main():
         prob = backend.ResidentProblem(params, X, devices=devices)
     else:
         prob = backend.ResidentProblem(params, X, device=local_rank, rank=rank, world=world)
+        if world > 1 and args.exchange == 2:
+            from plssvm_amd.sharding import connect_peers
+
+            connect_peers(dist, prob)  # HIP IPC: every rank maps every rank's partial vector
     prob.cg_begin(y, 1e-30)  # eps^2 underflows: the loop only stops early on delta == 0 (fixed iteration count)
     if args.warmup > 0:
         prob.cg_step(args.warmup)
@@ -253,7 +272,7 @@ def main():
 
     elapsed = t1 - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     steps_done = int(i1["iterations"] - i0["iterations"])
@@ -306,7 +325,8 @@ def main():
         elif devices is not None:
             parallelism = f"row-block sharding x{shards}, one process driving devices {devices}"
         else:
-            parallelism = f"row-block sharding x{world}, one process per GPU"
+            parallelism = f"row-block sharding x{world}, one process per GPU" if rank_devices is None else f"row-block sharding x{world}, one process per rank on devices {rank_devices}"
+            parallelism += ", partial vectors over HIP IPC" if args.exchange == 2 else ", partial vectors over RCCL"
         out = {
             "metric": "effective K*d GFLOP/s of the CG iteration (2*n^2*d per iteration / time), RBF fp32 N x d" if wl["kernel"] == "rbf" and wl["dtype"] == "float32"
             else f"effective K*d GFLOP/s of the CG iteration, {wl['kernel']} {wl['dtype']}",
@@ -362,10 +382,13 @@ def main():
                 out["cpu_baseline_release"] = line_b
         print(json.dumps(out), flush=True)
 
+    if dist is not None:
+        dist.barrier()  # (HIP IPC: a rank's partial vector stays mapped by its peers until every rank is done)
     if prob is not None:
         prob.close()
     if dist is not None:
-        backend.comm_destroy()
+        if args.exchange != 2:
+            backend.comm_destroy()
         dist.destroy_process_group()
 
 

@@ -166,7 +166,8 @@ typedef struct lssvm_mi355_problem lssvm_mi355_problem; /* opaque */
 
 /* Row-block sharding descriptor.  rank r of `world` owns a contiguous block of output rows of the
  * implicit matrix; the data matrix is replicated.  world == 1: single GPU, no communicator needed.
- * For world > 1 the communicator must have been created with lssvm_mi355_comm_init on this rank first. */
+ * For world > 1 the ranks exchange their partial K*v once per implicit matvec: over RCCL (lssvm_mi355_comm_init on this rank first)
+ * or over HIP IPC (lssvm_mi355_problem_ipc_export / _connect after the problem exists); option "exchange" selects. */
 typedef struct lssvm_shard {
     int32_t rank;
     int32_t world;
@@ -185,6 +186,19 @@ int lssvm_mi355_shard_blocks(size_t num_points, int world, int rank, int symmetr
 int lssvm_mi355_comm_get_unique_id(unsigned char id_out[LSSVM_UNIQUE_ID_BYTES]);
 int lssvm_mi355_comm_init(int device, int rank, int world, const unsigned char id[LSSVM_UNIQUE_ID_BYTES]);
 int lssvm_mi355_comm_destroy(void);
+
+/* One process per GPU WITHOUT RCCL (option "exchange" = 2, or "exchange" = 0 and no communicator in this process): the ranks of one
+ * node map each other's partial K*v vectors with HIP IPC and every rank sums (symmetric variant) or gathers (full square) them in
+ * rank order with the peer kernel the single-process mode uses -- the same bits on every rank.  The ranks meet at host flags in
+ * POSIX shared memory, twice per implicit matvec.  After lssvm_mi355_problem_create(..., shard) on every rank:
+ *   1. every rank: lssvm_mi355_problem_ipc_export -> LSSVM_IPC_BLOB_BYTES bytes,
+ *   2. the application hands every rank the blobs of ALL ranks, concatenated in rank order (bench.py: torch.distributed all_gather),
+ *   3. every rank: lssvm_mi355_problem_ipc_connect.
+ * HSA_ENABLE_IPC_MODE_LEGACY=0 must be set where the host driver only supports dmabuf IPC.  A rank that waits longer than option
+ * "ipc_timeout_s" for its peers fails with LSSVM_ERR_COMM and makes the others fail too. */
+#define LSSVM_IPC_BLOB_BYTES 256
+int lssvm_mi355_problem_ipc_export(lssvm_mi355_problem *p, void *blob_out, size_t blob_bytes);
+int lssvm_mi355_problem_ipc_connect(lssvm_mi355_problem *p, const void *blobs, size_t total_bytes);
 
 /* upload X (N x d row-major, dtype per `dtype`), compute q, QA_cost and the per-row norms on `device`. */
 int lssvm_mi355_problem_create(lssvm_mi355_problem **out, const lssvm_params *params, int dtype, const void *X, int mem_kind,
@@ -261,7 +275,10 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *   "colslab_limit_mb" upper bound of the band slab (default 98304); 0 switches the symmetric variant off (full square)
  *   "exchange"      several devices in one process (the _multi entry points): 0 = automatic (RCCL when the listed devices are distinct, peer
  *                   kernels otherwise; default), 1 = RCCL all-reduce / all-gather, 2 = peer kernels: every device adds the partial vectors of all
- *                   devices through its xGMI peer mappings in rank order (bit-equal on all devices, deterministic)
+ *                   devices through its xGMI peer mappings in rank order (bit-equal on all devices, deterministic).
+ *                   One process per GPU (lssvm_shard): 0 = RCCL when lssvm_mi355_comm_init was called in this process, else HIP IPC;
+ *                   1 = RCCL; 2 = HIP IPC + the peer kernel (lssvm_mi355_problem_ipc_export / _connect)
+ *   "ipc_timeout_s" one process per GPU over HIP IPC: seconds a rank waits for its peers at an exchange before it fails (default 600)
  *   "check_shards"  1 = cg_finish verifies that the CG scalars of all local shards are bit-equal (default), 0 = skip the check
  *   "force_collective" 1 = run the per-matvec RCCL collective even with a world of 1 (testing aid; default 0)
  *   "skip_collective"  1 = problems created with world > 1 need no communicator and do NOT exchange their partial K*v (testing aid:

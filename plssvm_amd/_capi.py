@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "lssvm_mi355_generate_q_f32", "lssvm_mi355_generate_q_f64", "lssvm_mi355_run_device_kernel_f32", "lssvm_mi355_run_device_kernel_f64",
     "lssvm_mi355_calculate_w_f32", "lssvm_mi355_calculate_w_f64",
     "lssvm_mi355_shard_blocks", "lssvm_mi355_comm_get_unique_id", "lssvm_mi355_comm_init", "lssvm_mi355_comm_destroy",
-    "lssvm_mi355_problem_create", "lssvm_mi355_problem_create_multi", "lssvm_mi355_problem_destroy", "lssvm_mi355_problem_get_q", "lssvm_mi355_problem_matvec",
+    "lssvm_mi355_problem_create", "lssvm_mi355_problem_create_multi", "lssvm_mi355_problem_ipc_export", "lssvm_mi355_problem_ipc_connect", "lssvm_mi355_problem_destroy", "lssvm_mi355_problem_get_q", "lssvm_mi355_problem_matvec",
     "lssvm_mi355_cg_begin", "lssvm_mi355_cg_step", "lssvm_mi355_cg_finish", "lssvm_mi355_problem_synchronize", "lssvm_mi355_problem_info",
     "lssvm_mi355_set_option", "lssvm_mi355_get_option",
     "lssvm_mi355_libsvm_open", "lssvm_mi355_libsvm_fill_f32", "lssvm_mi355_libsvm_fill_f64", "lssvm_mi355_libsvm_close",
@@ -119,9 +119,10 @@ def device_name(device: int = 0) -> str:
 
 
 ABI_VERSION = 2
+LSSVM_IPC_BLOB_BYTES = 256
 # every tuning knob of lssvm_mi355_set_option (include/plssvm_amd.h)
 OPTION_NAMES = ["rbf_form", "rbf_direct_above", "rbf_fold", "j_chunk_tiles", "symmetric", "tile_kernel", "xcd_map", "lds_extra_kb", "debug_ablate", "item_order", "gram_mode", "mfma_shape",
-                "colslab_band_mb", "colslab_limit_mb", "force_collective", "skip_collective", "exchange", "check_shards"]
+                "colslab_band_mb", "colslab_limit_mb", "force_collective", "skip_collective", "exchange", "check_shards", "ipc_timeout_s"]
 
 
 def int_array(values):

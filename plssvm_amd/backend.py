@@ -249,3 +249,15 @@ class ResidentProblem:
 
     def synchronize(self):
         check(lib.lssvm_mi355_problem_synchronize(self._h))
+
+    def ipc_export(self) -> bytes:
+        """One process per GPU over HIP IPC: this rank's ``LSSVM_IPC_BLOB_BYTES`` blob (``lssvm_mi355_problem_ipc_export``)."""
+        buf = (C.c_ubyte * _capi.LSSVM_IPC_BLOB_BYTES)()
+        check(lib.lssvm_mi355_problem_ipc_export(self._h, buf, C.c_size_t(_capi.LSSVM_IPC_BLOB_BYTES)))
+        return bytes(buf)
+
+    def ipc_connect(self, blobs) -> None:
+        """``blobs``: the exports of ALL ranks in rank order (``lssvm_mi355_problem_ipc_connect``)."""
+        joined = b"".join(bytes(b) for b in blobs)
+        buf = (C.c_ubyte * len(joined)).from_buffer_copy(joined) if joined else None
+        check(lib.lssvm_mi355_problem_ipc_connect(self._h, buf, C.c_size_t(len(joined))))

@@ -264,6 +264,12 @@ int lssvm_mi355_problem_create_multi(lssvm_mi355_problem **out, const lssvm_para
         *out = reinterpret_cast<lssvm_mi355_problem *>(h.release());
     });
 }
+int lssvm_mi355_problem_ipc_export(lssvm_mi355_problem *p, void *blob_out, size_t blob_bytes) {
+    return guarded([&] { impl_of(p)->ipc_export(blob_out, blob_bytes); });
+}
+int lssvm_mi355_problem_ipc_connect(lssvm_mi355_problem *p, const void *blobs, size_t total_bytes) {
+    return guarded([&] { impl_of(p)->ipc_connect(blobs, total_bytes); });
+}
 int lssvm_mi355_problem_destroy(lssvm_mi355_problem *p) {
     return guarded([&] { delete reinterpret_cast<Handle *>(p); });
 }
@@ -340,6 +346,9 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
             lssvm::options().exchange = value;
         } else if (n == "check_shards") {
             lssvm::options().check_shards = value != 0 ? 1 : 0;
+        } else if (n == "ipc_timeout_s") {
+            LSSVM_REQUIRE(value >= 1, "ipc_timeout_s must be at least 1");
+            lssvm::options().ipc_timeout_s = value;
         } else if (n == "item_order") {
             LSSVM_REQUIRE(value >= 0 && value <= 2, "item_order must be 0, 1 or 2");
             lssvm::options().item_order = value;
@@ -386,6 +395,8 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             *value_out = lssvm::options().exchange;
         } else if (n == "check_shards") {
             *value_out = lssvm::options().check_shards;
+        } else if (n == "ipc_timeout_s") {
+            *value_out = lssvm::options().ipc_timeout_s;
         } else if (n == "item_order") {
             *value_out = lssvm::options().item_order;
         } else {

@@ -7,9 +7,14 @@
 #include "lssvm_kernels.hip.hpp"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <mutex>
+#include <thread>
+#include <cstdlib>
 
 namespace lssvm {
 
@@ -302,6 +307,128 @@ static T host_self_kernel(const lssvm_params &p, const std::vector<T> &x) {
     return std::pow(std::fma(static_cast<T>(p.gamma), val, static_cast<T>(p.coef0)), static_cast<T>(p.degree));
 }
 
+/* ------------------------------------------------------------------ IpcPeers: one process per GPU without RCCL ------------------------------------------------------------------ */
+constexpr uint32_t IPC_MAGIC = 0x4956534Cu;  // "LSVI"
+
+IpcPeers::IpcPeers(int rank_in, int world_in) : rank(rank_in), world(world_in), flags(static_cast<size_t>(world_in), nullptr), vectors(static_cast<size_t>(world_in), nullptr) {
+    static std::atomic<unsigned> serial{ 0 };
+    own_name = "/plssvm_amd." + std::to_string(static_cast<long>(getpid())) + "." + std::to_string(serial.fetch_add(1)) + "." + std::to_string(rank);
+    const int fd = shm_open(own_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) throw Error(LSSVM_ERR_COMM, "shm_open(" + own_name + ") failed: " + std::strerror(errno));
+    if (ftruncate(fd, 4096) != 0) {
+        (void) close(fd);
+        (void) shm_unlink(own_name.c_str());
+        throw Error(LSSVM_ERR_COMM, "ftruncate of the flag page failed");
+    }
+    void *m = mmap(nullptr, 4096, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    (void) close(fd);
+    if (m == MAP_FAILED) {
+        (void) shm_unlink(own_name.c_str());
+        throw Error(LSSVM_ERR_COMM, "mmap of the flag page failed");
+    }
+    own = new (m) IpcFlags{};  // a fresh segment is zero filled: ready = consumed = abort = 0
+    flags[static_cast<size_t>(rank)] = own;
+}
+
+IpcPeers::~IpcPeers() {
+    for (int r = 0; r < world; ++r) {
+        if (r == rank) continue;
+        if (vectors[static_cast<size_t>(r)] != nullptr) (void) hipIpcCloseMemHandle(vectors[static_cast<size_t>(r)]);
+        if (flags[static_cast<size_t>(r)] != nullptr) (void) munmap(flags[static_cast<size_t>(r)], 4096);
+    }
+    if (own != nullptr) (void) munmap(own, 4096);
+    if (!own_name.empty()) (void) shm_unlink(own_name.c_str());
+}
+
+void IpcPeers::connect(const IpcBlob *blobs, void *own_vector) {
+    LSSVM_REQUIRE(!connected, "the peers of this problem are connected already");
+    for (int r = 0; r < world; ++r) {
+        const IpcBlob &b = blobs[r];
+        LSSVM_REQUIRE(b.magic == IPC_MAGIC && b.rank == r && b.world == world, "blob " + std::to_string(r) + " is not the export of rank " + std::to_string(r) + " of this world");
+        if (r == rank) {
+            vectors[static_cast<size_t>(r)] = own_vector;
+            continue;
+        }
+        char name[sizeof(b.shm_name) + 1] = {};
+        std::memcpy(name, b.shm_name, sizeof(b.shm_name));
+        const int fd = shm_open(name, O_RDONLY, 0);
+        if (fd < 0) throw Error(LSSVM_ERR_COMM, std::string("shm_open(") + name + ") of rank " + std::to_string(r) + " failed: " + std::strerror(errno) + " (all ranks must run on one node)");
+        void *m = mmap(nullptr, 4096, PROT_READ, MAP_SHARED, fd, 0);
+        (void) close(fd);
+        if (m == MAP_FAILED) throw Error(LSSVM_ERR_COMM, "mmap of the flag page of rank " + std::to_string(r) + " failed");
+        flags[static_cast<size_t>(r)] = static_cast<IpcFlags *>(m);
+        void *ptr = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&ptr, b.mem, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void) hipGetLastError();
+            throw Error(LSSVM_ERR_COMM, "hipIpcOpenMemHandle of rank " + std::to_string(r) + "'s vector failed: " + hipGetErrorString(e) + " (HSA_ENABLE_IPC_MODE_LEGACY=0 set on every rank?)");
+        }
+        vectors[static_cast<size_t>(r)] = ptr;
+    }
+    connected = true;
+}
+
+void IpcPeers::wait_all(int which, uint64_t seq, double timeout_s) {
+    const double t0 = now_ms();
+    for (int r = 0; r < world; ++r) {
+        if (r == rank) continue;
+        const IpcFlags *f = flags[static_cast<size_t>(r)];
+        const std::atomic<uint64_t> &counter = which == 0 ? f->ready : f->consumed;
+        unsigned spins = 0;
+        while (counter.load(std::memory_order_acquire) < seq) {
+            if (f->abort.load(std::memory_order_acquire) != 0) {
+                own->abort.store(1, std::memory_order_release);
+                throw Error(LSSVM_ERR_COMM, "rank " + std::to_string(r) + " gave up (see its error)");
+            }
+            if (++spins > 2000) {
+                std::this_thread::yield();
+                if ((spins & 1023u) == 0 && now_ms() - t0 > timeout_s * 1e3) {
+                    own->abort.store(1, std::memory_order_release);
+                    throw Error(LSSVM_ERR_COMM, "rank " + std::to_string(r) + " did not reach implicit matvec " + std::to_string(seq) + " within " + std::to_string(timeout_s) + " s");
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ work-item geometry of the symmetric variant ------------------------------------------------------------------ */
+static long pairs_below(long b) { return b * (b - 1) / 2; }
+
+/* Row-block BANDS of equal triangle AREA whose column-sum records fit the slab budget (see Problem's constructor). */
+static std::vector<int> band_edges(int ib_begin, int ib_end_all, size_t real_size, const Options &o) {
+    const double rec_bytes = static_cast<double>(TILE) * real_size;
+    const double total_bytes = static_cast<double>(pairs_below(ib_end_all) - pairs_below(ib_begin)) * rec_bytes;
+    const double band_bytes = static_cast<double>(std::min(std::max<int64_t>(o.colslab_band_mb, 1), o.colslab_limit_mb)) * 1048576.0;
+    const int nbands = static_cast<int>(std::min<double>(std::max(1.0, std::ceil(total_bytes / band_bytes)), std::max(ib_end_all - ib_begin, 1)));
+    // equal areas: band k of this device ends where the triangle area reaches (k + 1) / nbands of the device's share
+    const double a0 = static_cast<double>(ib_begin) * ib_begin, a1 = static_cast<double>(ib_end_all) * ib_end_all;
+    std::vector<int> edge(nbands + 1, ib_begin);
+    for (int k = 1; k < nbands; ++k) {
+        const int e = static_cast<int>(std::llround(std::sqrt(a0 + (a1 - a0) * static_cast<double>(k) / nbands)));
+        edge[k] = std::min<int>(std::max(e, edge[k - 1]), ib_end_all);
+    }
+    edge[nbands] = ib_end_all;
+    return edge;
+}
+
+/* The (row block, column chunk) work items of one band in DISPATCH order: column chunk major (concurrent workgroups share the chunk; the
+   hardware dispatches workgroups in item order as CU slots free up).  item_order >= 1: the items cut short by the diagonal go last in
+   their band, longest first, so that the final dispatch round is made of the shortest items.  .x = absolute row block, .y = chunk. */
+static std::vector<int2> band_items(int band_begin, int band_end, int jc_tiles, int num_jc, int order) {
+    std::vector<int2> full, cut;
+    for (int jc = 0; jc < num_jc; ++jc) {
+        for (int kk = band_begin; kk < band_end; ++kk) {
+            const int ib = order == 2 ? band_end - 1 - (kk - band_begin) : kk;
+            if (jc * jc_tiles > ib) continue;
+            const bool is_cut = (jc + 1) * jc_tiles > ib + 1;  // fewer than jc_tiles tiles
+            (order >= 1 && is_cut ? cut : full).push_back(make_int2(ib, jc));
+        }
+    }
+    std::stable_sort(cut.begin(), cut.end(), [&](const int2 &x, const int2 &y) { return (x.x + 1 - x.y * jc_tiles) > (y.x + 1 - y.y * jc_tiles); });
+    full.insert(full.end(), cut.begin(), cut.end());
+    return full;
+}
+
 /* ------------------------------------------------------------------ Problem: one device's shard ------------------------------------------------------------------ */
 template <typename T>
 Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *X, int mem_kind, size_t num_points, size_t num_features, int device, int rank, int world) :
@@ -351,9 +478,14 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         // (measured 16 -> 64 tiles: +1.5 % at 100 000 points, +2 % at 300 000; the native kernels are flat or lose beyond 16)
         const bool split = std::is_same_v<T, float> && opt_.gram_mode == 1 && v2_eligible(opt_, ldx_probe, rbf_direct_)
                            && round_up(static_cast<long>(num_features), 64) <= SPLIT_MAX_FEATURES;
-        jc_tiles_ = static_cast<int>(std::min<long>(split ? 64 : 16, std::max<long>(2, (area + 2048) / 4096)));
+        const long cap = split ? 64 : 16;
+        jc_tiles_ = static_cast<int>(std::min<long>(cap, std::max<long>(2, (area + 2048) / 4096)));
     }
     num_jc_ = (num_tiles_ + jc_tiles_ - 1) / jc_tiles_;
+    if (const char *dbg = std::getenv("LSSVM_MI355_DEBUG"); dbg != nullptr && dbg[0] == '1') {
+        std::fprintf(stderr, "[plssvm_amd] shard %d/%d on device %d: row blocks [%d, %d) of %d, %d tiles per work item, symmetric %d\n", rank_, world_, device_, ib_begin_,
+                     ib_begin_ + num_ib_, num_tiles_, jc_tiles_, sym_ ? 1 : 0);
+    }
     inv_cost_ = static_cast<double>(T(1) / static_cast<T>(params_.cost));  // "1 / params.cost" in real_type, csvm.cpp:297
 
     // QA_cost = k(x_last, x_last) + 1/C, evaluated on the host in the real type (csvm.cpp:86)
@@ -421,46 +553,17 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         // (15.6 GB at 1M points in fp32); instead the device's row blocks are cut into bands of equal AREA whose records fit
         // colslab_band_mb, the tile kernel runs band by band into the SAME slab and the band's records are folded into K*v before the
         // next band overwrites them.  One band for up to ~360 000 points per device at the default 2 GiB.
-        const long ib_end_all = ib_begin_ + num_ib_;
-        const auto pairs_below = [](long b) { return b * (b - 1) / 2; };
-        const double rec_bytes = static_cast<double>(TILE) * sizeof(T);
-        const double total_bytes = static_cast<double>(pairs_below(ib_end_all) - pairs_below(ib_begin_)) * rec_bytes;
-        const double band_bytes = static_cast<double>(std::min(std::max<int64_t>(opt_.colslab_band_mb, 1), opt_.colslab_limit_mb)) * 1048576.0;
-        const int nbands = static_cast<int>(std::min<double>(std::max(1.0, std::ceil(total_bytes / band_bytes)), std::max(num_ib_, 1)));
-        // equal areas: band k of this device ends where the triangle area reaches (k + 1) / nbands of the device's share
-        const double a0 = static_cast<double>(ib_begin_) * ib_begin_, a1 = static_cast<double>(ib_end_all) * ib_end_all;
-        std::vector<int> edge(nbands + 1, ib_begin_);
-        for (int k = 1; k < nbands; ++k) {
-            const int e = static_cast<int>(std::llround(std::sqrt(a0 + (a1 - a0) * static_cast<double>(k) / nbands)));
-            edge[k] = std::min<int>(std::max(e, edge[k - 1]), static_cast<int>(ib_end_all));
-        }
-        edge[nbands] = static_cast<int>(ib_end_all);
-        // work items = the non-empty (row block, column chunk) pairs, band by band, column chunk major inside a band (concurrent
-        // workgroups share the chunk; the hardware dispatches workgroups in item order as CU slots free up).  item_order >= 1: the
-        // items cut short by the diagonal go last in their band, longest first, so that the final dispatch round is made of the shortest items.
+        const int ib_end_all = ib_begin_ + num_ib_;
+        const std::vector<int> edge = band_edges(ib_begin_, ib_end_all, sizeof(T), opt_);
         std::vector<int2> items;
-        const int order = static_cast<int>(opt_.item_order);
         long max_records = 1;
-        for (int k = 0; k < nbands; ++k) {
+        for (size_t k = 0; k + 1 < edge.size(); ++k) {
             Band band{};
             band.ib_begin = edge[k];
             band.ib_end = edge[k + 1];
             band.item_begin = static_cast<int>(items.size());
             band.pair_origin = pairs_below(band.ib_begin);
-            std::vector<int2> full, cut;
-            for (int jc = 0; jc < num_jc_; ++jc) {
-                for (int kk = band.ib_begin; kk < band.ib_end; ++kk) {
-                    const int ib = order == 2 ? band.ib_end - 1 - (kk - band.ib_begin) : kk;
-                    if (jc * jc_tiles_ > ib) continue;
-                    const bool is_cut = (jc + 1) * jc_tiles_ > ib + 1;  // fewer than jc_tiles tiles
-                    (order >= 1 && is_cut ? cut : full).push_back(make_int2(ib - ib_begin_, jc));
-                }
-            }
-            std::stable_sort(cut.begin(), cut.end(), [&](const int2 &x, const int2 &y) {
-                return (ib_begin_ + x.x + 1 - x.y * jc_tiles_) > (ib_begin_ + y.x + 1 - y.y * jc_tiles_);
-            });
-            items.insert(items.end(), full.begin(), full.end());
-            items.insert(items.end(), cut.begin(), cut.end());
+            for (const int2 &it : band_items(band.ib_begin, band.ib_end, jc_tiles_, num_jc_, static_cast<int>(opt_.item_order))) items.push_back(make_int2(it.x - ib_begin_, it.y));
             band.item_count = static_cast<int>(items.size()) - band.item_begin;
             max_records = std::max(max_records, pairs_below(band.ib_end) - band.pair_origin);
             if (band.ib_end > band.ib_begin) bands_.push_back(band);
@@ -653,10 +756,18 @@ Solver<T>::Solver(const lssvm_params &params, const void *X, int mem_kind, size_
         rank0 = shard->rank;
         world_ = shard->world;
         if (opt_.skip_collective == 0) {
-            LSSVM_REQUIRE(comm().comm != nullptr && comm().world == world_ && comm().rank == rank0,
-                          "row-block sharding requested but lssvm_mi355_comm_init was not called with the same rank/world");
-            LSSVM_REQUIRE(comm().device == devices[0], "the communicator was created for another device");
-            exchange_ = Exchange::process_rccl;
+            // exchange 1: RCCL (lssvm_mi355_comm_init first); 2: HIP IPC + peer kernels (lssvm_mi355_problem_ipc_export / _connect after
+            // the problem exists); 0: RCCL when this process has a communicator, else IPC
+            const bool have_comm = comm().comm != nullptr;
+            if (opt_.exchange == 1 || (opt_.exchange == 0 && have_comm)) {
+                LSSVM_REQUIRE(have_comm && comm().world == world_ && comm().rank == rank0,
+                              "row-block sharding over RCCL requested but lssvm_mi355_comm_init was not called with the same rank/world");
+                LSSVM_REQUIRE(comm().device == devices[0], "the communicator was created for another device");
+                exchange_ = Exchange::process_rccl;
+            } else {
+                LSSVM_REQUIRE(world_ <= MAX_LOCAL_DEVICES, "the peer exchange handles at most " + std::to_string(MAX_LOCAL_DEVICES) + " ranks");
+                exchange_ = Exchange::process_peer;
+            }
         }
     } else if (devices.size() == 1) {
         if (opt_.force_collective != 0 && comm().comm != nullptr && comm().world == 1) exchange_ = Exchange::process_rccl;
@@ -672,6 +783,13 @@ Solver<T>::Solver(const lssvm_params &params, const void *X, int mem_kind, size_
         shards_.push_back(std::make_unique<Problem<T>>(opt_, params, X, mem_kind, num_points, num_features, devices[r], rank0 + static_cast<int>(r), world_));
     }
     if (exchange_ == Exchange::local_rccl) local_comms_ = local_comms_for(devices);
+    if (exchange_ == Exchange::process_peer) {
+        Problem<T> &p = *shards_[0];
+        p.activate();
+        ipc_ = std::make_unique<IpcPeers>(rank0, world_);
+        p.Ksum_.alloc_zero(p.nvec_, p.stream());
+        p.Kres_ = p.Ksum_.p;
+    }
     if (exchange_ == Exchange::peer) {
         for (auto &p : shards_) {
             p->activate();
@@ -698,6 +816,54 @@ Solver<T>::~Solver() {
         (void) hipSetDevice(p->device_);
         (void) hipStreamSynchronize(p->stream());
     }
+    if (ipc_ && ipc_->connected && xseq_ > 0 && ipc_->own->abort.load() == 0) {
+        // the peers read this rank's partial vector through their IPC mapping: it may be freed only after their last read
+        try {
+            ipc_->wait_all(1, xseq_, 30.0);
+        } catch (...) {
+        }
+    }
+}
+
+template <typename T>
+void Solver<T>::ipc_export(void *blob_out, size_t blob_bytes) {
+    LSSVM_REQUIRE(exchange_ == Exchange::process_peer, "this problem does not use the IPC peer exchange (one process per GPU, option exchange = 2 or no RCCL communicator)");
+    LSSVM_REQUIRE(blob_out != nullptr && blob_bytes >= IPC_BLOB_BYTES, "the blob buffer must hold LSSVM_IPC_BLOB_BYTES bytes");
+    Problem<T> &p = *shards_[0];
+    p.activate();
+    LSSVM_HIP_CHECK(hipStreamSynchronize(p.stream()));
+    IpcBlob b{};
+    b.magic = IPC_MAGIC;
+    b.rank = ipc_->rank;
+    b.world = world_;
+    b.device = p.device_;
+    b.nvec = static_cast<uint64_t>(p.nvec_);
+    b.real_size = sizeof(T);
+    b.pid = static_cast<int32_t>(getpid());
+    const hipError_t e = hipIpcGetMemHandle(&b.mem, p.Kv_.p);
+    if (e != hipSuccess) {
+        (void) hipGetLastError();
+        throw Error(LSSVM_ERR_COMM, std::string("hipIpcGetMemHandle failed: ") + hipGetErrorString(e) + " (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)");
+    }
+    LSSVM_REQUIRE(ipc_->own_name.size() < sizeof(b.shm_name), "flag page name too long");
+    std::memcpy(b.shm_name, ipc_->own_name.data(), ipc_->own_name.size());
+    std::memset(blob_out, 0, IPC_BLOB_BYTES);
+    std::memcpy(blob_out, &b, sizeof(b));
+}
+
+template <typename T>
+void Solver<T>::ipc_connect(const void *blobs, size_t total_bytes) {
+    LSSVM_REQUIRE(exchange_ == Exchange::process_peer, "this problem does not use the IPC peer exchange");
+    LSSVM_REQUIRE(blobs != nullptr && total_bytes == static_cast<size_t>(world_) * IPC_BLOB_BYTES, "expected world x LSSVM_IPC_BLOB_BYTES bytes, the exports of all ranks in rank order");
+    Problem<T> &p = *shards_[0];
+    p.activate();
+    std::vector<IpcBlob> all(static_cast<size_t>(world_));
+    for (int r = 0; r < world_; ++r) {
+        std::memcpy(&all[static_cast<size_t>(r)], static_cast<const unsigned char *>(blobs) + static_cast<size_t>(r) * IPC_BLOB_BYTES, sizeof(IpcBlob));
+        LSSVM_REQUIRE(all[static_cast<size_t>(r)].nvec == static_cast<uint64_t>(p.nvec_) && all[static_cast<size_t>(r)].real_size == sizeof(T),
+                      "rank " + std::to_string(r) + " holds a problem of another size or type");
+    }
+    ipc_->connect(all.data(), p.Kv_.p);
 }
 
 template <typename T>
@@ -743,6 +909,31 @@ void Solver<T>::exchange() {
             nccl_check(c.pGroupEnd(), "ncclGroupEnd");
             break;
         }
+        case Exchange::process_peer: {
+            // one process per GPU without RCCL.  Kernel boundaries are the only device-side ordering used: a rank publishes "ready" on its
+            // flag page (host memory shared by the node's ranks) AFTER its stream has drained, i.e. after the tile kernels that wrote the
+            // partial vector have ended; the peers then read that vector through their IPC mapping in a kernel launched afterwards
+            Problem<T> &p = *shards_[0];
+            LSSVM_REQUIRE(ipc_ && ipc_->connected, "the peers of this problem were not connected (lssvm_mi355_problem_ipc_export on every rank, then lssvm_mi355_problem_ipc_connect)");
+            p.activate();
+            const double timeout_s = static_cast<double>(std::max<int64_t>(opt_.ipc_timeout_s, 1));
+            ++xseq_;
+            LSSVM_HIP_CHECK(hipStreamSynchronize(p.stream()));
+            ipc_->own->ready.store(xseq_, std::memory_order_release);
+            ipc_->wait_all(0, xseq_, timeout_s);
+            PeerPtrs src{};
+            for (int r = 0; r < world_; ++r) src.p[r] = ipc_->vectors[static_cast<size_t>(r)];
+            const int n = static_cast<int>(count);
+            if (sym) {
+                hipLaunchKernelGGL(k_peer_sum<T>, dim3((n + 255) / 256), dim3(256), 0, p.stream(), src, world_, n, p.Ksum_.p);
+            } else {
+                hipLaunchKernelGGL(k_peer_gather<T>, dim3((n + 255) / 256), dim3(256), 0, p.stream(), src, static_cast<int>(slice), n, p.Ksum_.p);
+            }
+            LSSVM_HIP_CHECK(hipGetLastError());
+            LSSVM_HIP_CHECK(hipStreamSynchronize(p.stream()));
+            ipc_->own->consumed.store(xseq_, std::memory_order_release);
+            break;
+        }
         case Exchange::peer: {
             PeerPtrs src{};
             for (size_t r = 0; r < shards_.size(); ++r) src.p[r] = shards_[r]->Kv_.p;
@@ -780,6 +971,10 @@ template <typename T>
 void Solver<T>::apply_K(Vec which) {
     const bool skip = world_ > 1 && opt_.skip_collective != 0;  // testing aid: this rank's share only
     const bool collective = exchange_ != Exchange::none;
+    if (exchange_ == Exchange::process_peer && xseq_ > 0 && !skip) {
+        // this rank's partial vector is about to be overwritten: every peer must have read the previous one
+        ipc_->wait_all(1, xseq_, static_cast<double>(std::max<int64_t>(opt_.ipc_timeout_s, 1)));
+    }
     for (auto &p : shards_) {
         p->activate();
         p->enqueue_apply_K_local(vec_of(*p, which), (p->sym_ && collective) || skip);
@@ -991,7 +1186,7 @@ void Solver<T>::fill_info(lssvm_cg_info *info) {
     info->rbf_direct = p0.rbf_direct_ ? 1 : 0;
     info->rbf_exponent_scale = p0.rbf_r2_;
     info->tile_launches_per_matvec = static_cast<int32_t>(std::max<size_t>(p0.bands_.size(), 1));
-    info->exchange = exchange_ == Exchange::none ? 0 : (exchange_ == Exchange::peer ? 2 : 1);
+    info->exchange = exchange_ == Exchange::none ? 0 : ((exchange_ == Exchange::peer || exchange_ == Exchange::process_peer) ? 2 : 1);
 }
 
 template class Solver<float>;

@@ -21,6 +21,7 @@
 #include <rccl/rccl.h>  // types and prototypes only: the library is dlopen'ed lazily (single-GPU use needs no RCCL)
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -76,6 +77,7 @@ struct Options {
     int64_t skip_collective = 0;   // testing aid: sharded problems (world > 1) need no communicator and leave their PARTIAL K*v un-exchanged
     int64_t exchange = 0;          // several devices in ONE process: 0 = automatic (RCCL when the devices are distinct, else peer kernels), 1 = RCCL all-reduce / all-gather
                                    // (ncclCommInitAll), 2 = peer kernels: every device sums the partial vectors of all devices over xGMI in rank order
+    int64_t ipc_timeout_s = 600;   // one process per GPU over HIP IPC: how long a rank waits for its peers at an exchange before it gives up
     int64_t check_shards = 1;      // several devices in ONE process: cg_finish verifies that the CG scalars of all shards are bit-equal
 };
 /* process-wide DEFAULTS (lssvm_mi355_set_option); every problem takes a snapshot when it is created */
@@ -309,6 +311,47 @@ struct ProblemBase {
     virtual void cg_finish(void *alpha_out, double *rho_out, lssvm_cg_info *info) = 0;
     virtual void synchronize() = 0;
     virtual void fill_info(lssvm_cg_info *info) = 0;
+    virtual void ipc_export(void *blob_out, size_t blob_bytes) = 0;
+    virtual void ipc_connect(const void *blobs, size_t total_bytes) = 0;
+};
+
+/* ------------------------------------------------------------------ one process per GPU without RCCL: HIP IPC + host flags ------------------------------------------------------------------ */
+/* What one rank hands to the others (plain bytes; the application moves them, like the RCCL unique id). */
+constexpr size_t IPC_BLOB_BYTES = 256;
+struct IpcBlob {
+    uint32_t magic;
+    int32_t rank, world, device;
+    uint64_t nvec;
+    uint32_t real_size;
+    int32_t pid;
+    hipIpcMemHandle_t mem;  // this rank's partial K*v vector
+    char shm_name[64];      // this rank's flag page (POSIX shared memory)
+};
+static_assert(sizeof(IpcBlob) <= IPC_BLOB_BYTES, "IpcBlob must fit the published blob size");
+
+/* one rank's flag page: sequence numbers of the implicit matvecs, written by the owner only */
+struct IpcFlags {
+    std::atomic<uint64_t> ready;     // matvec s: my partial vector is complete in HBM
+    std::atomic<uint64_t> consumed;  // matvec s: I have read every peer's partial vector
+    std::atomic<uint32_t> abort;     // I gave up (error / timeout): peers stop waiting
+};
+
+class IpcPeers {
+  public:
+    IpcPeers(int rank, int world);
+    ~IpcPeers();
+    IpcPeers(const IpcPeers &) = delete;
+    IpcPeers &operator=(const IpcPeers &) = delete;
+    void connect(const IpcBlob *blobs, void *own_vector);
+    /* block until every peer's `ready` (which = 0) or `consumed` (which = 1) counter has reached seq */
+    void wait_all(int which, uint64_t seq, double timeout_s);
+
+    int rank, world;
+    std::string own_name;
+    IpcFlags *own = nullptr;
+    std::vector<IpcFlags *> flags;  // [world], own included
+    std::vector<void *> vectors;    // [world]: the partial K*v vectors, own = the local pointer
+    bool connected = false;
 };
 
 /* communicators of the devices of ONE process (ncclCommInitAll); cached per device list, destroyed at exit */
@@ -339,9 +382,11 @@ class Solver final : public ProblemBase {
     void cg_finish(void *alpha_out, double *rho_out, lssvm_cg_info *info) override;
     void synchronize() override;
     void fill_info(lssvm_cg_info *info) override;
+    void ipc_export(void *blob_out, size_t blob_bytes) override;
+    void ipc_connect(const void *blobs, size_t total_bytes) override;
 
   private:
-    enum class Exchange { none, process_rccl, local_rccl, peer };
+    enum class Exchange { none, process_rccl, local_rccl, peer, process_peer };
     enum class Vec { d, x, tmp };
     void apply_K(Vec which);  // every shard: Kres_ <- K * v (all rows)
     void exchange();
@@ -352,6 +397,8 @@ class Solver final : public ProblemBase {
     std::vector<std::unique_ptr<Problem<T>>> shards_;
     Exchange exchange_ = Exchange::none;
     std::shared_ptr<LocalComms> local_comms_;
+    std::unique_ptr<IpcPeers> ipc_;  // Exchange::process_peer
+    uint64_t xseq_ = 0;              // implicit matvecs exchanged so far
     int world_ = 1;  // shards of the problem in total (all processes)
 
     // CG state (host side)

@@ -14,7 +14,7 @@ from __future__ import annotations
 
 TILE = 128  # rows per block of the tile kernel (plssvm_amd/csrc/lssvm_types.hpp)
 
-__all__ = ["TILE", "row_block_partition", "sym_block_partition", "work_share", "triangle_share", "padded_vector_length", "exchange_unique_id", "init_library_communicator"]
+__all__ = ["TILE", "row_block_partition", "sym_block_partition", "work_share", "triangle_share", "padded_vector_length", "exchange_unique_id", "init_library_communicator", "connect_peers"]
 
 
 def row_block_partition(n: int, world: int):
@@ -94,9 +94,19 @@ def exchange_unique_id(dist, get_unique_id, device=None) -> bytes:
     return bytes(uid.cpu().numpy().tobytes())
 
 
-def init_library_communicator(dist, local_device: int) -> None:
-    """Create libplssvm_amd's own RCCL communicator for this process from a torch.distributed (nccl) process group."""
+def init_library_communicator(dist, local_device: int, device="cuda") -> None:
+    """Create libplssvm_amd's own RCCL communicator for this process from a torch.distributed process group (``device`` = where the
+    id travels: "cuda" for the nccl backend, None for gloo)."""
     from . import backend
 
-    uid = exchange_unique_id(dist, backend.comm_get_unique_id, device="cuda")
+    uid = exchange_unique_id(dist, backend.comm_get_unique_id, device=device)
     backend.comm_init(local_device, dist.get_rank(), dist.get_world_size(), uid)
+
+
+def connect_peers(dist, problem) -> None:
+    """One process per GPU over HIP IPC (no RCCL inside the library): every rank exports its blob, all ranks receive all blobs in rank
+    order through ``dist.all_gather_object`` (any backend) and connect (``lssvm_mi355_problem_ipc_export`` / ``_connect``)."""
+    blobs = [None] * dist.get_world_size()
+    dist.all_gather_object(blobs, problem.ipc_export())
+    problem.ipc_connect(blobs)
+    dist.barrier()  # every rank has mapped every vector before anyone starts to exchange

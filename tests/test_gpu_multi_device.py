@@ -160,21 +160,54 @@ def test_options_are_snapshotted_per_problem():
         assert prob.info()["gram_mode"] == 0 and prob.info()["symmetric"] == 0
 
 
+def _run_ranks(tmp_path, world, extra, one_device):
+    """Start `world` fresh child processes of tests/tools/mp_rank.py (one rank each) and collect what they wrote."""
+    port = 29000 + (os.getpid() * 7 + len(os.listdir(tmp_path)) * 13 + world) % 2000
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if one_device else str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "tools", "mp_rank.py"), "--out", str(tmp_path / f"rank{r}.json"), *extra], env=env, cwd=ROOT))
+    codes = []
+    try:
+        for pr in procs:
+            codes.append(pr.wait(timeout=420))
+    finally:
+        for pr in procs:  # (exactly the processes started above)
+            if pr.poll() is None:
+                pr.kill()
+    assert codes == [0] * world
+    return [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+
+
 @pytest.mark.parametrize("sym", [1, 0])
-def test_one_process_per_gpu_world_of_two_through_the_library(tmp_path, sym):
+def test_one_process_per_gpu_world_of_two_over_rccl(tmp_path, sym):
     """Two fresh child processes, RCCL between them: rank r creates ResidentProblem(rank=r, world=2) after lssvm_mi355_comm_init and
     runs a matvec and CG steps; rank 0 compares with its own single-GPU run (tests/tools/mp_rank.py)."""
     if _capi.device_count() < 2:
         pytest.skip("needs two devices (RCCL refuses two ranks on one device)")
-    port = 29000 + os.getpid() % 2000 + sym
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "tools", "mp_rank.py"), "--symmetric", str(sym), "--out", str(tmp_path / f"rank{r}.json")],
-                                      env=env, cwd=ROOT))
-    codes = [pr.wait(timeout=600) for pr in procs]
-    assert codes == [0, 0]
-    res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    res = _run_ranks(tmp_path, 2, ["--symmetric", str(sym), "--exchange", "1"], one_device=False)
     assert res[0]["alpha_sha"] == res[1]["alpha_sha"]  # both ranks hold the same bits
     assert res[0]["matvec_err"] < 64 * np.finfo(np.float32).eps and res[0]["alpha_err64"] < 2 * res[0]["single_err64"] + 1e-4
     assert res[0]["devices_used"] == 2 and res[0]["exchange"] == 1
+
+
+@pytest.mark.parametrize("world, sym, kernel, dtype, steps", [(2, 1, "rbf", "float32", 8), (2, 0, "rbf", "float32", 8), (3, 1, "polynomial", "float64", 3),
+                                                              (3, 0, "linear", "float32", 8), (4, 1, "linear", "float32", 55)])
+def test_one_process_per_rank_over_hip_ipc(tmp_path, world, sym, kernel, dtype, steps):
+    """One process per rank THROUGH THE LIBRARY without RCCL: the ranks map each other's partial K*v with HIP IPC and sum / gather them
+    with the peer kernel (lssvm_mi355_problem_ipc_export / _connect).  Runs with all ranks on one device too (this pool's boxes have
+    one), and on one device per rank where there are enough.  Every rank must end with the same bits; the full-square variant must
+    reproduce the single-GPU bits (row-owned sums).  (fp64: three iterations -- the CG recursion amplifies the
+    re-association of the sharded sums from iteration to iteration; the 55-step case crosses the residual refresh.)"""
+    one_device = _capi.device_count() < world
+    res = _run_ranks(tmp_path, world, ["--symmetric", str(sym), "--exchange", "2", "--kernel", kernel, "--dtype", dtype, "--points", "5000", "--features", "96", "--steps", str(steps)],
+                     one_device=one_device)
+    assert len({r["alpha_sha"] for r in res}) == 1 and len({r["rho"] for r in res}) == 1
+    assert all(r["devices_used"] == world and r["exchange"] == 2 and r["symmetric"] == sym for r in res)
+    eps = np.finfo(np.dtype(dtype)).eps
+    if sym:
+        assert res[0]["matvec_err"] < 64 * eps
+        assert res[0]["alpha_err64"] < 2 * res[0]["single_err64"] + (1e-4 if dtype == "float32" else 1e-8)
+    else:
+        assert res[0]["matvec_equal_bits"] and res[0]["alpha_equal_bits"]

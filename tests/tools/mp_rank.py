@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One rank of a one-process-per-GPU run THROUGH THE LIBRARY (tests/test_gpu_multi_device.py starts two of these as fresh child
-processes; it also runs under torchrun).  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment.  The RCCL unique id is
-handed over through a gloo process group (CPU), so the only RCCL user in the process is libplssvm_amd.so itself.  Rank r runs
+processes; it also runs under torchrun).  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment.  --exchange 1: the RCCL
+unique id is handed over through a gloo process group (CPU), so the only RCCL user in the process is libplssvm_amd.so itself;
+--exchange 2: no RCCL at all, the ranks map each other's partial vectors with HIP IPC (works with several ranks on ONE device).  Rank r runs
 ResidentProblem(rank=r, world=W): one implicit matvec and a few CG iterations; rank 0 also runs the single-GPU problem and writes
 the distances.  Every rank writes a hash of its alpha: all ranks must hold the same bits."""
 
@@ -20,6 +21,10 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--symmetric", type=int, default=1)
+    ap.add_argument("--exchange", type=int, default=1, choices=[1, 2])
+    ap.add_argument("--kernel", default="rbf")
+    ap.add_argument("--dtype", default="float32")
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--points", type=int, default=6000)
     ap.add_argument("--features", type=int, default=128)
     ap.add_argument("--out", required=True)
@@ -32,40 +37,51 @@ def main():
     from plssvm_amd import _capi, backend
     from plssvm_amd.datagen import make_blobs_pm1
     from plssvm_amd.parameter import Parameter
-    from plssvm_amd.sharding import exchange_unique_id
+    from plssvm_amd.sharding import connect_peers, exchange_unique_id
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        uid = exchange_unique_id(dist, backend.comm_get_unique_id, device=None)
-        backend.comm_init(local, rank, world, uid)
+        if args.exchange == 1:
+            uid = exchange_unique_id(dist, backend.comm_get_unique_id, device=None)
+            backend.comm_init(local, rank, world, uid)
+        _capi.set_option("exchange", args.exchange)
         _capi.set_option("symmetric", args.symmetric)
-        X, y = make_blobs_pm1(args.points, args.features, seed=5, dtype=np.float32)
-        p = Parameter(kernel_type="rbf")
+        if not args.symmetric:
+            _capi.set_option("j_chunk_tiles", 2)  # equal chunking for every world size: the full-square rows associate identically
+        dt = np.dtype(args.dtype)
+        X, y = make_blobs_pm1(args.points, args.features, seed=5, dtype=dt)
+        p = Parameter(kernel_type=args.kernel)
         n = args.points - 1
-        v = np.random.default_rng(9).uniform(-1, 1, size=n).astype(np.float32)
-        zero = np.zeros(n, np.float32)
+        v = np.random.default_rng(9).uniform(-1, 1, size=n).astype(dt)
+        zero = np.zeros(n, dt)
         with backend.ResidentProblem(p, X, device=local, rank=rank, world=world) as prob:
+            if args.exchange == 2:
+                connect_peers(dist, prob)
             got = prob.matvec(v, zero, 1.0)
             prob.cg_begin(y, 1e-30)
-            prob.cg_step(12)
+            prob.cg_step(args.steps)
             alpha, rho, info = prob.cg_finish()
+            dist.barrier()  # (IPC: a rank's vector stays mapped by its peers until they are done)
         out = {"rank": rank, "alpha_sha": hashlib.sha256(alpha.tobytes()).hexdigest(), "rho": float(rho), "devices_used": int(info["devices_used"]),
                "exchange": int(info["exchange"]), "symmetric": int(info["symmetric"])}
         if rank == 0:
             with backend.ResidentProblem(p, X, device=local) as single:
                 want = single.matvec(v, zero, 1.0)
                 single.cg_begin(y, 1e-30)
-                single.cg_step(12)
+                single.cg_step(args.steps)
                 a1, rho1, _ = single.cg_finish()
             with backend.ResidentProblem(p, X.astype(np.float64), device=local) as truth:  # the same iterations in float64: the yardstick
                 truth.cg_begin(y.astype(np.float64), 1e-30)
-                truth.cg_step(12)
+                truth.cg_step(args.steps)
                 a64, _, _ = truth.cg_finish()
             out["matvec_err"] = float(np.max(np.abs(got - want)) / np.max(np.abs(want)))
+            out["matvec_equal_bits"] = bool(np.array_equal(got, want))
+            out["alpha_equal_bits"] = bool(np.array_equal(alpha, a1))
             out["alpha_err64"] = float(np.max(np.abs(alpha - a64)) / np.max(np.abs(a64)))
             out["single_err64"] = float(np.max(np.abs(a1 - a64)) / np.max(np.abs(a64)))
         dist.barrier()
-        backend.comm_destroy()
+        if args.exchange == 1:
+            backend.comm_destroy()
         with open(args.out, "w") as f:
             json.dump(out, f)
     finally:
