@@ -209,6 +209,7 @@ def main():
     n_gpus = len(set(devices)) if devices is not None else (len(set(rank_devices)) if rank_devices is not None else world)
 
     dist = None
+    exchange_note = None
     if world > 1:
         import torch.distributed as dist
 
@@ -218,10 +219,23 @@ def main():
         else:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         if args.exchange != 2:
-            # hand rank 0's RCCL unique id to every rank, then build the library's own communicator (one per process)
+            # hand rank 0's RCCL unique id to every rank, then build the library's own communicator (one per process); if ANY rank fails
+            # to build it, every rank falls back to the HIP IPC exchange (same partition, same sum order) and the JSON line says so
             from plssvm_amd.sharding import init_library_communicator
 
-            init_library_communicator(dist, local_rank, device="cuda" if args.dist_backend == "nccl" else None)
+            ok, why = 1, ""
+            try:
+                init_library_communicator(dist, local_rank, device="cuda" if args.dist_backend == "nccl" else None)
+            except Exception as e:  # noqa: BLE001  (PlssvmError from the library, or a torch.distributed error)
+                ok, why = 0, f"{type(e).__name__}: {e}"
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if ok:
+                    backend.comm_destroy()
+                args.exchange = 2
+                exchange_note = "the library's RCCL communicator could not be built on every rank" + (f" ({why})" if why else "") + ": HIP IPC exchange instead"
+                print(f"[bench rank {rank}] {exchange_note}", file=sys.stderr, flush=True)
 
     wl = WORKLOADS[args.workload]
     N, d = wl["n"], wl["d"]
@@ -327,6 +341,8 @@ def main():
         else:
             parallelism = f"row-block sharding x{world}, one process per GPU" if rank_devices is None else f"row-block sharding x{world}, one process per rank on devices {rank_devices}"
             parallelism += ", partial vectors over HIP IPC" if args.exchange == 2 else ", partial vectors over RCCL"
+            if exchange_note:
+                parallelism += f" [{exchange_note}]"
         out = {
             "metric": "effective K*d GFLOP/s of the CG iteration (2*n^2*d per iteration / time), RBF fp32 N x d" if wl["kernel"] == "rbf" and wl["dtype"] == "float32"
             else f"effective K*d GFLOP/s of the CG iteration, {wl['kernel']} {wl['dtype']}",

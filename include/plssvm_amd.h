@@ -279,6 +279,10 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *                   One process per GPU (lssvm_shard): 0 = RCCL when lssvm_mi355_comm_init was called in this process, else HIP IPC;
  *                   1 = RCCL; 2 = HIP IPC + the peer kernel (lssvm_mi355_problem_ipc_export / _connect)
  *   "ipc_timeout_s" one process per GPU over HIP IPC: seconds a rank waits for its peers at an exchange before it fails (default 600)
+ *   "enqueue_ahead_below_us" CG loop: while an implicit matvec takes less than this many microseconds (default 5000), the direction update and
+ *                   the NEXT matvec are enqueued before the host reads the stop test of the current iteration, so the device never waits for
+ *                   the host; they touch d and K*d only, so a converged solve ends exactly where the reference's does, one matvec is discarded.
+ *                   0 = the host reads every stop test before it enqueues anything further
  *   "check_shards"  1 = cg_finish verifies that the CG scalars of all local shards are bit-equal (default), 0 = skip the check
  *   "force_collective" 1 = run the per-matvec RCCL collective even with a world of 1 (testing aid; default 0)
  *   "skip_collective"  1 = problems created with world > 1 need no communicator and do NOT exchange their partial K*v (testing aid:

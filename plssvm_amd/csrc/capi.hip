@@ -349,6 +349,9 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
         } else if (n == "ipc_timeout_s") {
             LSSVM_REQUIRE(value >= 1, "ipc_timeout_s must be at least 1");
             lssvm::options().ipc_timeout_s = value;
+        } else if (n == "enqueue_ahead_below_us") {
+            LSSVM_REQUIRE(value >= 0, "enqueue_ahead_below_us must not be negative");
+            lssvm::options().enqueue_ahead_below_us = value;
         } else if (n == "item_order") {
             LSSVM_REQUIRE(value >= 0 && value <= 2, "item_order must be 0, 1 or 2");
             lssvm::options().item_order = value;
@@ -397,6 +400,8 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             *value_out = lssvm::options().check_shards;
         } else if (n == "ipc_timeout_s") {
             *value_out = lssvm::options().ipc_timeout_s;
+        } else if (n == "enqueue_ahead_below_us") {
+            *value_out = lssvm::options().enqueue_ahead_below_us;
         } else if (n == "item_order") {
             *value_out = lssvm::options().item_order;
         } else {

@@ -77,6 +77,7 @@ struct Options {
     int64_t skip_collective = 0;   // testing aid: sharded problems (world > 1) need no communicator and leave their PARTIAL K*v un-exchanged
     int64_t exchange = 0;          // several devices in ONE process: 0 = automatic (RCCL when the devices are distinct, else peer kernels), 1 = RCCL all-reduce / all-gather
                                    // (ncclCommInitAll), 2 = peer kernels: every device sums the partial vectors of all devices over xGMI in rank order
+    int64_t enqueue_ahead_below_us = 5000;  // CG: implicit matvecs shorter than this are enqueued ahead of the previous iteration's stop test (0 = never)
     int64_t ipc_timeout_s = 600;   // one process per GPU over HIP IPC: how long a rank waits for its peers at an exchange before it gives up
     int64_t check_shards = 1;      // several devices in ONE process: cg_finish verifies that the CG scalars of all shards are bit-equal
 };
@@ -399,6 +400,7 @@ class Solver final : public ProblemBase {
     std::shared_ptr<LocalComms> local_comms_;
     std::unique_ptr<IpcPeers> ipc_;  // Exchange::process_peer
     uint64_t xseq_ = 0;              // implicit matvecs exchanged so far
+    Event ev_delta_;                 // shard 0's stream: delta of the iteration is on the host
     int world_ = 1;  // shards of the problem in total (all processes)
 
     // CG state (host side)

@@ -469,6 +469,32 @@ def test_resident_problem_stepping_equals_one_shot():
     assert np.array_equal(a, a2) and rho == rho2
 
 
+@pytest.mark.parametrize("kernel, dtype, devices", [("rbf", np.float32, None), ("linear", np.float64, None), ("polynomial", np.float32, [0, 0, 0])])
+def test_matvecs_enqueued_ahead_of_the_stop_test_change_nothing(kernel, dtype, devices):
+    """Option enqueue_ahead_below_us: the direction update and the next implicit matvec enter the queue before the host has read the
+    stop test.  Same bits, same iteration count, same stop as the fully synchronous loop -- in a solve that converges (one discarded
+    matvec), in one that runs out of iterations, stepped in pieces across the residual refresh, and sharded."""
+    X, y = make_blobs_pm1(1500, 40, seed=21, dtype=dtype)
+    p = Parameter(kernel_type=kernel, cost=3.0)
+    runs = {}
+    for ahead in (0, 5000):
+        _capi.set_option("enqueue_ahead_below_us", ahead)
+        conv = backend.solve_system_of_linear_equations(p, X, y, 1e-3, 1500, devices=devices)
+        fixed = backend.solve_system_of_linear_equations(p, X, y, 1e-30, 57, devices=devices)
+        with backend.ResidentProblem(p, X, **({"devices": devices} if devices else {})) as prob:
+            prob.cg_begin(y, 1e-30)
+            for k in (3, 1, 44, 9):
+                prob.cg_step(k)
+            stepped = prob.cg_finish()
+        runs[ahead] = (conv, fixed, stepped)
+    (c0, f0, s0), (c1, f1, s1) = runs[0], runs[5000]
+    assert c0[2]["converged"] == 1 and c1[2]["converged"] == 1 and c0[2]["iterations"] == c1[2]["iterations"] < 1500
+    assert c1[2]["matvec_launches"] == c0[2]["matvec_launches"] + 1  # the matvec that was in the queue when the stop test fired
+    for (a, rho, info), (b, rho_b, info_b) in ((c0, c1), (f0, f1), (s0, s1), (f0, s1)):
+        assert np.array_equal(a, b) and rho == rho_b and info["iterations"] == info_b["iterations"] and info["residuum"] == info_b["residuum"]
+    assert f1[2]["matvec_launches"] == f0[2]["matvec_launches"] == 57 + 2
+
+
 def test_sub_sampled_rows_of_a_large_matvec_vs_oracle(oracle):
     """BASELINE configs[1] shape (50 000 x 128 rbf fp32): the full CPU product takes minutes, so 256 seeded rows of one
     implicit matvec are checked against the oracle's row-owned product."""
