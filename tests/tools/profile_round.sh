@@ -11,6 +11,9 @@ for wl in c2 c3 c4 c5; do
   st=10; [ $wl = c5 ] && st=5
   python3 bench.py --workload $wl --steps $st --warmup 2 > $O/${TAG}_bench_${wl}_n1.json 2> $O/${TAG}_bench_${wl}.err
 done
+# what a BARE bf16 MFMA loop sustains on THIS box (the chip lowers its clock under matrix-core load): the practical ceiling beside the bench lines
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tests/tools/microbench_bf16.hip -o /tmp/microbench_bf16 && timeout 300 /tmp/microbench_bf16 > $O/${TAG}_microbench_bf16_same_box.log 2>&1
+python3 bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline --no-native-reference > $O/${TAG}_bench_c5_n1_after_microbench.json 2>/dev/null
 # the native v_mfma_f32 path of the fp32 workloads, for reference (the library default is the bf16x6 split)
 for wl in c2 c5; do
   python3 bench.py --workload $wl --steps 5 --warmup 2 --gram-mode 0 --no-cpu-baseline > $O/${TAG}_bench_${wl}_n1_native_f32_mfma.json 2> $O/${TAG}_bench_${wl}_native.err
@@ -31,4 +34,5 @@ for wl in c2 c4 c5; do
   rm -rf $O/pmc_$wl   # raw per-dispatch CSVs are large; the summary is what is kept
 done
 cat $O/${TAG}_pmc_tile_matvec.txt | grep "=>"
+grep "normal(0,1)" $O/${TAG}_microbench_bf16_same_box.log
 for wl in c2 c3 c4 c5; do cat $O/${TAG}_bench_${wl}_n1.json; done
