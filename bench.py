@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=20480)  # 4 implicit matvecs of ~3 s each on 128 host cores: about 12 s of CPU work per line
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-native-reference", action="store_true", help="skip the extra native v_mfma_f32 run reported beside a bf16x6 headline")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the bare bf16 MFMA loop (about 4 s) whose rate on this device is reported beside roofline.frac")
     ap.add_argument("--seed", type=int, default=42)
     args = ap.parse_args()
 
@@ -389,6 +390,30 @@ def main():
             nat.close()
             _capi.set_option("gram_mode", 1)
             prob = None
+        if bf16x6 and shards == 1 and not args.no_ceiling:
+            # what a loop of NOTHING BUT the Gram kernel's MFMA instruction sustains on this device, now (the chip lowers its clock under
+            # matrix-core load): reported beside roofline.frac, never instead of it -- `peak` stays the nominal figure
+            if prob is not None:
+                prob.close()
+                prob = None
+            import ctypes as C
+
+            def ceiling(b_from_lds):
+                tf, ghz, nominal = C.c_double(0), C.c_double(0), C.c_double(0)
+                _capi.check(_capi.lib.lssvm_mi355_measure_bf16_mfma_ceiling(C.c_int(local_rank), C.c_int(b_from_lds), C.c_double(1500.0), C.byref(tf), C.byref(ghz), C.byref(nominal)))
+                return tf.value, ghz.value, nominal.value
+
+            regs_tf, regs_ghz, nominal = ceiling(0)
+            lds_tf, lds_ghz, _ = ceiling(1)
+            out["roofline"]["bare_mfma_loop"] = {
+                "what": "v_mfma_f32_16x16x32_bf16 only, 64x64 wave tiles, two waves per SIMD, normal(0,1) operands, 1.5 s of back-to-back launches before timing "
+                        "(lssvm_mi355_measure_bf16_mfma_ceiling); same device, same process, after the timed region",
+                "operands_in_registers": {"tflops": regs_tf, "frac_of_peak": regs_tf / peak, "clock_ghz": regs_ghz},
+                "b_fragments_from_lds": {"tflops": lds_tf, "frac_of_peak": lds_tf / peak, "clock_ghz": lds_ghz},
+                "nominal_peak_tflops": nominal,
+                "kernel_vs_bare_register_loop": achieved / regs_tf if regs_tf > 0 else None,
+                "kernel_vs_bare_lds_fed_loop": achieved / lds_tf if lds_tf > 0 else None,
+            }
         # the CPU legs come LAST: the OpenMP runtime's workers keep spinning after a parallel region and would slow the host side of
         # the GPU legs down (measured: 16 ms instead of 2.6 ms per c2 iteration in a native leg that followed them)
         if not args.no_cpu_baseline and shards == 1:

@@ -298,6 +298,13 @@ int lssvm_mi355_problem_info(lssvm_mi355_problem *p, lssvm_cg_info *info) {
     });
 }
 
+int lssvm_mi355_measure_bf16_mfma_ceiling(int device, int b_from_lds, double settle_ms, double *tflops_out, double *clock_ghz_out, double *nominal_tflops_out) {
+    return guarded([&] {
+        LSSVM_REQUIRE(settle_ms >= 0.0 && settle_ms <= 60000.0, "settle_ms must lie in [0, 60000]");
+        lssvm::measure_bf16_mfma_ceiling(device, b_from_lds, settle_ms, tflops_out, clock_ghz_out, nominal_tflops_out);
+    });
+}
+
 int lssvm_mi355_set_option(const char *name, int64_t value) {
     return guarded([&] {
         LSSVM_REQUIRE(name != nullptr, "name must not be NULL");

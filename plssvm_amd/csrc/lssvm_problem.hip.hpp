@@ -413,6 +413,9 @@ class Solver final : public ProblemBase {
     double setup_ms_ = 0.0, cg_wall_ms_ = 0.0;
 };
 
+/* measurement utility (mfma_ceiling.hip): TFLOP/s and held clock of a bare v_mfma_f32_16x16x32_bf16 loop on `device` */
+void measure_bf16_mfma_ceiling(int device, int b_from_lds, double settle_ms, double *tflops_out, double *clock_ghz_out, double *nominal_tflops_out);
+
 /* one-shot helpers used by the C ABI */
 template <typename T>
 void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t nfeat, const T *alpha, T rho, T *w_inout, int *w_valid, const T *points,

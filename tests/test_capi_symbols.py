@@ -76,6 +76,15 @@ def test_argument_validation_happens_without_a_device():
     with pytest.raises(InvalidParameterError, match="unknown option"):
         _capi.set_option("no_such_option", 1)
     assert _capi.get_option("rbf_form") == 0 and _capi.get_option("j_chunk_tiles") == 0
+    # the IPC entry points of the one-process-per-GPU mode: NULL handles and bad options are refused before anything touches a device
+    blob = (C.c_ubyte * _capi.LSSVM_IPC_BLOB_BYTES)()
+    with pytest.raises(InvalidParameterError, match="handle"):
+        _capi.check(_capi.lib.lssvm_mi355_problem_ipc_export(None, blob, C.c_size_t(_capi.LSSVM_IPC_BLOB_BYTES)))
+    with pytest.raises(InvalidParameterError, match="handle"):
+        _capi.check(_capi.lib.lssvm_mi355_problem_ipc_connect(None, blob, C.c_size_t(_capi.LSSVM_IPC_BLOB_BYTES)))
+    with pytest.raises(InvalidParameterError, match="ipc_timeout_s"):
+        _capi.set_option("ipc_timeout_s", 0)
+    assert _capi.get_option("ipc_timeout_s") == 600 and _capi.get_option("enqueue_ahead_below_us") == 5000
 
 
 @pytest.mark.skipif(has_gpu, reason="only meaningful on a box without a GPU")

@@ -61,6 +61,11 @@ def test_bench_json_contract_small_workload():
     if r["gram_mode"] == "bf16x6":  # the native v_mfma_f32 path of the same workload is reported beside the headline
         nat = j["native_f32_path"]
         assert nat["ms_per_step"] > j["ms_per_step"] and 0.05 < nat["frac_of_f32_mfma_peak"] < 1.0
+        # ... and so is what a bare loop of the kernel's MFMA instruction sustains on this device (the practical ceiling under the nominal peak)
+        bare = r["bare_mfma_loop"]
+        assert 0.4 < bare["b_fragments_from_lds"]["frac_of_peak"] < 1.0 and 0.4 < bare["operands_in_registers"]["frac_of_peak"] < 1.0
+        assert 1.0 < bare["operands_in_registers"]["clock_ghz"] < 2.6 and abs(bare["nominal_peak_tflops"] - r["peak"]) < 0.01 * r["peak"]
+        assert 0.3 < bare["kernel_vs_bare_register_loop"] < 1.0
     assert r["gram_mode"] in ("bf16x6", "native") and abs(r["achieved"] - planes * r["fp32_equivalent"]) < 1e-9 * r["achieved"]
     assert r["effective_full_square"] >= r["fp32_equivalent"] and planes * r["full_square_flop_per_launch"] >= r["executed_flop_per_launch"] * 0.99
     c = j["cpu_baseline"]
