@@ -20,7 +20,7 @@ for wl in c2 c5; do
 done
 for wl in c2 c4 c5; do
   rm -rf $O/prof_$wl
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -- python3 bench.py --workload $wl --steps 5 --warmup 1 --no-cpu-baseline --no-native-reference > $O/prof_$wl.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -- python3 bench.py --workload $wl --steps 5 --warmup 1 --no-cpu-baseline --no-native-reference --no-ceiling > $O/prof_$wl.log 2>&1
   f=$(find $O/prof_$wl -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" $O/${TAG}_rocprofv3_kernel_stats_bench_${wl}.csv
   grep "^{" $O/prof_$wl.log | tail -1 > $O/${TAG}_rocprofv3_bench_line_${wl}.json
