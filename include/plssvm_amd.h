@@ -267,7 +267,7 @@ int lssvm_mi355_measure_bf16_mfma_ceiling(int device, int b_from_lds, double set
  *                   0 = full square (row-owned sums, results independent of the GPU count)
  *   "tile_kernel"   0 = automatic: the "resident row panel" kernels for num_features <= 512 (fp32) / 256 (fp64) (default), 1 = always the generic kernel
  *   "xcd_map"       1 = XCD-aware block -> work item mapping (8 x 8 super-tiles per XCD), 0 = linear (default)
- *   "lds_extra_kb"  experiment knob: extra dynamic LDS (KiB) per workgroup of the fp32 v2 kernel, lowers the workgroups per CU
+ *   "lds_extra_kb"  experiment knob: extra dynamic LDS (KiB) per workgroup of the fp32 tile kernels (native and bf16x6), lowers the workgroups per CU
  *   "debug_ablate"  timing-only ablation bits of the fp32 tile kernel; effective only in -DLSSVM_ENABLE_ABLATION builds
  *   "item_order"    symmetric variant: 0 = work items in column-chunk major order, 1 = the same with the short items that end on the
  *                   diagonal moved to the end, longest first (default: shortens the last dispatch round), 2 = 1 with row blocks descending

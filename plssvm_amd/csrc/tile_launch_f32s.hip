@@ -11,6 +11,7 @@ namespace lssvm {
 template <int KT, bool SYM>
 static void launch_s6_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
     const dim3 block(TILE_THREADS);
+    const size_t V2_LDS_BYTES = lssvm::V2_LDS_BYTES + static_cast<size_t>(a.lds_extra_kb) * 1024;  // experiment knob: limits workgroups per CU
 #define LSSVM_S6_CASE(N)                                                                                  \
     case N:                                                                                               \
         if (a.mfma_shape == 2) {                                                                          \
