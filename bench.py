@@ -358,6 +358,11 @@ def main():
                        "residuum_after_timed_steps": i1["residuum"]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_source": traffic_source,
+                         # the HBM side of the same launch (SURVEY.md 8d asks for both fractions): algorithmic bytes n*d*s + 4*n*s, the measured
+                         # fabric traffic over the kernel time against the 8 TB/s peak -- far from binding, the launch is matrix-core bound
+                         "hbm": {"algorithmic_bytes_per_launch": float(n) * d * dt.itemsize + 4.0 * n * dt.itemsize,
+                                 "traffic_rate_TBps": (traffic / kern_s / 1e12) if (traffic is not None and kern_ms > 0) else None,
+                                 "traffic_frac_of_hbm_peak": (traffic / kern_s / 1e12 / 8.0) if (traffic is not None and kern_ms > 0) else None},
                          "kernel": "lssvm::tile_matvec (implicit K*d tile kernel)", "launches": launches, "avg_launch_ms": kern_ms,
                          "tile_launches_per_matvec": bands,
                          "launch_note": "a 'launch' here is ONE implicit matvec = the sum of its row-block band launches of the tile kernel (rocprofv3 lists the bands one by one)",
