@@ -2,7 +2,7 @@
 
 The compute path is the HIP library ``plssvm_amd/lib/libplssvm_amd.so`` (C ABI: ``include/plssvm_amd.h``); importing a module
 that needs it (``backend``, ``csvm``, ``svc``, ``cli``) fails loudly when the library has not been built.  Pure host-side
-modules (``parameter``, ``io_libsvm``, ``data_set``, ``model``, ``datagen``, ``sharding``) import without it.
+modules (``parameter``, ``io_libsvm``, ``io_scaling_factors``, ``data_set``, ``model``, ``datagen``, ``sharding``) import without it.
 """
 
 __version__ = "0.1.0"
@@ -20,9 +20,9 @@ def __getattr__(name):
     if name == "SVC":
         from .svc import SVC
         return SVC
-    if name in ("DataSet",):
-        from .data_set import DataSet
-        return DataSet
+    if name in ("DataSet", "Scaling"):
+        from . import data_set
+        return getattr(data_set, name)
     if name in ("Model",):
         from .model import Model
         return Model

@@ -1,8 +1,10 @@
-"""``plssvm-train`` / ``plssvm-predict`` compatible command lines (src/main_train.cpp:24-70, src/main_predict.cpp:29-100,
-src/plssvm/detail/cmd/parser_train.cpp:41-73, parser_predict.cpp:44-60) on top of the MI355X backend.
+"""``plssvm-train`` / ``plssvm-predict`` / ``plssvm-scale`` compatible command lines (src/main_train.cpp:24-70,
+src/main_predict.cpp:29-100, src/main_scale.cpp:25-85, src/plssvm/detail/cmd/parser_train.cpp:41-73, parser_predict.cpp:44-60,
+parser_scale.cpp:41-135) on top of the MI355X backend.
 
     python -m plssvm_amd.train   [-t -d -g -r -c -e -i -b -p --use_strings_as_labels --use_float_as_real_type --verbosity -q] training_set_file [model_file]
     python -m plssvm_amd.predict [-b -p --use_strings_as_labels --use_float_as_real_type --verbosity -q] test_file model_file [output_file]
+    python -m plssvm_amd.scale   [-l -u -f -s -r --use_strings_as_labels --use_float_as_real_type --verbosity -q] input_file [scaled_file]
 """
 
 from __future__ import annotations
@@ -15,7 +17,7 @@ import time
 import numpy as np
 
 from .csvm import BackendType, TargetPlatform, make_csvm
-from .data_set import DataSet
+from .data_set import DataSet, Scaling
 from .exceptions import PlssvmError
 from .model import Model
 from .parameter import Parameter
@@ -150,6 +152,69 @@ def predict_main(argv=None) -> int:
         if data.has_labels():
             correct = sum(1 for p, c in zip(predicted, data.labels()) if p == c)
             _log(verb, ("full", "libsvm"), f"Accuracy = {100.0 * correct / len(predicted)}% ({correct}/{len(predicted)}) (classification)")  # main_predict.cpp:78-84
+        _log(verb, ("full", "timing"), f"\nTotal runtime: {(time.perf_counter() - t0) * 1e3:.0f}ms")
+    except PlssvmError as e:
+        print(f"{e}\nException type: {type(e).__name__}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def scale_main(argv=None) -> int:
+    """``plssvm-scale``: scale every feature of a LIBSVM file to [lower, upper] with factors computed from the file (optionally saved,
+    -s) or restored from an earlier run (-r: the way a test set gets the scaling of its training set)."""
+    ap = argparse.ArgumentParser(prog="plssvm-scale", description="LS-SVM with multiple (GPU-)backends")
+    ap.add_argument("-l", "--lower", type=float, default=None, help="lower is the lowest (minimal) value allowed in each dimension (default: -1)")
+    ap.add_argument("-u", "--upper", type=float, default=None, help="upper is the highest (maximal) value allowed in each dimension (default: 1)")
+    ap.add_argument("-f", "--format", default="libsvm", help="the file format to output the scaled data set to (libsvm; the reference's arff writer is not part of this package)")
+    ap.add_argument("-s", "--save_filename", default=None, help="the file to which the scaling factors should be saved")
+    ap.add_argument("-r", "--restore_filename", default=None, help="the file from which previous scaling factors should be loaded")
+    ap.add_argument("--use_strings_as_labels", action="store_true", help="use strings as labels instead of plane numbers")
+    ap.add_argument("--use_float_as_real_type", action="store_true", help="use floats as real types instead of doubles")
+    ap.add_argument("--verbosity", choices=VERBOSITY, default=None, help="choose the level of verbosity: full|timing|libsvm|quiet (default: full)")
+    ap.add_argument("-q", "--quiet", action="store_true", help="quiet mode (no outputs regardless the provided verbosity level!)")
+    ap.add_argument("-v", "--version", action="store_true", help="print version information")
+    ap.add_argument("input", nargs="?", help="input_file")
+    ap.add_argument("scaled", nargs="?", help="scaled_file")
+    args = ap.parse_args(argv)
+    if args.version:
+        print("plssvm_amd (MI355X-native LS-SVM CG backend), C ABI version 2")
+        return 0
+    lower = -1.0 if args.lower is None else args.lower
+    upper = 1.0 if args.upper is None else args.upper
+    if lower >= upper:  # parser_scale.cpp:89-93
+        print(f"Error invalid scaling range [lower, upper] with [{_fmt(lower)}, {_fmt(upper)}]!", file=sys.stderr)
+        return 1
+    if args.format.lower() != "libsvm":
+        print(f"Error: only the libsvm output format is available here, but \"{args.format}\" was requested!", file=sys.stderr)
+        return 1
+    if args.input is None:
+        print("Error missing input file!", file=sys.stderr)
+        return 1
+    if args.save_filename is not None and args.restore_filename is not None:
+        print("Error cannot use -s (--save_filename) and -r (--restore_filename) simultaneously!", file=sys.stderr)
+        return 1
+    if args.restore_filename is not None and (args.lower is not None or args.upper is not None):
+        print("Warning: provided -l (--lower) and/or -u (--upper) together with -r (--restore_filename); ignoring -l/-u", file=sys.stderr)
+    verb = _verbosity(args)
+    try:
+        t0 = time.perf_counter()
+        real_type = np.float32 if args.use_float_as_real_type else np.float64
+        label_type = str if args.use_strings_as_labels else float
+        from .io_libsvm import parse_libsvm_data, write_libsvm_data
+        X, labels = parse_libsvm_data(args.input, dtype=real_type, label_type=label_type)
+        scaling = Scaling(filename=args.restore_filename, real_type=real_type) if args.restore_filename is not None else Scaling(real_type(lower), real_type(upper))
+        data = DataSet(X, labels, real_type=real_type, scaling=scaling)  # (labelled data: exactly two classes, as in the reference's data_set)
+        _log(verb, ("full", "timing"), f"Scaled the data set to the range [{_fmt(scaling.lower)}, {_fmt(scaling.upper)}].")
+        if args.scaled is not None:
+            write_libsvm_data(args.scaled, data.data(), labels=data.labels())
+        else:  # main_scale.cpp:41-62: the scaled data goes to stdout, "{label} {index}:{value:.10e} ..." per point
+            print()
+            Xs = data.data()
+            for i in range(Xs.shape[0]):
+                head = f"{_fmt(data.labels()[i])} " if data.has_labels() else ""
+                print(head + "".join(f"{j + 1}:{float(Xs[i, j]):.10e} " for j in range(Xs.shape[1]) if Xs[i, j] != 0))
+        if args.save_filename is not None:
+            data.scaling_factors().save(args.save_filename)
         _log(verb, ("full", "timing"), f"\nTotal runtime: {(time.perf_counter() - t0) * 1e3:.0f}ms")
     except PlssvmError as e:
         print(f"{e}\nException type: {type(e).__name__}", file=sys.stderr)

@@ -1,7 +1,7 @@
 """``DataSet``: the data / label container on the input side of the hot path, mirroring ``plssvm::data_set``
 (include/plssvm/data_set.hpp) as far as the path needs it: LIBSVM file or array input, the binary label mapping
-(first label in sorted order -> -1, second -> +1; data_set.hpp:438-454, :653-667) and optional min-max scaling
-(data_set.hpp:670-730)."""
+(first label in sorted order -> -1, second -> +1; data_set.hpp:438-454, :653-667) and optional min-max scaling with
+factors that can be saved and restored (``data_set::scaling``, data_set.hpp:290-375, :670-730; ``plssvm-scale -s / -r``)."""
 
 from __future__ import annotations
 
@@ -9,8 +9,9 @@ import numpy as np
 
 from .exceptions import InvalidParameterError, PlssvmError
 from .io_libsvm import parse_libsvm_data, write_libsvm_data
+from .io_scaling_factors import _fmt, parse_scaling_factors, write_scaling_factors
 
-__all__ = ["DataSet", "DataSetError", "LabelMapper"]
+__all__ = ["DataSet", "DataSetError", "LabelMapper", "Scaling"]
 
 
 class DataSetError(PlssvmError):
@@ -41,10 +42,27 @@ class LabelMapper:
         raise DataSetError(f'Mapped value "{mapped_value}" unknown in this label mapping!')
 
 
+class Scaling:
+    """``data_set::scaling`` (data_set.hpp:290-375): the interval ``[lower, upper]`` plus, per feature that is not zero everywhere,
+    its ``(feature, min, max)`` -- computed by the first data set that is scaled with this object, or restored from a file written
+    by an earlier run (``plssvm-scale -s`` / ``-r``)."""
+
+    def __init__(self, lower=None, upper=None, filename=None, real_type=np.float64):
+        if filename is not None:
+            (self.lower, self.upper), self.factors = parse_scaling_factors(filename, real_type)
+        else:
+            if lower >= upper:
+                raise DataSetError(f"Inconsistent scaling interval specification: lower ({_fmt(lower)}) must be less than upper ({_fmt(upper)})!")
+            self.lower, self.upper, self.factors = lower, upper, []
+
+    def save(self, filename) -> None:
+        write_scaling_factors(filename, (self.lower, self.upper), self.factors)
+
+
 class DataSet:
     def __init__(self, data=None, labels=None, filename=None, real_type=np.float64, label_type=float, scaling=None):
-        """Either ``filename`` (LIBSVM format) or ``data`` (+ optional ``labels``).  ``scaling=(lower, upper)`` scales every
-        feature to that interval (data_set.hpp:670-730)."""
+        """Either ``filename`` (LIBSVM format) or ``data`` (+ optional ``labels``).  ``scaling``: ``(lower, upper)`` or a
+        :class:`Scaling` (possibly restored from a file) -- every feature is scaled to that interval (data_set.hpp:670-730)."""
         self.real_type = np.dtype(real_type)
         if self.real_type not in (np.dtype(np.float32), np.dtype(np.float64)):
             raise InvalidParameterError("real_type must be float32 or float64")
@@ -64,24 +82,52 @@ class DataSet:
         self._labels = labels
         self.mapping = None
         self._y = None
-        self.scaling_factors = None
+        self.scaling_factors_ = None
         if labels is not None:
             self.mapping = LabelMapper(labels)
             self._y = np.array([self.mapping.mapped(lab) for lab in labels], dtype=self.real_type)
         if scaling is not None:
-            self._scale(*scaling)
+            self._scaling = scaling if isinstance(scaling, Scaling) else Scaling(*scaling)
+            self._scale()
+            self.scaling_factors_ = self._scaling
 
-    def _scale(self, lower, upper):
-        if lower >= upper:
-            raise DataSetError(f"Inconsistent scaling interval specification: lower ({lower}) must be less than upper ({upper})!")
-        mn, mx = self._X.min(axis=0), self._X.max(axis=0)
-        span = np.where(mx > mn, mx - mn, 1.0)
-        self._X = (lower + (upper - lower) * (self._X - mn) / span).astype(self.real_type)
-        self.scaling_factors = (lower, upper, mn, mx)
+    def _scale(self):
+        """data_set::scale (data_set.hpp:670-730), statement for statement in its semantics: factors are computed unless they were
+        restored; a feature that is zero everywhere gets no factor and stays zero; a feature that is constant but not zero divides
+        by zero exactly as the reference does."""
+        sc = self._scaling
+        rt = self.real_type.type
+        lower, upper = rt(sc.lower), rt(sc.upper)
+        nfeat = self._X.shape[1]
+        if not sc.factors:
+            mn, mx = self._X.min(axis=0), self._X.max(axis=0)
+            sc.factors = [(f, mn[f], mx[f]) for f in range(nfeat) if not (mn[f] == 0 and mx[f] == 0)]
+        else:
+            if len(sc.factors) > nfeat:
+                raise DataSetError(f"Need at most as much scaling factors as features in the data set are present ({nfeat}), but {len(sc.factors)} were given!")
+            sc.factors = sorted(sc.factors, key=lambda t: t[0])
+            if sc.factors[-1][0] >= nfeat:
+                raise DataSetError(f"The maximum scaling feature index most not be greater than {nfeat - 1}, but is {sc.factors[-1][0]}!")
+            for a, b in zip(sc.factors, sc.factors[1:]):
+                if a[0] == b[0]:
+                    raise DataSetError(f"Found more than one scaling factor for the feature index {a[0]}!")
+        X = self._X.copy()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            for f, lo, hi in sc.factors:
+                lo, hi = rt(lo), rt(hi)
+                X[:, f] = lower + (upper - lower) * (X[:, f] - lo) / (hi - lo)
+        self._X = X
 
     # accessors named after the reference's (data_set.hpp:150-230)
     def data(self):
         return self._X
+
+    def is_scaled(self):
+        return self.scaling_factors_ is not None
+
+    def scaling_factors(self):
+        """The :class:`Scaling` this data set was scaled with (``data_set::scaling_factors``), or None."""
+        return self.scaling_factors_
 
     def has_labels(self):
         return self._labels is not None
