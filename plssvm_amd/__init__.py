@@ -2,7 +2,7 @@
 
 The compute path is the HIP library ``plssvm_amd/lib/libplssvm_amd.so`` (C ABI: ``include/plssvm_amd.h``); importing a module
 that needs it (``backend``, ``csvm``, ``svc``, ``cli``) fails loudly when the library has not been built.  Pure host-side
-modules (``parameter``, ``io_libsvm``, ``io_scaling_factors``, ``data_set``, ``model``, ``datagen``, ``sharding``) import without it.
+modules (``parameter``, ``io_libsvm``, ``io_arff``, ``io_scaling_factors``, ``data_set``, ``model``, ``datagen``, ``sharding``) import without it.
 """
 
 __version__ = "0.1.0"

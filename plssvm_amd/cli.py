@@ -165,7 +165,7 @@ def scale_main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="plssvm-scale", description="LS-SVM with multiple (GPU-)backends")
     ap.add_argument("-l", "--lower", type=float, default=None, help="lower is the lowest (minimal) value allowed in each dimension (default: -1)")
     ap.add_argument("-u", "--upper", type=float, default=None, help="upper is the highest (maximal) value allowed in each dimension (default: 1)")
-    ap.add_argument("-f", "--format", default="libsvm", help="the file format to output the scaled data set to (libsvm; the reference's arff writer is not part of this package)")
+    ap.add_argument("-f", "--format", default="libsvm", help="the file format to output the scaled data set to: libsvm|arff")
     ap.add_argument("-s", "--save_filename", default=None, help="the file to which the scaling factors should be saved")
     ap.add_argument("-r", "--restore_filename", default=None, help="the file from which previous scaling factors should be loaded")
     ap.add_argument("--use_strings_as_labels", action="store_true", help="use strings as labels instead of plane numbers")
@@ -184,8 +184,8 @@ def scale_main(argv=None) -> int:
     if lower >= upper:  # parser_scale.cpp:89-93
         print(f"Error invalid scaling range [lower, upper] with [{_fmt(lower)}, {_fmt(upper)}]!", file=sys.stderr)
         return 1
-    if args.format.lower() != "libsvm":
-        print(f"Error: only the libsvm output format is available here, but \"{args.format}\" was requested!", file=sys.stderr)
+    if args.format.lower() not in ("libsvm", "arff"):
+        print(f"Error: the output format must be libsvm or arff, but \"{args.format}\" was given!", file=sys.stderr)
         return 1
     if args.input is None:
         print("Error missing input file!", file=sys.stderr)
@@ -200,13 +200,12 @@ def scale_main(argv=None) -> int:
         t0 = time.perf_counter()
         real_type = np.float32 if args.use_float_as_real_type else np.float64
         label_type = str if args.use_strings_as_labels else float
-        from .io_libsvm import parse_libsvm_data, write_libsvm_data
-        X, labels = parse_libsvm_data(args.input, dtype=real_type, label_type=label_type)
         scaling = Scaling(filename=args.restore_filename, real_type=real_type) if args.restore_filename is not None else Scaling(real_type(lower), real_type(upper))
-        data = DataSet(X, labels, real_type=real_type, scaling=scaling)  # (labelled data: exactly two classes, as in the reference's data_set)
+        # (a name ending in .arff is read with the ARFF parser; labelled data: exactly two classes, as in the reference's data_set)
+        data = DataSet(filename=args.input, real_type=real_type, label_type=label_type, scaling=scaling)
         _log(verb, ("full", "timing"), f"Scaled the data set to the range [{_fmt(scaling.lower)}, {_fmt(scaling.upper)}].")
         if args.scaled is not None:
-            write_libsvm_data(args.scaled, data.data(), labels=data.labels())
+            data.save(args.scaled, file_format=args.format)
         else:  # main_scale.cpp:41-62: the scaled data goes to stdout, "{label} {index}:{value:.10e} ..." per point
             print()
             Xs = data.data()

@@ -8,6 +8,7 @@ from __future__ import annotations
 import numpy as np
 
 from .exceptions import InvalidParameterError, PlssvmError
+from .io_arff import parse_arff_data, write_arff_data
 from .io_libsvm import parse_libsvm_data, write_libsvm_data
 from .io_scaling_factors import _fmt, parse_scaling_factors, write_scaling_factors
 
@@ -42,6 +43,14 @@ class LabelMapper:
         raise DataSetError(f'Mapped value "{mapped_value}" unknown in this label mapping!')
 
 
+def _file_format(name) -> str:
+    """file_format_type (file_format_types.hpp): "libsvm" or "arff", case-insensitive."""
+    fmt = str(name).lower()
+    if fmt not in ("libsvm", "arff"):
+        raise InvalidParameterError(f'The file format must be one of "libsvm" or "arff", but is "{name}"!')
+    return fmt
+
+
 class Scaling:
     """``data_set::scaling`` (data_set.hpp:290-375): the interval ``[lower, upper]`` plus, per feature that is not zero everywhere,
     its ``(feature, min, max)`` -- computed by the first data set that is scaled with this object, or restored from a file written
@@ -60,14 +69,20 @@ class Scaling:
 
 
 class DataSet:
-    def __init__(self, data=None, labels=None, filename=None, real_type=np.float64, label_type=float, scaling=None):
-        """Either ``filename`` (LIBSVM format) or ``data`` (+ optional ``labels``).  ``scaling``: ``(lower, upper)`` or a
+    def __init__(self, data=None, labels=None, filename=None, real_type=np.float64, label_type=float, scaling=None, file_format=None):
+        """Either ``filename`` or ``data`` (+ optional ``labels``).  A file is read with the ARFF parser if ``file_format`` is "arff" or,
+        without ``file_format``, if its name ends with ``.arff``; otherwise with the LIBSVM parser (data_set.hpp:494-505).
+        ``scaling``: ``(lower, upper)`` or a
         :class:`Scaling` (possibly restored from a file) -- every feature is scaled to that interval (data_set.hpp:670-730)."""
         self.real_type = np.dtype(real_type)
         if self.real_type not in (np.dtype(np.float32), np.dtype(np.float64)):
             raise InvalidParameterError("real_type must be float32 or float64")
         if filename is not None:
-            X, labels = parse_libsvm_data(filename, dtype=self.real_type, label_type=label_type)
+            fmt = _file_format(file_format) if file_format is not None else ("arff" if str(filename).endswith(".arff") else "libsvm")
+            if fmt == "arff":
+                X, labels = parse_arff_data(filename, dtype=self.real_type, label_type=label_type)
+            else:
+                X, labels = parse_libsvm_data(filename, dtype=self.real_type, label_type=label_type)
         else:
             X = np.ascontiguousarray(np.asarray(data), dtype=self.real_type)
             if X.ndim != 2 or X.shape[0] == 0:
@@ -151,5 +166,17 @@ class DataSet:
         """y in {-1, +1} (data_set::y_ptr_)."""
         return self._y
 
-    def save(self, filename):
-        write_libsvm_data(filename, self._X, labels=self._labels)
+    def save(self, filename, file_format=None):
+        """data_set::save (data_set.hpp:580-622): the format is given or follows the extension (.libsvm / .arff)."""
+        name = str(filename)
+        if file_format is None:
+            if name.endswith(".libsvm"):
+                file_format = "libsvm"
+            elif name.endswith(".arff"):
+                file_format = "arff"
+            else:
+                raise DataSetError(f'Unrecognized file extension for file "{name}" (must be one of: .libsvm or .arff)!')
+        if _file_format(file_format) == "arff":
+            write_arff_data(filename, self._X, labels=self._labels)
+        else:
+            write_libsvm_data(filename, self._X, labels=self._labels)

@@ -112,6 +112,15 @@ def test_scale_command_line(tmp_path):
     assert rows[0] == "" and len(rows) == 9 and rows[1].startswith("-1 1:") and rows[1].endswith(" ")
     first = np.array([float(t.split(":")[1]) for t in rows[1].split()[1:]])
     assert np.allclose(first, (X[0] * 0.5 - X.min(0)) / (X.max(0) - X.min(0)), rtol=0, atol=2e-10)
+    # -f arff: the scaled set in the reference's other data format; an .arff input is read with the ARFF parser
+    out_arff = _scale("-q", "-r", tmp_path / "factors.txt", "-f", "arff", test, tmp_path / "test.scaled.arff")
+    assert out_arff.returncode == 0, out_arff.stderr
+    from plssvm_amd.io_arff import parse_arff_data
+    Xa, ya = parse_arff_data(tmp_path / "test.scaled.arff")
+    assert ya == y[:8] and np.allclose(Xa, (X[:8] * 0.5 - X.min(0)) / (X.max(0) - X.min(0)), rtol=0, atol=2e-10)
+    again = _scale("-q", "-l", "0", "-u", "1", tmp_path / "test.scaled.arff")
+    assert again.returncode == 0 and len(again.stdout.splitlines()) == 9
+    assert "the output format must be libsvm or arff" in _scale("-f", "csv", train).stderr
     # the parser's errors (parser_scale.cpp:89-93, :131-135, :122-126)
     assert "Error invalid scaling range [lower, upper] with [1, 1]!" in _scale("-l", "1", "-u", "1", train).stderr
     assert "Error cannot use -s (--save_filename) and -r (--restore_filename) simultaneously!" in _scale("-s", "a", "-r", "b", train).stderr
