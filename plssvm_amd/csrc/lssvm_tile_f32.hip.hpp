@@ -411,7 +411,8 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
         if (tid < TILE) {
             const float *cr_ = colred + (t & 1) * 512;
             const float sum = (cr_[tid] + cr_[128 + tid]) + (cr_[256 + tid] + cr_[384 + tid]);
-            float *rec = a.colslab + (rec0 + jt_begin + t) * TILE;  // uniform base + 32-bit lane offset
+            // (an explicit GLOBAL pointer: through the generic one the store is a flat_store, which counts in lgkmcnt as well and completes out of order)
+            auto *rec = (__attribute__((address_space(1))) float *) (a.colslab + (rec0 + jt_begin + t) * TILE);  // uniform base + 32-bit lane offset
             rec[static_cast<unsigned>(tid)] = sum;
         }
     };

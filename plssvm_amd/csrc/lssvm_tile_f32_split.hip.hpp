@@ -199,7 +199,8 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
         if (tid < TILE) {
             const float *cr_ = colred + (t & 1) * 512;
             const float sum = (cr_[tid] + cr_[128 + tid]) + (cr_[256 + tid] + cr_[384 + tid]);
-            float *rec = a.colslab + (rec0 + jt_begin + t) * TILE;  // uniform base + 32-bit lane offset
+            // (an explicit GLOBAL pointer: through the generic one the store is a flat_store, which counts in lgkmcnt as well and completes out of order)
+            auto *rec = (__attribute__((address_space(1))) float *) (a.colslab + (rec0 + jt_begin + t) * TILE);  // uniform base + 32-bit lane offset
             rec[static_cast<unsigned>(tid)] = sum;
         }
     };
@@ -564,7 +565,8 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
             const float *cr_ = colred + (t & 1) * 512;
             const float sum = (cr_[tid] + cr_[128 + tid]) + (cr_[256 + tid] + cr_[384 + tid]);
             // uniform base in SGPRs + 32-bit lane offset (a 64-bit per-lane pointer would be hoisted out of the tile loop and spilled)
-            float *rec = const_cast<float *>(reinterpret_cast<const float *>(sgpr_ptr(a.colslab + (rec0 + jt_begin + t) * TILE)));
+            // (and an explicit GLOBAL pointer: through the generic one the store is a flat_store, which counts in lgkmcnt as well and completes out of order)
+            auto *rec = (__attribute__((address_space(1))) float *) const_cast<char *>(sgpr_ptr(a.colslab + (rec0 + jt_begin + t) * TILE));
             rec[lane_off(static_cast<unsigned>(tid))] = sum;
         }
     };

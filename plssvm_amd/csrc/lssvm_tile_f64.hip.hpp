@@ -370,7 +370,8 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
     auto flush_cols = [&](int t) {  // fixed-order sum of the four waves' column sums of sub-tile t -> its slab record
         if (tid < 64) {
             const double *cr_ = colred + (t & 1) * 256;
-            double *rec = a.colslab + (rec0 + st_begin + t) * 64;  // uniform base + 32-bit lane offset
+            // (an explicit GLOBAL pointer: through the generic one the store is a flat_store, which counts in lgkmcnt as well and completes out of order)
+            auto *rec = (__attribute__((address_space(1))) double *) (a.colslab + (rec0 + st_begin + t) * 64);  // uniform base + 32-bit lane offset
             rec[static_cast<unsigned>(tid)] = (cr_[tid] + cr_[64 + tid]) + (cr_[128 + tid] + cr_[192 + tid]);
         }
     };
