@@ -187,6 +187,12 @@ def main():
     if not args.single_process and world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
+    if world > 1:
+        # all ranks live on ONE node (the contract of this script): RCCL's bootstrap need not scan the network interfaces (it took
+        # 100-600 s on some boxes of the pool), and the host driver only supports dmabuf IPC
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
     import numpy as np
     import torch  # plumbing only: device selection, synchronisation, torch.distributed (RCCL) for the barrier / id exchange
 
