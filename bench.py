@@ -143,10 +143,30 @@ def spawn_ranks(n: int) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # poll ALL children: a rank that dies leaves its siblings blocked in the exchange (RCCL, or the IPC wait with its 600 s default), so
+    # on the first non-zero exit the others get SIGTERM, a short grace period, then SIGKILL -- these are children this parent started itself
     worst = 0
-    for p in procs:
-        rc = p.wait()
-        worst = worst or rc
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and worst == 0:
+                worst = rc
+                for q in live:
+                    q.terminate()
+                deadline = time.time() + 10.0
+                for q in live:
+                    try:
+                        q.wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+                        q.wait()
+                live = []
+                break
     return worst
 
 
@@ -165,8 +185,9 @@ def main():
     ap.add_argument("--rank-devices", default=None,
                     help="one process per GPU: comma separated HIP ordinal per local rank (default: the local rank).  Repeats put several ranks on one device "
                          "-- a functional check of the rank path on a one-GPU box (needs --exchange 2 --dist-backend gloo: RCCL refuses two ranks on one device)")
-    ap.add_argument("--gram-mode", type=int, default=None, choices=[0, 1],
-                    help="fp32 only: 1 = bf16x6 split on the bf16 matrix cores (library default), 0 = native v_mfma_f32 chains")
+    ap.add_argument("--gram-mode", type=int, default=None, choices=[0, 1, 2, 3],
+                    help="fp32 only: 3 (library default) = f16x3 where the data passes the representability check, else bf16x6; 2 = f16x3 unchecked; "
+                         "1 = bf16x6; 0 = native v_mfma_f32 chains")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="set a library tuning knob (lssvm_mi355_set_option) before the problem is created; repeatable")
     ap.add_argument("--cpu-sample-rows", type=int, default=20480)  # 4 implicit matvecs of ~3 s each on 128 host cores: about 12 s of CPU work per line
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -324,11 +345,14 @@ def main():
     executed = exec_launch / kern_s / 1e12 if kern_ms > 0 else 0.0
     effective = square_launch / kern_s / 1e12 if kern_ms > 0 else 0.0
     peak = PEAK_TFLOPS[wl["dtype"]]
-    # fp32 default "bf16x6": every fp32 multiply-add runs as SIX bf16 plane products on the bf16 MFMA (exact 3-way split of
-    # the operands, fp32 accumulation, fp32-equivalent accuracy: DESIGN.md 4.1).  The roofline of that kernel is the dense bf16 MFMA
-    # peak (16 x the f32 MFMA rate, MI355X_MICROARCH.md "Matrix cores"), and the algorithm's own flop count is 6 x the fp32 count.
-    bf16x6 = bool(i1.get("gram_mode", 0))
-    plane_products = 6.0 if bf16x6 else 1.0
+    # fp32 split modes: every fp32 multiply-add runs as THREE f16 plane products ("f16x3": two f16 planes per operand, the default where
+    # the data allows) or SIX bf16 plane products ("bf16x6": exact 3-way split) on the 16-bit MFMA with fp32 accumulation, at
+    # fp32-equivalent accuracy.  The roofline of those kernels is the dense 16-bit MFMA peak (16 x the f32 MFMA rate,
+    # MI355X_MICROARCH.md "Matrix cores": f16 and bf16 take the same cycles), and the kernel's own flop count is 3 x / 6 x the fp32 count.
+    gram_mode = int(i1.get("gram_mode", 0))
+    gram_name = {0: "native", 1: "bf16x6", 2: "f16x3"}[gram_mode]
+    bf16x6 = gram_mode != 0  # (a split mode on the 16-bit matrix cores)
+    plane_products = {0: 1.0, 1: 6.0, 2: 3.0}[gram_mode]
     fp32_equivalent = achieved
     if bf16x6:
         peak = PEAK_TFLOPS["bf16"]
@@ -357,8 +381,9 @@ def main():
             "n_gpus": n_gpus, "steps": steps_done, "warmup": args.warmup, "ms_per_step": elapsed / max(steps_done, 1) * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if wl["dtype"] == "float32" else "f64", "data": "synthetic",
-            "arithmetic": ("fp32 operands split exactly into 3 bf16 planes, 6 plane products per multiply-add accumulated in fp32 on the bf16 matrix cores"
-                           if bf16x6 else "native " + wl["dtype"] + " matrix-core fma chains"),
+            "arithmetic": {1: "fp32 operands split exactly into 3 bf16 planes, 6 plane products per multiply-add accumulated in fp32 on the bf16 matrix cores",
+                           2: "fp32 operands as 2 f16 planes (hi + mid, representation checked on the data at set-up), 3 plane products per multiply-add "
+                              "accumulated in fp32 on the f16 matrix cores"}.get(gram_mode, "native " + wl["dtype"] + " matrix-core fma chains"),
             "config": {"workload": wl["desc"], "num_points": N, "num_features": d, "kernel": wl["kernel"], "gamma": 1.0 / d, "cost": 1.0,
                        "seed": args.seed, "library_options": args.option, "parallelism": parallelism, "shards": shards, "exchange": exchange_names.get(int(i1.get("exchange", 0)), "?"),
                        "residuum_after_timed_steps": i1["residuum"]},
@@ -374,7 +399,7 @@ def main():
                          "launch_note": "a 'launch' here is ONE implicit matvec = the sum of its row-block band launches of the tile kernel (rocprofv3 lists the bands one by one)",
                          "algorithmic_flop_per_launch": useful_launch * plane_products, "symmetric": symmetric,
                          "executed_flop_per_launch": exec_launch * plane_products, "executed": executed, "executed_frac": executed / peak,
-                         "gram_mode": "bf16x6" if bf16x6 else "native", "fp32_equivalent": fp32_equivalent, "fp32_mfma_peak": PEAK_TFLOPS["float32"],
+                         "gram_mode": gram_name, "plane_products": plane_products, "fp32_equivalent": fp32_equivalent, "fp32_mfma_peak": PEAK_TFLOPS["float32"],
                          # the same launch priced with the full-square convention of `value` (can exceed the peak when symmetric)
                          "full_square_flop_per_launch": square_launch, "effective_full_square": effective},
         }
@@ -399,7 +424,7 @@ def main():
                                       "tile_kernel_ms": nk_ms, "useful_tflops": useful_launch / (nk_ms * 1e-3) / 1e12 if nk_ms > 0 else 0.0,
                                       "frac_of_f32_mfma_peak": useful_launch / (nk_ms * 1e-3) / 1e12 / PEAK_TFLOPS["float32"] if nk_ms > 0 else 0.0}
             nat.close()
-            _capi.set_option("gram_mode", 1)
+            _capi.set_option("gram_mode", 3)
             prob = None
         if bf16x6 and shards == 1 and not args.no_ceiling:
             # what a loop of NOTHING BUT the Gram kernel's MFMA instruction sustains on this device, now (the chip lowers its clock under

@@ -122,7 +122,7 @@ struct gamma_tag {};
 struct degree_tag {};
 struct coef0_tag {};
 struct cost_tag {};
-struct num_devices_tag {};  // mi355 backend only: devices used by one solve (0 = automatic)
+struct num_devices_tag {};  // mi355 backend only: devices used by one solve (default 1; 0 = automatic: every visible device)
 
 template <typename T>
 struct is_argument : std::false_type {};
@@ -436,7 +436,7 @@ class csvm : public ::plssvm_amd::csvm {
     }
 
     int num_devices_{ 0 };  // visible devices
-    int use_devices_{ 0 };  // devices per solve (0 = automatic)
+    int use_devices_{ 1 };  // devices per solve: 1 by default (several devices are opt-in: plssvm_amd::num_devices = k, 0 = every visible device)
     mutable lssvm_cg_info info_{};
 };
 

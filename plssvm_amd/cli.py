@@ -151,7 +151,10 @@ def predict_main(argv=None) -> int:
         _log(verb, ("full", "timing"), f"Write {len(predicted)} predictions to the file '{out_file}'.")
         if data.has_labels():
             correct = sum(1 for p, c in zip(predicted, data.labels()) if p == c)
-            _log(verb, ("full", "libsvm"), f"Accuracy = {100.0 * correct / len(predicted)}% ({correct}/{len(predicted)}) (classification)")  # main_predict.cpp:78-84
+            # main_predict.cpp:75-79: the ratio in the real type, printed with {fmt}'s {} (shortest round trip: 100, 99.2)
+            acc = real_type(correct) / real_type(len(predicted)) * real_type(100)
+            acc_text = str(int(acc)) if float(acc).is_integer() else str(acc)
+            _log(verb, ("full", "libsvm"), f"Accuracy = {acc_text}% ({correct}/{len(predicted)}) (classification)")
         _log(verb, ("full", "timing"), f"\nTotal runtime: {(time.perf_counter() - t0) * 1e3:.0f}ms")
     except PlssvmError as e:
         print(f"{e}\nException type: {type(e).__name__}", file=sys.stderr)
@@ -228,9 +231,17 @@ def _fmt(label):
     return str(int(f)) if f.is_integer() else repr(f)
 
 
-def _has_two_labels(filename, label_type):
+def _parse_by_extension(filename, dtype, label_type):
+    """the test file through the parser its name asks for, like data_set's constructor (data_set.hpp:494-505): *.arff -> ARFF, else LIBSVM"""
+    if str(filename).endswith(".arff"):
+        from .io_arff import parse_arff_data
+        return parse_arff_data(filename, dtype=dtype, label_type=label_type)
     from .io_libsvm import parse_libsvm_data
-    _, labels = parse_libsvm_data(filename, label_type=label_type)
+    return parse_libsvm_data(filename, dtype=dtype, label_type=label_type)
+
+
+def _has_two_labels(filename, label_type):
+    _, labels = _parse_by_extension(filename, np.float64, label_type)
     return labels is not None and len(set(labels)) == 2
 
 
@@ -241,8 +252,7 @@ class _Unlabeled(DataSet):
 def _unlabeled(filename, real_type, label_type=float):
     """a test file without labels, or with a single class: usable for prediction only (labels kept for the accuracy line, parsed with the
     label type the command line asked for: --use_strings_as_labels must not turn "cat" into a float conversion error)"""
-    from .io_libsvm import parse_libsvm_data
-    X, labels = parse_libsvm_data(filename, dtype=real_type, label_type=label_type)
+    X, labels = _parse_by_extension(filename, real_type, label_type)
     ds = DataSet(X, None, real_type=real_type)
     ds._labels = labels
     return ds

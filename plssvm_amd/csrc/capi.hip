@@ -335,10 +335,10 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
         } else if (n == "force_collective") {
             lssvm::options().force_collective = value != 0 ? 1 : 0;
         } else if (n == "gram_mode") {
-            LSSVM_REQUIRE(value == 0 || value == 1, "gram_mode must be 0 or 1");
+            LSSVM_REQUIRE(value >= 0 && value <= 3, "gram_mode must be 0 (v_mfma_f32), 1 (bf16x6), 2 (f16x3 unchecked) or 3 (f16x3 where the data allows, else bf16x6)");
             lssvm::options().gram_mode = value;
         } else if (n == "mfma_shape") {
-            LSSVM_REQUIRE(value >= 0 && value <= 2, "mfma_shape must be 0 (32x32x16), 1 (16x16x32) or 2 (16x16x32, hand-scheduled groups)");
+            LSSVM_REQUIRE(value == 1 || value == 2, "mfma_shape must be 1 (compiler-scheduled MFMA groups) or 2 (hand-scheduled groups)");
             lssvm::options().mfma_shape = value;
         } else if (n == "colslab_band_mb") {
             LSSVM_REQUIRE(value >= 1, "colslab_band_mb must be positive");

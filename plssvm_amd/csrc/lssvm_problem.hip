@@ -116,6 +116,13 @@ int select_device_checked(int device) {
 constexpr int MAX_LOCAL_DEVICES = 16;
 constexpr double FOLD_MAX_R2 = 200.0;    // folded rbf records (KT_RBFF) only while |c| = R2 / 2 <= 100: 2^c and 2^acc stay far inside the fp32 range
 constexpr int SPLIT_MAX_FEATURES = 384;  // the bf16x6 kernels exist for 1 ... 6 chunks of 64 features (row panel = 3 planes in registers)
+constexpr int F16_MAX_FEATURES = 512;    // the f16x3 kernels exist for 1 ... 8 chunks of 64 features (row panel = 2 planes in registers)
+constexpr int F16_RBF_MAX_FEATURES = 384;  // ... rbf: 1 ... 6 chunks (three row planes in registers: the shifted planes, see make_planes)
+constexpr int F16_RBF_SHIFT = 6;         // rbf: the planes are (2^-6 hi, 2^6 mid, 2^6 hi)
+constexpr int F16_TARGET_EXP = 14;       // f16x3, linear / polynomial: the planes carry 2^k x with max |2^k x| in [2^14, 2^15) (f16 overflows at 65504)
+constexpr int F16_MAX_SHIFT = 40;        // |k| is clamped here (2^(-2k) must stay a normal float beside gamma)
+constexpr float F16_REL2_MAX = 0x1p-44f; // accepted relative representation error of a row, squared: |x - (hi + mid)| <= 2^-22 |x| in the 2-norm
+constexpr float F16_ABS_MAX = 0x1p-22f;  // rbf: accepted bound on the ABSOLUTE error of the exponent from the representation, 2 max|rest| max|x|
 
 std::vector<int> resolve_devices(const int *devices, int num_devices, size_t num_points) {
     const int count = device_count_checked();
@@ -289,6 +296,107 @@ void half_neg_norms(const DeviceMatrix<T> &M, DevBuf<T> &c, hipStream_t s) {
     c.alloc_zero(M.rows_alloc, s);
     hipLaunchKernelGGL(k_half_neg_norms<T>, dim3((M.rows_alloc + 3) / 4), dim3(256), 0, s, M.data.p, M.ldx, M.rows_alloc, c.p);
     LSSVM_HIP_CHECK(hipGetLastError());
+}
+
+/* fp32: the (centred, scaled) data once more as operand planes of the split kernels; `M2` (predict: the points beside the support vectors)
+ * may be NULL and gets planes of the same kind and scale.
+ *   f16x3 (mode 2): two f16 planes, x ~ hi + mid (11 + 11 significant bits).  What limits them is f16's exponent range: mid ~ 2^-12 |x| turns
+ *     subnormal (loses bits) for |x| < 2^-2.  Linear and polynomial kernels: the planes carry 2^k x, k moves the largest entry to [2^14, 2^15)
+ *     so that mid stays a NORMAL f16 for entries down to 2^-17 of it -- undone exactly on the finished sums (TileArgs::out_scale) or inside
+ *     gamma.  rbf cannot pre-scale (the chain must leave the exponent itself, and a multiply per element in the epilogue costs matrix-core
+ *     time): it uses the SHIFTED planes (2^-6 hi, 2^6 mid, 2^6 hi) -- every product of a row plane and a column plane carries the net scale 1,
+ *     mid is normal for |x| in [2^-8, 2^10), which covers everything the exponent scale allows (|x| <= sqrt(rbf_direct_above)); the price is a
+ *     third row plane in registers, none in the column stream.  Whether the planes carry THIS data as well as fp32 does is measured, not
+ *     assumed: k_split_f16x2 returns the largest relative representation error of a row; above 2^-22 (data with a dynamic range beyond the
+ *     planes', or planes that overflow) the answer is no -- for rbf an absolute bound on the exponent's error is accepted as well.
+ *   bf16x6 (mode 1): three bf16 planes, exact for every fp32 input (8 exponent bits), twice the matrix-core work.
+ * option gram_mode: 0 = none (native v_mfma_f32 kernels), 1 = bf16x6, 2 = f16x3 without the check (A/B, tests), 3 = f16x3 if the data passes, else bf16x6. */
+static void make_planes(const Options &o, const lssvm_params &p, bool rbf_direct, const DeviceMatrix<float> &M, const DeviceMatrix<float> *M2, PlaneSet &out, PlaneSet *out2,
+                        hipStream_t s) {
+    out.mode = 0;
+    if (out2 != nullptr) out2->mode = 0;
+    const int ldx16 = static_cast<int>(round_up(static_cast<long>(M.dfeat), 64));
+    if (o.gram_mode == 0 || rbf_direct || !v2_eligible(o, M.ldx, false)) return;
+    auto alloc = [&](int nplanes) {
+        out.ldx16 = ldx16;
+        out.buf.alloc_zero(static_cast<size_t>(nplanes) * M.rows_alloc * ldx16, s);
+        if (M2 != nullptr) {
+            out2->ldx16 = ldx16;
+            out2->buf.alloc_zero(static_cast<size_t>(nplanes) * M2->rows_alloc * ldx16, s);
+        }
+    };
+    const bool rbf = p.kernel_type == LSSVM_KERNEL_RBF;
+    if ((o.gram_mode == 2 || o.gram_mode == 3) && ldx16 <= (rbf ? F16_RBF_MAX_FEATURES : F16_MAX_FEATURES)) {
+        DevBuf<unsigned> stats;
+        stats.alloc_zero(4, s);
+        int shift = 0;
+        unsigned host[4] = { 0, 0, 0, 0 };
+        if (p.kernel_type != LSSVM_KERNEL_RBF) {
+            absmax_f32(M.data.p, M.ldx, M.dfeat, static_cast<size_t>(M.rows), stats.p + 3, s);
+            if (M2 != nullptr) absmax_f32(M2->data.p, M2->ldx, M2->dfeat, static_cast<size_t>(M2->rows), stats.p + 3, s);
+            LSSVM_HIP_CHECK(hipMemcpyAsync(host, stats.p, sizeof(host), hipMemcpyDeviceToHost, s));
+            LSSVM_HIP_CHECK(hipStreamSynchronize(s));
+            float amax = 0.0f;
+            std::memcpy(&amax, &host[3], sizeof(float));
+            if (amax > 0.0f && std::isfinite(amax)) shift = std::min(std::max(F16_TARGET_EXP - std::ilogb(amax), -F16_MAX_SHIFT), F16_MAX_SHIFT);
+        }
+        alloc(rbf ? 3 : 2);
+        const float scale = std::ldexp(1.0f, shift);
+        const int pshift = rbf ? F16_RBF_SHIFT : 0;
+        split_f16_planes(M.data.p, M.ldx, M.dfeat, static_cast<size_t>(M.rows_alloc), ldx16, scale, pshift, out.buf.p, static_cast<size_t>(M.rows_alloc) * ldx16, stats.p, s);
+        if (M2 != nullptr) {
+            split_f16_planes(M2->data.p, M2->ldx, M2->dfeat, static_cast<size_t>(M2->rows_alloc), ldx16, scale, pshift, out2->buf.p, static_cast<size_t>(M2->rows_alloc) * ldx16, stats.p, s);
+        }
+        LSSVM_HIP_CHECK(hipMemcpyAsync(host, stats.p, sizeof(host), hipMemcpyDeviceToHost, s));
+        LSSVM_HIP_CHECK(hipStreamSynchronize(s));
+        float rel2 = 0.0f, rest2 = 0.0f, x2 = 0.0f;
+        std::memcpy(&rel2, &host[0], sizeof(float));
+        std::memcpy(&rest2, &host[1], sizeof(float));
+        std::memcpy(&x2, &host[2], sizeof(float));
+        bool ok = rel2 <= F16_REL2_MAX;  // (false for a NaN: an overflowing plane)
+        if (!ok && p.kernel_type == LSSVM_KERNEL_RBF) ok = std::isfinite(rel2) && 2.0 * std::sqrt(static_cast<double>(rest2) * static_cast<double>(x2)) <= static_cast<double>(F16_ABS_MAX);
+        if (const char *dbg = std::getenv("LSSVM_MI355_DEBUG"); dbg != nullptr && dbg[0] == '1') {
+            std::fprintf(stderr, "[plssvm_amd] f16 planes: shift %d, max relative representation error of a row %.3g (accepted up to %.3g), max |rest| %.3g, max |x| %.3g -> %s\n", shift,
+                         std::sqrt(static_cast<double>(rel2)), std::sqrt(static_cast<double>(F16_REL2_MAX)), std::sqrt(static_cast<double>(rest2)), std::sqrt(static_cast<double>(x2)),
+                         ok ? "f16x3" : (o.gram_mode == 2 ? "f16x3 (forced)" : "bf16x6"));
+        }
+        if (ok || o.gram_mode == 2) {
+            out.mode = 2;
+            out.shift = shift;
+            if (out2 != nullptr) {
+                out2->mode = 2;
+                out2->shift = shift;
+            }
+            return;
+        }
+        out.buf.release();
+        if (out2 != nullptr) out2->buf.release();
+    }
+    if ((o.gram_mode == 1 || o.gram_mode == 3) && ldx16 <= SPLIT_MAX_FEATURES) {
+        alloc(3);
+        split_bf16_planes(M.data.p, M.ldx, M.dfeat, static_cast<size_t>(M.rows_alloc), ldx16, out.buf.p, static_cast<size_t>(M.rows_alloc) * ldx16, s);
+        out.mode = 1;
+        if (M2 != nullptr) {
+            split_bf16_planes(M2->data.p, M2->ldx, M2->dfeat, static_cast<size_t>(M2->rows_alloc), ldx16, out2->buf.p, static_cast<size_t>(M2->rows_alloc) * ldx16, s);
+            out2->mode = 1;
+        }
+    }
+}
+
+/* the plane fields of TileArgs; `gamma` must hold the kernel's own gamma already */
+static void set_plane_args(TileArgs<float> &a, const lssvm_params &p, const PlaneSet &cols, const PlaneSet &rows, size_t col_rows_alloc, size_t row_rows_alloc) {
+    a.Xr16 = rows.buf.p;
+    a.Xc16 = cols.buf.p;
+    a.plane_stride = col_rows_alloc * cols.ldx16;
+    a.plane_stride_r = row_rows_alloc * rows.ldx16;
+    a.ldx16 = cols.ldx16;
+    a.planes_f16 = cols.mode == 2 ? 1 : 0;
+    a.out_scale = 1.0f;
+    if (cols.mode == 2 && cols.shift != 0) {
+        const float undo = std::ldexp(1.0f, -2 * cols.shift);
+        if (p.kernel_type == LSSVM_KERNEL_LINEAR) a.out_scale = undo;
+        if (p.kernel_type == LSSVM_KERNEL_POLYNOMIAL) a.gamma *= undo;
+    }
 }
 
 /* host restatement of kernel_function(x, x) for QA_cost (csvm.cpp:86): the same fma chain in the same precision */
@@ -476,8 +584,8 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         const long area = sym_ ? (ib_end * (ib_end + 1) - static_cast<long>(ib_begin_) * (ib_begin_ + 1)) / 2 : static_cast<long>(num_ib_) * num_tiles_;
         // the bf16x6 kernel has the costlier work-item prologue (three planes of the row panel) and the faster tiles: longer chunks
         // (measured 16 -> 64 tiles: +1.5 % at 100 000 points, +2 % at 300 000; the native kernels are flat or lose beyond 16)
-        const bool split = std::is_same_v<T, float> && opt_.gram_mode == 1 && v2_eligible(opt_, ldx_probe, rbf_direct_)
-                           && round_up(static_cast<long>(num_features), 64) <= SPLIT_MAX_FEATURES;
+        const bool split = std::is_same_v<T, float> && opt_.gram_mode != 0 && v2_eligible(opt_, ldx_probe, rbf_direct_)
+                           && round_up(static_cast<long>(num_features), 64) <= ((opt_.gram_mode == 1 || params_.kernel_type == LSSVM_KERNEL_RBF) ? SPLIT_MAX_FEATURES : F16_MAX_FEATURES);
         const long cap = split ? 64 : 16;
         jc_tiles_ = static_cast<int>(std::min<long>(cap, std::max<long>(2, (area + 2048) / 4096)));
     }
@@ -532,16 +640,10 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         }
     }
     if constexpr (std::is_same_v<T, float>) {
-        // gram_mode = 1 (default): the (centred, scaled) data once more as three bf16 planes, features in natural order
-        const int ldx16 = round_up(static_cast<long>(num_features), 64);
-        if (opt_.gram_mode == 1 && !rbf_direct_ && v2_eligible(opt_, X_.ldx, false) && ldx16 <= SPLIT_MAX_FEATURES) {
-            ldx16_ = ldx16;
-            const size_t plane_stride = static_cast<size_t>(X_.rows_alloc) * ldx16;
-            planes_.alloc_zero(3 * plane_stride, st);
-            split_bf16_planes(X_.data.p, X_.ldx, X_.dfeat, static_cast<size_t>(X_.rows_alloc), ldx16, planes_.p, plane_stride, st);
-            // rbf on the 16x16x32 kernels: folded records while the exponent terms stay small (rbf_r2_ = 2 max|c| in the exponent's unit)
-            dc_folded_ = params_.kernel_type == LSSVM_KERNEL_RBF && opt_.mfma_shape >= 1 && opt_.rbf_fold != 0 && rbf_r2_ <= FOLD_MAX_R2;
-        }
+        // the (centred, scaled) data once more as operand planes of the split kernels (features in natural order): see make_planes
+        make_planes(opt_, params_, rbf_direct_, X_, nullptr, planes_, nullptr, st);
+        // rbf: folded records while the exponent terms stay small (rbf_r2_ = 2 max|c| in the exponent's unit)
+        if (planes_.mode != 0) dc_folded_ = params_.kernel_type == LSSVM_KERNEL_RBF && opt_.rbf_fold != 0 && rbf_r2_ <= FOLD_MAX_R2;
     }
     interleave_features<T>(X_, st);
     if ((std::is_same_v<T, float> && v2_eligible(opt_, X_.ldx, rbf_direct_)) || (std::is_same_v<T, double> && v2_eligible_f64(opt_, X_.ldx))) {
@@ -601,11 +703,6 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     a.cc = c_.p;
     a.dvec = v_dev;
     a.dc = dc_.p;
-    a.Xr16 = planes_.p;
-    a.Xc16 = planes_.p;
-    a.plane_stride = static_cast<size_t>(X_.rows_alloc) * ldx16_;
-    a.plane_stride_r = a.plane_stride;
-    a.ldx16 = ldx16_;
     a.items = sym_ ? items_.p : nullptr;  // (the symmetric variant launches band by band: enqueue_apply_K_local offsets these two)
     a.num_items = num_items_;
     a.colslab = colslab_.p;
@@ -621,6 +718,9 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     a.ncols_valid = n_;
     set_kernel_scalars(a, params_, rbf_direct_);
     if (poly_prescaled_) a.gamma = T(1);
+    if constexpr (std::is_same_v<T, float>) {
+        if (planes_.mode != 0) set_plane_args(a, params_, planes_, planes_, static_cast<size_t>(X_.rows_alloc), static_cast<size_t>(X_.rows_alloc));
+    }
     set_launch_options(a, opt_);
     a.dc_folded = dc_folded_ ? 1 : 0;
     return a;
@@ -1115,7 +1215,12 @@ void Solver<T>::cg_step(uint64_t iterations, int *done_out) {
         // launches the next kernels (about 4 % of a 50 000-point iteration).  So the direction update and the NEXT implicit matvec go
         // into the queue BEFORE the stop test is read: they touch d, K*d and the partial slabs only -- never x or r -- so a solve that
         // turns out to have converged is exactly where the reference stops (csvm.cpp:155-158), at the price of one discarded matvec.
-        const double matvec_us = p0.matvec_launches_ > 0 ? p0.matvec_ms_ / static_cast<double>(p0.matvec_launches_) * 1e3 : 1e30;
+        // The decision must be the same on every rank of a sharded solve (a rank that went ahead has one more collective in its queue than
+        // one that did not: a hang at convergence, or every later collective paired one position off), so it is derived from the problem
+        // alone -- size, feature count, world -- never from this rank's own event timings: an implicit matvec is priced at 500 TFLOP/s of
+        // full-square work per device (the fp32 split kernels; slower paths then go ahead for somewhat longer matvecs, which is harmless).
+        const double n_d = static_cast<double>(p0.n_);
+        const double matvec_us = 2.0 * n_d * n_d * static_cast<double>(p0.X_.dfeat) / static_cast<double>(world_) / 500e12 * 1e6;
         const bool ahead = opt_.enqueue_ahead_below_us > 0 && matvec_us < static_cast<double>(opt_.enqueue_ahead_below_us) && k + 1 < iterations
                            && exchange_ != Exchange::process_peer;
         if (ahead) {
@@ -1205,7 +1310,7 @@ void Solver<T>::fill_info(lssvm_cg_info *info) {
     info->devices_used = world_;
     info->converged = converged_ ? 1 : 0;
     info->symmetric = p0.sym_ ? 1 : 0;
-    info->gram_mode = p0.planes_.p != nullptr ? 1 : 0;
+    info->gram_mode = p0.planes_.mode;
     info->local_devices = static_cast<int32_t>(shards_.size());
     info->rbf_direct = p0.rbf_direct_ ? 1 : 0;
     info->rbf_exponent_scale = p0.rbf_r2_;
@@ -1293,18 +1398,12 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
             poly_prescaled = true;
         }
     }
-    // fp32, gram_mode = 1: both sides once more as three bf16 planes (the bf16x6 kernels, full-square instance: rows = points, columns = support vectors)
-    DevBuf<uint16_t> planesS, planesP;
-    int ldx16 = 0;
+    // fp32: both sides once more as operand planes (the split kernels, full-square instance: rows = points, columns = support vectors)
+    PlaneSet planesS, planesP;
     if constexpr (std::is_same_v<T, float>) {
-        const int l16 = round_up(static_cast<long>(nfeat), 64);
-        if (opt.gram_mode == 1 && v2 && l16 <= SPLIT_MAX_FEATURES) {
-            ldx16 = l16;
-            planesS.alloc_zero(3 * static_cast<size_t>(S.rows_alloc) * ldx16, s);
-            planesP.alloc_zero(3 * static_cast<size_t>(P.rows_alloc) * ldx16, s);
-            split_bf16_planes(S.data.p, S.ldx, S.dfeat, static_cast<size_t>(S.rows_alloc), ldx16, planesS.p, static_cast<size_t>(S.rows_alloc) * ldx16, s);
-            split_bf16_planes(P.data.p, P.ldx, P.dfeat, static_cast<size_t>(P.rows_alloc), ldx16, planesP.p, static_cast<size_t>(P.rows_alloc) * ldx16, s);
-            dc_folded = (params.kernel_type == LSSVM_KERNEL_RBF && opt.mfma_shape >= 1 && opt.rbf_fold != 0 && rbf_r2 <= FOLD_MAX_R2) ? 1 : 0;
+        if (v2) {
+            make_planes(opt, params, rbf_direct, S, &P, planesS, &planesP, s);
+            if (planesS.mode != 0) dc_folded = (params.kernel_type == LSSVM_KERNEL_RBF && opt.rbf_fold != 0 && rbf_r2 <= FOLD_MAX_R2) ? 1 : 0;
         }
     }
     interleave_features<T>(S, s);
@@ -1344,11 +1443,6 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     }
     ta.dc = dc.p;
     ta.dc_folded = dc_folded;
-    ta.Xr16 = planesP.p;
-    ta.Xc16 = planesS.p;
-    ta.plane_stride = static_cast<size_t>(S.rows_alloc) * ldx16;
-    ta.plane_stride_r = static_cast<size_t>(P.rows_alloc) * ldx16;
-    ta.ldx16 = ldx16;
     ta.partial = partial.p;
     ta.part_stride = P.rows_alloc;
     ta.ldx = S.ldx;
@@ -1360,6 +1454,9 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     ta.ncols_valid = S.rows;
     set_kernel_scalars(ta, params, rbf_direct);
     if (poly_prescaled) ta.gamma = T(1);
+    if constexpr (std::is_same_v<T, float>) {
+        if (planesS.mode != 0) set_plane_args(ta, params, planesS, planesP, static_cast<size_t>(S.rows_alloc), static_cast<size_t>(P.rows_alloc));
+    }
     set_launch_options(ta, opt);
     launch_tile_kernel<T>(ta, params.kernel_type, rbf_direct, num_jc, s);
     hipLaunchKernelGGL(k_reduce_partials<T>, dim3((P.rows_alloc + 255) / 256), dim3(256), 0, s, partial.p, ta.part_stride, num_jc, 0, P.rows_alloc, Kv.p);

@@ -68,9 +68,11 @@ struct Options {
     int64_t lds_extra_kb = 0;      // experiment knob: extra dynamic LDS per workgroup of the fp32 v2 kernel (lowers workgroups per CU)
     int64_t debug_ablate = 0;      // diagnostic timing ablations of the fp32 tile kernel (results are wrong when != 0)
     int64_t item_order = 1;        // symmetric variant, order of the work items: 0 column-chunk major, 1 = 0 with the short (diagonal) items moved to the end, longest first
-    int64_t gram_mode = 1;         // fp32, <= 256 features: 1 = exact 3-way bf16 split of the operands, six plane products on the bf16 MFMA (default), 0 = v_mfma_f32
-    int64_t mfma_shape = 2;        // bf16x6 kernel: 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16 (same matrix-core cycles, the chip holds a higher
-                                   // clock under it), 2 = 1 with hand-scheduled MFMA groups for <= 128 features (default; more features run as 1)
+    int64_t gram_mode = 3;         // fp32 Gram tiles: 0 = v_mfma_f32 chains; 1 = "bf16x6": exact 3-way bf16 split of the operands, six plane products on the bf16
+                                   // MFMA (<= 384 features); 2 = "f16x3": two f16 planes of the pre-scaled operands, three plane products on the f16 MFMA (<= 512
+                                   // features), without the representability check; 3 (default) = f16x3 where the data passes that check, else bf16x6
+    int64_t mfma_shape = 2;        // split kernels (v_mfma_f32_16x16x32_*): 1 = compiler-scheduled MFMA groups, 2 = hand-scheduled groups for <= 128 features
+                                   // (default; more features run as 1).  (0 was round 1's 32x32x16 form, retired)
     int64_t colslab_band_mb = 2048;    // symmetric variant: the column-sum records of ONE row-block band may take this many MiB; the tile kernel runs band by band
     int64_t colslab_limit_mb = 98304;  // symmetric variant only while its column slab (per device) stays below this many MiB (96 GiB of the 288 GB)
     int64_t force_collective = 0;  // testing aid: run the per-matvec collective even for a world of one (needs lssvm_mi355_comm_init(.., 0, 1, ..))
@@ -217,9 +219,21 @@ template <typename T>
 void interleave_features(DeviceMatrix<T> &M, hipStream_t s);
 bool v2_eligible(const Options &o, int ldx, bool rbf_direct);
 void split_bf16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, uint16_t *planes, size_t plane_stride, hipStream_t s);  // tile_launch_f32s.hip
+/* the f16 planes of `scale` * X (scale = a power of two; shift = 0: two planes, shift > 0: the three shifted planes of the rbf kernels) + the representation
+ * statistics {max rel^2, max |rest|^2, max |y|^2} as float bits */
+void split_f16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, float scale, int shift, uint16_t *planes, size_t plane_stride, unsigned *stats, hipStream_t s);  // tile_launch_f32h.hip
+void absmax_f32(const float *X, int ldx, int dfeat, size_t rows, unsigned *out, hipStream_t s);  // tile_launch_f32h.hip
 bool v2_eligible_f64(const Options &o, int ldx);
 int sym_block_boundary(int num_tiles, int r, int world);
 void shard_blocks(int num_tiles, int world, int rank, bool symmetric, int &begin, int &end);
+
+/* fp32: a data matrix once more as operand planes of the split tile kernels (make_planes in lssvm_problem.hip) */
+struct PlaneSet {
+    DevBuf<uint16_t> buf;
+    int ldx16 = 0;
+    int mode = 0;   // 0 none, 1 bf16x6 (three bf16 planes), 2 f16x3 (two f16 planes)
+    int shift = 0;  // f16x3: the planes carry 2^shift x
+};
 
 /* ------------------------------------------------------------------ one device's share of the problem ------------------------------------------------------------------ */
 /* Problem<T>: the data matrix resident on ONE device plus the CG vectors, and the row blocks `rank` of `world` of the implicit
@@ -263,8 +277,7 @@ class Problem {
     double rbf_r2_ = 0.0;  // fp32 rbf: 2 gamma log2(e) max|x - mean|^2
     bool dc_folded_ = false;  // the (d_j | c_j) records carry (2^c_j d_j | 2^c_j): rbf on the 16x16x32 bf16x6 kernels
     bool poly_prescaled_ = false;  // fp64 polynomial on the v2 kernel: X_ carries sqrt(gamma), the kernel sees gamma = 1
-    DevBuf<uint16_t> planes_;      // gram_mode 1: X as three bf16 planes [3][rows_alloc][ldx16]
-    int ldx16_ = 0;
+    PlaneSet planes_;              // fp32 split kernels: X as three bf16 planes (bf16x6) or two f16 planes (f16x3), [planes][rows_alloc][ldx16]
 
     DeviceMatrix<T> X_;
     DevBuf<T> c_;  // -0.5 |x|^2 (rbf, centred data)

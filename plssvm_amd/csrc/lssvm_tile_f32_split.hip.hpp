@@ -26,362 +26,40 @@ namespace lssvm {
 
 #include "lssvm_s6w_groups.inc"
 
-template <int KT, int NK64, bool SYM>
-__global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec_f32_s6(const TileArgs<float> a) {
-    constexpr int NKC = 3 * NK64;  // plane-chunks (steps) per tile: for every 64-feature chunk the planes hi, mid, lo
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    char *ring = smem_raw;                                                          // [V2_RING][128 rows][128 B]
-    char *dcs = smem_raw + V2_RING * V2_SLOT_BYTES;                                 // [V2_DC_SLOTS][256 floats]
-    float *cis = reinterpret_cast<float *>(dcs + V2_DC_SLOTS * 1024);               // [128] c_i of the row panel (rbf)
-    float *dis = cis + TILE;                                                        // [128] d_i of the row panel (SYM)
-    float *colred = dis + TILE;                                                     // [2][4 waves][128] column sums of a tile (SYM)
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31;
-    const int h = lane >> 5;
-
-    // SYM: the kernel matrix is symmetric, so only the tiles on or below the diagonal are evaluated (as the reference does,
-    // svm_kernel.cpp:39); an off-diagonal tile K_IJ contributes K_IJ d_J to the rows of I AND K_IJ^T d_I to the rows of J.
-    // Work items come from a host-built list of the non-empty (row block, column chunk) pairs.
-    int ibl, jc;
-    if constexpr (SYM) {
-        const int2 it = a.items[blockIdx.x];
-        ibl = __builtin_amdgcn_readfirstlane(it.x);  // uniform, but loaded through the vector memory path: move to SGPRs so
-        jc = __builtin_amdgcn_readfirstlane(it.y);   // that everything derived from it is scalar arithmetic
+/* one plane product on the matrix cores: bf16 planes (bf16x6) or f16 planes (f16x3); same operand maps, same cycles */
+using f16x8 = _Float16 __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ f32x4 plane_mfma(const bf16x8 &av, const bf16x8 &bv, const f32x4 &c) {
+    if constexpr (F16) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
     } else {
-        if (!decode_work_item(a, ibl, jc)) return;
-    }
-    const int ib = a.ib_begin + ibl;
-    const int row0 = ib * TILE;
-    const int jt_begin = jc * a.jc_tiles;
-    const int jt_end = SYM ? min(jt_begin + a.jc_tiles, ib + 1) : min(jt_begin + a.jc_tiles, a.num_jt);
-    const int ntiles = jt_end - jt_begin;
-    if (ntiles <= 0) return;
-    const int nsteps = ntiles * NKC;
-    // record index of (ib, jt) in the packed strictly-lower-triangular column slab of this device
-    const long rec0 = SYM ? (static_cast<long>(ib) * (ib - 1) / 2 - a.pair_origin) : 0;
-
-    // ---- the row panel: A fragments of this wave's 32 rows, all features, all three planes: lane (r, h) holds features
-    // 16 s + 8 h .. + 7 of row r for k-step s (cdna_hip_programming.md, operand map of v_mfma_f32_32x32x16_bf16) ----
-    bf16x8 afrag[3][4 * NK64];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        const uint16_t *xr = a.Xr16 + p * a.plane_stride_r + static_cast<size_t>(row0 + wave * 32 + r) * a.ldx16 + 8 * h;
-#pragma unroll
-        for (int s = 0; s < 4 * NK64; ++s) afrag[p][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(xr + 16 * s));
-    }
-    if constexpr (KT == KT_RBF) {
-        if (tid < TILE) cis[tid] = a.cr[row0 + tid];
-    }
-    if constexpr (SYM) {
-        if (tid < TILE) dis[tid] = a.dvec[row0 + tid];
-    }
-    // make the compiler retire these ordinary loads HERE, before any LDS-DMA is in flight
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int s = 0; s < 4 * NK64; ++s) asm volatile("" : "+v"(afrag[p][s]));
-
-    // ---- LDS-DMA addressing ----
-    // instruction q = 4*wave + i moves rows 8q .. 8q+7 of a chunk; lane L -> row 8q + L/8, physical 16-B slot L%8, which
-    // holds logical slot (L%8) ^ ((row >> 1) & 7)
-    // The source address of a DMA is (uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset): the saddr form of
-    // global_load_lds, so a piece costs no 64-bit vector address arithmetic and one VGPR
-    unsigned dma_off[4];  // byte offset of this lane's 16 bytes inside a (tile, chunk) = 4 * (row * ldx + 4 * logical_slot)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 8 * (4 * wave + i) + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        dma_off[i] = 2u * static_cast<unsigned>(row * a.ldx16 + 8 * c);
-    }
-    auto issue_chunk = [&](int step) {  // step = linear (tile, chunk) index of this work item
-        if (LSSVM_DBG(a, 16) && step > 3) return;  // ablation: no DMA after the prologue
-        const int t = LSSVM_DBG(a, 1) ? 0 : step / NKC;  // ablation bit 1: always the same (L2-resident) tile
-        const int kc = LSSVM_DBG(a, 1) ? 0 : step - t * NKC;
-        const char *base = sgpr_ptr(a.Xc16 + (kc % 3) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (kc / 3) * 64);
-        char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES + wave * 4096;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + lane_off(dma_off[i])), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
-        }
-    };
-    // one of the four DMA instructions of a chunk (steady state: spread over the MFMA groups that follow the hand-over, an
-    // LDS-DMA issue costs the wave ~60-100 cycles, MI355X_MICROARCH.md "LDS-DMA piece issue cost")
-    auto issue_chunk_part = [&](int step, int i) {
-        const int t = step / NKC;
-        const int kc = step - t * NKC;
-        const char *base = sgpr_ptr(a.Xc16 + (kc % 3) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (kc / 3) * 64);
-        char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES + wave * 4096;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + lane_off(dma_off[i])), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
-    };
-    auto issue_dc = [&](int t) {  // (d_j | c_j) of tile jt_begin + t: 1 KiB, each wave moves a quarter with 16 lanes
-        if (lane < 16) {
-            const char *src = sgpr_ptr(a.dc + static_cast<size_t>(jt_begin + t) * 256) + __builtin_amdgcn_readfirstlane(wave * 256);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (src + 16u * (lane_off(threadIdx.x) & 15u)), (lds_ptr_t) (dcs + (t % V2_DC_SLOTS) * 1024 + wave * 256), 16, 0, 0);
-        }
-    };
-
-    // ---- read addressing: lane (r, h) reads 16-B logical slot 2*mm + h of row cb*32 + r (swizzle depends on r only) ----
-    int rd_off[4];
-#pragma unroll
-    for (int mm = 0; mm < 4; ++mm) rd_off[mm] = r * 128 + (((2 * mm + h) ^ ((r >> 1) & 7)) << 4);
-
-    float rowpart[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) rowpart[i] = 0.0f;
-    f32x16 acc[4];
-    bool padcol[4] = { false, false, false, false };
-
-    // ---- prologue: chunks 0, 1, 2 (each preceded by the record of the tile that starts with it) ----
-    issue_dc(0);
-    issue_chunk(0);
-#pragma unroll
-    for (int pre = 1; pre <= 2; ++pre) {
-        if (pre < nsteps) {
-            if (pre % NKC == 0) issue_dc(pre / NKC);
-            issue_chunk(pre);
-        }
-    }
-    // chunk 0 (and record 0, and cis) complete: everything but the DMA instructions of the younger chunks is done
-    if (nsteps >= 3) {
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    } else if (nsteps == 2) {
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    f32x4 bcur[4];  // B fragments of the group about to be multiplied (double buffered against bnext in the loop)
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) bcur[cb] = *reinterpret_cast<const f32x4 *>(ring + cb * 4096 + rd_off[0]);
-
-    // ---- hand-over of the NEXT chunk, executed in the MIDDLE of a step (in the shadow of that step's MFMAs) ----
-    // Called half-way through step `step`: this wave's DMA of chunk step+1 (issued 2 steps ago) is complete once all but its
-    // 4 youngest DMA instructions (chunk step+2) are done; the barrier makes every wave's part visible, so the next step
-    // starts reading at once, with no wait and no barrier at its head.  Ring of 4 slots: the DMA issued here (chunk step+3)
-    // overwrites the slot of chunk step-1, which every wave finished reading before it arrived at this barrier.
-    // CHECKED = false: steady state, step + 3 < nsteps is known, the code is branch free (one basic block per tile, so the
-    // compiler can place the scalar address arithmetic and the DMA issue in the shadow of the MFMAs); CHECKED = true: the
-    // last tiles of the work item.
-    auto handover = [&](int step, int kc_plus3_mod, auto checked) {
-        constexpr bool CHECKED = decltype(checked)::value;
-        if constexpr (!CHECKED) {
-            if (!LSSVM_DBG(a, 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            if (!LSSVM_DBG(a, 8)) __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            // the record of a tile is issued right BEFORE the first chunk of that tile: "chunk landed" implies "record landed"
-            if (kc_plus3_mod == 0) issue_dc((step + 3) / NKC);
-            // the four DMA instructions of chunk step+3 follow one by one between the MFMAs of this step's second half
-        } else {
-            if (step + 1 < nsteps) {
-                if (step + 2 < nsteps) {
-                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (step + 3 < nsteps) {
-                    if (kc_plus3_mod == 0) issue_dc((step + 3) / NKC);
-                    issue_chunk(step + 3);
-                }
-            }
-        }
-    };
-
-    // SYM: the four waves' column sums of tile t (written to colred by its epilogue, made visible by the next barrier) are
-    // added in a fixed order and stored to the tile's record of the column slab
-    auto flush_cols = [&](int t) {
-        if (tid < TILE) {
-            const float *cr_ = colred + (t & 1) * 512;
-            const float sum = (cr_[tid] + cr_[128 + tid]) + (cr_[256 + tid] + cr_[384 + tid]);
-            // (an explicit GLOBAL pointer: through the generic one the store is a flat_store, which counts in lgkmcnt as well and completes out of order)
-            auto *rec = (__attribute__((address_space(1))) float *) (a.colslab + (rec0 + jt_begin + t) * TILE);  // uniform base + 32-bit lane offset
-            rec[static_cast<unsigned>(tid)] = sum;
-        }
-    };
-
-    auto tile_body = [&](int t, auto checked) {
-        const int s0 = t * NKC;
-        const bool tile_sym = SYM && (jt_begin + t < ib);  // strictly below the diagonal
-        {
-            // tile_init: accumulator start values (the record became visible at the last hand-over).  d_j is read from the record in the
-            // epilogue and c_j only here, so that neither lives in registers across the MFMA steps (a spill reloaded inside the loop is a
-            // vector-memory operation: its vmcnt(0) drains the LDS-DMA queue)
-            const float *dcr = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);
-            if constexpr (KT == KT_POLY) {
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) padcol[cb] = (a.degree < 0) && ((jt_begin + t) * TILE + cb * 32 + r >= a.ncols_valid);
-            }
-            // rbf: the accumulators start at c_i + c_j (vector adds; producing the sum with one extra MFMA per accumulator --
-            // A = (c_i, 1), B = (1, c_j) -- was measured 0.8 % slower at c5: the adds overlap with the other workgroup's MFMAs)
-            if constexpr (KT == KT_RBF) {
-                float cj[4];
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) cj[cb] = dcr[128 + cb * 32 + r];
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const f32x4 civ = *reinterpret_cast<const f32x4 *>(cis + wave * 32 + 8 * g4 + 4 * h);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int cb = 0; cb < 4; ++cb) acc[cb][4 * g4 + e] = civ[e] + cj[cb];
-                }
-            }
-            // the other kernels start the chain with the constant 0 as the C operand of the first MFMA (no v_mov per register)
-        }
-#pragma unroll
-        for (int kc = 0; kc < NKC; ++kc) {
-            const int step = s0 + kc;
-            const char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES;
-            const char *slot_next = ring + ((step + 1) % V2_RING) * V2_SLOT_BYTES;
-#pragma unroll
-            for (int mm = 0; mm < 4; ++mm) {
-                // software prefetch of the NEXT group's B fragments (next chunk for mm == 3: visible since this step's hand-over),
-                // issued before the hand-over barrier so that LDS latency and barrier skew hide behind the 16 MFMAs below
-                f32x4 bnext[4];
-                if (mm < 3) {
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) bnext[cb] = *reinterpret_cast<const f32x4 *>(slot + cb * 4096 + rd_off[mm + 1]);
-                }
-                if (mm == 2) {
-                    if constexpr (SYM) {
-                        // the colred writes of the previous tile's epilogue must have completed before the barrier publishes them
-                        if (kc == 0 && t > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    }
-                    handover(step, (kc + 3) % NKC, checked);
-                    if constexpr (SYM) {
-                        if (kc == 0 && t > 0) flush_cols(t - 1);  // every tile before the last one of an item is off-diagonal
-                    }
-                }
-                if (mm == 3) {
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) bnext[cb] = *reinterpret_cast<const f32x4 *>(slot_next + cb * 4096 + rd_off[0]);
-                }
-                // plane p of the column chunk meets the row planes q with p + q <= 2: hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid --
-                // every product of significance >= 2^-16 relative to x*y, the dropped ones (mid*lo, lo*mid, lo*lo) are below 2^-24
-                const int chunk = kc / 3, plane = kc % 3;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    if (q + plane > 2) continue;
-                    const bf16x8 av = afrag[q][4 * chunk + mm];
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) {
-                        const bf16x8 bv = __builtin_bit_cast(bf16x8, bcur[cb]);
-                        if (KT != KT_RBF && kc == 0 && mm == 0 && q == 0) {
-                            const f32x16 zero = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
-                            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, zero, 0, 0, 0);
-                        } else {
-                            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[cb], 0, 0, 0);
-                        }
-                        if constexpr (!decltype(checked)::value) {
-                            if (q == 0 && mm >= 2 && (cb & 1) == 0) issue_chunk_part(step + 3, (mm - 2) * 2 + (cb >> 1));
-                        }
-                    }
-                }
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) bcur[cb] = bnext[cb];
-            }
-        }
-        // epilogue of the tile: K_ij = f(acc), row partial += K_ij * d_j; SYM, off-diagonal tile: column partial += K_ij * d_i
-        // (vector ALU, fused; the Gram tile itself is never written)
-        if (!LSSVM_DBG(a, 4))
-        {  // (the polynomial degree class is a template parameter here: KT_POLY2 / KT_POLY3 / generic KT_POLY)
-            auto epilogue = [&](auto with_cols) {
-                constexpr bool COLS = decltype(with_cols)::value;
-                float di[16];
-                float colacc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-                if constexpr (COLS) {
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const f32x4 dv = *reinterpret_cast<const f32x4 *>(dis + wave * 32 + 8 * g4 + 4 * h);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) di[4 * g4 + e] = dv[e];
-                    }
-                }
-                const float *dcr = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);  // the record stays valid until tile t + 4 is announced
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    const float djv = dcr[cb * 32 + r];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        float kv = apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(acc[cb][i], a);
-                        if constexpr (KT == KT_POLY) {
-                            if (padcol[cb]) kv = 0.0f;
-                        }
-                        rowpart[i] = fmaf(kv, djv, rowpart[i]);
-                        if constexpr (COLS) colacc[cb] = fmaf(kv, di[i], colacc[cb]);
-                    }
-                }
-                if constexpr (COLS) {
-                    float *cw = colred + (t & 1) * 512 + wave * 128;
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) colacc[cb] = sum_with_lane_xor32(colacc[cb]);  // the two lane halves hold different rows (no LDS round trip)
-                    if (h == 0) {
-#pragma unroll
-                        for (int cb = 0; cb < 4; ++cb) cw[cb * 32 + r] = colacc[cb];
-                    }
-                }
-            };
-            if (tile_sym) {
-                epilogue(std::true_type{});
-            } else {
-                epilogue(std::false_type{});
-            }
-        }
-    };
-
-    // steady state: every tile whose last step still has step + 3 < nsteps; then the (1..3) tail tiles with the checked hand-over
-    constexpr int TAIL_TILES = (3 + NKC - 1) / NKC;
-    const int nmain = ntiles > TAIL_TILES ? ntiles - TAIL_TILES : 0;
-    int t = 0;
-    for (; t < nmain; ++t) tile_body(t, std::false_type{});
-    for (; t < ntiles; ++t) tile_body(t, std::true_type{});
-    if constexpr (SYM) {
-        if (jt_begin + ntiles - 1 < ib) {  // the last tile was off-diagonal: publish its column sums
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            flush_cols(ntiles - 1);
-        }
-    }
-
-    // every wave owns its rows: reduce over the 32 lanes of a lane-half and store
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        float v = rowpart[i];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 8);
-        v += __shfl_xor(v, 4);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 1);
-        rowpart[i] = v;
-    }
-    if (r == 0) {
-        float *dst = a.partial + static_cast<size_t>(jc) * a.part_stride + ibl * TILE + wave * 32 + 4 * h;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dst[(i & 3) + 8 * (i >> 2)] = rowpart[i];
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
     }
 }
 
 /*
- * The same kernel on v_mfma_f32_16x16x32_bf16 (option mfma_shape = 1).  Same data movement (LDS-DMA ring, swizzled 128-byte rows, records,
- * hand-over), same number of matrix-core cycles; what changes is the instruction shape: a wave's 32 rows x 128 columns are 2 x 8 blocks of
- * 16 x 16 (64 accumulator registers, as before), one B fragment (16 columns x 32 features, one ds_read_b128) feeds up to 6 MFMAs (2 row
- * blocks x up to 3 row planes) instead of 3.  Why: in the power-bound regime this kernel runs in, MI355X holds a higher clock on the 16x16x32
- * shape (MI355X_MICROARCH.md "DVFS give-back" (7): 1.12-1.15 x the FLOP/s of the 32x32x16 loop at equal cycles per FLOP, on random data).
+ * The split kernel on v_mfma_f32_16x16x32_{bf16,f16}.  (Round 1's 32x32x16 form of it -- each wave 4 accumulators of 32 x 32 -- was retired in
+ * round 3: same matrix-core cycles, but in the power-bound regime this kernel runs in MI355X holds a higher clock on the 16x16x32 shape,
+ * MI355X_MICROARCH.md "DVFS give-back" (7); measured 511 against 477 ms at 1 000 000 x 128, profiles/r02_ab_mfma_shape_c5.log.)
+ * A wave's 32 rows x 128 columns are 2 x 8 blocks of 16 x 16 (64 accumulator registers), one B fragment (16 columns x 32 features, one
+ * ds_read_b128) feeds up to 6 MFMAs (2 row blocks x up to 3 row planes).
  * Operand maps (cdna_hip_programming.md section 3): lane l holds A[row l & 15][k = 8 (l >> 4) + j] and B[k = 8 (l >> 4) + j][col l & 15], j = 0..7;
  * the result has col = l & 15, row = 4 (l >> 4) + reg.
  * A step (= one plane of one 64-feature chunk) is processed in four groups mm = (k32 step kk = mm >> 1, column half cbh = mm & 1) of four column
  * blocks each, so that the B fragments stay double buffered in 2 x 16 registers and the hand-over sits in the middle of a step as before.
  */
-template <int KT, int NK64, bool SYM, bool HAND>
+template <int KT, int NK64, bool SYM, bool HAND, int PL>
 __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
-    constexpr int NKC = 3 * NK64;  // plane-chunks (steps) per tile: for every 64-feature chunk the planes hi, mid, lo
+    static_assert(PL == 3 || PL == 2, "three bf16 planes (bf16x6) or two f16 planes (f16x3)");
+    constexpr bool F16 = PL == 2;
+    constexpr int NKC = PL * NK64;  // plane-chunks (steps) per tile: for every 64-feature chunk the planes hi, mid (, lo)
+    // ROW planes held in registers.  bf16x6: the three planes.  f16x3: the two planes -- or, for rbf (which cannot pre-scale the data: the
+    // chain must leave the exponent itself), the SHIFTED planes P0 = 2^-6 hi, P1 = 2^6 mid, P2 = 2^6 hi (k_split_f16x2): the columns stream
+    // (P0, P1), the rows hold (P2, P1) against column plane P0 and P0 against column plane P1, so that every product carries the net scale 1
+    // while mid stays a normal f16 for entries down to 2^-8 instead of 2^-2.
+    constexpr int PLA = F16 ? ((KT == KT_RBF || KT == KT_RBFF) ? 3 : 2) : 3;
+    // row plane of the q-th product of column plane p
+    constexpr auto row_plane = [](int p, int q) constexpr { return (F16 && PLA == 3) ? (p == 0 ? (q == 0 ? 2 : 1) : 0) : q; };
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char *ring = smem_raw;                                                          // [V2_RING][128 rows][128 B]
     char *dcs = smem_raw + V2_RING * V2_SLOT_BYTES;                                 // [V2_DC_SLOTS][256 floats]
@@ -414,9 +92,9 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
 
     // ---- the row panel: A fragments of this wave's 32 rows (two blocks of 16), all features, all three planes: lane (r, g) holds features
     // 32 kk + 8 g .. + 7 of row 16 rb + r for k32 step kk ----
-    bf16x8 afrag[3][2 * NK64][2];
+    bf16x8 afrag[PLA][2 * NK64][2];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < PLA; ++p) {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const uint16_t *xr = a.Xr16 + p * a.plane_stride_r + static_cast<size_t>(row0 + wave * 32 + 16 * rb + r) * a.ldx16 + 8 * g;
@@ -432,7 +110,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
     }
     // make the compiler retire these ordinary loads HERE, before any LDS-DMA is in flight
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < PLA; ++p)
 #pragma unroll
         for (int kk = 0; kk < 2 * NK64; ++kk)
 #pragma unroll
@@ -450,7 +128,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
         if (LSSVM_DBG(a, 16) && step > 3) return;  // ablation: no DMA after the prologue
         const int t = LSSVM_DBG(a, 1) ? 0 : step / NKC;  // ablation bit 1: always the same (L2-resident) tile
         const int kc = LSSVM_DBG(a, 1) ? 0 : step - t * NKC;
-        const char *base = sgpr_ptr(a.Xc16 + (kc % 3) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (kc / 3) * 64);
+        const char *base = sgpr_ptr(a.Xc16 + (kc % PL) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (kc / PL) * 64);
         char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES + wave * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -468,7 +146,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
         if (LSSVM_DBG(a, 16)) return;
         if (LSSVM_DBG(a, 64) && i != 0) return;   // bit 64: a quarter of the DMA instructions (timing only)
         if (LSSVM_DBG(a, 128) && wave != 0) return;  // bit 128: only wave 0 issues DMA
-        const char *base = xc_tile + (KC3 >= NKC ? tile_bytes : size_t(0)) + (KC % 3) * plane_bytes + (KC / 3) * 128;
+        const char *base = xc_tile + (KC3 / NKC) * tile_bytes + (KC % PL) * plane_bytes + (KC / PL) * 128;  // (f16x3 at 64 features: NKC = 2, three steps ahead can be TWO tiles ahead)
         char *slot = ring + slot_idx * V2_SLOT_BYTES + wave * 4096;
         __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + lane_off(dma_off[i])), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
     };
@@ -602,7 +280,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
         const unsigned phase = static_cast<unsigned>(s0) & (V2_RING - 1);  // ring slot of the tile's first step (uniform)
         static_for<0, NKC>([&](auto kc_c) {
             constexpr int kc = decltype(kc_c)::value;
-            constexpr int chunk = kc / 3, plane = kc % 3;
+            constexpr int chunk = kc / PL, plane = kc % PL;
             const int step = s0 + kc;
             const unsigned slot_off = ((phase + kc) & (V2_RING - 1)) * V2_SLOT_BYTES;
             const unsigned slot_next_off = ((phase + kc + 1) & (V2_RING - 1)) * V2_SLOT_BYTES;
@@ -614,8 +292,8 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
                 // is there a group after this one?  (steady state: always; last tiles of the work item: not after the very last group)
                 const bool more = !decltype(checked)::value || mm < 3 || step + 1 < nsteps;
                 if constexpr (HAND) {
-                    constexpr int NQ = 3 - plane;
-                    constexpr bool ZC = (KT != KT_RBF) && kc == 0 && kk == 0;  // first MFMA of every accumulator of this column half: C = 0 (or c_i: KT_RBFF)
+                    constexpr int NQ = PL - plane;
+                    constexpr int Z = ((KT != KT_RBF) && kc == 0 && kk == 0) ? (KT == KT_RBFF ? 2 : 1) : 0;  // first MFMA of every accumulator of this column half: C = 0 (or c_i: KT_RBFF)
                     constexpr int CUR = mm & 1;
                     if constexpr (mm == 2) {
                         if constexpr (SYM) {
@@ -632,53 +310,18 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
                     constexpr int PO = mm < 3 ? 4 * NH * 2048 : 0;
                     f32x4 &c0 = acc[0][4 * cbh + 0], &c1 = acc[1][4 * cbh + 0], &c2 = acc[0][4 * cbh + 1], &c3 = acc[1][4 * cbh + 1];
                     f32x4 &c4 = acc[0][4 * cbh + 2], &c5 = acc[1][4 * cbh + 2], &c6 = acc[0][4 * cbh + 3], &c7 = acc[1][4 * cbh + 3];
-                    const bf16x8 &a00 = afrag[0][2 * chunk + kk][0], &a01 = afrag[0][2 * chunk + kk][1];
-                    if constexpr (NQ == 3) {
-                        const bf16x8 &a10 = afrag[1][2 * chunk + kk][0], &a11 = afrag[1][2 * chunk + kk][1];
-                        const bf16x8 &a20 = afrag[2][2 * chunk + kk][0], &a21 = afrag[2][2 * chunk + kk][1];
-                        if constexpr (ZC && KT == KT_RBFF) {
-                            if constexpr (CUR == 0) {
-                                if (more) s6w_group_q3_b0_p1_z2<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, civ0[0], civ0[1], paddr);
-                                else s6w_group_q3_b0_p0_z2<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, civ0[0], civ0[1], paddr);
-                            } else {
-                                if (more) s6w_group_q3_b1_p1_z2<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, civ0[0], civ0[1], paddr);
-                                else s6w_group_q3_b1_p0_z2<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, civ0[0], civ0[1], paddr);
-                            }
-                        } else if constexpr (ZC) {
-                            if constexpr (CUR == 0) {
-                                if (more) s6w_group_q3_b0_p1_z1<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
-                                else s6w_group_q3_b0_p0_z1<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
-                            } else {
-                                if (more) s6w_group_q3_b1_p1_z1<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
-                                else s6w_group_q3_b1_p0_z1<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
-                            }
-                        } else {
-                            if constexpr (CUR == 0) {
-                                if (more) s6w_group_q3_b0_p1_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
-                                else s6w_group_q3_b0_p0_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
-                            } else {
-                                if (more) s6w_group_q3_b1_p1_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
-                                else s6w_group_q3_b1_p0_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, paddr);
-                            }
-                        }
-                    } else if constexpr (NQ == 2) {
-                        const bf16x8 &a10 = afrag[1][2 * chunk + kk][0], &a11 = afrag[1][2 * chunk + kk][1];
-                        if constexpr (CUR == 0) {
-                            if (more) s6w_group_q2_b0_p1_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, paddr);
-                            else s6w_group_q2_b0_p0_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, paddr);
-                        } else {
-                            if (more) s6w_group_q2_b1_p1_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, paddr);
-                            else s6w_group_q2_b1_p0_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, paddr);
-                        }
-                    } else {
-                        if constexpr (CUR == 0) {
-                            if (more) s6w_group_q1_b0_p1_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, paddr);
-                            else s6w_group_q1_b0_p0_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, paddr);
-                        } else {
-                            if (more) s6w_group_q1_b1_p1_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, paddr);
-                            else s6w_group_q1_b1_p0_z0<PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, paddr);
-                        }
-                    }
+                    // row planes 0 .. NQ - 1 of this k32 step (the dispatcher ignores the operands beyond 2 NQ)
+                    constexpr int P0 = row_plane(plane, 0), P1 = NQ >= 2 ? row_plane(plane, 1) : P0, P2 = NQ >= 3 ? row_plane(plane, 2) : P0;
+                    const bf16x8 &a00 = afrag[P0][2 * chunk + kk][0], &a01 = afrag[P0][2 * chunk + kk][1];
+                    const bf16x8 &a10 = afrag[P1][2 * chunk + kk][0], &a11 = afrag[P1][2 * chunk + kk][1];
+                    const bf16x8 &a20 = afrag[P2][2 * chunk + kk][0], &a21 = afrag[P2][2 * chunk + kk][1];
+                    // ONE form of every group, also for the very last one of the work item (whose prefetch then reads a stale but valid slot and is
+                    // never used): a branch between a prefetching and a non-prefetching variant made the compiler merge the accumulators of the two
+                    // arms with v_mov copies two instructions behind the MFMAs that write them -- inside an asm statement it inserts none of the
+                    // wait states an XDL write needs before a VALU read, so the copies read registers still in flight (NaNs in every work item of two
+                    // or more tiles: f16x3 rbf at 128 features; most likely also round 2's NaN of the one-wave bf16x6 form).
+                    // tests/tools/audit_hand_asm.py checks the generated code for such copies.
+                    s6_group<F16, NQ, CUR, 1, Z, PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, civ0[0], civ0[1], paddr);
                     // the LDS-DMA of chunk step + 3 goes between the groups of the step's second half (two instructions behind each)
                     if constexpr (!decltype(checked)::value && mm >= 2) {
                         issue_part_static(std::integral_constant<int, kc + 3>{}, (phase + kc + 3) & (V2_RING - 1), (mm - 2) * 2 + 0);
@@ -716,22 +359,22 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
                     LSSVM_SCHED_BARRIER();
                 }
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    if (q + plane > 2) continue;
+                for (int q = 0; q < PL; ++q) {
+                    if (q + plane > PL - 1) continue;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const int cb = 4 * cbh + c;
                         const bf16x8 bv = __builtin_bit_cast(bf16x8, bcur[c]);
 #pragma unroll
                         for (int rb = 0; rb < 2; ++rb) {
-                            const bf16x8 av = afrag[q][2 * chunk + kk][rb];
+                            const bf16x8 av = afrag[row_plane(plane, q)][2 * chunk + kk][rb];
                             if (KT == KT_RBFF && kc == 0 && kk == 0 && q == 0) {
-                                acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, civ0[rb], 0, 0, 0);
+                                acc[rb][cb] = plane_mfma<F16>(av, bv, civ0[rb]);
                             } else if (KT != KT_RBF && kc == 0 && kk == 0 && q == 0) {
                                 const f32x4 zero = { 0.f, 0.f, 0.f, 0.f };
-                                acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, zero, 0, 0, 0);
+                                acc[rb][cb] = plane_mfma<F16>(av, bv, zero);
                             } else {
-                                acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[rb][cb], 0, 0, 0);
+                                acc[rb][cb] = plane_mfma<F16>(av, bv, acc[rb][cb]);
                             }
                         }
                         if constexpr (!decltype(checked)::value) {
@@ -782,6 +425,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
                     for (int cb = 0; cb < 8; ++cb) {
                         float v = sum_with_lane_xor16(sum_with_lane_xor32(colacc[cb]));
                         if constexpr (KT == KT_RBFF) v *= dcr[128 + cb * 16 + r];  // K_ij = 2^acc * 2^c_j: the column's factor once per column
+                        if constexpr (KT == KT_LINEAR && F16) v *= a.out_scale;  // planes pre-scaled by 2^k: undo 2^(2k) (exact)
                         colacc[cb] = v;
                     }
                     if (g == 0) {
@@ -820,6 +464,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
         v += __shfl_xor(v, 4);
         v += __shfl_xor(v, 2);
         v += __shfl_xor(v, 1);
+        if constexpr (KT == KT_LINEAR && F16) v *= a.out_scale;
         rowpart[i] = v;
     }
     if (r == 0) {
@@ -829,35 +474,42 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
     }
 }
 
+/* The hand-scheduled kernels keep their B fragments in v[224:255], registers the compiler must never allocate.  The cap is the function attribute
+ * "amdgpu-num-vgpr" -- which on gfx950 (unified 512-entry VGPR/AGPR file) counts HALF registers: the backend doubles the requested number
+ * (GCNSubtarget::getBaseMaxNumVGPRs) before it reserves everything above it, so amdgpu_num_vgpr(224) reserves nothing below v448 and is silently
+ * ineffective -- round 2 shipped it that way and was saved by kernels that happened to need fewer than 224 registers; the f16x3 rbf form needed 229,
+ * the compiler put epilogue temporaries into v224 ... v228, and every work item of two or more tiles returned NaNs.  amdgpu_num_vgpr(112) is the
+ * cap that holds (measured: highest compiler-allocated register v223, spills instead of trespassing); tests/tools/audit_hand_asm.py checks every
+ * hand-scheduled instantiation for compiler code that touches v224 and above, and for scratch traffic. */
+#define LSSVM_HAND_VGPR_CAP __attribute__((amdgpu_num_vgpr(112)))
+
 /* the two kernels around s6w_body: compiler-scheduled groups (any supported feature count), and hand-scheduled groups for the
  * two-waves-per-SIMD instantiations, where the compiler is confined to v0..v223 so that v[224:255] can hold the B fragments */
 template <int KT, int NK64, bool SYM>
 __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec_f32_s6w(const TileArgs<float> a) {
-    s6w_body<KT, NK64, SYM, false>(a);
+    s6w_body<KT, NK64, SYM, false, 3>(a);
 }
 template <int KT, int NK64, bool SYM>
-__global__ __launch_bounds__(TILE_THREADS, 2) __attribute__((amdgpu_num_vgpr(224))) void tile_matvec_f32_s6h(const TileArgs<float> a) {
+__global__ __launch_bounds__(TILE_THREADS, 2) LSSVM_HAND_VGPR_CAP void tile_matvec_f32_s6h(const TileArgs<float> a) {
     static_assert(NK64 <= 2, "the hand-scheduled groups assume the 256-register budget of two waves per SIMD");
-    s6w_body<KT, NK64, SYM, true>(a);
+    s6w_body<KT, NK64, SYM, true, 3>(a);
 }
-
-/* x = hi + mid + lo, each rounded to nearest-even bf16 of the remainder (exact: the remainders are representable in fp32).
- * X: [rows][ldx] fp32, features in natural order; planes: [3][rows][ldx16] bf16, zero padded. */
-__global__ void k_split_bf16x3(const float *__restrict__ X, int ldx, int dfeat, size_t rows, int ldx16, uint16_t *__restrict__ planes, size_t plane_stride) {
-    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const size_t total = rows * static_cast<size_t>(ldx16);
-    if (idx >= total) return;
-    const size_t row = idx / ldx16;
-    const int f = static_cast<int>(idx - row * ldx16);
-    const float x = f < dfeat ? X[row * ldx + f] : 0.0f;
-    const __bf16 hi = static_cast<__bf16>(x);
-    const float r1 = x - static_cast<float>(hi);
-    const __bf16 mid = static_cast<__bf16>(r1);
-    const float r2 = r1 - static_cast<float>(mid);
-    const __bf16 lo = static_cast<__bf16>(r2);
-    planes[idx] = __builtin_bit_cast(uint16_t, hi);
-    planes[plane_stride + idx] = __builtin_bit_cast(uint16_t, mid);
-    planes[2 * plane_stride + idx] = __builtin_bit_cast(uint16_t, lo);
+/* "f16x3": the same kernels on TWO f16 planes (x = hi + mid, 11 + 11 significant bits, k_split_f16x2) and the three plane products
+ * hi*hi + hi*mid + mid*hi on v_mfma_f32_16x16x32_f16 -- half the matrix-core work of bf16x6 and two thirds of its column stream.  What is
+ * dropped (mid*mid and the split remainder) is below 2^-23 |x||y| per product while the planes stay in f16's normal range, which the set-up
+ * checks row by row on the data itself (Problem<T>: `f16_planes_ok`); data that fails the check runs as bf16x6.  Row panel = 2 planes: 64
+ * registers at 128 features, 256 at 512 features. */
+constexpr int f16_max_nk64(int kt) { return (kt == KT_RBF || kt == KT_RBFF) ? 6 : 8; }  // rbf holds three row planes (see s6w_body)
+template <int KT, int NK64, bool SYM>
+__global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec_f32_f3w(const TileArgs<float> a) {
+    static_assert(NK64 <= f16_max_nk64(KT), "row panel does not fit the register file");
+    s6w_body<KT, NK64, SYM, false, 2>(a);
+}
+constexpr int F16_HAND_MAX_NK64 = 2;
+template <int KT, int NK64, bool SYM>
+__global__ __launch_bounds__(TILE_THREADS, 2) LSSVM_HAND_VGPR_CAP void tile_matvec_f32_f3h(const TileArgs<float> a) {
+    static_assert(NK64 <= F16_HAND_MAX_NK64, "the hand-scheduled groups assume the 256-register budget of two waves per SIMD");
+    s6w_body<KT, NK64, SYM, true, 2>(a);
 }
 
 }  // namespace lssvm

@@ -40,8 +40,12 @@ struct TileArgs {
     const T *dvec;    // [num_jt*TILE] vector multiplied from the right, EXACT zeros beyond the valid columns
     const T *dc;      // v2 kernels: packed [num_jt][256] records (d_j | c_j) for LDS-DMA (k_pack_dc); KT_RBFF: (2^c_j d_j | 2^c_j)
     int dc_folded;    // host side only: 1 if the records carry the folded form (rbf on the 16x16x32 bf16x6 kernels while |c| stays small)
-    const uint16_t *Xr16;  // fp32 split kernel: the row side as three bf16 planes [3][rows][ldx16] (hi, mid, lo: x = hi + mid + lo exactly)
-    const uint16_t *Xc16;  // fp32 split kernel: the column side, same layout
+    const uint16_t *Xr16;  // fp32 split kernels: the row side as three bf16 planes [3][rows][ldx16] (hi, mid, lo: x = hi + mid + lo exactly; "bf16x6")
+                           // or as two f16 planes [2][rows][ldx16] (hi, mid of 2^k x; "f16x3")
+    const uint16_t *Xc16;  // fp32 split kernels: the column side, same layout
+    int planes_f16;        // host side only: 1 if the planes are the two f16 planes (f16x3 kernels), 0 for the three bf16 planes
+    T out_scale;           // f16x3, linear kernel: 2^(-2k), undoes the power-of-two pre-scale of the planes on the finished sums (exact);
+                           // polynomial: folded into gamma; rbf: k = 0
     size_t plane_stride;   // elements between the planes of the COLUMN side
     size_t plane_stride_r; // elements between the planes of the ROW side (training: the same matrix; predict_values: the points to predict)
     int ldx16;             // padded features of the planes (multiple of 64)

@@ -42,5 +42,7 @@ static unsigned finish_mapping(TileArgs<T> &a, int num_jc) {
 
 /* fp32 "bf16x6" split kernel (tile_launch_f32s.hip); `grid` is used by the full-square variant only */
 void launch_split_tile_kernel(const TileArgs<float> &a, int kernel_type, dim3 grid, hipStream_t s);
+/* fp32 "f16x3" split kernel (tile_launch_f32h.hip) */
+void launch_f16_tile_kernel(const TileArgs<float> &a, int kernel_type, dim3 grid, hipStream_t s);
 
 }  // namespace lssvm

@@ -32,8 +32,12 @@ void launch_tile_kernel<float>(TileArgs<float> &a, int kernel_type, bool rbf_dir
     const dim3 block(TILE_THREADS);
     if (grid.x == 0) return;
     constexpr size_t lds = static_cast<size_t>(4) * TILE * F32_LS * sizeof(float) + TILE * sizeof(float);  // staging ring + c_i of the row block
-    if (a.dc != nullptr && a.Xc16 != nullptr) {  // option gram_mode = 1: the three-plane bf16 data exists
-        launch_split_tile_kernel(a, kernel_type, grid, s);
+    if (a.dc != nullptr && a.Xc16 != nullptr) {  // the data exists as planes: two f16 planes (f16x3) or three bf16 planes (bf16x6)
+        if (a.planes_f16 != 0) {
+            launch_f16_tile_kernel(a, kernel_type, grid, s);
+        } else {
+            launch_split_tile_kernel(a, kernel_type, grid, s);
+        }
         return;
     }
     if (a.dc != nullptr) {  // the records exist only where the v2 kernel was chosen when the data was prepared (v2_eligible)

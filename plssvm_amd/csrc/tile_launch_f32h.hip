@@ -1,0 +1,152 @@
+/*
+ * tile_launch_f32h.hip -- instantiates and launches the fp32 "f16x3" split tile kernels (lssvm_tile_f32_split.hip.hpp: two f16 planes,
+ * three plane products on v_mfma_f32_16x16x32_f16) and their set-up kernels.  A translation unit of its own so that it builds beside the
+ * bf16x6 instantiations.  Compiled for gfx950 only.
+ */
+#include "tile_launch.hip.hpp"
+
+#include "lssvm_tile_f32_split.hip.hpp"
+
+namespace lssvm {
+
+/* "f16x3" planes of y = scale * x (scale = 2^k, exact).  One wave per row.
+ *   shift = 0 (linear, polynomial):  hi = f16(y), mid = f16(y - hi); planes [2][rows][ldx16] = (hi, mid).
+ *   shift = s > 0 (rbf):             P0 = f16(2^-s y), P1 = f16(2^s (y - 2^s P0)), P2 = 2^(2s) P0 (exact); planes [3][rows][ldx16] = (P0, P1, P2).
+ *     hi = 2^s P0 = 2^-s P2 and mid = 2^-s P1 are defined by the STORED values, so the pair is consistent whatever P0 loses to f16's subnormals;
+ *     |y| must stay below 2^(16 - 2s) (P2 would overflow: reported as a NaN statistic).
+ * Besides the planes the kernel leaves what the set-up needs to decide whether two f16 planes represent this data as well as fp32 does:
+ * stats[0] = max over the rows of |rest|^2 / |y|^2 (rest = y - hi - mid: relative representation error of a row, squared), stats[1] = max |rest|^2,
+ * stats[2] = max |y|^2 -- as float bit patterns combined with atomicMax (non-negative floats order like their bit patterns; a NaN stays on top).
+ * X: [rows][ldx] fp32, features in natural order; planes zero padded. */
+__global__ void k_split_f16x2(const float *__restrict__ X, int ldx, int dfeat, size_t rows, int ldx16, float scale, int shift, uint16_t *__restrict__ planes,
+                              size_t plane_stride, unsigned *__restrict__ stats) {
+    const size_t row = static_cast<size_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float up = __builtin_ldexpf(1.0f, shift), down = __builtin_ldexpf(1.0f, -shift);
+    float sr = 0.0f, sx = 0.0f;
+    bool overflow = false;
+    for (int f = lane; f < ldx16; f += 64) {
+        const float y = f < dfeat ? X[row * ldx + f] * scale : 0.0f;
+        const _Float16 p0 = static_cast<_Float16>(y * down);
+        const float hi = static_cast<float>(p0) * up;
+        const float r1 = y - hi;
+        const _Float16 p1 = static_cast<_Float16>(r1 * up);
+        const float r2 = r1 - static_cast<float>(p1) * down;
+        planes[row * ldx16 + f] = __builtin_bit_cast(uint16_t, p0);
+        planes[plane_stride + row * ldx16 + f] = __builtin_bit_cast(uint16_t, p1);
+        if (shift != 0) {
+            const float p2 = hi * up;
+            overflow = overflow || !(fabsf(p2) <= 65504.0f);
+            planes[2 * plane_stride + row * ldx16 + f] = __builtin_bit_cast(uint16_t, static_cast<_Float16>(p2));
+        }
+        sr = fmaf(r2, r2, sr);
+        sx = fmaf(y, y, sx);
+    }
+    if (overflow) sr = __builtin_nanf("");
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sr += __shfl_xor(sr, off);
+        sx += __shfl_xor(sx, off);
+    }
+    if (lane == 0 && (sx > 0.0f || sx != sx || sr != sr)) {
+        atomicMax(stats + 0, __builtin_bit_cast(unsigned, sr / sx));
+        atomicMax(stats + 1, __builtin_bit_cast(unsigned, sr));
+        atomicMax(stats + 2, __builtin_bit_cast(unsigned, sx));
+    }
+}
+
+/* max |x| over the valid entries of X (as a float bit pattern, atomicMax) */
+__global__ void k_absmax(const float *__restrict__ X, int ldx, int dfeat, size_t rows, unsigned *__restrict__ out) {
+    const size_t total = rows * static_cast<size_t>(ldx);
+    float m = 0.0f;
+    for (size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total; idx += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const int f = static_cast<int>(idx % ldx);
+        if (f < dfeat) {
+            const float v = fabsf(X[idx]);
+            m = (v > m || v != v) ? v : m;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(m, off);
+        m = (o > m || o != o) ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
+
+
+template <int KT, bool SYM>
+static void launch_f3_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
+    const dim3 block(TILE_THREADS);
+    const size_t V2_LDS_BYTES = lssvm::V2_LDS_BYTES + static_cast<size_t>(a.lds_extra_kb) * 1024;  // experiment knob: limits workgroups per CU
+#define LSSVM_F3_CASE(N)                                                                                  \
+    case N:                                                                                               \
+        if constexpr (N > f16_max_nk64(KT)) {                                                             \
+            throw Error(LSSVM_ERR_INTERNAL, "no f16x3 rbf tile kernel for this number of features");       \
+        } else if (a.mfma_shape == 2) {                                                                          \
+            if constexpr (KT != KT_POLY && N <= F16_HAND_MAX_NK64) { /* (generic integer power: its epilogue does not fit the capped register budget without spills) */                                                       \
+                ensure_dynamic_lds(tile_matvec_f32_f3h<KT, N, SYM>, V2_LDS_BYTES);                        \
+                hipLaunchKernelGGL((tile_matvec_f32_f3h<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);   \
+                break;                                                                                    \
+            }                                                                                             \
+        }                                                                                                 \
+        if constexpr (N <= f16_max_nk64(KT)) {                                                            \
+            ensure_dynamic_lds(tile_matvec_f32_f3w<KT, N, SYM>, V2_LDS_BYTES);                            \
+            hipLaunchKernelGGL((tile_matvec_f32_f3w<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);       \
+        }                                                                                                 \
+        break;
+    switch (a.ldx16 / 64) {
+#ifdef LSSVM_DEV_SUBSET  // development builds (make DEV=1): 128 and 256 features only, a quarter of the compile time
+        LSSVM_F3_CASE(2) LSSVM_F3_CASE(4)
+#else
+        LSSVM_F3_CASE(1) LSSVM_F3_CASE(2) LSSVM_F3_CASE(3) LSSVM_F3_CASE(4) LSSVM_F3_CASE(5) LSSVM_F3_CASE(6) LSSVM_F3_CASE(7) LSSVM_F3_CASE(8)
+#endif
+        default: throw Error(LSSVM_ERR_INTERNAL, "no f16x3 tile kernel for this number of features");
+    }
+#undef LSSVM_F3_CASE
+}
+
+template <bool SYM>
+static void launch_f3(const TileArgs<float> &a, int kernel_type, dim3 grid, hipStream_t s) {
+    switch (kernel_type) {
+        case KT_LINEAR: launch_f3_kt<KT_LINEAR, SYM>(a, grid, s); break;
+        case KT_POLY:
+            if (a.degree == 3) {
+                launch_f3_kt<KT_POLY3, SYM>(a, grid, s);
+            } else if (a.degree == 2) {
+                launch_f3_kt<KT_POLY2, SYM>(a, grid, s);
+            } else {
+                launch_f3_kt<KT_POLY, SYM>(a, grid, s);
+            }
+            break;
+        default:
+            if (a.dc_folded != 0) {
+                launch_f3_kt<KT_RBFF, SYM>(a, grid, s);
+            } else {
+                launch_f3_kt<KT_RBF, SYM>(a, grid, s);
+            }
+            break;
+    }
+}
+
+void launch_f16_tile_kernel(const TileArgs<float> &a, int kernel_type, dim3 grid, hipStream_t s) {
+    if (a.items != nullptr) {
+        launch_f3<true>(a, kernel_type, dim3(static_cast<unsigned>(a.num_items)), s);
+    } else {
+        launch_f3<false>(a, kernel_type, grid, s);
+    }
+    LSSVM_HIP_CHECK(hipGetLastError());
+}
+
+void split_f16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, float scale, int shift, uint16_t *planes, size_t plane_stride, unsigned *stats, hipStream_t s) {
+    hipLaunchKernelGGL(k_split_f16x2, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, X, ldx, dfeat, rows, ldx16, scale, shift, planes, plane_stride, stats);
+    LSSVM_HIP_CHECK(hipGetLastError());
+}
+
+void absmax_f32(const float *X, int ldx, int dfeat, size_t rows, unsigned *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_absmax, dim3(1024), dim3(256), 0, s, X, ldx, dfeat, rows, out);
+    LSSVM_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace lssvm

@@ -8,6 +8,26 @@
 
 namespace lssvm {
 
+/* x = hi + mid + lo, each rounded to nearest-even bf16 of the remainder (exact: the remainders are representable in fp32).
+ * X: [rows][ldx] fp32, features in natural order; planes: [3][rows][ldx16] bf16, zero padded. */
+__global__ void k_split_bf16x3(const float *__restrict__ X, int ldx, int dfeat, size_t rows, int ldx16, uint16_t *__restrict__ planes, size_t plane_stride) {
+    const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t total = rows * static_cast<size_t>(ldx16);
+    if (idx >= total) return;
+    const size_t row = idx / ldx16;
+    const int f = static_cast<int>(idx - row * ldx16);
+    const float x = f < dfeat ? X[row * ldx + f] : 0.0f;
+    const __bf16 hi = static_cast<__bf16>(x);
+    const float r1 = x - static_cast<float>(hi);
+    const __bf16 mid = static_cast<__bf16>(r1);
+    const float r2 = r1 - static_cast<float>(mid);
+    const __bf16 lo = static_cast<__bf16>(r2);
+    planes[idx] = __builtin_bit_cast(uint16_t, hi);
+    planes[plane_stride + idx] = __builtin_bit_cast(uint16_t, mid);
+    planes[2 * plane_stride + idx] = __builtin_bit_cast(uint16_t, lo);
+}
+
+
 template <int KT, bool SYM>
 static void launch_s6_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
     const dim3 block(TILE_THREADS);
@@ -15,24 +35,21 @@ static void launch_s6_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
 #define LSSVM_S6_CASE(N)                                                                                  \
     case N:                                                                                               \
         if (a.mfma_shape == 2) {                                                                          \
-            if constexpr (N <= 2) {                                                                       \
+            if constexpr (KT != KT_POLY && N <= 2) { /* (generic integer power: its epilogue does not fit the capped register budget without spills) */                                                                       \
                 ensure_dynamic_lds(tile_matvec_f32_s6h<KT, N, SYM>, V2_LDS_BYTES);                        \
                 hipLaunchKernelGGL((tile_matvec_f32_s6h<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);   \
                 break;                                                                                    \
             }                                                                                             \
         }                                                                                                 \
-        if (a.mfma_shape >= 1) {                                                                          \
-            ensure_dynamic_lds(tile_matvec_f32_s6w<KT, N, SYM>, V2_LDS_BYTES);                            \
-            hipLaunchKernelGGL((tile_matvec_f32_s6w<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);       \
-        } else if constexpr (KT != KT_RBFF) {                                                             \
-            ensure_dynamic_lds(tile_matvec_f32_s6<KT, N, SYM>, V2_LDS_BYTES);                             \
-            hipLaunchKernelGGL((tile_matvec_f32_s6<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);        \
-        } else {                                                                                          \
-            throw Error(LSSVM_ERR_INTERNAL, "folded rbf records need the 16x16x32 kernels");              \
-        }                                                                                                 \
+        ensure_dynamic_lds(tile_matvec_f32_s6w<KT, N, SYM>, V2_LDS_BYTES);                                \
+        hipLaunchKernelGGL((tile_matvec_f32_s6w<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);           \
         break;
     switch (a.ldx16 / 64) {
+#ifdef LSSVM_DEV_SUBSET  // development builds (make DEV=1): 128 and 256 features only
+        LSSVM_S6_CASE(2) LSSVM_S6_CASE(4)
+#else
         LSSVM_S6_CASE(1) LSSVM_S6_CASE(2) LSSVM_S6_CASE(3) LSSVM_S6_CASE(4) LSSVM_S6_CASE(5) LSSVM_S6_CASE(6)
+#endif
         default: throw Error(LSSVM_ERR_INTERNAL, "no split tile kernel for this number of features");
     }
 #undef LSSVM_S6_CASE
@@ -53,7 +70,7 @@ static void launch_s6(const TileArgs<float> &a, int kernel_type, dim3 grid, hipS
             break;
         default:
             if (a.dc_folded != 0) {
-                launch_s6_kt<KT_RBFF, SYM>(a, grid, s);  // only the 16x16x32 kernels understand the folded records (Problem sets the flag with mfma_shape >= 1)
+                launch_s6_kt<KT_RBFF, SYM>(a, grid, s);
             } else {
                 launch_s6_kt<KT_RBF, SYM>(a, grid, s);
             }

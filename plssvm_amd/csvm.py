@@ -113,9 +113,11 @@ class CSVM:
 class MI355CSVM(CSVM):
     """The MI355X backend (counterpart of plssvm::hip::csvm, HIP/csvm.hpp:39-99, csvm.hip.cpp:47-85)."""
 
-    def __init__(self, target=TargetPlatform.AUTOMATIC, params: Parameter | None = None, num_devices: int = 0, **kwargs):
-        """``num_devices``: devices ONE solve is sharded over -- 0 = automatic (every visible device, at least 4096 points each; the reference's
-        backends take every device they find, csvm.hip.cpp:66-75), 1 = device 0 only, k = devices 0 .. k-1 (gpu_csvm.hpp:283-299)."""
+    def __init__(self, target=TargetPlatform.AUTOMATIC, params: Parameter | None = None, num_devices: int = 1, **kwargs):
+        """``num_devices``: devices ONE solve is sharded over -- 1 (default) = device 0 only, k = devices 0 .. k-1 (gpu_csvm.hpp:283-299),
+        0 = automatic (every visible device, at least 4096 points each, as the reference's backends take every device they find,
+        csvm.hip.cpp:66-75).  Several devices are OPT-IN: results then depend on the device count through the order of the sums, the exchange
+        bootstraps RCCL inside the process, and that path has not run on a multi-GPU box yet."""
         if isinstance(target, Parameter):
             target, params = TargetPlatform.AUTOMATIC, target
         super().__init__(params, **kwargs)

@@ -17,6 +17,7 @@ import time
 import numpy as np
 
 from .exceptions import InvalidFileFormatError
+from .string_conversion import int_prefix, real_prefix
 from .io_libsvm import read_lines
 
 __all__ = ["parse_arff_header", "parse_arff_data", "write_arff_data"]
@@ -39,14 +40,10 @@ def _convert(token: str, t):
     tok = token.strip(_WS)
     if t is str:
         return tok
-    try:
-        if t is int:
-            return int(tok)
-        if t is float:
-            return float(tok)
-        return np.dtype(t).type(float(tok))
-    except ValueError:
-        raise InvalidFileFormatError(f"Can't convert '{token}' to a value of type {_type_name(t)}!") from None
+    value = int_prefix(tok) if t is int else real_prefix(tok)  # the reference converts the longest valid prefix (string_conversion.py)
+    if value is None:
+        raise InvalidFileFormatError(f"Can't convert '{token}' to a value of type {_type_name(t)}!")
+    return value if t in (int, float) else np.dtype(t).type(value)
 
 
 def _show(label) -> str:

@@ -15,6 +15,7 @@ import os
 import numpy as np
 
 from .exceptions import FileNotFoundPlssvmError, InvalidFileFormatError
+from .string_conversion import real_prefix
 
 __all__ = ["read_lines", "parse_libsvm_data", "write_libsvm_data"]
 
@@ -34,10 +35,10 @@ def read_lines(filename, comment: str = "#") -> list[str]:
 
 
 def _to_float(token: str, what: str) -> float:
-    try:
-        return float(token)
-    except ValueError:
-        raise InvalidFileFormatError(f"Can't convert '{token}' to a value of type {what}!") from None
+    value = real_prefix(token)  # the reference converts the longest valid prefix (string_conversion.py)
+    if value is None:
+        raise InvalidFileFormatError(f"Can't convert '{token}' to a value of type {what}!")
+    return value
 
 
 def _to_index(token: str) -> int:

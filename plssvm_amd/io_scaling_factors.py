@@ -15,6 +15,7 @@ import numpy as np
 
 from .exceptions import InvalidFileFormatError
 from .io_libsvm import read_lines
+from .string_conversion import real_prefix
 
 __all__ = ["parse_scaling_factors", "write_scaling_factors"]
 
@@ -27,10 +28,10 @@ def _split_as_real(line: str, dtype):
     """detail::split_as<real_type> (string_utility / string_conversion): whitespace separated numbers of the real type."""
     out = []
     for token in line.split():
-        try:
-            out.append(np.dtype(dtype).type(float(token)))
-        except ValueError:
-            raise InvalidFileFormatError(f"Can't convert '{token}' to a value of type {_type_name(dtype)}!") from None
+        value = real_prefix(token)  # the reference converts the longest valid prefix (string_conversion.py)
+        if value is None:
+            raise InvalidFileFormatError(f"Can't convert '{token}' to a value of type {_type_name(dtype)}!")
+        out.append(np.dtype(dtype).type(value))
     return out
 
 

@@ -57,8 +57,8 @@ def test_bench_json_contract_small_workload():
     # `effective_full_square` prices the launch like `value` does (2 n^2 d)
     assert 0.05 < r["frac"] <= r["executed_frac"] < 1.0 and r["symmetric"] in (True, False)
     # fp32 default: the Gram tiles run as six bf16 plane products per multiply-add; the roofline is the bf16 MFMA peak
-    planes = 6.0 if r["gram_mode"] == "bf16x6" else 1.0
-    if r["gram_mode"] == "bf16x6":  # the native v_mfma_f32 path of the same workload is reported beside the headline
+    planes = {"f16x3": 3.0, "bf16x6": 6.0, "native": 1.0}[r["gram_mode"]]
+    if r["gram_mode"] != "native":  # the native v_mfma_f32 path of the same workload is reported beside the headline
         nat = j["native_f32_path"]
         assert nat["ms_per_step"] > j["ms_per_step"] and 0.05 < nat["frac_of_f32_mfma_peak"] < 1.0
         # ... and so is what a bare loop of the kernel's MFMA instruction sustains on this device (the practical ceiling under the nominal peak)
@@ -66,7 +66,7 @@ def test_bench_json_contract_small_workload():
         assert 0.4 < bare["b_fragments_from_lds"]["frac_of_peak"] < 1.0 and 0.4 < bare["operands_in_registers"]["frac_of_peak"] < 1.0
         assert 1.0 < bare["operands_in_registers"]["clock_ghz"] < 2.6 and abs(bare["nominal_peak_tflops"] - r["peak"]) < 0.01 * r["peak"]
         assert 0.3 < bare["kernel_vs_bare_register_loop"] < 1.0
-    assert r["gram_mode"] in ("bf16x6", "native") and abs(r["achieved"] - planes * r["fp32_equivalent"]) < 1e-9 * r["achieved"]
+    assert r["gram_mode"] in ("f16x3", "bf16x6", "native") and abs(r["achieved"] - planes * r["fp32_equivalent"]) < 1e-9 * r["achieved"]
     assert r["effective_full_square"] >= r["fp32_equivalent"] and planes * r["full_square_flop_per_launch"] >= r["executed_flop_per_launch"] * 0.99
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0

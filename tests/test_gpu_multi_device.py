@@ -154,7 +154,7 @@ def test_options_are_snapshotted_per_problem():
         before = prob.matvec(v, zero, 1.0)
         _capi.set_option("gram_mode", 0)
         _capi.set_option("symmetric", 0)
-        assert prob.info()["gram_mode"] == 1 and prob.info()["symmetric"] == 1
+        assert prob.info()["gram_mode"] == 2 and prob.info()["symmetric"] == 1
         assert np.array_equal(prob.matvec(v, zero, 1.0), before)
     with backend.ResidentProblem(p, X) as prob:
         assert prob.info()["gram_mode"] == 0 and prob.info()["symmetric"] == 0

@@ -111,7 +111,7 @@ def _rho_from_alpha(kernel, X, y, alpha, P, oracle):
 
 @pytest.mark.parametrize("name", DATASETS)
 @pytest.mark.parametrize("kernel", KERNELS)
-@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("mode", [3, 2, 1, 0])
 def test_solve_f32_tight_goldens_traces_and_rho(golden, inputs, oracle, name, kernel, mode):
     """The fp32 `cg_tight` goldens (eps = 1e-5) and the per-iteration delta traces of the reference, for both Gram modes.
 
@@ -164,7 +164,7 @@ def test_rho_of_both_gram_modes_at_4096x128(oracle, kernel):
     a64, rho64, _ = backend.solve_system_of_linear_equations(p, X.astype(np.float64), y.astype(np.float64), 1e-6, 400)
     eps32 = np.finfo(np.float32).eps
     errs = {}
-    for mode in (1, 0):
+    for mode in (2, 1, 0):
         _capi.set_option("gram_mode", mode)
         a, rho, info = backend.solve_system_of_linear_equations(p, X, y, 1e-6, 400)
         assert info["gram_mode"] == mode
@@ -177,7 +177,7 @@ def test_rho_of_both_gram_modes_at_4096x128(oracle, kernel):
     # restated), whose distance to the float64 solution both Gram modes must not exceed by more than 2x
     a_cpu, _, _ = oracle.solve(kernel, X, y, 1e-6, 400, degree=3, gamma=1.0 / 128, coef0=0.0, cost=1.0)
     err_cpu = ol.rel_inf(a_cpu, a64)
-    assert errs[1] <= max(2 * err_cpu, 1e-3) and errs[0] <= max(2 * err_cpu, 1e-3), (errs, err_cpu)
+    assert all(errs[m] <= max(2 * err_cpu, 1e-3) for m in (2, 1, 0)), (errs, err_cpu)
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
@@ -207,8 +207,9 @@ def test_predict_values_known_answer(dt):
 @pytest.mark.parametrize("nsv, npts, d", [(1300, 700, 128), (777, 130, 40), (520, 1025, 384), (300, 200, 500)])
 def test_predict_values_on_the_bf16_matrix_cores(oracle, kernel, nsv, npts, d):
     """predict_values is the rectangular instance of the tile kernel (HIP/predict_kernel.hip.hpp:63-117: rows = points to predict,
-    columns = support vectors).  In fp32 with gram_mode = 1 it runs on the bf16x6 kernels for up to 384 features (500 features: the native
-    v_mfma_f32 kernel in both modes); both modes must match the float64 oracle on the scale of each point's summands."""
+    columns = support vectors).  In fp32 it runs on the f16x3 kernels (gram_mode 2 / 3, up to 512 features) or the bf16x6 kernels
+    (gram_mode 1, up to 384 features; 500 features: the native v_mfma_f32 kernel); every mode must match the float64 oracle on the scale
+    of each point's summands."""
     rng = np.random.default_rng(nsv + d)
     sv = rng.uniform(-1, 1, size=(nsv, d)).astype(np.float32)
     alpha = rng.uniform(-1, 1, size=nsv).astype(np.float32)
@@ -224,14 +225,19 @@ def test_predict_values_on_the_bf16_matrix_cores(oracle, kernel, nsv, npts, d):
         K = (G / d + 0.5) ** 3
     scale = np.abs(K) @ np.abs(alpha.astype(np.float64)) + 0.125
     out = {}
-    for mode in (1, 0):
+    for mode in (3, 2, 1, 0):
         _capi.set_option("gram_mode", mode)
         out[mode], _ = backend.predict_values(p, sv, alpha, 0.125, None, pts)
         assert np.max(np.abs(out[mode] - want) / scale) < 16 * np.finfo(np.float32).eps, mode
-    if d <= 384:
-        assert not np.array_equal(out[0], out[1])  # two different kernels ran
+    assert np.array_equal(out[3], out[2])          # uniform [-1, 1] data passes the f16 representability check: the default is f16x3
+    if kernel == "rbf" and d > 384:
+        assert np.array_equal(out[0], out[2])      # rbf above 384 features: the native kernel in every mode (three row planes do not fit)
     else:
-        assert np.array_equal(out[0], out[1])      # above 384 features both modes are the native kernel
+        assert not np.array_equal(out[0], out[2])  # different kernels ran
+    if d <= 384:
+        assert not np.array_equal(out[0], out[1]) and not np.array_equal(out[1], out[2])
+    else:
+        assert np.array_equal(out[0], out[1])      # above 384 features gram_mode 1 is the native kernel
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
@@ -384,7 +390,7 @@ def test_rbf_folded_and_unfolded_column_records_agree(oracle):
             _capi.set_option("rbf_fold", fold)
             with backend.ResidentProblem(p, X) as prob:
                 info = prob.info()
-                assert info["rbf_direct"] == 0 and info["gram_mode"] == 1 and 4 < info["rbf_exponent_scale"] < 200
+                assert info["rbf_direct"] == 0 and info["gram_mode"] in (1, 2) and 4 < info["rbf_exponent_scale"] < 200
                 err, _, _ = _sampled_rows_vs_oracle_gamma(oracle, prob, X, rows, 0.5)
             assert err < 2.0 ** -22 * max(info["rbf_exponent_scale"], 32.0), (sym, fold, err / eps)  # the matrix-core bound of INTEGRATION.md section 6
     for fold in (1, 0):
@@ -554,7 +560,7 @@ def test_baseline_configs_at_full_size(oracle, cfg, kernel, dt, N, d):
     rows = np.sort(np.random.default_rng(3).choice(n, size=64, replace=False))
     rows[0], rows[-1] = 0, n - 1  # first row (longest mirrored column) and last row (longest row of the triangle)
     with backend.ResidentProblem(p, X) as prob:
-        assert prob.info()["symmetric"] == 1 and prob.info()["gram_mode"] == (1 if dt == np.float32 else 0)
+        assert prob.info()["symmetric"] == 1 and prob.info()["gram_mode"] == (2 if dt == np.float32 else 0)  # fp32: f16x3 (the data passes the check)
         err, Au, u = _sampled_rows_vs_oracle(oracle, prob, kernel, X, rows)
         assert err < 16 * eps, (cfg, err / eps)
         v = np.random.default_rng(1).uniform(-1, 1, size=n).astype(dt)
@@ -789,12 +795,13 @@ def test_column_slab_budget_falls_back_to_the_full_square():
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
-@pytest.mark.parametrize("N, d", [(300, 7), (1500, 64), (4097, 128), (2300, 200), (1100, 256), (1300, 320), (900, 384)])
+@pytest.mark.parametrize("N, d", [(300, 7), (1500, 64), (4097, 128), (2300, 200), (1100, 256), (1300, 320), (900, 384), (700, 448), (1000, 512)])
 @pytest.mark.parametrize("sym", [1, 0])
 def test_bf16_split_gram_mode_is_fp32_accurate(oracle, kernel, N, d, sym):
-    """gram_mode = 1 (the DEFAULT for up to 384 features): the fp32 operands are split exactly into three bf16 planes and the six
-    significant plane products are accumulated in fp32 on the bf16 matrix cores; gram_mode = 0: native v_mfma_f32 chains.  Both must
-    meet the same bar: no farther from the float64 product than 4x the fp32 CPU oracle (or 64 eps)."""
+    """The split Gram modes against the native one.  gram_mode = 2 ("f16x3", the default where the data passes the representability check,
+    up to 512 features): two f16 planes of the pre-scaled operands, three plane products on the f16 matrix cores; gram_mode = 1 ("bf16x6",
+    up to 384 features): exact three-way bf16 split, six plane products; gram_mode = 0: native v_mfma_f32 chains.  All must meet the same
+    bar: no farther from the float64 product than 4x the fp32 CPU oracle (or 64 eps)."""
     X, y = make_blobs_pm1(N, d, seed=27, dtype=np.float32)
     p = Parameter(kernel_type=kernel)
     rhs = np.random.default_rng(6).uniform(-1, 1, size=N - 1).astype(np.float32)
@@ -802,21 +809,119 @@ def test_bf16_split_gram_mode_is_fp32_accurate(oracle, kernel, N, d, sym):
     out = {}
     _capi.set_option("symmetric", sym)
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 2, 3):
             _capi.set_option("gram_mode", mode)
             with backend.ResidentProblem(p, X) as prob:
                 q, QA = prob.q()
+                f16_limit = 384 if kernel == "rbf" else 512  # rbf holds three row planes in registers (the shifted planes)
+                assert prob.info()["gram_mode"] == {0: 0, 1: 1 if d <= 384 else 0, 2: 2 if d <= f16_limit else 0, 3: 2 if d <= f16_limit else 0}[mode]
                 out[mode] = prob.matvec(rhs, zero, 1.0)
                 prob.cg_begin(y, 1e-30)
                 prob.cg_step(5)
                 out[("a", mode)] = prob.cg_finish()[0]
     finally:
-        _capi.set_option("gram_mode", 1)  # the library default
+        _capi.set_option("gram_mode", 3)  # the library default
         _capi.set_option("symmetric", 1)
     kw = dict(degree=3, gamma=1.0 / d, coef0=0.0)
     want = oracle.matvec(kernel, X, q, rhs, zero, QA, 1.0, 1.0, **kw)
     truth = oracle.matvec(kernel, X.astype(np.float64), q.astype(np.float64), rhs.astype(np.float64), np.zeros(N - 1), float(QA), 1.0, 1.0, **kw)
     scale = np.max(np.abs(truth))
     tol = max(4.0 * np.max(np.abs(want - truth)), 64 * np.finfo(np.float32).eps * scale)
-    assert np.max(np.abs(out[1] - truth)) < tol and np.max(np.abs(out[0] - truth)) < tol
-    assert np.all(np.isfinite(out[("a", 1)]))
+    errs = {mode: float(np.max(np.abs(out[mode] - truth))) for mode in (0, 1, 2)}
+    assert all(e < tol for e in errs.values()), (errs, tol)
+    assert np.array_equal(out[3], out[2])  # this data passes the check: the default mode IS f16x3
+    assert np.all(np.isfinite(out[("a", 1)])) and np.all(np.isfinite(out[("a", 2)]))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_f16_planes_prescale_check_and_fallback(oracle, kernel):
+    """The default Gram mode (3) decides ON THE DATA whether two f16 planes represent it as well as fp32 does (make_planes in
+    lssvm_problem.hip): (a) data of tiny magnitude is moved into f16's normal range by an exact power-of-two pre-scale (linear /
+    polynomial: undone on the finished sums / inside gamma; rbf works on the exponent's own scale and accepts an absolute bound) and stays
+    on f16x3; (b) data whose dynamic range exceeds what two f16 planes carry fails the check and runs as bf16x6, which is exact for every
+    fp32 input -- and forcing f16x3 onto it (gram_mode = 2) is measurably worse, i.e. the check is what keeps the default accurate."""
+    rng = np.random.default_rng(11)
+    N, d = 1500, 96
+    y = np.where(np.arange(N) % 2 == 0, 1.0, -1.0).astype(np.float32)
+    rhs = rng.uniform(-1, 1, size=N - 1).astype(np.float32)
+    zero = np.zeros(N - 1, np.float32)
+    eps = np.finfo(np.float32).eps
+
+    def run(X, mode, gamma):
+        p = Parameter(kernel_type=kernel, degree=3, gamma=gamma, coef0=0.25)
+        _capi.set_option("gram_mode", mode)
+        with backend.ResidentProblem(p, X) as prob:
+            q, QA = prob.q()
+            got = prob.matvec(rhs, zero, 1.0).astype(np.float64)
+            used = prob.info()["gram_mode"]
+        # float64 evaluation of A v = K v + v / C + (QA S - q.v) 1 - S q with the kernel matrix formed explicitly; every row's error is
+        # measured on the scale of THAT row's summands (a few huge entries must not hide the rows made of small ones)
+        X64, v64, q64 = X.astype(np.float64)[:N - 1], rhs.astype(np.float64), q.astype(np.float64)
+        G = X64 @ X64.T
+        if kernel == "linear":
+            K = G
+        elif kernel == "polynomial":
+            K = (gamma * G + 0.25) ** 3
+        else:
+            sq = np.einsum("ij,ij->i", X64, X64)
+            K = np.exp(-gamma * np.maximum(sq[:, None] + sq[None, :] - 2.0 * G, 0.0))
+        S, qv = float(v64.sum()), float(q64 @ v64)
+        truth = K @ v64 + v64 + (float(QA) * S - qv) - S * q64
+        scale = np.abs(K) @ np.abs(v64) + np.abs(v64) + abs(float(QA) * S) + abs(qv) + np.abs(S * q64)
+        return used, float(np.max(np.abs(got - truth) / scale))
+
+    # (a) entries ~1e-4: the mid plane would be subnormal without the pre-scale (rbf: without the shifted planes)
+    Xa = (1e-4 * rng.standard_normal((N, d))).astype(np.float32)
+    ga = 1.0 / (d * 1e-8)  # gamma of the same effect as 1/d on unit-variance data
+    used, err = run(Xa, 3, ga)
+    assert used == 2, used
+    assert err < 8 * eps, err / eps
+    if kernel != "rbf":
+        # (b) two populations of points, entries ~1e+4 and ~1e-4 (eight decades apart): the pre-scale that keeps the large ones below f16's
+        # overflow leaves the small ones without a usable mid plane.  The right-hand side is zero on the large points, so that the rows of
+        # the small points sum small * small products only and show what their planes are worth.
+        big = np.arange(N) % 2 == 0
+        Xb = rng.standard_normal((N, d)).astype(np.float32)
+        Xb[big] *= np.float32(1e4)
+        Xb[~big] *= np.float32(1e-4)
+        rhs[big[:N - 1]] = 0.0
+        gb = 1.0 / (d * 1e8)
+        used, err = run(Xb, 3, gb)
+        assert used == 1, used
+        assert err < 8 * eps, err / eps
+        used_forced, err_forced = run(Xb, 2, gb)
+        assert used_forced == 2
+        if kernel == "linear":  # (the polynomial kernel's values are dominated by coef0 here and do not show the difference)
+            assert err_forced > 100 * err, (err_forced / eps, err / eps)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("d", [64, 128, 192, 256, 320, 384, 448, 512])
+@pytest.mark.parametrize("mode", [2, 1])
+def test_split_kernels_steady_state_at_every_chunk_count(oracle, kernel, d, mode):
+    """Work items of FIVE tiles, so that the branch-free steady-state tiles of the split kernels run at every number of 64-feature chunks
+    (the automatic chunk length gives these small problems two tiles per item, which never leaves the checked tail -- round 3 found the
+    LDS-DMA source of the 64-feature f16x3 form two tiles ahead wrong that way), in both variants, against the float64 oracle."""
+    if mode == 1 and d > 384 or (mode == 2 and kernel == "rbf" and d > 384):
+        pytest.skip("no such kernel: bf16x6 and the rbf form of f16x3 hold three row planes (up to 384 features)")
+    N = 1700
+    X, _ = make_blobs_pm1(N, d, seed=d, dtype=np.float32)
+    p = Parameter(kernel_type=kernel)
+    rhs = np.random.default_rng(d).uniform(-1, 1, size=N - 1).astype(np.float32)
+    zero = np.zeros(N - 1, np.float32)
+    kw = dict(degree=3, gamma=1.0 / d, coef0=0.0)
+    _capi.set_option("gram_mode", mode)
+    _capi.set_option("j_chunk_tiles", 5)
+    out = {}
+    for sym in (1, 0):
+        _capi.set_option("symmetric", sym)
+        with backend.ResidentProblem(p, X) as prob:
+            assert prob.info()["gram_mode"] == mode and prob.info()["symmetric"] == sym
+            q, QA = prob.q()
+            out[sym] = prob.matvec(rhs, zero, 1.0)
+    truth = oracle.matvec(kernel, X.astype(np.float64), q.astype(np.float64), rhs.astype(np.float64), np.zeros(N - 1), float(QA), 1.0, 1.0, **kw)
+    want = oracle.matvec(kernel, X, q, rhs, zero, QA, 1.0, 1.0, **kw)
+    scale = np.max(np.abs(truth))
+    tol = max(4.0 * np.max(np.abs(want - truth)), 64 * np.finfo(np.float32).eps * scale)
+    for sym in (1, 0):
+        assert np.max(np.abs(out[sym] - truth)) < tol, (sym, float(np.max(np.abs(out[sym] - truth))), tol)

@@ -2,7 +2,7 @@
 # Collect PMC counters of the bench in separate passes (rocprofv3 --pmc only; no trace domains), as
 # /opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass).
 # usage: tests/tools/pmc_passes.sh <workload> <steps> <outdir> [extra bench.py arguments, e.g. --option mfma_shape=1]
-WL=${1:-c2}; STEPS=${2:-5}; OUT=${3:-gpurun_out/pmc_$WL}; shift 3 2>/dev/null; EXTRA="$@"
+WL=${1:-c2}; STEPS=${2:-5}; OUT=${3:-gpurun_out/pmc_$WL}; if [ $# -ge 3 ]; then shift 3; else shift $#; fi; EXTRA="$@"
 export TMPDIR=/tmp
 mkdir -p "$OUT"
 run() { name=$1; shift; timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py --workload "$WL" --steps "$STEPS" --warmup 1 --no-cpu-baseline --no-native-reference --no-ceiling $EXTRA > "$OUT/$name.log" 2>&1; echo "$name rc=$?"; }
