@@ -181,7 +181,13 @@ def main():
     ap.add_argument("--exchange", type=int, default=None, choices=[0, 1, 2],
                     help="how the partial K*v vectors meet.  --single-process: 0 automatic, 1 RCCL, 2 peer kernels over xGMI.  One process per GPU: 1 (default) the "
                          "library's RCCL communicator, 2 HIP IPC + the peer kernel (no RCCL inside the library)")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the ranks' barrier / id exchange (nccl = RCCL)")
+    ap.add_argument("--dist-backend", default="gloo", choices=["gloo", "nccl"],
+                    help="torch.distributed backend of the ranks' SIDE channel (barrier, id exchange, max over ranks).  gloo (default): the data path -- one "
+                         "all-reduce per implicit matvec -- is the library's own RCCL communicator either way, and a side channel that does not depend on RCCL is "
+                         "what lets the ranks agree on a fall-back when the RCCL bootstrap fails or hangs")
+    ap.add_argument("--rccl-timeout-s", type=float, default=120.0,
+                    help="one process per GPU: how long the library's ncclCommInitRank may take before the ranks give up on RCCL (bootstrap hangs of minutes were "
+                         "seen on single-GPU boxes of this pool)")
     ap.add_argument("--rank-devices", default=None,
                     help="one process per GPU: comma separated HIP ordinal per local rank (default: the local rank).  Repeats put several ranks on one device "
                          "-- a functional check of the rank path on a one-GPU box (needs --exchange 2 --dist-backend gloo: RCCL refuses two ranks on one device)")
@@ -246,24 +252,49 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        side_device = "cuda" if args.dist_backend == "nccl" else "cpu"
         if args.exchange != 2:
-            # hand rank 0's RCCL unique id to every rank, then build the library's own communicator (one per process); if ANY rank fails
-            # to build it, every rank falls back to the HIP IPC exchange (same partition, same sum order) and the JSON line says so
+            # Hand rank 0's RCCL unique id to every rank, then build the library's own communicator (one per process) -- in a worker thread, so
+            # that a bootstrap that hangs cannot take the launcher's whole timeout: after --rccl-timeout-s the ranks compare notes over the
+            # side channel.  Every rank built it: RCCL exchange.  Some rank FAILED (an error came back): every rank drops its communicator and
+            # all use the HIP IPC exchange (same partition, same sum order); the JSON line says so.  Some rank is still STUCK inside RCCL: that
+            # process cannot be trusted to continue (the call cannot be cancelled), so every rank exits non-zero with a clear message.
+            import threading
+
             from plssvm_amd.sharding import init_library_communicator
 
-            ok, why = 1, ""
-            try:
-                init_library_communicator(dist, local_rank, device="cuda" if args.dist_backend == "nccl" else None)
-            except Exception as e:  # noqa: BLE001  (PlssvmError from the library, or a torch.distributed error)
-                ok, why = 0, f"{type(e).__name__}: {e}"
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if args.dist_backend == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
+            result = {}
+
+            def build():
+                try:
+                    init_library_communicator(dist, local_rank, device="cuda" if args.dist_backend == "nccl" else None)
+                    result["ok"] = True
+                except Exception as e:  # noqa: BLE001  (PlssvmError from the library, or a torch.distributed error)
+                    result["error"] = f"{type(e).__name__}: {e}"
+
+            worker = threading.Thread(target=build, daemon=True)
+            t_boot = time.perf_counter()
+            worker.start()
+            worker.join(args.rccl_timeout_s)
+            stuck = worker.is_alive()
+            ok = 1 if (not stuck and result.get("ok")) else 0
+            why = "still inside ncclCommInitRank after %.0f s" % args.rccl_timeout_s if stuck else result.get("error", "")
+            if dist.get_backend() == "nccl" and stuck:
+                raise SystemExit(f"[bench rank {rank}] the library's RCCL communicator: {why} (and the side channel is RCCL too: nothing to agree over)")
+            flags = torch.tensor([ok, 0 if stuck else 1], dtype=torch.int32, device=side_device)
+            dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+            all_ok, none_stuck = int(flags[0].item()), int(flags[1].item())
+            if not none_stuck:
+                print(f"[bench rank {rank}] giving up: a rank is stuck inside the RCCL bootstrap" + (f" (this one: {why})" if stuck else ""), file=sys.stderr, flush=True)
+                os._exit(3)  # (not sys.exit: a worker thread may be blocked inside RCCL)
+            if not all_ok:
                 if ok:
                     backend.comm_destroy()
                 args.exchange = 2
                 exchange_note = "the library's RCCL communicator could not be built on every rank" + (f" ({why})" if why else "") + ": HIP IPC exchange instead"
                 print(f"[bench rank {rank}] {exchange_note}", file=sys.stderr, flush=True)
+            elif rank == 0:
+                print(f"[bench] RCCL communicator of {world} ranks built in {time.perf_counter() - t_boot:.1f} s", file=sys.stderr, flush=True)
 
     wl = WORKLOADS[args.workload]
     N, d = wl["n"], wl["d"]
@@ -314,7 +345,7 @@ def main():
 
     elapsed = t1 - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")  # (the side channel: gloo by default)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     steps_done = int(i1["iterations"] - i0["iterations"])

@@ -241,14 +241,6 @@ int lssvm_mi355_libsvm_fill_f32(lssvm_mi355_libsvm_file *file, float *X, uint64_
 int lssvm_mi355_libsvm_fill_f64(lssvm_mi355_libsvm_file *file, double *X, uint64_t ldx, double *labels);
 int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
 
-/* Measurement utility, not on the solve path and without a counterpart in the reference: what a BARE loop of v_mfma_f32_16x16x32_bf16
- * (the instruction of the fp32 "bf16x6" Gram kernel; 64 x 64 wave tiles, two waves per SIMD, normal(0,1) operands, nothing else in the
- * loop) sustains on `device` after `settle_ms` of back-to-back launches.  b_from_lds != 0: the B fragments are re-read from LDS every
- * pass, as the Gram kernel does.  Returns TFLOP/s, the in-kernel clock (s_memtime / s_memrealtime, median over workgroups) and the
- * nominal peak (4096 FLOP/clk/CU x CUs x nominal clock).  The chip lowers its clock under matrix-core load, so this -- not the
- * nominal peak -- is what a kernel on this device is up against; bench.py prints it beside roofline.frac. */
-int lssvm_mi355_measure_bf16_mfma_ceiling(int device, int b_from_lds, double settle_ms, double *tflops_out, double *clock_ghz_out, double *nominal_tflops_out);
-
 /* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT).  set_option changes the process-wide DEFAULTS;
  * every problem / solve takes a snapshot of them when it is created, so later changes never affect a live problem.  The defaults can
  * be preset from the environment: LSSVM_MI355_OPTIONS="name=value,name=value" (read once when the library is loaded):
@@ -261,22 +253,23 @@ int lssvm_mi355_measure_bf16_mfma_ceiling(int device, int b_from_lds, double set
  *                   2^(acc + c_j); used while the exponent scale R2 <= 200 keeps both factors far inside the fp32 range); 0 = start values c_i + c_j
  *   "rbf_direct_above" threshold of rbf_form 0 (default 32: [-1,1]-scaled data with gamma = 1 / num_features has R2 <= 3)
  *   "j_chunk_tiles" number of 128-column tiles per work item; 0 = automatic (default: about 4096 work items per device, 2 ... 16 tiles each,
- *                   up to 64 for the bf16x6 kernel)
+ *                   up to 64 for the split kernels)
  *   "symmetric"     1 = evaluate only the kernel-matrix tiles on/below the diagonal and mirror them (default; num_features <= 512 in fp32,
  *                   <= 256 in fp64; a negative polynomial degree always runs the full square),
  *                   0 = full square (row-owned sums, results independent of the GPU count)
  *   "tile_kernel"   0 = automatic: the "resident row panel" kernels for num_features <= 512 (fp32) / 256 (fp64) (default), 1 = always the generic kernel
  *   "xcd_map"       1 = XCD-aware block -> work item mapping (8 x 8 super-tiles per XCD), 0 = linear (default)
- *   "lds_extra_kb"  experiment knob: extra dynamic LDS (KiB) per workgroup of the fp32 tile kernels (native and bf16x6), lowers the workgroups per CU
- *   "debug_ablate"  timing-only ablation bits of the fp32 tile kernel; effective only in -DLSSVM_ENABLE_ABLATION builds
  *   "item_order"    symmetric variant: 0 = work items in column-chunk major order, 1 = the same with the short items that end on the
  *                   diagonal moved to the end, longest first (default: shortens the last dispatch round), 2 = 1 with row blocks descending
- *   "gram_mode"     fp32, num_features <= 256: 1 = "bf16x6" (default): every operand is split EXACTLY into three bf16 planes and the
- *                   six significant plane products are accumulated in fp32 on v_mfma_f32_32x32x16_bf16 -- fp32-equivalent accuracy,
- *                   different summation order; 0 = Gram tiles on v_mfma_f32_32x32x2_f32 (exact fmaf chains)
- *   "mfma_shape"    bf16x6 kernel: 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16 (same matrix-core cycles; the chip holds a higher
- *                   clock under the second shape, MI355X_MICROARCH.md "DVFS give-back"), 2 = 1 with hand-scheduled MFMA groups (B fragments in
- *                   registers the compiler does not own, counted LDS waits) for num_features <= 128; default 2
+ *   "gram_mode"     fp32 Gram tiles on the 16-bit matrix cores with fp32 accumulation, at fp32-equivalent accuracy:
+ *                   3 (default) = "f16x3" where the data allows, else "bf16x6"; 2 = "f16x3": every operand as TWO f16 planes (hi + mid; rbf: shifted by
+ *                   2^-6 / 2^6, others pre-scaled by a power of two), three plane products on v_mfma_f32_16x16x32_f16, num_features <= 512 (rbf 384)
+ *                   -- without the check whether two f16 planes represent THIS data as well as fp32 does, which mode 3 makes at set-up;
+ *                   1 = "bf16x6": exact split into THREE bf16 planes, six plane products on v_mfma_f32_16x16x32_bf16, num_features <= 384;
+ *                   0 = Gram tiles on v_mfma_f32_32x32x2_f32 (exact fmaf chains)
+ *   "mfma_shape"    split kernels: 1 = MFMA groups scheduled by the compiler, 2 (default) = hand-scheduled MFMA groups (B fragments in registers the
+ *                   compiler does not own) for num_features <= 128, 3 = 2 plus the software-pipelined one-wave-per-SIMD kernel where it exists
+ *                   (f16x3 rbf, 65 ... 128 features, symmetric: bit-identical results, measured slower: DESIGN.md section 4.1)
  *   "colslab_band_mb" the symmetric variant leaves one record of 128 column sums per evaluated off-diagonal tile; the device's row blocks are
  *                   cut into bands of equal area whose records fit this many MiB (default 2048), the tile kernel runs band by band into one
  *                   slab and every band is folded into K*v before the next (1M points in fp32: 15.6 GB of records -> 8 bands, 2 GiB)
@@ -292,9 +285,6 @@ int lssvm_mi355_measure_bf16_mfma_ceiling(int device, int b_from_lds, double set
  *                   the host; they touch d and K*d only, so a converged solve ends exactly where the reference's does, one matvec is discarded.
  *                   0 = the host reads every stop test before it enqueues anything further
  *   "check_shards"  1 = cg_finish verifies that the CG scalars of all local shards are bit-equal (default), 0 = skip the check
- *   "force_collective" 1 = run the per-matvec RCCL collective even with a world of 1 (testing aid; default 0)
- *   "skip_collective"  1 = problems created with world > 1 need no communicator and do NOT exchange their partial K*v (testing aid:
- *                      lets one GPU evaluate every rank's share in turn; default 0)
  */
 int lssvm_mi355_set_option(const char *name, int64_t value);
 int lssvm_mi355_get_option(const char *name, int64_t *value_out);

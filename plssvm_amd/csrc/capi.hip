@@ -338,7 +338,7 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
             LSSVM_REQUIRE(value >= 0 && value <= 3, "gram_mode must be 0 (v_mfma_f32), 1 (bf16x6), 2 (f16x3 unchecked) or 3 (f16x3 where the data allows, else bf16x6)");
             lssvm::options().gram_mode = value;
         } else if (n == "mfma_shape") {
-            LSSVM_REQUIRE(value == 1 || value == 2, "mfma_shape must be 1 (compiler-scheduled MFMA groups) or 2 (hand-scheduled groups)");
+            LSSVM_REQUIRE(value >= 1 && value <= 3, "mfma_shape must be 1 (compiler-scheduled MFMA groups), 2 (hand-scheduled groups) or 3 (2 + the software-pipelined kernel where it exists)");
             lssvm::options().mfma_shape = value;
         } else if (n == "colslab_band_mb") {
             LSSVM_REQUIRE(value >= 1, "colslab_band_mb must be positive");

@@ -84,7 +84,7 @@ static void launch_f3_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
     case N:                                                                                               \
         if constexpr (N > f16_max_nk64(KT)) {                                                             \
             throw Error(LSSVM_ERR_INTERNAL, "no f16x3 rbf tile kernel for this number of features");       \
-        } else if (a.mfma_shape == 2) {                                                                          \
+        } else if (a.mfma_shape >= 2) {                                                                          \
             if constexpr (KT != KT_POLY && N <= F16_HAND_MAX_NK64) { /* (generic integer power: its epilogue does not fit the capped register budget without spills) */                                                       \
                 ensure_dynamic_lds(tile_matvec_f32_f3h<KT, N, SYM>, V2_LDS_BYTES);                        \
                 hipLaunchKernelGGL((tile_matvec_f32_f3h<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);   \
@@ -131,6 +131,7 @@ static void launch_f3(const TileArgs<float> &a, int kernel_type, dim3 grid, hipS
 }
 
 void launch_f16_tile_kernel(const TileArgs<float> &a, int kernel_type, dim3 grid, hipStream_t s) {
+    if (a.mfma_shape >= 3 && launch_f3p_tile_kernel(a, kernel_type, s)) return;  // software-pipelined, one wave per SIMD, where such a kernel exists
     if (a.items != nullptr) {
         launch_f3<true>(a, kernel_type, dim3(static_cast<unsigned>(a.num_items)), s);
     } else {

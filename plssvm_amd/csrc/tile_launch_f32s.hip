@@ -34,7 +34,7 @@ static void launch_s6_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
     const size_t V2_LDS_BYTES = lssvm::V2_LDS_BYTES + static_cast<size_t>(a.lds_extra_kb) * 1024;  // experiment knob: limits workgroups per CU
 #define LSSVM_S6_CASE(N)                                                                                  \
     case N:                                                                                               \
-        if (a.mfma_shape == 2) {                                                                          \
+        if (a.mfma_shape >= 2) {                                                                          \
             if constexpr (KT != KT_POLY && N <= 2) { /* (generic integer power: its epilogue does not fit the capped register budget without spills) */                                                                       \
                 ensure_dynamic_lds(tile_matvec_f32_s6h<KT, N, SYM>, V2_LDS_BYTES);                        \
                 hipLaunchKernelGGL((tile_matvec_f32_s6h<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);   \

@@ -14,17 +14,26 @@ from plssvm_amd import _capi, backend
 from plssvm_amd.exceptions import BackendError, InvalidParameterError
 from plssvm_amd.parameter import Parameter
 
-HEADER = os.path.join(ROOT, "include", "plssvm_amd.h")
+HEADER = os.path.join(ROOT, "include", "plssvm_amd.h")                   # the boundary a PLSSVM maintainer binds
+TESTING_HEADER = os.path.join(ROOT, "include", "plssvm_amd_testing.h")   # measurement / test aids of bench.py and tests/ (same library)
 
 
-def declared_symbols():
-    text = open(HEADER).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(lssvm_mi355_\w+)\s*\(", text)))
+def declared_symbols(headers=(HEADER, TESTING_HEADER)):
+    found = set()
+    for header in headers:
+        text = open(header).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        found.update(re.findall(r"\b(lssvm_mi355_\w+)\s*\(", text))
+    return sorted(found)
 
 
 def test_header_and_binding_agree():
     assert declared_symbols() == sorted(_capi.EXPORTED_SYMBOLS)
+    # the public header carries no measurement / test entry point and documents no test knob
+    assert "lssvm_mi355_measure_bf16_mfma_ceiling" not in declared_symbols((HEADER,))
+    public = open(HEADER).read()
+    for knob in ("debug_ablate", "lds_extra_kb", "skip_collective", "force_collective"):
+        assert knob not in public, knob
 
 
 def test_library_exports_every_declared_symbol():

@@ -75,6 +75,25 @@ def test_bench_json_contract_small_workload():
     assert abs(j["value"] - 2.0 * n * n * d / (j["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * j["value"]
 
 
+def test_bench_rank_path_two_ranks_on_one_device():
+    """bench.py's one-process-per-GPU path as the driver runs it -- the parent starts its ranks as child processes, torch.distributed side
+    channel, row-block partition, exchange of the partial vectors, max-over-ranks timing, ONE JSON line from rank 0 -- on a one-GPU box: two
+    ranks share device 0 and exchange over HIP IPC (RCCL refuses two ranks on one device; with distinct devices the same path runs the
+    library's RCCL communicator)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--exchange", "2", "--dist-backend", "gloo", "--rank-devices", "0,0",
+                          "--workload", "c2", "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=900, env=dict(os.environ))
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout  # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["scaling"] == "strong" and j["config"]["shards"] == 2
+    assert "HIP IPC" in j["config"]["parallelism"] and j["config"]["exchange"].startswith("peer kernels")
+    assert j["roofline"]["symmetric"] is True and 0.05 < j["roofline"]["frac"] < 1.0 and j["ms_per_step"] > 0
+    # value is whole-job: 2 n^2 d per step / ms_per_step
+    n, d = 49_999, 128
+    assert abs(j["value"] - 2.0 * n * n * d / (j["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * j["value"]
+
+
 def test_rccl_all_gather_path_with_a_world_of_one():
     """One GPU per box here, so the multi-rank exchange is exercised with world = 1: the library dlopens RCCL, builds its own
     communicator from a unique id and runs ncclAllGather (in place, on the solver stream) after every implicit matvec."""

@@ -925,3 +925,61 @@ def test_split_kernels_steady_state_at_every_chunk_count(oracle, kernel, d, mode
     tol = max(4.0 * np.max(np.abs(want - truth)), 64 * np.finfo(np.float32).eps * scale)
     for sym in (1, 0):
         assert np.max(np.abs(out[sym] - truth)) < tol, (sym, float(np.max(np.abs(out[sym] - truth))), tol)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_wide_data_at_the_reference_test_shape(oracle, kernel, dt):
+    """The reference's own kernel tests run on 5000 x 2000 data (tests/CMakeLists.txt:36-69, generic_csvm_tests.hpp:372-493).  2000 features
+    are far beyond what the resident-row-panel kernels hold in registers (512 in fp32, 256 in fp64): this shape runs the generic tile
+    kernels (both operands staged through LDS, full square).  q and one implicit matvec against the float64 oracle at 1000 x 2000, with the
+    reference's test parameters, on the scale of each row's summands."""
+    N, d = 1000, 2000
+    rng = np.random.default_rng(2000)
+    X = rng.uniform(-1, 1, size=(N, d)).astype(dt)
+    P = dict(degree=2, gamma=0.001, coef0=1.0, cost=0.1)  # generic_csvm_tests.hpp:372-493
+    p = prm(kernel, P)
+    rhs = rng.uniform(-1, 1, size=N - 1).astype(dt)
+    zero = np.zeros(N - 1, dt)
+    kw = dict(degree=2, gamma=0.001, coef0=1.0)
+    with backend.ResidentProblem(p, X) as prob:
+        info = prob.info()
+        assert info["gram_mode"] == 0 and info["symmetric"] == 0   # the generic kernel
+        q, QA = prob.q()
+        got = prob.matvec(rhs, zero, 1.0).astype(np.float64)
+    X64 = X.astype(np.float64)
+    q64 = oracle.q(kernel, X64, **kw)
+    eps = np.finfo(dt).eps
+    assert ol.rel_inf(q, q64) < 64 * eps
+    truth = oracle.matvec(kernel, X64, q64, rhs.astype(np.float64), np.zeros(N - 1), float(oracle.kernel_function(kernel, X64[-1], X64[-1], **kw)) + 1.0 / 0.1, 1.0 / 0.1, 1.0, **kw)  # (the kernels take 1 / cost, svm_kernel.cpp:27)
+    G = X64[:N - 1] @ X64[:N - 1].T
+    if kernel == "linear":
+        K = G
+    elif kernel == "polynomial":
+        K = (0.001 * G + 1.0) ** 2
+    else:
+        sq = np.einsum("ij,ij->i", X64[:N - 1], X64[:N - 1])
+        K = np.exp(-0.001 * np.maximum(sq[:, None] + sq[None, :] - 2.0 * G, 0.0))
+    v64 = rhs.astype(np.float64)
+    S = float(v64.sum())
+    scale = np.abs(K) @ np.abs(v64) + np.abs(v64) / 0.1 + abs(float(QA) * S) + abs(float(q64 @ v64)) + np.abs(S * q64)
+    assert np.max(np.abs(got - truth) / scale) < 16 * eps, float(np.max(np.abs(got - truth) / scale) / eps)
+
+
+@pytest.mark.parametrize("N, jct", [(129, 0), (385, 0), (1500, 0), (1500, 1), (1500, 5), (4097, 0)])
+def test_software_pipelined_kernel_is_bit_identical(N, jct):
+    """Option mfma_shape = 3: the one-wave-per-SIMD kernel whose epilogue of tile t - 1 is interleaved by a generator with the MFMAs of tile t
+    (lssvm_tile_f32_pipe.hip.hpp, gen_f3p.py; rbf, folded records, 65 ... 128 features, symmetric).  Same arithmetic in the same order as
+    the hand-scheduled two-waves-per-SIMD kernel: the results must be EQUAL, bit for bit, at every work-item shape (1 ... 5 tiles, items
+    that end on the diagonal, odd and even tile counts)."""
+    d = 128
+    X, _ = make_blobs_pm1(N, d, seed=3, dtype=np.float32)
+    v = np.random.default_rng(1).uniform(-1, 1, N - 1).astype(np.float32)
+    out = {}
+    _capi.set_option("gram_mode", 2)
+    _capi.set_option("j_chunk_tiles", jct)
+    for shape in (2, 3):
+        _capi.set_option("mfma_shape", shape)
+        with backend.ResidentProblem(Parameter(kernel_type="rbf", gamma=1.0 / d), X) as prob:
+            out[shape] = prob.matvec(v, np.zeros(N - 1, np.float32), 1.0)
+    assert np.all(np.isfinite(out[3])) and np.array_equal(out[2], out[3])

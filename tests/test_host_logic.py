@@ -126,3 +126,21 @@ def test_native_libsvm_reader_declines_what_it_cannot_vouch_for(tmp_path, text):
     f = tmp_path / "bad.libsvm"
     f.write_text(text)
     assert _parse_native(str(f), np.float64, 0, float) is None
+
+
+def test_bench_parent_stops_when_its_ranks_fail():
+    """`python bench.py --gpus 2` without a launcher starts its ranks as child processes.  Here there is no GPU: every rank exits with an error,
+    and the parent must come back with a non-zero code instead of waiting on a blocked sibling (it polls all children and stops the rest on
+    the first failure)."""
+    import os
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode != 0 and time.time() - t0 < 300
+    assert "no HIP device is visible" in out.stderr or "needs an MI355X" in out.stderr, out.stderr[-500:]

@@ -3,7 +3,7 @@
 then: python tests/tools/audit_hand_asm.py plssvm_amd/lib/asm/*gfx950.s).
 
 The kernels tile_matvec_f32_s6h / _f3h keep their B fragments in v[224:255], registers that only the generated asm groups
-(lssvm_s6w_groups.inc) may touch, and their accumulators are written by MFMAs inside asm statements, where the compiler pads no hazards.
+(lssvm_s6w_groups.inc) may touch (the software-pipelined tile_matvec_f32_f3p: everything from v64 / a64, lssvm_f3p_tiles.inc), and their accumulators are written by MFMAs inside asm statements, where the compiler pads no hazards.
 Three things can silently break that contract, none of which the compiler reports:
   1. compiler-generated code that touches v224 and above (the register cap not holding: round 3 found amdgpu_num_vgpr(224) ineffective on
      gfx950, the attribute counts half registers -- NaNs);
@@ -16,7 +16,12 @@ import re
 import subprocess
 import sys
 
-HAND = re.compile(r"tile_matvec_f32_(s6h|f3h)")
+HAND = re.compile(r"tile_matvec_f32_(s6h|f3h|f3p)")
+
+
+def first_private(name):
+    """first register of the kernel's private range (VGPR and AGPR alike): s6h / f3h keep v[224:255], the software-pipelined f3p everything from 64"""
+    return 64 if "f3p" in name else 224
 NEAR = 4  # compiler instructions behind an MFMA group inside which an accumulator access counts as too early
 
 
@@ -70,7 +75,7 @@ def audit(path):
             r = regs_of(t.split(";")[0])
             if r:
                 maxreg = max(maxreg, max(r))
-            if any(x >= 224 for x in r):
+            if any(x >= first_private(name) for x in r) or any(int(m.group(1)) >= first_private(name) for m in re.finditer(r"\ba\[?(\d+)", t.split(";")[0])):
                 trespass.append((no + 1, t[:90]))
             if "scratch_" in t:
                 scratch_any += 1
@@ -88,7 +93,7 @@ def audit(path):
             bad += 1
         print(f"{status:6s} {name}: highest compiler VGPR v{maxreg}, scratch ops {scratch_any} ({scratch_loop} inside loops)")
         for no, t in trespass[:5]:
-            print(f"        line {no}: compiler code touches v224+: {t}")
+            print(f"        line {no}: compiler code touches the private registers (v{first_private(name)}+ / a{first_private(name)}+): {t}")
         for no, k, t in early[:5]:
             print(f"        line {no}: accumulator accessed {k} instruction(s) behind its MFMA group: {t}")
     return bad, names
