@@ -465,15 +465,17 @@ def main():
                 prob = None
             import ctypes as C
 
+            f16_bit = 2 if gram_mode == 2 else 0  # the bare loop runs the instruction of the kernel it is compared with
+
             def ceiling(b_from_lds):
                 tf, ghz, nominal = C.c_double(0), C.c_double(0), C.c_double(0)
-                _capi.check(_capi.lib.lssvm_mi355_measure_bf16_mfma_ceiling(C.c_int(local_rank), C.c_int(b_from_lds), C.c_double(1500.0), C.byref(tf), C.byref(ghz), C.byref(nominal)))
+                _capi.check(_capi.lib.lssvm_mi355_measure_bf16_mfma_ceiling(C.c_int(local_rank), C.c_int(b_from_lds | f16_bit), C.c_double(1500.0), C.byref(tf), C.byref(ghz), C.byref(nominal)))
                 return tf.value, ghz.value, nominal.value
 
             regs_tf, regs_ghz, nominal = ceiling(0)
             lds_tf, lds_ghz, _ = ceiling(1)
             out["roofline"]["bare_mfma_loop"] = {
-                "what": "v_mfma_f32_16x16x32_bf16 only, 64x64 wave tiles, two waves per SIMD, normal(0,1) operands, 1.5 s of back-to-back launches before timing "
+                "what": ("v_mfma_f32_16x16x32_f16" if gram_mode == 2 else "v_mfma_f32_16x16x32_bf16") + " only, 64x64 wave tiles, two waves per SIMD, normal(0,1) operands, 1.5 s of back-to-back launches before timing "
                         "(lssvm_mi355_measure_bf16_mfma_ceiling); same device, same process, after the timed region",
                 "operands_in_registers": {"tflops": regs_tf, "frac_of_peak": regs_tf / peak, "clock_ghz": regs_ghz},
                 "b_fragments_from_lds": {"tflops": lds_tf, "frac_of_peak": lds_tf / peak, "clock_ghz": lds_ghz},

@@ -14,8 +14,8 @@ extern "C" {
 
 /* Measurement utility, not on the solve path and without a counterpart in the reference: what a BARE loop of v_mfma_f32_16x16x32_bf16
  * (the instruction of the fp32 "bf16x6" Gram kernel; 64 x 64 wave tiles, two waves per SIMD, normal(0,1) operands, nothing else in the
- * loop) sustains on `device` after `settle_ms` of back-to-back launches.  b_from_lds != 0: the B fragments are re-read from LDS every
- * pass, as the Gram kernel does.  Returns TFLOP/s, the in-kernel clock (s_memtime / s_memrealtime, median over workgroups) and the
+ * loop) sustains on `device` after `settle_ms` of back-to-back launches.  b_from_lds bit 0: the B fragments are re-read from LDS every
+ * pass, as the Gram kernel does; bit 1: v_mfma_f32_16x16x32_f16 on f16 operands (the instruction of the "f16x3" kernels) instead of the bf16 form.  Returns TFLOP/s, the in-kernel clock (s_memtime / s_memrealtime, median over workgroups) and the
  * nominal peak (4096 FLOP/clk/CU x CUs x nominal clock).  The chip lowers its clock under matrix-core load, so this -- not the
  * nominal peak -- is what a kernel on this device is up against; bench.py prints it beside roofline.frac. */
 int lssvm_mi355_measure_bf16_mfma_ceiling(int device, int b_from_lds, double settle_ms, double *tflops_out, double *clock_ghz_out, double *nominal_tflops_out);

@@ -117,6 +117,8 @@ constexpr int MAX_LOCAL_DEVICES = 16;
 constexpr double FOLD_MAX_R2 = 200.0;    // folded rbf records (KT_RBFF) only while |c| = R2 / 2 <= 100: 2^c and 2^acc stay far inside the fp32 range
 constexpr int SPLIT_MAX_FEATURES = 384;  // the bf16x6 kernels exist for 1 ... 6 chunks of 64 features (row panel = 3 planes in registers)
 constexpr int F16_MAX_FEATURES = 512;    // the f16x3 kernels exist for 1 ... 8 chunks of 64 features (row panel = 2 planes in registers)
+constexpr int F16_PANEL_FEATURES = 512;   // linear kernel beyond 512 features: K = sum over feature panels of X_p X_p^T, one launch of the f16x3 kernels per panel
+constexpr int F16_LINEAR_MAX_FEATURES = 1 << 20;
 constexpr int F16_RBF_MAX_FEATURES = 384;  // ... rbf: 1 ... 6 chunks (three row planes in registers: the shifted planes, see make_planes)
 constexpr int F16_RBF_SHIFT = 6;         // rbf: the planes are (2^-6 hi, 2^6 mid, 2^6 hi)
 constexpr int F16_TARGET_EXP = 14;       // f16x3, linear / polynomial: the planes carry 2^k x with max |2^k x| in [2^14, 2^15) (f16 overflows at 65504)
@@ -316,7 +318,8 @@ static void make_planes(const Options &o, const lssvm_params &p, bool rbf_direct
     out.mode = 0;
     if (out2 != nullptr) out2->mode = 0;
     const int ldx16 = static_cast<int>(round_up(static_cast<long>(M.dfeat), 64));
-    if (o.gram_mode == 0 || rbf_direct || !v2_eligible(o, M.ldx, false)) return;
+    const bool wide_linear = p.kernel_type == LSSVM_KERNEL_LINEAR && ldx16 > F16_MAX_FEATURES && o.tile_kernel != 1;  // feature panels (f16x3 only)
+    if (o.gram_mode == 0 || rbf_direct || (!v2_eligible(o, M.ldx, false) && !wide_linear)) return;
     auto alloc = [&](int nplanes) {
         out.ldx16 = ldx16;
         out.buf.alloc_zero(static_cast<size_t>(nplanes) * M.rows_alloc * ldx16, s);
@@ -326,7 +329,8 @@ static void make_planes(const Options &o, const lssvm_params &p, bool rbf_direct
         }
     };
     const bool rbf = p.kernel_type == LSSVM_KERNEL_RBF;
-    if ((o.gram_mode == 2 || o.gram_mode == 3) && ldx16 <= (rbf ? F16_RBF_MAX_FEATURES : F16_MAX_FEATURES)) {
+    const int f16_limit = rbf ? F16_RBF_MAX_FEATURES : (p.kernel_type == LSSVM_KERNEL_LINEAR ? F16_LINEAR_MAX_FEATURES : F16_MAX_FEATURES);
+    if ((o.gram_mode == 2 || o.gram_mode == 3) && ldx16 <= f16_limit) {
         DevBuf<unsigned> stats;
         stats.alloc_zero(4, s);
         int shift = 0;
@@ -390,6 +394,7 @@ static void set_plane_args(TileArgs<float> &a, const lssvm_params &p, const Plan
     a.plane_stride = col_rows_alloc * cols.ldx16;
     a.plane_stride_r = row_rows_alloc * rows.ldx16;
     a.ldx16 = cols.ldx16;
+    a.nk64 = cols.ldx16 / 64;
     a.planes_f16 = cols.mode == 2 ? 1 : 0;
     a.out_scale = 1.0f;
     if (cols.mode == 2 && cols.shift != 0) {
@@ -564,7 +569,20 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     rbf_direct_ = rbf_wants_direct_form<T>(opt_, params_, X_, nullptr, st, &rbf_r2_);
     // symmetric variant: v2 kernels only; a negative polynomial degree can give inf on zero-padded rows -> full square
     const int ldx_probe = padded_features<T>(num_features);
-    const bool v2_ok = std::is_same_v<T, float> ? v2_eligible(opt_, ldx_probe, rbf_direct_) : v2_eligible_f64(opt_, ldx_probe);
+    bool v2_ok = std::is_same_v<T, float> ? v2_eligible(opt_, ldx_probe, rbf_direct_) : v2_eligible_f64(opt_, ldx_probe);
+    if constexpr (std::is_same_v<T, float>) {
+        // linear kernel on more than 512 features: K*v = sum over feature panels of (X_p X_p^T) v, every panel one launch of the f16x3 kernels
+        // (enqueue_apply_K_local).  Whether the data allows f16 planes decides it, so the planes are built HERE (the linear kernel needs the raw data).
+        if (!v2_ok && params_.kernel_type == LSSVM_KERNEL_LINEAR && num_features > static_cast<size_t>(F16_MAX_FEATURES)) {
+            make_planes(opt_, params_, false, X_, nullptr, planes_, nullptr, st);
+            if (planes_.mode == 2 && opt_.symmetric != 0 && opt_.colslab_limit_mb != 0) {  // (the panel passes exist for the symmetric variant)
+                v2_ok = wide_linear_ = true;
+            } else {
+                planes_.buf.release();
+                planes_.mode = 0;
+            }
+        }
+    }
     sym_ = opt_.symmetric != 0 && v2_ok && !(params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree < 0);
     // the symmetric variant keeps one 128-entry record per evaluated off-diagonal tile of the row-block BAND in flight (see the bands
     // below); colslab_limit_mb = 0 switches the variant off (a rule in the options only, so every rank of a sharded solve decides alike)
@@ -584,7 +602,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         const long area = sym_ ? (ib_end * (ib_end + 1) - static_cast<long>(ib_begin_) * (ib_begin_ + 1)) / 2 : static_cast<long>(num_ib_) * num_tiles_;
         // the bf16x6 kernel has the costlier work-item prologue (three planes of the row panel) and the faster tiles: longer chunks
         // (measured 16 -> 64 tiles: +1.5 % at 100 000 points, +2 % at 300 000; the native kernels are flat or lose beyond 16)
-        const bool split = std::is_same_v<T, float> && opt_.gram_mode != 0 && v2_eligible(opt_, ldx_probe, rbf_direct_)
+        const bool split = wide_linear_ || std::is_same_v<T, float> && opt_.gram_mode != 0 && v2_eligible(opt_, ldx_probe, rbf_direct_)
                            && round_up(static_cast<long>(num_features), 64) <= ((opt_.gram_mode == 1 || params_.kernel_type == LSSVM_KERNEL_RBF) ? SPLIT_MAX_FEATURES : F16_MAX_FEATURES);
         const long cap = split ? 64 : 16;
         jc_tiles_ = static_cast<int>(std::min<long>(cap, std::max<long>(2, (area + 2048) / 4096)));
@@ -641,12 +659,12 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     }
     if constexpr (std::is_same_v<T, float>) {
         // the (centred, scaled) data once more as operand planes of the split kernels (features in natural order): see make_planes
-        make_planes(opt_, params_, rbf_direct_, X_, nullptr, planes_, nullptr, st);
+        if (!wide_linear_) make_planes(opt_, params_, rbf_direct_, X_, nullptr, planes_, nullptr, st);
         // rbf: folded records while the exponent terms stay small (rbf_r2_ = 2 max|c| in the exponent's unit)
         if (planes_.mode != 0) dc_folded_ = params_.kernel_type == LSSVM_KERNEL_RBF && opt_.rbf_fold != 0 && rbf_r2_ <= FOLD_MAX_R2;
     }
     interleave_features<T>(X_, st);
-    if ((std::is_same_v<T, float> && v2_eligible(opt_, X_.ldx, rbf_direct_)) || (std::is_same_v<T, double> && v2_eligible_f64(opt_, X_.ldx))) {
+    if ((std::is_same_v<T, float> && (v2_eligible(opt_, X_.ldx, rbf_direct_) || wide_linear_)) || (std::is_same_v<T, double> && v2_eligible_f64(opt_, X_.ldx))) {
         dc_.alloc_zero(static_cast<size_t>(std::max(num_tiles_, 1)) * 256, st);  // (d_j | c_j) records: 256 reals per 128 columns
     }
     if (sym_) {
@@ -769,33 +787,48 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
         }
     }
     const int nrows = num_ib_ * TILE;
+    // wide linear problems: one pass per panel of 512 features, every pass ADDS its K_p * v (rows and mirrored columns) into K*v
+    int npanels = 1;
+    if constexpr (std::is_same_v<T, float>) {
+        if (wide_linear_) npanels = (planes_.ldx16 + F16_PANEL_FEATURES - 1) / F16_PANEL_FEATURES;
+    }
     if (sym_) {
         bool first = true;
-        for (const Band &band : bands_) {
-            TileArgs<T> ab = a;
-            ab.items = items_.p + band.item_begin;
-            ab.num_items = band.item_count;
-            ab.pair_origin = band.pair_origin;
-            EvPair *ev = free_event();
-            if (ev != nullptr) LSSVM_HIP_CHECK(hipEventRecord(ev->a.e, st));
-            launch_tile_kernel<T>(ab, params_.kernel_type, rbf_direct_, num_jc_, st);
-            if (ev != nullptr) {
-                LSSVM_HIP_CHECK(hipEventRecord(ev->b.e, st));
-                ev->pending = true;
-                ev->first_of_matvec = first;
-            }
-            first = false;
-            // fold the band's mirrored column sums into K*v before the next band re-uses the slab
-            if (band.ib_end > 1) {
-                if constexpr (std::is_same_v<T, float>) {
-                    hipLaunchKernelGGL((k_reduce_colslab<T, 128>), dim3(band.ib_end - 1), dim3(1024), 0, st, colslab_.p, band.pair_origin, band.ib_begin, band.ib_end, Kv_.p);
-                } else {  // fp64: records per 64-column sub-tile
-                    hipLaunchKernelGGL((k_reduce_colslab<T, 64>), dim3(2 * (band.ib_end - 1)), dim3(1024), 0, st, colslab_.p, band.pair_origin, band.ib_begin, band.ib_end, Kv_.p);
+        for (int panel = 0; panel < npanels; ++panel) {
+            TileArgs<T> ap = a;
+            if constexpr (std::is_same_v<T, float>) {
+                if (wide_linear_) {
+                    ap.Xr16 += static_cast<size_t>(panel) * F16_PANEL_FEATURES;
+                    ap.Xc16 += static_cast<size_t>(panel) * F16_PANEL_FEATURES;
+                    ap.nk64 = std::min(F16_PANEL_FEATURES, planes_.ldx16 - panel * F16_PANEL_FEATURES) / 64;
                 }
             }
+            for (const Band &band : bands_) {
+                TileArgs<T> ab = ap;
+                ab.items = items_.p + band.item_begin;
+                ab.num_items = band.item_count;
+                ab.pair_origin = band.pair_origin;
+                EvPair *ev = free_event();
+                if (ev != nullptr) LSSVM_HIP_CHECK(hipEventRecord(ev->a.e, st));
+                launch_tile_kernel<T>(ab, params_.kernel_type, rbf_direct_, num_jc_, st);
+                if (ev != nullptr) {
+                    LSSVM_HIP_CHECK(hipEventRecord(ev->b.e, st));
+                    ev->pending = true;
+                    ev->first_of_matvec = first;
+                }
+                first = false;
+                // fold the band's mirrored column sums into K*v before the next band re-uses the slab
+                if (band.ib_end > 1) {
+                    if constexpr (std::is_same_v<T, float>) {
+                        hipLaunchKernelGGL((k_reduce_colslab<T, 128>), dim3(band.ib_end - 1), dim3(1024), 0, st, colslab_.p, band.pair_origin, band.ib_begin, band.ib_end, Kv_.p);
+                    } else {  // fp64: records per 64-column sub-tile
+                        hipLaunchKernelGGL((k_reduce_colslab<T, 64>), dim3(2 * (band.ib_end - 1)), dim3(1024), 0, st, colslab_.p, band.pair_origin, band.ib_begin, band.ib_end, Kv_.p);
+                    }
+                }
+            }
+            // rows of this device's blocks: the slabs of the column chunks that exist for each block, added on top
+            hipLaunchKernelGGL(k_reduce_partials_sym<T>, dim3((nrows + 255) / 256), dim3(256), 0, st, partial_.p, a.part_stride, jc_tiles_, ib_begin_, nrows, Kv_.p, 1);
         }
-        // rows of this device's blocks: the slabs of the column chunks that exist for each block, added on top
-        hipLaunchKernelGGL(k_reduce_partials_sym<T>, dim3((nrows + 255) / 256), dim3(256), 0, st, partial_.p, a.part_stride, jc_tiles_, ib_begin_, nrows, Kv_.p, 1);
     } else {
         EvPair *ev = free_event();
         if (ev != nullptr) LSSVM_HIP_CHECK(hipEventRecord(ev->a.e, st));

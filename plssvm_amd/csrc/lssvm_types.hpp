@@ -48,7 +48,8 @@ struct TileArgs {
                            // polynomial: folded into gamma; rbf: k = 0
     size_t plane_stride;   // elements between the planes of the COLUMN side
     size_t plane_stride_r; // elements between the planes of the ROW side (training: the same matrix; predict_values: the points to predict)
-    int ldx16;             // padded features of the planes (multiple of 64)
+    int ldx16;             // padded features of the planes (multiple of 64): the row stride of the planes
+    int nk64;              // host side only: 64-feature chunks THIS launch contracts over (= ldx16 / 64, or one feature panel of a wide linear problem)
     const int2 *items; // symmetric variant: list of the non-empty (local row block, column chunk) work items
     int num_items;    // symmetric variant: length of `items` = grid size
     T *colslab;       // symmetric variant: [packed (ib, jt) pairs with jt < ib][TILE] column sums of the off-diagonal tiles

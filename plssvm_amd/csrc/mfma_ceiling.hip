@@ -11,6 +11,7 @@ namespace lssvm {
 
 using f32x4_c = float __attribute__((ext_vector_type(4)));
 using bf16x8_c = __bf16 __attribute__((ext_vector_type(8)));
+using f16x8_c = _Float16 __attribute__((ext_vector_type(8)));
 using u32x4_c = unsigned __attribute__((ext_vector_type(4)));
 
 struct CeilingStamp {
@@ -18,8 +19,9 @@ struct CeilingStamp {
 };
 
 /* a 64 x 64 wave tile = 4 x 4 accumulators of 16 x 16, 64 deep per pass (2 k-steps of 32): 32 MFMAs per pass.
- * LDSB = 1: the B fragments are re-read from LDS (ds_read_b128) every pass, as the Gram kernel does; 0: both operands stay in registers */
-template <int LDSB>
+ * LDSB = 1: the B fragments are re-read from LDS (ds_read_b128) every pass, as the Gram kernel does; 0: both operands stay in registers.
+ * F16: v_mfma_f32_16x16x32_f16 on f16 operands (the f16x3 kernels' instruction) instead of the bf16 form (same cycles; the operand bits differ) */
+template <int LDSB, bool F16>
 __global__ __launch_bounds__(256, 2) void k_bare_mfma_bf16(float *out, const u32x4_c *src, CeilingStamp *stamps, int passes) {
     __shared__ u32x4_c lds_b[4][4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -48,7 +50,13 @@ __global__ __launch_bounds__(256, 2) void k_bare_mfma_bf16(float *out, const u32
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[k], acc[i][k], 0, 0, 0);
+                for (int k = 0; k < 4; ++k) {
+                    if constexpr (F16) {
+                        acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_c, a[i]), __builtin_bit_cast(f16x8_c, b[k]), acc[i][k], 0, 0, 0);
+                    } else {
+                        acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[k], acc[i][k], 0, 0, 0);
+                    }
+                }
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
@@ -76,7 +84,16 @@ void measure_bf16_mfma_ceiling(int device, int b_from_lds, double settle_ms, dou
     std::vector<uint16_t> host(n16 * 8);
     std::mt19937 gen(7);
     std::normal_distribution<float> nd(0.f, 1.f);
-    for (uint16_t &v : host) v = bf16_bits(nd(gen));
+    const bool f16 = (b_from_lds & 2) != 0;  // bit 1 of the flag: f16 operands and the f16 MFMA
+    for (uint16_t &v : host) {
+        const float x = nd(gen);
+        if (f16) {
+            const _Float16 h = static_cast<_Float16>(x);
+            std::memcpy(&v, &h, 2);
+        } else {
+            v = bf16_bits(x);
+        }
+    }
     Stream st;
     st.create();
     DevBuf<u32x4_c> src;
@@ -91,10 +108,12 @@ void measure_bf16_mfma_ceiling(int device, int b_from_lds, double settle_ms, dou
     ea.create(true);
     eb.create(true);
     const auto launch = [&] {
-        if (b_from_lds != 0) {
-            hipLaunchKernelGGL(k_bare_mfma_bf16<1>, dim3(blocks), dim3(256), 0, st.s, out.p, src.p, stamps.p, passes);
+        if ((b_from_lds & 1) != 0) {
+            if (f16) hipLaunchKernelGGL((k_bare_mfma_bf16<1, true>), dim3(blocks), dim3(256), 0, st.s, out.p, src.p, stamps.p, passes);
+            else hipLaunchKernelGGL((k_bare_mfma_bf16<1, false>), dim3(blocks), dim3(256), 0, st.s, out.p, src.p, stamps.p, passes);
         } else {
-            hipLaunchKernelGGL(k_bare_mfma_bf16<0>, dim3(blocks), dim3(256), 0, st.s, out.p, src.p, stamps.p, passes);
+            if (f16) hipLaunchKernelGGL((k_bare_mfma_bf16<0, true>), dim3(blocks), dim3(256), 0, st.s, out.p, src.p, stamps.p, passes);
+            else hipLaunchKernelGGL((k_bare_mfma_bf16<0, false>), dim3(blocks), dim3(256), 0, st.s, out.p, src.p, stamps.p, passes);
         }
     };
     // settle the clock under load, then time ten more launches

@@ -96,7 +96,7 @@ static void launch_f3_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
             hipLaunchKernelGGL((tile_matvec_f32_f3w<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);       \
         }                                                                                                 \
         break;
-    switch (a.ldx16 / 64) {
+    switch (a.nk64) {
 #ifdef LSSVM_DEV_SUBSET  // development builds (make DEV=1): 128 and 256 features only, a quarter of the compile time
         LSSVM_F3_CASE(2) LSSVM_F3_CASE(4)
 #else

@@ -44,7 +44,7 @@ static void launch_s6_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
         ensure_dynamic_lds(tile_matvec_f32_s6w<KT, N, SYM>, V2_LDS_BYTES);                                \
         hipLaunchKernelGGL((tile_matvec_f32_s6w<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);           \
         break;
-    switch (a.ldx16 / 64) {
+    switch (a.nk64) {
 #ifdef LSSVM_DEV_SUBSET  // development builds (make DEV=1): 128 and 256 features only
         LSSVM_S6_CASE(2) LSSVM_S6_CASE(4)
 #else

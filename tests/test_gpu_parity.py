@@ -932,7 +932,8 @@ def test_split_kernels_steady_state_at_every_chunk_count(oracle, kernel, d, mode
 def test_wide_data_at_the_reference_test_shape(oracle, kernel, dt):
     """The reference's own kernel tests run on 5000 x 2000 data (tests/CMakeLists.txt:36-69, generic_csvm_tests.hpp:372-493).  2000 features
     are far beyond what the resident-row-panel kernels hold in registers (512 in fp32, 256 in fp64): this shape runs the generic tile
-    kernels (both operands staged through LDS, full square).  q and one implicit matvec against the float64 oracle at 1000 x 2000, with the
+    kernels (both operands staged through LDS, full square) -- except the fp32 LINEAR kernel, whose Gram matrix is a sum over feature
+    panels and runs as four passes of the f16x3 kernels.  q and one implicit matvec against the float64 oracle at 1000 x 2000, with the
     reference's test parameters, on the scale of each row's summands."""
     N, d = 1000, 2000
     rng = np.random.default_rng(2000)
@@ -944,7 +945,11 @@ def test_wide_data_at_the_reference_test_shape(oracle, kernel, dt):
     kw = dict(degree=2, gamma=0.001, coef0=1.0)
     with backend.ResidentProblem(p, X) as prob:
         info = prob.info()
-        assert info["gram_mode"] == 0 and info["symmetric"] == 0   # the generic kernel
+        if kernel == "linear" and dt == np.float32:
+            # fp32 linear kernel: K = sum over feature panels of X_p X_p^T, four passes of the f16x3 kernels over panels of 512 features
+            assert info["gram_mode"] == 2 and info["symmetric"] == 1
+        else:
+            assert info["gram_mode"] == 0 and info["symmetric"] == 0   # the generic kernel
         q, QA = prob.q()
         got = prob.matvec(rhs, zero, 1.0).astype(np.float64)
     X64 = X.astype(np.float64)
