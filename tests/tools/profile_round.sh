@@ -14,11 +14,12 @@ done
 # what a BARE bf16 MFMA loop sustains on THIS box (the chip lowers its clock under matrix-core load): the practical ceiling beside the bench lines
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tests/tools/microbench_bf16.hip -o /tmp/microbench_bf16 && timeout 300 /tmp/microbench_bf16 > $O/${TAG}_microbench_bf16_same_box.log 2>&1
 python3 bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline --no-native-reference > $O/${TAG}_bench_c5_n1_after_microbench.json 2>/dev/null
-# the native v_mfma_f32 path of the fp32 workloads, for reference (the library default is the bf16x6 split)
-for wl in c2 c5; do
+# the native v_mfma_f32 path and the bf16x6 split of the fp32 workloads, same box, for reference (the library default is f16x3 where the data allows)
+for wl in c2 c3 c5; do
   python3 bench.py --workload $wl --steps 5 --warmup 2 --gram-mode 0 --no-cpu-baseline > $O/${TAG}_bench_${wl}_n1_native_f32_mfma.json 2> $O/${TAG}_bench_${wl}_native.err
+  python3 bench.py --workload $wl --steps 5 --warmup 2 --gram-mode 1 --no-cpu-baseline --no-native-reference > $O/${TAG}_bench_${wl}_n1_bf16x6.json 2> $O/${TAG}_bench_${wl}_bf16x6.err
 done
-for wl in c2 c4 c5; do
+for wl in c2 c3 c4 c5; do
   rm -rf $O/prof_$wl
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -- python3 bench.py --workload $wl --steps 5 --warmup 1 --no-cpu-baseline --no-native-reference --no-ceiling > $O/prof_$wl.log 2>&1
   f=$(find $O/prof_$wl -name "*kernel_stats.csv" | head -1)
@@ -26,7 +27,7 @@ for wl in c2 c4 c5; do
   grep "^{" $O/prof_$wl.log | tail -1 > $O/${TAG}_rocprofv3_bench_line_${wl}.json
 done
 : > $O/${TAG}_pmc_tile_matvec.txt
-for wl in c2 c4 c5; do
+for wl in c2 c3 c4 c5; do
   rm -rf $O/pmc_$wl
   bash tests/tools/pmc_passes.sh $wl 3 $O/pmc_$wl
   python3 tests/tools/pmc_summarize.py $wl $O/pmc_$wl --json $O/${TAG}_hbm_traffic.json --key ${wl}_n1 --profile profiles/${TAG}_pmc_tile_matvec.txt >> $O/${TAG}_pmc_tile_matvec.txt 2>&1
