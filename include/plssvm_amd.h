@@ -77,7 +77,7 @@ typedef struct lssvm_cg_info {
     int32_t gram_mode;       /* fp32: 1 if the Gram tiles ran as the exact 3-way bf16 split on the bf16 matrix cores ("bf16x6"), else 0 */
     int32_t local_devices;   /* devices driven by THIS process (1 for a single GPU and for one process per GPU) */
     int32_t exchange;        /* how the partial K*v vectors were combined per matvec: 0 none, 1 RCCL (all-reduce / all-gather), 2 peer kernels over xGMI */
-    int32_t tile_launches_per_matvec; /* row-block bands per implicit matvec (option colslab_band_mb); matvec_kernel_ms is their SUM */
+    int32_t tile_launches_per_matvec; /* tile-kernel launches per implicit matvec: row-block bands (option colslab_band_mb) x feature panels of a wide linear problem; matvec_kernel_ms is their SUM */
     int32_t rbf_direct;      /* fp32 rbf: 1 if the formula-exact (x_i - x_j)^2 kernel ran instead of the matrix-core norm expansion (option rbf_form) */
     double rbf_exponent_scale; /* fp32 rbf, rbf_form 0: 2 gamma log2(e) max|x - mean|^2, the quantity compared with rbf_direct_above */
 } lssvm_cg_info;
@@ -279,6 +279,8 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *                   devices through its xGMI peer mappings in rank order (bit-equal on all devices, deterministic).
  *                   One process per GPU (lssvm_shard): 0 = RCCL when lssvm_mi355_comm_init was called in this process, else HIP IPC;
  *                   1 = RCCL; 2 = HIP IPC + the peer kernel (lssvm_mi355_problem_ipc_export / _connect)
+ *   "linear_panel_features" fp32 linear kernel on the f16x3 kernels: K = sum over feature panels of X_p X_p^T, one pass of the tile kernel per panel of this
+ *                   many features (multiple of 64, at most 512; default 128: two waves per SIMD and hand-scheduled groups in every pass), any width
  *   "ipc_timeout_s" one process per GPU over HIP IPC: seconds a rank waits for its peers at an exchange before it fails (default 600)
  *   "enqueue_ahead_below_us" CG loop: while an implicit matvec takes less than this many microseconds (default 5000), the direction update and
  *                   the NEXT matvec are enqueued before the host reads the stop test of the current iteration, so the device never waits for

@@ -353,6 +353,9 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
             lssvm::options().exchange = value;
         } else if (n == "check_shards") {
             lssvm::options().check_shards = value != 0 ? 1 : 0;
+        } else if (n == "linear_panel_features") {
+            LSSVM_REQUIRE(value >= 64 && value <= 512 && value % 64 == 0, "linear_panel_features must be a multiple of 64 between 64 and 512");
+            lssvm::options().linear_panel_features = value;
         } else if (n == "ipc_timeout_s") {
             LSSVM_REQUIRE(value >= 1, "ipc_timeout_s must be at least 1");
             lssvm::options().ipc_timeout_s = value;
@@ -405,6 +408,8 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             *value_out = lssvm::options().exchange;
         } else if (n == "check_shards") {
             *value_out = lssvm::options().check_shards;
+        } else if (n == "linear_panel_features") {
+            *value_out = lssvm::options().linear_panel_features;
         } else if (n == "ipc_timeout_s") {
             *value_out = lssvm::options().ipc_timeout_s;
         } else if (n == "enqueue_ahead_below_us") {

@@ -117,7 +117,6 @@ constexpr int MAX_LOCAL_DEVICES = 16;
 constexpr double FOLD_MAX_R2 = 200.0;    // folded rbf records (KT_RBFF) only while |c| = R2 / 2 <= 100: 2^c and 2^acc stay far inside the fp32 range
 constexpr int SPLIT_MAX_FEATURES = 384;  // the bf16x6 kernels exist for 1 ... 6 chunks of 64 features (row panel = 3 planes in registers)
 constexpr int F16_MAX_FEATURES = 512;    // the f16x3 kernels exist for 1 ... 8 chunks of 64 features (row panel = 2 planes in registers)
-constexpr int F16_PANEL_FEATURES = 512;   // linear kernel beyond 512 features: K = sum over feature panels of X_p X_p^T, one launch of the f16x3 kernels per panel
 constexpr int F16_LINEAR_MAX_FEATURES = 1 << 20;
 constexpr int F16_RBF_MAX_FEATURES = 384;  // ... rbf: 1 ... 6 chunks (three row planes in registers: the shifted planes, see make_planes)
 constexpr int F16_RBF_SHIFT = 6;         // rbf: the planes are (2^-6 hi, 2^6 mid, 2^6 hi)
@@ -318,7 +317,7 @@ static void make_planes(const Options &o, const lssvm_params &p, bool rbf_direct
     out.mode = 0;
     if (out2 != nullptr) out2->mode = 0;
     const int ldx16 = static_cast<int>(round_up(static_cast<long>(M.dfeat), 64));
-    const bool wide_linear = p.kernel_type == LSSVM_KERNEL_LINEAR && ldx16 > F16_MAX_FEATURES && o.tile_kernel != 1;  // feature panels (f16x3 only)
+    const bool wide_linear = p.kernel_type == LSSVM_KERNEL_LINEAR && ldx16 > static_cast<int>(o.linear_panel_features) && o.tile_kernel != 1;  // feature panels (f16x3 only)
     if (o.gram_mode == 0 || rbf_direct || (!v2_eligible(o, M.ldx, false) && !wide_linear)) return;
     auto alloc = [&](int nplanes) {
         out.ldx16 = ldx16;
@@ -573,7 +572,9 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     if constexpr (std::is_same_v<T, float>) {
         // linear kernel on more than 512 features: K*v = sum over feature panels of (X_p X_p^T) v, every panel one launch of the f16x3 kernels
         // (enqueue_apply_K_local).  Whether the data allows f16 planes decides it, so the planes are built HERE (the linear kernel needs the raw data).
-        if (!v2_ok && params_.kernel_type == LSSVM_KERNEL_LINEAR && num_features > static_cast<size_t>(F16_MAX_FEATURES)) {
+        // (option linear_panel_features, default 512: narrower panels also for problems the one-pass kernels could hold)
+        if (params_.kernel_type == LSSVM_KERNEL_LINEAR && opt_.gram_mode >= 2 && opt_.tile_kernel != 1
+            && round_up(static_cast<long>(num_features), 64) > static_cast<long>(opt_.linear_panel_features)) {
             make_planes(opt_, params_, false, X_, nullptr, planes_, nullptr, st);
             if (planes_.mode == 2 && opt_.symmetric != 0 && opt_.colslab_limit_mb != 0) {  // (the panel passes exist for the symmetric variant)
                 v2_ok = wide_linear_ = true;
@@ -789,8 +790,9 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
     const int nrows = num_ib_ * TILE;
     // wide linear problems: one pass per panel of 512 features, every pass ADDS its K_p * v (rows and mirrored columns) into K*v
     int npanels = 1;
+    const int panel_features = static_cast<int>(opt_.linear_panel_features);
     if constexpr (std::is_same_v<T, float>) {
-        if (wide_linear_) npanels = (planes_.ldx16 + F16_PANEL_FEATURES - 1) / F16_PANEL_FEATURES;
+        if (wide_linear_) npanels = (planes_.ldx16 + panel_features - 1) / panel_features;
     }
     if (sym_) {
         bool first = true;
@@ -798,9 +800,9 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
             TileArgs<T> ap = a;
             if constexpr (std::is_same_v<T, float>) {
                 if (wide_linear_) {
-                    ap.Xr16 += static_cast<size_t>(panel) * F16_PANEL_FEATURES;
-                    ap.Xc16 += static_cast<size_t>(panel) * F16_PANEL_FEATURES;
-                    ap.nk64 = std::min(F16_PANEL_FEATURES, planes_.ldx16 - panel * F16_PANEL_FEATURES) / 64;
+                    ap.Xr16 += static_cast<size_t>(panel) * panel_features;
+                    ap.Xc16 += static_cast<size_t>(panel) * panel_features;
+                    ap.nk64 = std::min(panel_features, planes_.ldx16 - panel * panel_features) / 64;
                 }
             }
             for (const Band &band : bands_) {
@@ -1347,7 +1349,7 @@ void Solver<T>::fill_info(lssvm_cg_info *info) {
     info->local_devices = static_cast<int32_t>(shards_.size());
     info->rbf_direct = p0.rbf_direct_ ? 1 : 0;
     info->rbf_exponent_scale = p0.rbf_r2_;
-    info->tile_launches_per_matvec = static_cast<int32_t>(std::max<size_t>(p0.bands_.size(), 1));
+    info->tile_launches_per_matvec = static_cast<int32_t>(std::max<size_t>(p0.bands_.size(), 1)) * p0.passes_per_matvec();  // bands x feature panels
     info->exchange = exchange_ == Exchange::none ? 0 : ((exchange_ == Exchange::peer || exchange_ == Exchange::process_peer) ? 2 : 1);
 }
 

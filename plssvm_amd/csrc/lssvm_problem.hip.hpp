@@ -80,6 +80,8 @@ struct Options {
     int64_t exchange = 0;          // several devices in ONE process: 0 = automatic (RCCL when the devices are distinct, else peer kernels), 1 = RCCL all-reduce / all-gather
                                    // (ncclCommInitAll), 2 = peer kernels: every device sums the partial vectors of all devices over xGMI in rank order
     int64_t enqueue_ahead_below_us = 5000;  // CG: implicit matvecs shorter than this are enqueued ahead of the previous iteration's stop test (0 = never)
+    int64_t linear_panel_features = 128;  // fp32 linear kernel on the f16x3 kernels: features per pass (multiple of 64, <= 512); more features run as several passes.
+                                          // 128: the hand-scheduled two-waves kernel per pass beats the wider one-wave kernels at every width measured (5 ... 12 %)
     int64_t ipc_timeout_s = 600;   // one process per GPU over HIP IPC: how long a rank waits for its peers at an exchange before it gives up
     int64_t check_shards = 1;      // several devices in ONE process: cg_finish verifies that the CG scalars of all shards are bit-equal
 };
@@ -256,6 +258,8 @@ class Problem {
     void enqueue_sum_and_qdot(const T *v_dev, int slot_sum, int slot_q);
     void drain_events();
     hipStream_t stream() const { return stream_.s; }
+    /* tile-kernel passes per row-block band: the feature panels of a wide fp32 linear problem, else 1 */
+    int passes_per_matvec() const { return wide_linear_ ? (planes_.ldx16 + static_cast<int>(opt_.linear_panel_features) - 1) / static_cast<int>(opt_.linear_panel_features) : 1; }
 
   private:
     friend class Solver<T>;
