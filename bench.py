@@ -48,7 +48,7 @@ WORKLOADS = {
 PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6, "bf16": 16 * 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md (bf16 = 16 x the f32 MFMA rate, ~2.5 PF)
 
 # the sources that decide how many bytes the tile kernel moves: profiles/hbm_traffic.json carries their hash, a stale entry is dropped
-TRAFFIC_SOURCES = ["plssvm_amd/csrc/lssvm_tile_f32_split.hip.hpp", "plssvm_amd/csrc/lssvm_tile_f32.hip.hpp", "plssvm_amd/csrc/lssvm_tile_f64.hip.hpp",
+TRAFFIC_SOURCES = ["plssvm_amd/csrc/lssvm_tile_f32_split.hip.hpp", "plssvm_amd/csrc/lssvm_s6w_groups.inc", "plssvm_amd/csrc/lssvm_tile_f32.hip.hpp", "plssvm_amd/csrc/lssvm_tile_f64.hip.hpp",
                    "plssvm_amd/csrc/lssvm_device_common.hip.hpp", "plssvm_amd/csrc/lssvm_problem.hip"]
 
 
