@@ -31,6 +31,7 @@
 #include <memory>
 #include <ostream>
 #include <stdexcept>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -334,7 +335,12 @@ class csvm : public ::plssvm_amd::csvm {
 
     /* cg tracking values of the last solve (what the reference logs, csvm.cpp:167-176).  The info block is written by the const
      * solve virtuals, like the reference's performance tracker it is not synchronised: one solve at a time per csvm object. */
-    [[nodiscard]] const lssvm_cg_info &last_cg_info() const noexcept { return info_; }
+    /* what the last solve of THIS object reported (a copy: several threads may call the const virtuals of one object, each solve then
+     * replaces the record as a whole under a lock -- the reference's backends keep no such record at all) */
+    [[nodiscard]] lssvm_cg_info last_cg_info() const {
+        const std::lock_guard<std::mutex> lock(info_mutex_);
+        return info_;
+    }
     [[nodiscard]] int num_available_devices() const noexcept { return num_devices_; }
     /* devices one solve is sharded over: 0 = automatic (every visible device, at least 4096 points each -- the reference's backends
      * also take every device they find, csvm.hip.cpp:66-75), 1 = device 0 only, k = devices 0 .. k-1 */
@@ -347,20 +353,21 @@ class csvm : public ::plssvm_amd::csvm {
     /* the tracking entries of the last solve in the layout of the reference's performance tracker (performance_tracker.cpp:139-190):
      * one YAML document with the groups `backend` (csvm.hip.cpp:59-60) and `cg` (csvm.cpp:167-174, csvm.hpp:318-320) */
     void write_tracking_yaml(std::ostream &out) const {
+        const lssvm_cg_info info = last_cg_info();
         out << "---\n"
             << "backend:\n"
             << "  backend: mi355\n"
             << "  target_platform: gpu_amd\n"
-            << "  num_devices: " << info_.devices_used << "\n"
+            << "  num_devices: " << info.devices_used << "\n"
             << "\n"
             << "cg:\n"
-            << "  iterations: " << info_.iterations << "\n"
-            << "  max_iterations: " << info_.max_iterations << "\n"
-            << "  residuum: " << info_.residuum << "\n"
-            << "  target_residuum: " << info_.target_residuum << "\n"
-            << "  avg_iteration_time: " << info_.avg_iteration_ms << "ms\n"
-            << "  epsilon: " << info_.epsilon << "\n"
-            << "  total_runtime: " << info_.total_ms << "ms\n"
+            << "  iterations: " << info.iterations << "\n"
+            << "  max_iterations: " << info.max_iterations << "\n"
+            << "  residuum: " << info.residuum << "\n"
+            << "  target_residuum: " << info.target_residuum << "\n"
+            << "  avg_iteration_time: " << info.avg_iteration_ms << "ms\n"
+            << "  epsilon: " << info.epsilon << "\n"
+            << "  total_runtime: " << info.total_ms << "ms\n"
             << "\n";
     }
 
@@ -404,7 +411,12 @@ class csvm : public ::plssvm_amd::csvm {
         std::vector<T> alpha(A.size());
         T rho{};
         // all devices of this process behind ONE call, like gpu_csvm::solve_system_of_linear_equations_impl (gpu_csvm.hpp:477-654)
-        detail::check(fn(&p, flat.data(), A.size(), A.front().size(), b.data(), eps, static_cast<uint64_t>(max_iter), alpha.data(), &rho, &info_, nullptr, use_devices_));
+        lssvm_cg_info info{};
+        detail::check(fn(&p, flat.data(), A.size(), A.front().size(), b.data(), eps, static_cast<uint64_t>(max_iter), alpha.data(), &rho, &info, nullptr, use_devices_));
+        {
+            const std::lock_guard<std::mutex> lock(info_mutex_);
+            info_ = info;
+        }
         return std::make_pair(std::move(alpha), rho);
     }
 
@@ -437,7 +449,8 @@ class csvm : public ::plssvm_amd::csvm {
 
     int num_devices_{ 0 };  // visible devices
     int use_devices_{ 1 };  // devices per solve: 1 by default (several devices are opt-in: plssvm_amd::num_devices = k, 0 = every visible device)
-    mutable lssvm_cg_info info_{};
+    mutable std::mutex info_mutex_;
+    mutable lssvm_cg_info info_{};  // record of the last solve (written by the const boundary virtuals: guarded)
 };
 
 }  // namespace mi355

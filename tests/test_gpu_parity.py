@@ -611,7 +611,7 @@ def test_baseline_config0_500x4_linear_fp64_through_the_libsvm_files(tmp_path):
         assert int(info["iterations"]) == int(fx[f"{tag}/iterations"])
         # the first N-1 entries are the CG iterate; alpha_N = -sum(alpha) and rho live in the direction of the all-ones vector, which the
         # converged solve determines worst: the reference's own 256-thread run on the GPU box leaves its 1-thread golden by 9e-8 there
-        # (and by 2e-13 at the default eps) -- measured, tests/tools/_dbg3.py in round 2; ours: 8.9e-8 / 2.9e-12
+        # (and by 2e-13 at the default eps) -- measured in round 2 with a throw-away script; ours: 8.9e-8 / 2.9e-12
         g = fx[f"{tag}/alpha"]
         tol, tol_sum = (1e-11, 1e-10) if tag == "default" else (1e-8, 1e-6)
         assert np.max(np.abs(model.alpha[:-1] - g[:-1])) < tol * np.max(np.abs(g))
