@@ -218,6 +218,7 @@ def main():
         # all ranks live on ONE node (the contract of this script): RCCL's bootstrap need not scan the network interfaces (it took
         # 100-600 s on some boxes of the pool), and the host driver only supports dmabuf IPC
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # (the side channel: a container's hostname need not resolve)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import numpy as np
