@@ -228,6 +228,47 @@ __device__ __forceinline__ float sum_with_lane_xor16(float v) {
     return a + b;
 }
 
+/* The same two butterfly steps for EIGHT values at once (the column sums of a tile's eight 16-column blocks: lane (g, r) holds its lane
+ * group's rows of column 16 cb + r in c[cb]) without copies: a swap of two DIFFERENT registers followed by one add reduces both by half --
+ * v_permlane32_swap a, b leaves a = [a.lo | b.lo], b = [a.hi | b.hi], so a + b = [a reduced over the halves | b reduced over the halves].
+ * Afterwards c[0] holds the finished sum of block q in lane group q (column = lane), c[4] that of block 4 + q (column = 64 + lane):
+ * 6 swaps + 6 adds instead of 16 + 16 (+ 16 copies), and the values come out one column per lane, so that the factor of the column record
+ * and the store are two instructions of all 64 lanes instead of eight of one lane group.  Every sum associates exactly as
+ * sum_with_lane_xor16(sum_with_lane_xor32(v)) does in lane group 0: (g0 + g2) + (g1 + g3) -- the bits do not change.
+ * (2 wait states between a VALU write and a swap that reads it: cdna_hip_programming.md T21.) */
+__device__ __forceinline__ void column_sums_of_8_blocks(float (&c)[8]) {
+    asm("s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %2\n\t"
+        "v_permlane32_swap_b32 %1, %3\n\t"
+        "v_permlane32_swap_b32 %4, %6\n\t"
+        "v_permlane32_swap_b32 %5, %7\n\t"
+        "v_add_f32 %0, %0, %2\n\t"
+        "v_add_f32 %1, %1, %3\n\t"
+        "v_add_f32 %4, %4, %6\n\t"
+        "v_add_f32 %5, %5, %7\n\t"
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\t"
+        "v_permlane16_swap_b32 %4, %5\n\t"
+        "v_add_f32 %0, %0, %1\n\t"
+        "v_add_f32 %4, %4, %5"
+        : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+}
+
+/* One LDS-DMA instruction, 16 bytes per lane: global (uniform base in SGPRs + 32-bit lane offset) -> LDS (uniform destination M0 = lds_base +
+ * LDS_OFF, lane l lands at + 16 l).  As inline asm because the builtin's operands go through the compiler's address selection: with the lane
+ * offsets living across the tile loop it copied each offset into a scratch register in front of every instruction (v_mov) and, where the base
+ * was a sum of uniform terms, built a 64-bit PER-LANE address with two v_lshl_add_u64 -- 24 vector instructions per tile beside the MFMA
+ * stream, each of which costs matrix-core issue time.  Here the base is pinned to SGPRs (scalar adds) and the offset
+ * register is used as it is.  The instruction counts in vmcnt like the builtin's; the kernels wait for it with counted s_waitcnt. */
+template <int LDS_OFF>
+__device__ __forceinline__ void lds_dma16(unsigned lane_offset, const char *uniform_base, unsigned uniform_lds_base) {
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(lane_offset), "s"(uniform_base), "s"(uniform_lds_base), "i"(LDS_OFF)
+                 : "memory", "scc");  // (M0 cannot be declared: it is a reserved register.  A kernel that uses this helper issues ALL its LDS-DMA through it,
+                                      //  so the compiler holds no M0 value of its own across these statements.)
+}
+
 __device__ __forceinline__ double sum_with_lane_xor32(double v) {
     const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
     unsigned alo = static_cast<unsigned>(bits), blo = alo, ahi = static_cast<unsigned>(bits >> 32), bhi = ahi;
@@ -239,6 +280,30 @@ __device__ __forceinline__ double sum_with_lane_xor16(double v) {
     unsigned alo = static_cast<unsigned>(bits), blo = alo, ahi = static_cast<unsigned>(bits >> 32), bhi = ahi;
     asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3" : "+v"(alo), "+v"(blo), "+v"(ahi), "+v"(bhi));
     return __builtin_bit_cast(double, (static_cast<unsigned long long>(ahi) << 32) | alo) + __builtin_bit_cast(double, (static_cast<unsigned long long>(bhi) << 32) | blo);
+}
+
+/* The paired butterfly for doubles (column sums of the fp64 sub-tile's four 16-column blocks).  A double is a register pair, which inline asm cannot
+ * address by halves; the builtin form of the swaps can (the compiler swaps the sub-registers in place and pads the hazards itself) and is
+ * correct as long as its two operands are DIFFERENT values, which they are here.  pair32(a, b) = [a summed over the wave's halves | b summed
+ * over the halves]; pair16(a, b) = [a0 + a1, b0 + b1, a2 + a3, b2 + b3] over the 16-lane rows. */
+__device__ __forceinline__ double swap_halves_and_add(double a, double b, std::integral_constant<int, 32>) {
+    const unsigned long long ab = __builtin_bit_cast(unsigned long long, a), bb = __builtin_bit_cast(unsigned long long, b);
+    const auto lo = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(ab), static_cast<unsigned>(bb), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(ab >> 32), static_cast<unsigned>(bb >> 32), false, false);
+    return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi[0]) << 32) | lo[0]) + __builtin_bit_cast(double, (static_cast<unsigned long long>(hi[1]) << 32) | lo[1]);
+}
+__device__ __forceinline__ double swap_halves_and_add(double a, double b, std::integral_constant<int, 16>) {
+    const unsigned long long ab = __builtin_bit_cast(unsigned long long, a), bb = __builtin_bit_cast(unsigned long long, b);
+    const auto lo = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(ab), static_cast<unsigned>(bb), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(ab >> 32), static_cast<unsigned>(bb >> 32), false, false);
+    return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi[0]) << 32) | lo[0]) + __builtin_bit_cast(double, (static_cast<unsigned long long>(hi[1]) << 32) | lo[1]);
+}
+/* c[cb] = this lane group's rows of column 16 cb + r  ->  returns the finished sum of block q in lane group q (column = lane): 6 swaps + 3 adds
+ * instead of 16 + 8 (+ the copies the one-value form needs).  Associates as sum_with_lane_xor16(sum_with_lane_xor32(v)) does in lane group 0. */
+__device__ __forceinline__ double column_sums_of_4_blocks(const double (&c)[4]) {
+    const double s02 = swap_halves_and_add(c[0], c[2], std::integral_constant<int, 32>{});
+    const double s13 = swap_halves_and_add(c[1], c[3], std::integral_constant<int, 32>{});
+    return swap_halves_and_add(s02, s13, std::integral_constant<int, 16>{});
 }
 
 /* The v2 kernels take the polynomial degree class as part of their kernel-type template parameter, so every instantiation

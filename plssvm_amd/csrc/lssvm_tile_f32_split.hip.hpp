@@ -124,36 +124,36 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         dma_off[i] = 2u * static_cast<unsigned>(row * a.ldx16 + 8 * c);
     }
+    const unsigned ring_lds = static_cast<unsigned>(reinterpret_cast<size_t>(ring));  // the low half of a generic LDS address is the LDS address
+    const unsigned dma_lds = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(ring_lds + static_cast<unsigned>(wave) * 4096u)));  // this wave's quarter of ring slot 0
+    const unsigned dc_lds = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(ring_lds + V2_RING * V2_SLOT_BYTES + static_cast<unsigned>(wave) * 256u)));  // this wave's quarter of record slot 0
     auto issue_chunk = [&](int step) {
         if (LSSVM_DBG(a, 16) && step > 3) return;  // ablation: no DMA after the prologue
         const int t = LSSVM_DBG(a, 1) ? 0 : step / NKC;  // ablation bit 1: always the same (L2-resident) tile
         const int kc = LSSVM_DBG(a, 1) ? 0 : step - t * NKC;
         const char *base = sgpr_ptr(a.Xc16 + (kc % PL) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (kc / PL) * 64);
-        char *slot = ring + (step % V2_RING) * V2_SLOT_BYTES + wave * 4096;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + lane_off(dma_off[i])), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
-        }
+        const unsigned slot = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(dma_lds + static_cast<unsigned>(step % V2_RING) * V2_SLOT_BYTES)));
+        static_for<0, 4>([&](auto i_c) { lds_dma16<decltype(i_c)::value * 1024>(dma_off[decltype(i_c)::value], base, slot); });
     };
     // steady state: the chunk (tile t or t + 1, plane-chunk KC known at compile time) costs two scalar adds per DMA instead of the divisions and
     // 64-bit multiplies of the generic form; `xc_tile` = first byte of column tile t in plane 0 (uniform), advanced once per tile
     const size_t tile_bytes = static_cast<size_t>(TILE) * a.ldx16 * 2;
     const size_t plane_bytes = a.plane_stride * 2;
     const char *xc_tile = reinterpret_cast<const char *>(a.Xc16) + static_cast<size_t>(jt_begin) * tile_bytes;
-    auto issue_part_static = [&](auto kc3_c, unsigned slot_idx, int i) {  // kc3 = kc + 3 of the issuing step, slot_idx = (step + 3) % V2_RING
+    auto issue_part_static = [&](auto kc3_c, unsigned slot_idx, auto i_c) {  // kc3 = kc + 3 of the issuing step, slot_idx = (step + 3) % V2_RING
         constexpr int KC3 = decltype(kc3_c)::value;
         constexpr int KC = KC3 % NKC;
+        constexpr int i = decltype(i_c)::value;
         if (LSSVM_DBG(a, 16)) return;
         if (LSSVM_DBG(a, 64) && i != 0) return;   // bit 64: a quarter of the DMA instructions (timing only)
         if (LSSVM_DBG(a, 128) && wave != 0) return;  // bit 128: only wave 0 issues DMA
         const char *base = xc_tile + (KC3 / NKC) * tile_bytes + (KC % PL) * plane_bytes + (KC / PL) * 128;  // (f16x3 at 64 features: NKC = 2, three steps ahead can be TWO tiles ahead)
-        char *slot = ring + slot_idx * V2_SLOT_BYTES + wave * 4096;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + lane_off(dma_off[i])), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
+        lds_dma16<i * 1024>(dma_off[i], sgpr_ptr(base), dma_lds + slot_idx * V2_SLOT_BYTES);
     };
     auto issue_dc = [&](int t) {
         if (lane < 16) {
             const char *src = sgpr_ptr(a.dc + static_cast<size_t>(jt_begin + t) * 256) + __builtin_amdgcn_readfirstlane(wave * 256);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (src + 16u * (lane_off(threadIdx.x) & 15u)), (lds_ptr_t) (dcs + (t % V2_DC_SLOTS) * 1024 + wave * 256), 16, 0, 0);
+            lds_dma16<0>(16u * (lane_off(threadIdx.x) & 15u), sgpr_ptr(src), static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(dc_lds + static_cast<unsigned>(t % V2_DC_SLOTS) * 1024u))));
         }
     };
 
@@ -205,7 +205,6 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
     // compiled with amdgpu_num_vgpr(224)); the groups are the hand-scheduled blocks of lssvm_s6w_groups.inc -- reads of the next group's
     // fragments, a COUNTED wait, the MFMAs.  Nothing can copy an in-flight register, because nothing else knows these registers.
     f32x4 bbuf[2][4];
-    const unsigned ring_lds = static_cast<unsigned>(reinterpret_cast<size_t>(ring));  // the low half of a generic LDS address is the LDS address
     const unsigned rdl[2] = { ring_lds + static_cast<unsigned>(rd_off[0]), ring_lds + static_cast<unsigned>(rd_off[1]) };
     if constexpr (HAND) {
         s6w_fill_b0<0, 2048, 4096, 6144>(rdl[0]);
@@ -324,13 +323,20 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
                     s6_group<F16, NQ, CUR, 1, Z, PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, civ0[0], civ0[1], paddr);
                     // the LDS-DMA of chunk step + 3 goes between the groups of the step's second half (two instructions behind each)
                     if constexpr (!decltype(checked)::value && mm >= 2) {
-                        issue_part_static(std::integral_constant<int, kc + 3>{}, (phase + kc + 3) & (V2_RING - 1), (mm - 2) * 2 + 0);
-                        issue_part_static(std::integral_constant<int, kc + 3>{}, (phase + kc + 3) & (V2_RING - 1), (mm - 2) * 2 + 1);
+                        issue_part_static(std::integral_constant<int, kc + 3>{}, (phase + kc + 3) & (V2_RING - 1), std::integral_constant<int, (mm - 2) * 2 + 0>{});
+                        issue_part_static(std::integral_constant<int, kc + 3>{}, (phase + kc + 3) & (V2_RING - 1), std::integral_constant<int, (mm - 2) * 2 + 1>{});
                     }
                     if constexpr (kc == NKC - 1 && mm == 3) {
                         // the epilogue's vector ALU instructions read what the last MFMAs write: the compiler cannot see inside the groups,
-                        // so the wait states an XDL write needs before a VALU read (8 passes: 11) are spent here, once per tile
-                        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+                        // so the wait states an XDL write needs before a VALU read (8 passes: 11) are spent here, once per tile.  The
+                        // accumulators are in/out operands of the statement: a "memory" clobber alone does not keep register arithmetic
+                        // behind it, and the scheduler did hoist an epilogue v_pk_fma_f32 to two instructions behind the last MFMA
+                        // (bf16x6 polynomial at 64 features; tests/tools/audit_hand_asm.py reports such accesses)
+                        asm volatile("s_nop 15\n\ts_nop 3"
+                                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[0][4]), "+v"(acc[0][5]), "+v"(acc[0][6]), "+v"(acc[0][7]),
+                                       "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]), "+v"(acc[1][4]), "+v"(acc[1][5]), "+v"(acc[1][6]), "+v"(acc[1][7])
+                                     :
+                                     : "memory");
                     }
                 } else {
                 f32x4(&bcur)[4] = bbuf[mm & 1];
@@ -377,10 +383,9 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
                                 acc[rb][cb] = plane_mfma<F16>(av, bv, acc[rb][cb]);
                             }
                         }
-                        if constexpr (!decltype(checked)::value) {
-                            if (q == 0 && mm >= 2 && (c & 1) == 0) {
-                                issue_part_static(std::integral_constant<int, kc + 3>{}, (phase + kc + 3) & (V2_RING - 1), (mm - 2) * 2 + (c >> 1));
-                            }
+                        if constexpr (!decltype(checked)::value && mm >= 2) {
+                            if (q == 0 && c == 0) issue_part_static(std::integral_constant<int, kc + 3>{}, (phase + kc + 3) & (V2_RING - 1), std::integral_constant<int, (mm - 2) * 2 + 0>{});
+                            if (q == 0 && c == 2) issue_part_static(std::integral_constant<int, kc + 3>{}, (phase + kc + 3) & (V2_RING - 1), std::integral_constant<int, (mm - 2) * 2 + 1>{});
                         }
                     }
                 }
@@ -392,7 +397,10 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
             auto epilogue = [&](auto with_cols) {
                 constexpr bool COLS = decltype(with_cols)::value;
                 f32x4 di[2];
-                float colacc[8] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+                using f32x2 = float __attribute__((ext_vector_type(2)));
+                float colacc[8];
+                f32x2 colacc2[8] = {};  // even / odd rows of the lane's four, added at the end
+                f32x2 kvp = { 0.f, 0.f };
                 if constexpr (COLS) {
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb) di[rb] = *reinterpret_cast<const f32x4 *>(dis + wave * 32 + 16 * rb + 4 * g);
@@ -414,23 +422,34 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
                                 continue;
                             }
                             rowpart[4 * rb + e] = fmaf(kv, djv, rowpart[4 * rb + e]);
-                            if constexpr (COLS) colacc[cb] = fmaf(kv, di[rb][e], colacc[cb]);
+                            // column sums: rows (e, e + 1) of a block as ONE v_pk_fma_f32 (the row sums above are packed by the compiler itself;
+                            // these it leaves scalar -- eight dependent chains of eight -- unless the pairs are spelled out)
+                            if constexpr (COLS) {
+                                kvp[e & 1] = kv;
+                                if (e & 1) {
+                                    const f32x2 dip = { di[rb][e - 1], di[rb][e] };
+                                    colacc2[cb] = __builtin_elementwise_fma(kvp, dip, colacc2[cb]);
+                                }
+                            }
                         }
                 }
                 if constexpr (COLS) {
-                    // the four lane groups hold different rows of the same column: two butterfly steps on the vector ALU (no LDS round trips),
-                    // then ONE branch for the eight stores, so that the whole epilogue stays a single basic block the compiler can overlap
+#pragma unroll
+                    for (int cb = 0; cb < 8; ++cb) colacc[cb] = colacc2[cb][0] + colacc2[cb][1];
+                }
+                if constexpr (COLS) {
+                    // the four lane groups hold different rows of the same column: two butterfly steps on the vector ALU (no LDS round trips) for
+                    // all eight blocks at once (column_sums_of_8_blocks: 6 swaps + 6 adds); the sums come out one column per lane -- block q in
+                    // lane group q of colacc[0], block 4 + q in colacc[4] -- so the record's factor and the store are two instructions of the
+                    // whole wave and the epilogue is a single basic block without a branch
                     float *cw = colred + (t & 1) * 512 + wave * 128;
+                    column_sums_of_8_blocks(colacc);
 #pragma unroll
-                    for (int cb = 0; cb < 8; ++cb) {
-                        float v = sum_with_lane_xor16(sum_with_lane_xor32(colacc[cb]));
-                        if constexpr (KT == KT_RBFF) v *= dcr[128 + cb * 16 + r];  // K_ij = 2^acc * 2^c_j: the column's factor once per column
+                    for (int h = 0; h < 2; ++h) {
+                        float v = colacc[4 * h];
+                        if constexpr (KT == KT_RBFF) v *= dcr[128 + 64 * h + lane];  // K_ij = 2^acc * 2^c_j: the column's factor once per column
                         if constexpr (KT == KT_LINEAR && F16) v *= a.out_scale;  // planes pre-scaled by 2^k: undo 2^(2k) (exact)
-                        colacc[cb] = v;
-                    }
-                    if (g == 0) {
-#pragma unroll
-                        for (int cb = 0; cb < 8; ++cb) cw[cb * 16 + r] = colacc[cb];
+                        cw[64 * h + lane] = v;
                     }
                 }
             };

@@ -278,21 +278,22 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
         const int ks = 4 * i + (lane >> 4);
         dma_off[i] = 8u * static_cast<unsigned>(col * a.ldx + 2 * ks);
     }
+    const unsigned ring_lds = static_cast<unsigned>(reinterpret_cast<size_t>(ring));  // the low half of a generic LDS address is the LDS address
+    const unsigned dma_lds = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(ring_lds + static_cast<unsigned>(wave) * 2048u)));  // this wave's quarter of ring slot 0
+    const unsigned dc_lds = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(ring_lds + V2D_RING * V2D_SLOT_BYTES + static_cast<unsigned>(wave) * 256u)));
     auto issue_chunk = [&](int step) {
         if (LSSVM_DBG(a, 16) && step > 2) return;  // ablation: no DMA after the prologue
         const int t = step / NKC;
         const int kc = step - t * NKC;
         const char *base = sgpr_ptr(a.Xc + static_cast<size_t>(st_begin + t) * 64 * a.ldx + kc * 16);
-        char *slot = ring + (step % V2D_RING) * V2D_SLOT_BYTES + wave * 2048;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (base + lane_off(dma_off[i])), (lds_ptr_t) (slot + i * 1024), 16, 0, 0);
-        }
+        const unsigned slot = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(dma_lds + static_cast<unsigned>(step % V2D_RING) * V2D_SLOT_BYTES)));
+        lds_dma16<0>(dma_off[0], base, slot);  // (inline asm: the builtin copied the lane offset into a scratch register in front of every instruction)
+        lds_dma16<1024>(dma_off[1], base, slot);
     };
     auto issue_dc = [&](int t) {
         if (lane < 16) {
             const char *src = sgpr_ptr(a.dc + static_cast<size_t>(st_begin + t) * 128) + __builtin_amdgcn_readfirstlane(wave * 256);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t) (src + 16u * (lane_off(threadIdx.x) & 15u)), (lds_ptr_t) (dcs + (t % V2D_DC_SLOTS) * 1024 + wave * 256), 16, 0, 0);
+            lds_dma16<0>(16u * (lane_off(threadIdx.x) & 15u), sgpr_ptr(src), static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(dc_lds + static_cast<unsigned>(t % V2D_DC_SLOTS) * 1024u))));
         }
     };
 
@@ -478,21 +479,17 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
                     }
                 if constexpr (COLS) {
                     double *cw = colred + (t & 1) * 256 + wave * 64;
-#pragma unroll
                     // the four quarter-waves hold different rows of the same column: butterfly on the vector ALU (v_permlane*_swap; __shfl_xor
-                    // is an LDS round trip per step and, with a store branch per column block, serialised them), then one store branch
-                    for (int cb = 0; cb < 4; ++cb) colacc[cb] = sum_with_lane_xor16(sum_with_lane_xor32(colacc[cb]));
-                    if (q == 0) {
-#pragma unroll
-                        for (int cb = 0; cb < 4; ++cb) cw[cb * 16 + r] = colacc[cb];
-                    }
+                    // is an LDS round trip per step and, with a store branch per column block, serialised them) for all four blocks at once;
+                    // the sums come out one column per lane (block q in lane group q), so the store is one instruction of the whole wave
+                    cw[lane] = column_sums_of_4_blocks(colacc);
                 }
             };
-            if (tile_sym) {
-                epilogue(std::true_type{});
-            } else {
-                epilogue(std::false_type{});
-            }
+            // (ONE epilogue per instantiation: with a branch between a column-sum and a row-only variant the compiler gave the eight row sums
+            // different registers in the two arms and merged them with 16 v_mov_b64 per sub-tile -- vector instructions that cost matrix-core
+            // time here.  The diagonal sub-tiles of a symmetric launch therefore compute column sums too; they are never flushed.)
+            (void) tile_sym;
+            epilogue(std::integral_constant<bool, SYM>{});
         }
     };
 
