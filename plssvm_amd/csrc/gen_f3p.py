@@ -10,7 +10,7 @@ wave and the MFMAs of the other do not interleave: the kernel's time is the SUM 
 The generated functions are inline-asm statements on PRIVATE registers, which the compiler never allocates (the kernel is compiled with
 amdgpu_num_vgpr(80): v0 ... v79 and a0 ... a79 belong to the compiler; see LSSVM_HAND_VGPR_CAP for what that attribute counts):
 
-    v[80:127]   epilogue state: d_j / e_j of four column blocks (rotating), two column sums, swap temporary, row sums (8), d_i (8), c_i (8)
+    v[80:127]   epilogue state: d_j / e_j of four column blocks (rotating), two column sums (+ their odd-row halves), swap temporary, row sums (8), d_i (8), c_i (8)
     v[128:191]  accumulator set 0: acc(rb, cb) = 128 + 4 (2 cb + rb)          (2 row blocks x 8 column blocks of 16 x 16)
     v[192:255]  accumulator set 1
     a[96:...]   the row panel: A fragments [plane][k32 step][row block], 4 registers each (MFMA operands may be AGPRs)
@@ -39,6 +39,7 @@ R_DJ = [80, 81, 82, 83]  # d_j of a column block: requested two blocks ahead, ro
 R_EJ = [84, 85, 86, 87]  # e_j = 2^c_j
 R_COL = [88, 89]         # column sum of a block (ping-pong: the LDS store of block cb is issued while block cb + 1 is evaluated)
 R_T0 = 90
+R_COLB = [91, 92]        # the odd rows' half of a block's column sum (s6w_body adds a lane's four rows as two packed pairs: even rows, odd rows, then their sum)
 R_ROWP = 96          # 8: rowpart[4 rb + e]
 R_DI = 104           # 8: d_i[4 rb + e]
 R_CI = 112           # 8: c_i[4 rb + e]  (first C operand of the rbf chains)
@@ -120,14 +121,17 @@ def epilogue_fillers(v, s_prev, cols, next_epilogue=True):
             for rb, e in elems:
                 valu.append((f"v_exp_f32_e32 {acc(s_prev, rb, cb, e)}, {acc(s_prev, rb, cb, e)}", COST_TRANS, "trans"))
         col = R_COL[cb & 1]
-        first = True
+        colb = R_COLB[cb & 1]
+        first = [True, True]
         for rb, e in elems:
             kv = acc(s_prev, rb, cb, e)
             valu.append((f"v_fmac_f32_e32 v{R_ROWP + 4 * rb + e}, {kv}, v{R_DJ[cb % 4]}", COST_VALU, "valu"))
             if cols:
-                valu.append((f"{'v_mul_f32_e32' if first else 'v_fmac_f32_e32'} v{col}, {kv}, v{R_DI + 4 * rb + e}", COST_VALU, "valu"))
-                first = False
+                # the order of s6w_body's v_pk_fma_f32 pairs: even rows into one sum, odd rows into the other (a chain that starts from 0 starts with a product)
+                valu.append((f"{'v_mul_f32_e32' if first[e & 1] else 'v_fmac_f32_e32'} v{colb if e & 1 else col}, {kv}, v{R_DI + 4 * rb + e}", COST_VALU, "valu"))
+                first[e & 1] = False
         if cols:
+            valu.append((f"v_add_f32_e32 v{col}, v{col}, v{colb}", COST_VALU, "valu"))
             # the four lane groups hold different rows of the same column: two butterfly steps (sum_with_lane_xor32, then _xor16), the column's
             # factor 2^c_j, one store per lane group (same address, same value)
             valu.append((f"v_mov_b32_e32 v{R_T0}, v{col}", COST_VALU, "valu"))
