@@ -313,12 +313,14 @@ void half_neg_norms(const DeviceMatrix<T> &M, DevBuf<T> &c, hipStream_t s) {
  *   bf16x6 (mode 1): three bf16 planes, exact for every fp32 input (8 exponent bits), twice the matrix-core work.
  * option gram_mode: 0 = none (native v_mfma_f32 kernels), 1 = bf16x6, 2 = f16x3 without the check (A/B, tests), 3 = f16x3 if the data passes, else bf16x6. */
 static void make_planes(const Options &o, const lssvm_params &p, bool rbf_direct, const DeviceMatrix<float> &M, const DeviceMatrix<float> *M2, PlaneSet &out, PlaneSet *out2,
-                        hipStream_t s) {
+                        hipStream_t s, bool wide_nl = false) {
     out.mode = 0;
     if (out2 != nullptr) out2->mode = 0;
-    const int ldx16 = static_cast<int>(round_up(static_cast<long>(M.dfeat), 64));
+    // (wide_nl: rbf / polynomial beyond the register-resident row panel -- the kernel walks feature panels of 128 inside a tile and exists for
+    // both plane kinds, so neither feature limit below applies; planes padded to whole panels)
+    const int ldx16 = static_cast<int>(round_up(static_cast<long>(M.dfeat), wide_nl ? 128 : 64));
     const bool wide_linear = p.kernel_type == LSSVM_KERNEL_LINEAR && ldx16 > static_cast<int>(o.linear_panel_features) && o.tile_kernel != 1;  // feature panels (f16x3 only)
-    if (o.gram_mode == 0 || rbf_direct || (!v2_eligible(o, M.ldx, false) && !wide_linear)) return;
+    if (o.gram_mode == 0 || rbf_direct || (!v2_eligible(o, M.ldx, false) && !wide_linear && !wide_nl)) return;
     auto alloc = [&](int nplanes) {
         out.ldx16 = ldx16;
         out.buf.alloc_zero(static_cast<size_t>(nplanes) * M.rows_alloc * ldx16, s);
@@ -329,7 +331,7 @@ static void make_planes(const Options &o, const lssvm_params &p, bool rbf_direct
     };
     const bool rbf = p.kernel_type == LSSVM_KERNEL_RBF;
     const int f16_limit = rbf ? F16_RBF_MAX_FEATURES : (p.kernel_type == LSSVM_KERNEL_LINEAR ? F16_LINEAR_MAX_FEATURES : F16_MAX_FEATURES);
-    if ((o.gram_mode == 2 || o.gram_mode == 3) && ldx16 <= f16_limit) {
+    if ((o.gram_mode == 2 || o.gram_mode == 3) && (ldx16 <= f16_limit || wide_nl)) {
         DevBuf<unsigned> stats;
         stats.alloc_zero(4, s);
         int shift = 0;
@@ -375,7 +377,7 @@ static void make_planes(const Options &o, const lssvm_params &p, bool rbf_direct
         out.buf.release();
         if (out2 != nullptr) out2->buf.release();
     }
-    if ((o.gram_mode == 1 || o.gram_mode == 3) && ldx16 <= SPLIT_MAX_FEATURES) {
+    if ((o.gram_mode == 1 || o.gram_mode == 3) && (ldx16 <= SPLIT_MAX_FEATURES || wide_nl)) {
         alloc(3);
         split_bf16_planes(M.data.p, M.ldx, M.dfeat, static_cast<size_t>(M.rows_alloc), ldx16, out.buf.p, static_cast<size_t>(M.rows_alloc) * ldx16, s);
         out.mode = 1;
@@ -584,6 +586,17 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
             }
         }
     }
+    if constexpr (std::is_same_v<T, float>) {
+        // rbf / polynomial on more features than the row panel of the split kernels holds in registers (f16x3: 384 rbf, 512 polynomial; bf16x6:
+        // 384): feature panels of 128 walked inside a tile (lssvm_tile_f32_wide.hip.hpp), symmetric variant, either plane kind -- decided from
+        // the shape and the options alone, so every rank of a sharded solve decides alike.  (The linear kernel has its panel passes above.)
+        const bool nonlinear = (params_.kernel_type == LSSVM_KERNEL_RBF && !rbf_direct_) || (params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree >= 0);
+        const long one_pass_limit = (params_.kernel_type == LSSVM_KERNEL_RBF || opt_.gram_mode == 1) ? SPLIT_MAX_FEATURES : F16_MAX_FEATURES;
+        if (nonlinear && opt_.gram_mode != 0 && opt_.tile_kernel != 1 && opt_.symmetric != 0 && opt_.colslab_limit_mb != 0
+            && round_up(static_cast<long>(num_features), 64) > one_pass_limit) {
+            v2_ok = wide_nl_ = true;
+        }
+    }
     sym_ = opt_.symmetric != 0 && v2_ok && !(params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree < 0);
     // the symmetric variant keeps one 128-entry record per evaluated off-diagonal tile of the row-block BAND in flight (see the bands
     // below); colslab_limit_mb = 0 switches the variant off (a rule in the options only, so every rank of a sharded solve decides alike)
@@ -603,7 +616,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         const long area = sym_ ? (ib_end * (ib_end + 1) - static_cast<long>(ib_begin_) * (ib_begin_ + 1)) / 2 : static_cast<long>(num_ib_) * num_tiles_;
         // the bf16x6 kernel has the costlier work-item prologue (three planes of the row panel) and the faster tiles: longer chunks
         // (measured 16 -> 64 tiles: +1.5 % at 100 000 points, +2 % at 300 000; the native kernels are flat or lose beyond 16)
-        const bool split = wide_linear_ || std::is_same_v<T, float> && opt_.gram_mode != 0 && v2_eligible(opt_, ldx_probe, rbf_direct_)
+        const bool split = wide_linear_ || wide_nl_ || std::is_same_v<T, float> && opt_.gram_mode != 0 && v2_eligible(opt_, ldx_probe, rbf_direct_)
                            && round_up(static_cast<long>(num_features), 64) <= ((opt_.gram_mode == 1 || params_.kernel_type == LSSVM_KERNEL_RBF) ? SPLIT_MAX_FEATURES : F16_MAX_FEATURES);
         const long cap = split ? 64 : 16;
         jc_tiles_ = static_cast<int>(std::min<long>(cap, std::max<long>(2, (area + 2048) / 4096)));
@@ -660,12 +673,13 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     }
     if constexpr (std::is_same_v<T, float>) {
         // the (centred, scaled) data once more as operand planes of the split kernels (features in natural order): see make_planes
-        if (!wide_linear_) make_planes(opt_, params_, rbf_direct_, X_, nullptr, planes_, nullptr, st);
+        if (!wide_linear_) make_planes(opt_, params_, rbf_direct_, X_, nullptr, planes_, nullptr, st, wide_nl_);
+        if (wide_nl_ && planes_.mode == 0) throw Error(LSSVM_ERR_INTERNAL, "no operand planes for the wide rbf / polynomial path");
         // rbf: folded records while the exponent terms stay small (rbf_r2_ = 2 max|c| in the exponent's unit)
         if (planes_.mode != 0) dc_folded_ = params_.kernel_type == LSSVM_KERNEL_RBF && opt_.rbf_fold != 0 && rbf_r2_ <= FOLD_MAX_R2;
     }
     interleave_features<T>(X_, st);
-    if ((std::is_same_v<T, float> && (v2_eligible(opt_, X_.ldx, rbf_direct_) || wide_linear_)) || (std::is_same_v<T, double> && v2_eligible_f64(opt_, X_.ldx))) {
+    if ((std::is_same_v<T, float> && (v2_eligible(opt_, X_.ldx, rbf_direct_) || wide_linear_ || wide_nl_)) || (std::is_same_v<T, double> && v2_eligible_f64(opt_, X_.ldx))) {
         dc_.alloc_zero(static_cast<size_t>(std::max(num_tiles_, 1)) * 256, st);  // (d_j | c_j) records: 256 reals per 128 columns
     }
     if (sym_) {
@@ -739,6 +753,7 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     if (poly_prescaled_) a.gamma = T(1);
     if constexpr (std::is_same_v<T, float>) {
         if (planes_.mode != 0) set_plane_args(a, params_, planes_, planes_, static_cast<size_t>(X_.rows_alloc), static_cast<size_t>(X_.rows_alloc));
+        a.wide_panels = wide_nl_ ? 1 : 0;
     }
     set_launch_options(a, opt_);
     a.dc_folded = dc_folded_ ? 1 : 0;

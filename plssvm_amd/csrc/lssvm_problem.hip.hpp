@@ -280,6 +280,7 @@ class Problem {
     bool rbf_direct_ = false;
     double rbf_r2_ = 0.0;  // fp32 rbf: 2 gamma log2(e) max|x - mean|^2
     bool dc_folded_ = false;  // the (d_j | c_j) records carry (2^c_j d_j | 2^c_j): rbf on the 16x16x32 bf16x6 kernels
+    bool wide_nl_ = false;         // fp32 rbf / polynomial on more features than the one-pass split kernels take: feature panels inside a tile (lssvm_tile_f32_wide.hip.hpp)
     bool wide_linear_ = false;     // fp32 linear kernel on more than 512 features: f16x3 over feature panels of 512, one tile-kernel pass per panel
     bool poly_prescaled_ = false;  // fp64 polynomial on the v2 kernel: X_ carries sqrt(gamma), the kernel sees gamma = 1
     PlaneSet planes_;              // fp32 split kernels: X as three bf16 planes (bf16x6) or two f16 planes (f16x3), [planes][rows_alloc][ldx16]

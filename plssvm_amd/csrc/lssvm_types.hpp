@@ -49,6 +49,7 @@ struct TileArgs {
     size_t plane_stride;   // elements between the planes of the COLUMN side
     size_t plane_stride_r; // elements between the planes of the ROW side (training: the same matrix; predict_values: the points to predict)
     int ldx16;             // padded features of the planes (multiple of 64): the row stride of the planes
+    int wide_panels;       // host side only: != 0 selects the kernel that walks feature panels of 128 inside a tile (rbf / polynomial beyond the register-resident row panel)
     int nk64;              // host side only: 64-feature chunks THIS launch contracts over (= ldx16 / 64, or one feature panel of a wide linear problem)
     const int2 *items; // symmetric variant: list of the non-empty (local row block, column chunk) work items
     int num_items;    // symmetric variant: length of `items` = grid size

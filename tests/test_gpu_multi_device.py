@@ -38,7 +38,7 @@ from plssvm_amd.parameter import Parameter
 pytestmark = pytest.mark.gpu
 
 CASES = [("rbf", np.float32, 3000, 128), ("linear", np.float32, 2100, 200), ("polynomial", np.float64, 2500, 64), ("rbf", np.float64, 1300, 40),
-         ("polynomial", np.float32, 700, 9), ("linear", np.float64, 260, 5)]
+         ("polynomial", np.float32, 700, 9), ("linear", np.float64, 260, 5), ("rbf", np.float32, 1700, 600)]  # (600 features: feature panels inside a tile)
 
 
 def _device_lists():

@@ -670,8 +670,8 @@ def test_predict_and_score_on_the_reference_fixture(kernel, dt):
 def test_symmetric_and_full_square_variants_agree(oracle, kernel, N, d, dtype):
     """The default path evaluates only the tiles on/below the diagonal and mirrors them (as the reference does); the
     full-square variant (option symmetric=0) sums every row independently.  Both must match the oracle and each other.
-    (More than 512 features in fp32 / 256 in fp64 run the v1 kernel, which has no symmetric variant: both settings then take the
-    same path.)"""
+    (fp64 on more than 256 features runs the v1 kernel, which has no symmetric variant: both settings then take the same path.  fp32 is
+    symmetric at any width: the linear kernel by passes over feature panels, rbf / polynomial by panels inside a tile.)"""
     X, y = make_blobs_pm1(N, d, seed=21, dtype=dtype)
     p = Parameter(kernel_type=kernel)
     rhs = np.random.default_rng(5).uniform(-1, 1, size=N - 1).astype(dtype)
@@ -689,8 +689,7 @@ def test_symmetric_and_full_square_variants_agree(oracle, kernel, N, d, dtype):
         finally:
             _capi.set_option("symmetric", 1)
     assert out[("sym", 0)] == 0
-    # (the fp32 linear kernel runs the symmetric variant at ANY width: passes over feature panels)
-    assert out[("sym", 1)] == (1 if d <= (512 if dtype == np.float32 else 256) or (kernel == "linear" and dtype == np.float32) else 0)
+    assert out[("sym", 1)] == (1 if dtype == np.float32 or d <= 256 else 0)
     kw = dict(degree=3, gamma=1.0 / d, coef0=0.0)
     want = oracle.matvec(kernel, X, q, rhs, np.zeros(N - 1, dtype), QA, 1.0, 1.0, **kw)
     scale = np.max(np.abs(want))
@@ -800,8 +799,9 @@ def test_column_slab_budget_falls_back_to_the_full_square():
 @pytest.mark.parametrize("sym", [1, 0])
 def test_bf16_split_gram_mode_is_fp32_accurate(oracle, kernel, N, d, sym):
     """The split Gram modes against the native one.  gram_mode = 2 ("f16x3", the default where the data passes the representability check,
-    up to 512 features): two f16 planes of the pre-scaled operands, three plane products on the f16 matrix cores; gram_mode = 1 ("bf16x6",
-    up to 384 features): exact three-way bf16 split, six plane products; gram_mode = 0: native v_mfma_f32 chains.  All must meet the same
+    up to 512 features in one pass): two f16 planes of the pre-scaled operands, three plane products on the f16 matrix cores; gram_mode = 1
+    ("bf16x6", up to 384 features in one pass): exact three-way bf16 split, six plane products; beyond the one-pass limits the symmetric
+    variant walks feature panels inside a tile (rbf / polynomial); gram_mode = 0: native v_mfma_f32 chains.  All must meet the same
     bar: no farther from the float64 product than 4x the fp32 CPU oracle (or 64 eps)."""
     X, y = make_blobs_pm1(N, d, seed=27, dtype=np.float32)
     p = Parameter(kernel_type=kernel)
@@ -815,7 +815,8 @@ def test_bf16_split_gram_mode_is_fp32_accurate(oracle, kernel, N, d, sym):
             with backend.ResidentProblem(p, X) as prob:
                 q, QA = prob.q()
                 f16_limit = 384 if kernel == "rbf" else 512  # rbf holds three row planes in registers (the shifted planes)
-                assert prob.info()["gram_mode"] == {0: 0, 1: 1 if d <= 384 else 0, 2: 2 if d <= f16_limit else 0, 3: 2 if d <= f16_limit else 0}[mode]
+                panels = sym == 1 and kernel != "linear"      # beyond the one-pass kernels: feature panels inside a tile (symmetric variant, either plane kind)
+                assert prob.info()["gram_mode"] == {0: 0, 1: 1 if d <= 384 or panels else 0, 2: 2 if d <= f16_limit or panels else 0, 3: 2 if d <= f16_limit or panels else 0}[mode]
                 out[mode] = prob.matvec(rhs, zero, 1.0)
                 prob.cg_begin(y, 1e-30)
                 prob.cg_step(5)
@@ -932,9 +933,9 @@ def test_split_kernels_steady_state_at_every_chunk_count(oracle, kernel, d, mode
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_wide_data_at_the_reference_test_shape(oracle, kernel, dt):
     """The reference's own kernel tests run on 5000 x 2000 data (tests/CMakeLists.txt:36-69, generic_csvm_tests.hpp:372-493).  2000 features
-    are far beyond what the resident-row-panel kernels hold in registers (512 in fp32, 256 in fp64): this shape runs the generic tile
-    kernels (both operands staged through LDS, full square) -- except the fp32 LINEAR kernel, whose Gram matrix is a sum over feature
-    panels and runs as four passes of the f16x3 kernels.  q and one implicit matvec against the float64 oracle at 1000 x 2000, with the
+    are far beyond what the resident-row-panel kernels hold in registers (512 in fp32, 256 in fp64): in fp64 this shape runs the generic
+    tile kernels (both operands staged through LDS, full square), in fp32 the f16x3 kernels over feature panels of 128 (linear: one pass
+    per panel; rbf / polynomial: the panels inside a tile).  q and one implicit matvec against the float64 oracle at 1000 x 2000, with the
     reference's test parameters, on the scale of each row's summands."""
     N, d = 1000, 2000
     rng = np.random.default_rng(2000)
@@ -946,8 +947,9 @@ def test_wide_data_at_the_reference_test_shape(oracle, kernel, dt):
     kw = dict(degree=2, gamma=0.001, coef0=1.0)
     with backend.ResidentProblem(p, X) as prob:
         info = prob.info()
-        if kernel == "linear" and dt == np.float32:
-            # fp32 linear kernel: K = sum over feature panels of X_p X_p^T, four passes of the f16x3 kernels over panels of 512 features
+        if dt == np.float32:
+            # fp32: the f16x3 kernels over feature panels -- linear: K = sum over the panels of X_p X_p^T, one pass per panel; rbf / polynomial:
+            # the panels walked inside a tile (lssvm_tile_f32_wide.hip.hpp)
             assert info["gram_mode"] == 2 and info["symmetric"] == 1
         else:
             assert info["gram_mode"] == 0 and info["symmetric"] == 0   # the generic kernel
@@ -970,6 +972,63 @@ def test_wide_data_at_the_reference_test_shape(oracle, kernel, dt):
     S = float(v64.sum())
     scale = np.abs(K) @ np.abs(v64) + np.abs(v64) / 0.1 + abs(float(QA) * S) + abs(float(q64 @ v64)) + np.abs(S * q64)
     assert np.max(np.abs(got - truth) / scale) < 16 * eps, float(np.max(np.abs(got - truth) / scale) / eps)
+
+
+@pytest.mark.parametrize("mode", [3, 1])
+@pytest.mark.parametrize("N, d, jct", [(700, 520, 0), (1500, 640, 2), (1500, 1030, 0), (2700, 400, 5)])
+@pytest.mark.parametrize("kernel", ["rbf", "polynomial"])
+def test_wide_rbf_and_polynomial_on_the_split_kernels(oracle, kernel, N, d, jct, mode):
+    """fp32 rbf / polynomial on more features than a row panel in registers holds (f16x3: 384 rbf / 512 polynomial, bf16x6: 384): the
+    kernel of lssvm_tile_f32_wide.hip.hpp walks feature panels of 128 inside a tile, re-loading the row panel per panel.  Feature counts that
+    are not multiples of 128 (zero-padded planes), 5 ... 9 panels, work items of 1 ... 12 tiles (items cut at the diagonal included), both
+    plane kinds (mode 3: f16x3 where the data allows, mode 1: bf16x6); against the float64 Gram matrix on the scale of each row's summands,
+    and the same solve trajectory as the full-square generic kernel.  (400 features: rbf only -- the polynomial kernel still fits one pass.)"""
+    X, y = make_blobs_pm1(N, d, seed=11, dtype=np.float32)
+    P = dict(degree=3, gamma=1.0 / d, coef0=0.5, cost=2.0)
+    p = prm(kernel, P)
+    n = N - 1
+    v = np.random.default_rng(5).uniform(-1, 1, n).astype(np.float32)
+    zero = np.zeros(n, np.float32)
+    _capi.set_option("gram_mode", mode)
+    _capi.set_option("j_chunk_tiles", jct)
+    with backend.ResidentProblem(p, X) as prob:
+        info = prob.info()
+        wide = d > (384 if kernel == "rbf" or mode == 1 else 512)
+        assert info["symmetric"] == 1 and info["gram_mode"] == (1 if mode == 1 else 2)
+        q, QA = prob.q()
+        got = prob.matvec(v, zero, 1.0).astype(np.float64)
+        prob.cg_begin(y, 1e-30)
+        prob.cg_step(4)
+        a_sym = prob.cg_finish()[0]
+    assert wide or d == 400
+    X64 = X.astype(np.float64)
+    G = X64[:n] @ X64[:n].T
+    if kernel == "polynomial":
+        K = (G / d + 0.5) ** 3
+    else:
+        sq = np.einsum("ij,ij->i", X64[:n], X64[:n])
+        K = np.exp(-np.maximum(sq[:, None] + sq[None, :] - 2.0 * G, 0.0) / d)
+    kw = dict(degree=3, gamma=1.0 / d, coef0=0.5)
+    q64 = oracle.q(kernel, X64, **kw)
+    v64 = v.astype(np.float64)
+    S = float(v64.sum())
+    QA64 = float(oracle.kernel_function(kernel, X64[-1], X64[-1], **kw)) + 0.5
+    truth = K @ v64 + v64 * 0.5 + (QA64 * S - float(q64 @ v64)) - S * q64
+    scale = np.abs(K) @ np.abs(v64) + np.abs(v64) * 0.5 + abs(QA64 * S) + abs(float(q64 @ v64)) + np.abs(S * q64)
+    eps = np.finfo(np.float32).eps
+    assert np.max(np.abs(got - truth) / scale) < 16 * eps, float(np.max(np.abs(got - truth) / scale) / eps)
+    # the same four CG iterations on the full-square generic kernel (native v_mfma_f32 chains)
+    _capi.set_option("symmetric", 0)
+    with backend.ResidentProblem(p, X) as prob:
+        assert prob.info()["symmetric"] == 0
+        prob.cg_begin(y, 1e-30)
+        prob.cg_step(4)
+        a_full = prob.cg_finish()[0]
+    with backend.ResidentProblem(p, X.astype(np.float64)) as prob:
+        prob.cg_begin(y.astype(np.float64), 1e-30)
+        prob.cg_step(4)
+        a64 = prob.cg_finish()[0]
+    assert ol.rel_inf(a_sym[:-1], a64[:-1]) < 2 * ol.rel_inf(a_full[:-1], a64[:-1]) + 1e-4
 
 
 @pytest.mark.parametrize("N, jct", [(129, 0), (385, 0), (1500, 0), (1500, 1), (1500, 5), (4097, 0)])
