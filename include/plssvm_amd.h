@@ -254,8 +254,8 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *   "rbf_direct_above" threshold of rbf_form 0 (default 32: [-1,1]-scaled data with gamma = 1 / num_features has R2 <= 3)
  *   "j_chunk_tiles" number of 128-column tiles per work item; 0 = automatic (default: about 4096 work items per device, 2 ... 16 tiles each,
  *                   up to 64 for the split kernels)
- *   "symmetric"     1 = evaluate only the kernel-matrix tiles on/below the diagonal and mirror them (default; num_features <= 512 in fp32,
- *                   <= 256 in fp64; a negative polynomial degree always runs the full square),
+ *   "symmetric"     1 = evaluate only the kernel-matrix tiles on/below the diagonal and mirror them (default; fp32 with the split Gram modes: any
+ *                   num_features, otherwise <= 512 in fp32, <= 256 in fp64; a negative polynomial degree always runs the full square),
  *                   0 = full square (row-owned sums, results independent of the GPU count)
  *   "tile_kernel"   0 = automatic: the "resident row panel" kernels for num_features <= 512 (fp32) / 256 (fp64) (default), 1 = always the generic kernel
  *   "xcd_map"       1 = XCD-aware block -> work item mapping (8 x 8 super-tiles per XCD), 0 = linear (default)
@@ -263,9 +263,11 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *                   diagonal moved to the end, longest first (default: shortens the last dispatch round), 2 = 1 with row blocks descending
  *   "gram_mode"     fp32 Gram tiles on the 16-bit matrix cores with fp32 accumulation, at fp32-equivalent accuracy:
  *                   3 (default) = "f16x3" where the data allows, else "bf16x6"; 2 = "f16x3": every operand as TWO f16 planes (hi + mid; rbf: shifted by
- *                   2^-6 / 2^6, others pre-scaled by a power of two), three plane products on v_mfma_f32_16x16x32_f16, num_features <= 512 (rbf 384)
+ *                   2^-6 / 2^6, others pre-scaled by a power of two), three plane products on v_mfma_f32_16x16x32_f16; num_features <= 512 (rbf 384)
+ *                   in one pass, beyond that over feature panels of 128 (linear: one launch per panel; rbf / polynomial: inside a tile, symmetric variant)
  *                   -- without the check whether two f16 planes represent THIS data as well as fp32 does, which mode 3 makes at set-up;
- *                   1 = "bf16x6": exact split into THREE bf16 planes, six plane products on v_mfma_f32_16x16x32_bf16, num_features <= 384;
+ *                   1 = "bf16x6": exact split into THREE bf16 planes, six plane products on v_mfma_f32_16x16x32_bf16, num_features <= 384 in one
+ *                   pass (rbf / polynomial beyond that: feature panels inside a tile);
  *                   0 = Gram tiles on v_mfma_f32_32x32x2_f32 (exact fmaf chains)
  *   "mfma_shape"    split kernels: 1 = MFMA groups scheduled by the compiler, 2 (default) = hand-scheduled MFMA groups (B fragments in registers the
  *                   compiler does not own) for num_features <= 128, 3 = 2 plus the software-pipelined one-wave-per-SIMD kernel where it exists

@@ -8,7 +8,8 @@
  * (lssvm_tile_f32_split.hip.hpp), whose structure this is -- same LDS-DMA ring of 128-column x 64-feature plane-chunks, same swizzle, same mid-step
  * hand-over, same records, same epilogue and symmetric variant:
  *   - the row panel (A fragments of the wave's 32 rows, 128 features, all row planes) is RE-LOADED from global memory at every tile-panel: as
- *     many bytes as the column stream, from L2 (a row block's planes: 128 rows x d x 2 bytes x planes -- 1.5 MB at 2 000 features);
+ *     many bytes as the column stream, from L2 (a row block's planes: 128 rows x d x 2 bytes x planes -- 1.5 MB at 2 000 features); a 64-feature
+ *     chunk's fragments are requested as soon as the previous tile-panel is through with that chunk, into the same registers;
  *   - the column stream walks (tile, panel, 64-feature chunk, plane) with run-time addressing and the checked hand-over throughout;
  *   - the accumulators are initialised explicitly at panel 0 (no "first MFMA takes C = 0 / c_i" forms: 64 moves per tile against >= 768 MFMAs).
  * Compiler-scheduled MFMA groups, two waves per SIMD (the register budget of the 128-feature kernels).  Symmetric variant only: the full-square
@@ -62,18 +63,20 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
     // (uniform base in SGPRs + ONE 32-bit lane offset: per-lane 64-bit row pointers for every plane and row block would live across the whole
     // work item and spill)
     const unsigned row_lane_off = 2u * static_cast<unsigned>(r * a.ldx16 + 8 * g);
-    auto load_row_panel = [&](int p) {
+    auto load_row_chunk = [&](int p, auto chunk_c) {  // the 64-feature chunk `chunk` of panel p: k32 steps 2 chunk, 2 chunk + 1
+        constexpr int chunk = decltype(chunk_c)::value;
 #pragma unroll
         for (int pl = 0; pl < PLA; ++pl) {
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
-                const char *base = sgpr_ptr(a.Xr16 + pl * a.plane_stride_r + static_cast<size_t>(row0 + wave * 32 + 16 * rb) * a.ldx16 + p * (64 * NK64));
+                const char *base = sgpr_ptr(a.Xr16 + pl * a.plane_stride_r + static_cast<size_t>(row0 + wave * 32 + 16 * rb) * a.ldx16 + p * (64 * NK64) + 64 * chunk);
                 const auto *xr = (const __attribute__((address_space(1))) char *) base + lane_off(row_lane_off);
 #pragma unroll
-                for (int kk = 0; kk < 2 * NK64; ++kk) afrag[pl][kk][rb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(xr + 64 * kk));
+                for (int kk = 0; kk < 2; ++kk) afrag[pl][2 * chunk + kk][rb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(xr + 64 * kk));
             }
         }
     };
+    auto load_row_panel = [&](int p) { static_for<0, NK64>([&](auto c) { load_row_chunk(p, c); }); };
     load_row_panel(0);
     if constexpr (KT == KT_RBF || KT == KT_RBFF) {
         if (tid < TILE) cis[tid] = a.cr[row0 + tid];
@@ -193,17 +196,9 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
                 for (int rb = 0; rb < 2; ++rb) acc[rb][cb] = civ0[rb];  // (zero for the polynomial kernels)
         }
         for (int p = 0; p < panels; ++p) {
-            if (t + p > 0) {
-                load_row_panel(p);
-                // all of the panel HERE, behind the chunks already in flight and before this tile-panel's first DMA: a wait for a fragment
-                // further down would be a vmcnt(0) behind DMA pieces issued a moment earlier
-#pragma unroll
-                for (int pl = 0; pl < PLA; ++pl)
-#pragma unroll
-                    for (int kk = 0; kk < 2 * NK64; ++kk)
-#pragma unroll
-                        for (int rb = 0; rb < 2; ++rb) asm volatile("" : "+v"(afrag[pl][kk][rb]));
-            }
+            // (the row panel of this tile-panel was requested chunk by chunk while the previous one was being multiplied: see below)
+            const bool more_panels = t + 1 < ntiles || p + 1 < panels;
+            const int p_next = p + 1 < panels ? p + 1 : 0;  // (the row panel depends on the feature panel only, not on the tile)
             const int s0 = t * steps_per_tile + p * NKC;
             const unsigned phase = static_cast<unsigned>(s0) & (V2_RING - 1);
             static_for<0, NKC>([&](auto kc_c) {
@@ -250,6 +245,11 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
                         }
                     }
                 });
+                // the last plane of a 64-feature chunk is through: its row fragments are dead, the registers take the same chunk of the NEXT
+                // tile-panel -- requested half a tile-panel or more before its first use instead of in front of it
+                if constexpr (plane == PL - 1) {
+                    if (more_panels) load_row_chunk(p_next, std::integral_constant<int, chunk>{});
+                }
             });
         }
         // ---- epilogue of the tile (s6w_body's, with the mirrored column sums where the tile is off the diagonal) ----
