@@ -158,6 +158,13 @@ bool v2_eligible_f64(const Options &o, int ldx) {
     return v2_chunk_count_ok(ldx / F64_KC) && o.tile_kernel != 1;
 }
 
+/* fp32 rbf / polynomial beyond the feature count the one-pass split kernels take (row panel in registers): the panel kernel applies */
+static bool wide_nonlinear(const Options &o, const lssvm_params &p, bool rbf_direct, size_t num_features) {
+    const bool nonlinear = (p.kernel_type == LSSVM_KERNEL_RBF && !rbf_direct) || (p.kernel_type == LSSVM_KERNEL_POLYNOMIAL && p.degree >= 0);
+    const long one_pass_limit = (p.kernel_type == LSSVM_KERNEL_RBF || o.gram_mode == 1) ? 384 : 512;  // SPLIT_MAX_FEATURES / F16_MAX_FEATURES (rbf: F16_RBF_MAX_FEATURES)
+    return nonlinear && o.gram_mode != 0 && o.tile_kernel != 1 && round_up(static_cast<long>(num_features), 64) > one_pass_limit;
+}
+
 /* first row block of rank r when the lower triangle is dealt by equal area: round(tiles * sqrt(r / world)) */
 int sym_block_boundary(int num_tiles, int r, int world) {
     if (r <= 0) return 0;
@@ -588,14 +595,9 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     }
     if constexpr (std::is_same_v<T, float>) {
         // rbf / polynomial on more features than the row panel of the split kernels holds in registers (f16x3: 384 rbf, 512 polynomial; bf16x6:
-        // 384): feature panels of 128 walked inside a tile (lssvm_tile_f32_wide.hip.hpp), symmetric variant, either plane kind -- decided from
+        // 384): feature panels of 128 walked inside a tile (lssvm_tile_f32_wide.hip.hpp), either variant, either plane kind -- decided from
         // the shape and the options alone, so every rank of a sharded solve decides alike.  (The linear kernel has its panel passes above.)
-        const bool nonlinear = (params_.kernel_type == LSSVM_KERNEL_RBF && !rbf_direct_) || (params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree >= 0);
-        const long one_pass_limit = (params_.kernel_type == LSSVM_KERNEL_RBF || opt_.gram_mode == 1) ? SPLIT_MAX_FEATURES : F16_MAX_FEATURES;
-        if (nonlinear && opt_.gram_mode != 0 && opt_.tile_kernel != 1 && opt_.symmetric != 0 && opt_.colslab_limit_mb != 0
-            && round_up(static_cast<long>(num_features), 64) > one_pass_limit) {
-            v2_ok = wide_nl_ = true;
-        }
+        if (wide_nonlinear(opt_, params_, rbf_direct_, num_features)) v2_ok = wide_nl_ = true;
     }
     sym_ = opt_.symmetric != 0 && v2_ok && !(params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree < 0);
     // the symmetric variant keeps one 128-entry record per evaluated off-diagonal tile of the row-block BAND in flight (see the bands
@@ -1436,7 +1438,9 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
         half_neg_norms<T>(S, cS, s);
         half_neg_norms<T>(P, cP, s);
     }
-    const bool v2 = std::is_same_v<T, float> ? v2_eligible(opt, S.ldx, rbf_direct) : v2_eligible_f64(opt, S.ldx);
+    bool wide = false;  // fp32 rbf / polynomial beyond the one-pass split kernels: feature panels inside a tile (full-square instance)
+    if constexpr (std::is_same_v<T, float>) wide = wide_nonlinear(opt, params, rbf_direct, nfeat);
+    const bool v2 = wide || (std::is_same_v<T, float> ? v2_eligible(opt, S.ldx, rbf_direct) : v2_eligible_f64(opt, S.ldx));
     bool poly_prescaled = false;
     if constexpr (std::is_same_v<T, double>) {
         // the fp64 v2 kernel evaluates the polynomial on data that carries sqrt(gamma) (see Problem<T>'s constructor)
@@ -1452,7 +1456,8 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     PlaneSet planesS, planesP;
     if constexpr (std::is_same_v<T, float>) {
         if (v2) {
-            make_planes(opt, params, rbf_direct, S, &P, planesS, &planesP, s);
+            make_planes(opt, params, rbf_direct, S, &P, planesS, &planesP, s, wide);
+            if (wide && planesS.mode == 0) throw Error(LSSVM_ERR_INTERNAL, "no operand planes for the wide rbf / polynomial path");
             if (planesS.mode != 0) dc_folded = (params.kernel_type == LSSVM_KERNEL_RBF && opt.rbf_fold != 0 && rbf_r2 <= FOLD_MAX_R2) ? 1 : 0;
         }
     }
@@ -1506,6 +1511,7 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     if (poly_prescaled) ta.gamma = T(1);
     if constexpr (std::is_same_v<T, float>) {
         if (planesS.mode != 0) set_plane_args(ta, params, planesS, planesP, static_cast<size_t>(S.rows_alloc), static_cast<size_t>(P.rows_alloc));
+        ta.wide_panels = wide ? 1 : 0;
     }
     set_launch_options(ta, opt);
     launch_tile_kernel<T>(ta, params.kernel_type, rbf_direct, num_jc, s);

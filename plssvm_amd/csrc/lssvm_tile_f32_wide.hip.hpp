@@ -12,8 +12,9 @@
  *     chunk's fragments are requested as soon as the previous tile-panel is through with that chunk, into the same registers;
  *   - the column stream walks (tile, panel, 64-feature chunk, plane) with run-time addressing and the checked hand-over throughout;
  *   - the accumulators are initialised explicitly at panel 0 (no "first MFMA takes C = 0 / c_i" forms: 64 moves per tile against >= 768 MFMAs).
- * Compiler-scheduled MFMA groups, two waves per SIMD (the register budget of the 128-feature kernels).  Symmetric variant only: the full-square
- * fall-backs (negative polynomial degree, symmetric = 0) stay on the generic native kernel.
+ * Compiler-scheduled MFMA groups, two waves per SIMD (the register budget of the 128-feature kernels).  Symmetric variant and full-square variant
+ * (option symmetric = 0; predict_values: rows = points, columns = support vectors); a negative polynomial degree (0^degree on padded columns) stays
+ * on the generic native kernel.
  * Reference semantics: /root/reference/include/plssvm/backends/HIP/svm_kernel.hip.hpp:129-270 (one code path for any feature count).
  */
 #pragma once
@@ -22,7 +23,7 @@
 
 namespace lssvm {
 
-template <int KT, int PL>
+template <int KT, int PL, bool SYM>
 __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
     static_assert(PL == 3 || PL == 2, "three bf16 planes (bf16x6) or two f16 planes (f16x3)");
     static_assert(KT != KT_LINEAR, "the linear kernel takes feature-panel passes of the 128-feature kernels");
@@ -44,19 +45,24 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
     const int r = lane & 15;
     const int g = lane >> 4;
 
-    const int2 it = a.items[blockIdx.x];
-    const int ibl = __builtin_amdgcn_readfirstlane(it.x);
-    const int jc = __builtin_amdgcn_readfirstlane(it.y);
+    int ibl, jc;
+    if constexpr (SYM) {
+        const int2 it = a.items[blockIdx.x];
+        ibl = __builtin_amdgcn_readfirstlane(it.x);
+        jc = __builtin_amdgcn_readfirstlane(it.y);
+    } else {
+        if (!decode_work_item(a, ibl, jc)) return;
+    }
     const int ib = a.ib_begin + ibl;
     const int row0 = ib * TILE;
     const int jt_begin = jc * a.jc_tiles;
-    const int jt_end = min(jt_begin + a.jc_tiles, ib + 1);
+    const int jt_end = SYM ? min(jt_begin + a.jc_tiles, ib + 1) : min(jt_begin + a.jc_tiles, a.num_jt);
     const int ntiles = jt_end - jt_begin;
     if (ntiles <= 0) return;
     const int panels = a.nk64 / NK64;          // (uniform; the planes are padded to a multiple of 128 features)
     const int steps_per_tile = panels * NKC;
     const int nsteps = ntiles * steps_per_tile;
-    const long rec0 = static_cast<long>(ib) * (ib - 1) / 2 - a.pair_origin;
+    const long rec0 = SYM ? (static_cast<long>(ib) * (ib - 1) / 2 - a.pair_origin) : 0;
 
     // ---- the row panel of ONE feature panel: lane (r, g) holds features 128 p + 32 kk + 8 g .. + 7 of row 16 rb + r ----
     bf16x8 afrag[PLA][2 * NK64][2];
@@ -81,7 +87,9 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
     if constexpr (KT == KT_RBF || KT == KT_RBFF) {
         if (tid < TILE) cis[tid] = a.cr[row0 + tid];
     }
-    if (tid < TILE) dis[tid] = a.dvec[row0 + tid];
+    if constexpr (SYM) {
+        if (tid < TILE) dis[tid] = a.dvec[row0 + tid];
+    }
     // make the compiler retire these ordinary loads HERE, before any LDS-DMA is in flight
 #pragma unroll
     for (int pl = 0; pl < PLA; ++pl)
@@ -177,7 +185,7 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
     };
 
     for (int t = 0; t < ntiles; ++t) {
-        const bool tile_sym = jt_begin + t < ib;  // strictly below the diagonal
+        const bool tile_sym = SYM && (jt_begin + t < ib);  // strictly below the diagonal
         const float *dcr = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);
         // start values of the chain: rbf c_i + c_j, rbf with folded records c_i (c_j is the factor 2^c_j of the record), polynomial 0
         if constexpr (KT == KT_RBF) {
@@ -221,9 +229,13 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
                     }
                     if constexpr (mm == 2) {
                         // (the colred writes of the previous tile's epilogue must have completed before the barrier publishes them)
-                        if (kc == 0 && p == 0 && t > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if constexpr (SYM) {
+                            if (kc == 0 && p == 0 && t > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        }
                         handover(step);
-                        if (kc == 0 && p == 0 && t > 0) flush_cols(t - 1);  // (tile t - 1 < t <= the diagonal tile: always off-diagonal)
+                        if constexpr (SYM) {
+                            if (kc == 0 && p == 0 && t > 0) flush_cols(t - 1);  // (tile t - 1 < t <= the diagonal tile: always off-diagonal)
+                        }
                         LSSVM_SCHED_BARRIER();
                     }
                     if constexpr (mm == 3) {  // first group of the next chunk: visible since this step's hand-over
@@ -301,11 +313,13 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
             epilogue(std::false_type{});
         }
     }
-    if (jt_begin + ntiles - 1 < ib) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        flush_cols(ntiles - 1);
+    if constexpr (SYM) {
+        if (jt_begin + ntiles - 1 < ib) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            flush_cols(ntiles - 1);
+        }
     }
 
     // every lane group owns its rows: reduce over the 16 columns of the group and store
@@ -326,9 +340,9 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
 }
 
 /* PL = 2: f16x3 (two f16 column planes), PL = 3: bf16x6 (three bf16 planes).  Two waves per SIMD. */
-template <int KT, int PL>
+template <int KT, int PL, bool SYM>
 __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32_wide(const TileArgs<float> a) {
-    s6x_body<KT, PL>(a);
+    s6x_body<KT, PL, SYM>(a);
 }
 
 }  // namespace lssvm

@@ -34,7 +34,7 @@ void launch_tile_kernel<float>(TileArgs<float> &a, int kernel_type, bool rbf_dir
     constexpr size_t lds = static_cast<size_t>(4) * TILE * F32_LS * sizeof(float) + TILE * sizeof(float);  // staging ring + c_i of the row block
     if (a.dc != nullptr && a.Xc16 != nullptr) {  // the data exists as planes: two f16 planes (f16x3) or three bf16 planes (bf16x6)
         if (a.wide_panels != 0) {
-            launch_wide_tile_kernel(a, kernel_type, s);
+            launch_wide_tile_kernel(a, kernel_type, grid, s);
         } else if (a.planes_f16 != 0) {
             launch_f16_tile_kernel(a, kernel_type, grid, s);
         } else {

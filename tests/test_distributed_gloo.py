@@ -170,7 +170,8 @@ def test_the_librarys_own_partition_equals_the_python_restatement(n, world):
 
 def test_bench_spawns_its_own_ranks_without_a_launcher():
     """`python bench.py --gpus 2` typed as is must start two child ranks itself (no torchrun).  Without a GPU every child stops at the
-    loud "needs an MI355X" check -- which proves the parent spawned them with RANK / WORLD_SIZE set and returned their exit code."""
+    loud "needs an MI355X" check -- which proves the parent spawned ranks with RANK / WORLD_SIZE set and returned their exit code
+    (tests/test_host_logic.py::test_bench_parent_stops_when_its_ranks_fail covers the sibling handling)."""
     import subprocess
     import sys
 
@@ -183,4 +184,5 @@ def test_bench_spawns_its_own_ranks_without_a_launcher():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "c2"],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode != 0
-    assert out.stderr.count("bench.py needs an MI355X") == 2, out.stderr
+    # (the parent stops the siblings of a rank that failed: the second rank may be terminated before it reaches its own check)
+    assert 1 <= out.stderr.count("bench.py needs an MI355X") <= 2, out.stderr

@@ -204,12 +204,12 @@ def test_predict_values_known_answer(dt):
 
 
 @pytest.mark.parametrize("kernel", ["polynomial", "rbf"])
-@pytest.mark.parametrize("nsv, npts, d", [(1300, 700, 128), (777, 130, 40), (520, 1025, 384), (300, 200, 500)])
+@pytest.mark.parametrize("nsv, npts, d", [(1300, 700, 128), (777, 130, 40), (520, 1025, 384), (300, 200, 500), (700, 520, 1100)])
 def test_predict_values_on_the_bf16_matrix_cores(oracle, kernel, nsv, npts, d):
     """predict_values is the rectangular instance of the tile kernel (HIP/predict_kernel.hip.hpp:63-117: rows = points to predict,
-    columns = support vectors).  In fp32 it runs on the f16x3 kernels (gram_mode 2 / 3, up to 512 features) or the bf16x6 kernels
-    (gram_mode 1, up to 384 features; 500 features: the native v_mfma_f32 kernel); every mode must match the float64 oracle on the scale
-    of each point's summands."""
+    columns = support vectors).  In fp32 it runs on the f16x3 kernels (gram_mode 2 / 3, up to 512 features in one pass, rbf 384) or the
+    bf16x6 kernels (gram_mode 1, up to 384 features in one pass), beyond that on the kernel that walks feature panels inside a tile (either
+    plane kind); every mode must match the float64 oracle on the scale of each point's summands."""
     rng = np.random.default_rng(nsv + d)
     sv = rng.uniform(-1, 1, size=(nsv, d)).astype(np.float32)
     alpha = rng.uniform(-1, 1, size=nsv).astype(np.float32)
@@ -230,14 +230,7 @@ def test_predict_values_on_the_bf16_matrix_cores(oracle, kernel, nsv, npts, d):
         out[mode], _ = backend.predict_values(p, sv, alpha, 0.125, None, pts)
         assert np.max(np.abs(out[mode] - want) / scale) < 16 * np.finfo(np.float32).eps, mode
     assert np.array_equal(out[3], out[2])          # uniform [-1, 1] data passes the f16 representability check: the default is f16x3
-    if kernel == "rbf" and d > 384:
-        assert np.array_equal(out[0], out[2])      # rbf above 384 features: the native kernel in every mode (three row planes do not fit)
-    else:
-        assert not np.array_equal(out[0], out[2])  # different kernels ran
-    if d <= 384:
-        assert not np.array_equal(out[0], out[1]) and not np.array_equal(out[1], out[2])
-    else:
-        assert np.array_equal(out[0], out[1])      # above 384 features gram_mode 1 is the native kernel
+    assert not np.array_equal(out[0], out[2]) and not np.array_equal(out[0], out[1]) and not np.array_equal(out[1], out[2])  # three different kernels ran
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
@@ -815,7 +808,7 @@ def test_bf16_split_gram_mode_is_fp32_accurate(oracle, kernel, N, d, sym):
             with backend.ResidentProblem(p, X) as prob:
                 q, QA = prob.q()
                 f16_limit = 384 if kernel == "rbf" else 512  # rbf holds three row planes in registers (the shifted planes)
-                panels = sym == 1 and kernel != "linear"      # beyond the one-pass kernels: feature panels inside a tile (symmetric variant, either plane kind)
+                panels = kernel != "linear"                   # beyond the one-pass kernels: feature panels inside a tile (either variant, either plane kind)
                 assert prob.info()["gram_mode"] == {0: 0, 1: 1 if d <= 384 or panels else 0, 2: 2 if d <= f16_limit or panels else 0, 3: 2 if d <= f16_limit or panels else 0}[mode]
                 out[mode] = prob.matvec(rhs, zero, 1.0)
                 prob.cg_begin(y, 1e-30)
@@ -981,8 +974,8 @@ def test_wide_rbf_and_polynomial_on_the_split_kernels(oracle, kernel, N, d, jct,
     """fp32 rbf / polynomial on more features than a row panel in registers holds (f16x3: 384 rbf / 512 polynomial, bf16x6: 384): the
     kernel of lssvm_tile_f32_wide.hip.hpp walks feature panels of 128 inside a tile, re-loading the row panel per panel.  Feature counts that
     are not multiples of 128 (zero-padded planes), 5 ... 9 panels, work items of 1 ... 12 tiles (items cut at the diagonal included), both
-    plane kinds (mode 3: f16x3 where the data allows, mode 1: bf16x6); against the float64 Gram matrix on the scale of each row's summands,
-    and the same solve trajectory as the full-square generic kernel.  (400 features: rbf only -- the polynomial kernel still fits one pass.)"""
+    plane kinds (mode 3: f16x3 where the data allows, mode 1: bf16x6), symmetric and full-square variant; against the float64 Gram matrix on
+    the scale of each row's summands, and the same solve trajectory as the full-square generic kernel.  (400 features: rbf only -- the polynomial kernel still fits one pass.)"""
     X, y = make_blobs_pm1(N, d, seed=11, dtype=np.float32)
     P = dict(degree=3, gamma=1.0 / d, coef0=0.5, cost=2.0)
     p = prm(kernel, P)
@@ -1017,10 +1010,16 @@ def test_wide_rbf_and_polynomial_on_the_split_kernels(oracle, kernel, N, d, jct,
     scale = np.abs(K) @ np.abs(v64) + np.abs(v64) * 0.5 + abs(QA64 * S) + abs(float(q64 @ v64)) + np.abs(S * q64)
     eps = np.finfo(np.float32).eps
     assert np.max(np.abs(got - truth) / scale) < 16 * eps, float(np.max(np.abs(got - truth) / scale) / eps)
-    # the same four CG iterations on the full-square generic kernel (native v_mfma_f32 chains)
+    # the full-square variant of the same kernels: rows only, no mirrored sums
     _capi.set_option("symmetric", 0)
     with backend.ResidentProblem(p, X) as prob:
-        assert prob.info()["symmetric"] == 0
+        assert prob.info()["symmetric"] == 0 and prob.info()["gram_mode"] == (1 if mode == 1 else 2)
+        got0 = prob.matvec(v, zero, 1.0).astype(np.float64)
+    assert np.max(np.abs(got0 - truth) / scale) < 16 * eps, float(np.max(np.abs(got0 - truth) / scale) / eps)
+    # the same four CG iterations on the full-square generic kernel (native v_mfma_f32 chains)
+    _capi.set_option("tile_kernel", 1)
+    with backend.ResidentProblem(p, X) as prob:
+        assert prob.info()["symmetric"] == 0 and prob.info()["gram_mode"] == 0
         prob.cg_begin(y, 1e-30)
         prob.cg_step(4)
         a_full = prob.cg_finish()[0]
