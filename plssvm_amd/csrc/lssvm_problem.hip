@@ -158,6 +158,10 @@ bool v2_eligible_f64(const Options &o, int ldx) {
     return v2_chunk_count_ok(ldx / F64_KC) && o.tile_kernel != 1;
 }
 
+/* features per pass of the fp64 linear kernel (see Problem<double>'s constructor) */
+int f64_linear_panel(const Options &o) { return o.linear_panel_features == 64 ? 64 : 128; }
+constexpr int F64_ONE_PASS_FEATURES = 256;
+
 /* fp32 rbf / polynomial beyond the feature count the one-pass split kernels take (row panel in registers): the panel kernel applies */
 static bool wide_nonlinear(const Options &o, const lssvm_params &p, bool rbf_direct, size_t num_features) {
     const bool nonlinear = (p.kernel_type == LSSVM_KERNEL_RBF && !rbf_direct) || (p.kernel_type == LSSVM_KERNEL_POLYNOMIAL && p.degree >= 0);
@@ -593,6 +597,16 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
             }
         }
     }
+    if constexpr (std::is_same_v<T, double>) {
+        // fp64 linear kernel on more than 256 features (the widest row panel the resident-row-panel kernel holds): the same sum over feature
+        // panels, one pass of that kernel per panel of 128 features (a remainder of 1 ... 8 sixteen-feature chunks always has its instantiation)
+        // -- the symmetric variant instead of the generic full-square kernel: 40 000 x 512 35.1 -> 12.3 ms per iteration, 20 000 x 2 000
+        // 34.2 -> 13.4 ms.  The panel width hardly matters (64 and 256 measure within 2 %: the linear epilogue is two fmas per element);
+        // up to 256 features the one pass stays.
+        if (params_.kernel_type == LSSVM_KERNEL_LINEAR && opt_.tile_kernel != 1 && opt_.symmetric != 0 && opt_.colslab_limit_mb != 0 && ldx_probe > F64_ONE_PASS_FEATURES) {
+            v2_ok = wide_linear_ = true;
+        }
+    }
     if constexpr (std::is_same_v<T, float>) {
         // rbf / polynomial on more features than the row panel of the split kernels holds in registers (f16x3: 384 rbf, 512 polynomial; bf16x6:
         // 384): feature panels of 128 walked inside a tile (lssvm_tile_f32_wide.hip.hpp), either variant, either plane kind -- decided from
@@ -681,7 +695,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         if (planes_.mode != 0) dc_folded_ = params_.kernel_type == LSSVM_KERNEL_RBF && opt_.rbf_fold != 0 && rbf_r2_ <= FOLD_MAX_R2;
     }
     interleave_features<T>(X_, st);
-    if ((std::is_same_v<T, float> && (v2_eligible(opt_, X_.ldx, rbf_direct_) || wide_linear_ || wide_nl_)) || (std::is_same_v<T, double> && v2_eligible_f64(opt_, X_.ldx))) {
+    if ((std::is_same_v<T, float> && (v2_eligible(opt_, X_.ldx, rbf_direct_) || wide_linear_ || wide_nl_)) || (std::is_same_v<T, double> && (v2_eligible_f64(opt_, X_.ldx) || wide_linear_))) {
         dc_.alloc_zero(static_cast<size_t>(std::max(num_tiles_, 1)) * 256, st);  // (d_j | c_j) records: 256 reals per 128 columns
     }
     if (sym_) {
@@ -806,11 +820,8 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
     }
     const int nrows = num_ib_ * TILE;
     // wide linear problems: one pass per panel of 512 features, every pass ADDS its K_p * v (rows and mirrored columns) into K*v
-    int npanels = 1;
-    const int panel_features = static_cast<int>(opt_.linear_panel_features);
-    if constexpr (std::is_same_v<T, float>) {
-        if (wide_linear_) npanels = (planes_.ldx16 + panel_features - 1) / panel_features;
-    }
+    const int npanels = passes_per_matvec();
+    const int panel_features = std::is_same_v<T, float> ? static_cast<int>(opt_.linear_panel_features) : f64_linear_panel(opt_);
     if (sym_) {
         bool first = true;
         for (int panel = 0; panel < npanels; ++panel) {
@@ -820,6 +831,12 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
                     ap.Xr16 += static_cast<size_t>(panel) * panel_features;
                     ap.Xc16 += static_cast<size_t>(panel) * panel_features;
                     ap.nk64 = std::min(panel_features, planes_.ldx16 - panel * panel_features) / 64;
+                }
+            } else {
+                if (wide_linear_) {  // (row-major fp64 data: a panel is a column range of X, the row stride stays)
+                    ap.Xr += static_cast<size_t>(panel) * panel_features;
+                    ap.Xc += static_cast<size_t>(panel) * panel_features;
+                    ap.kchunks = std::min(panel_features, X_.ldx - panel * panel_features) / F64_KC;
                 }
             }
             for (const Band &band : bands_) {

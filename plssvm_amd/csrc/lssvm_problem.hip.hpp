@@ -226,6 +226,7 @@ void split_bf16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx1
 void split_f16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, float scale, int shift, uint16_t *planes, size_t plane_stride, unsigned *stats, hipStream_t s);  // tile_launch_f32h.hip
 void absmax_f32(const float *X, int ldx, int dfeat, size_t rows, unsigned *out, hipStream_t s);  // tile_launch_f32h.hip
 bool v2_eligible_f64(const Options &o, int ldx);
+int f64_linear_panel(const Options &o);  // features per pass of the fp64 linear kernel
 int sym_block_boundary(int num_tiles, int r, int world);
 void shard_blocks(int num_tiles, int world, int rank, bool symmetric, int &begin, int &end);
 
@@ -259,7 +260,14 @@ class Problem {
     void drain_events();
     hipStream_t stream() const { return stream_.s; }
     /* tile-kernel passes per row-block band: the feature panels of a wide fp32 linear problem, else 1 */
-    int passes_per_matvec() const { return wide_linear_ ? (planes_.ldx16 + static_cast<int>(opt_.linear_panel_features) - 1) / static_cast<int>(opt_.linear_panel_features) : 1; }
+    int passes_per_matvec() const {  // feature panels of a wide linear problem: fp32 over the planes, fp64 over the row-major data
+        if (!wide_linear_) return 1;
+        if constexpr (std::is_same_v<T, float>) {
+            return (planes_.ldx16 + static_cast<int>(opt_.linear_panel_features) - 1) / static_cast<int>(opt_.linear_panel_features);
+        } else {
+            return (X_.ldx + f64_linear_panel(opt_) - 1) / f64_linear_panel(opt_);
+        }
+    }
 
   private:
     friend class Solver<T>;
@@ -281,7 +289,7 @@ class Problem {
     double rbf_r2_ = 0.0;  // fp32 rbf: 2 gamma log2(e) max|x - mean|^2
     bool dc_folded_ = false;  // the (d_j | c_j) records carry (2^c_j d_j | 2^c_j): rbf on the 16x16x32 bf16x6 kernels
     bool wide_nl_ = false;         // fp32 rbf / polynomial on more features than the one-pass split kernels take: feature panels inside a tile (lssvm_tile_f32_wide.hip.hpp)
-    bool wide_linear_ = false;     // fp32 linear kernel on more than 512 features: f16x3 over feature panels of 512, one tile-kernel pass per panel
+    bool wide_linear_ = false;     // linear kernel over feature panels, one tile-kernel pass per panel: fp32 f16x3 beyond linear_panel_features, fp64 beyond 256 features
     bool poly_prescaled_ = false;  // fp64 polynomial on the v2 kernel: X_ carries sqrt(gamma), the kernel sees gamma = 1
     PlaneSet planes_;              // fp32 split kernels: X as three bf16 planes (bf16x6) or two f16 planes (f16x3), [planes][rows_alloc][ldx16]
 

@@ -663,8 +663,9 @@ def test_predict_and_score_on_the_reference_fixture(kernel, dt):
 def test_symmetric_and_full_square_variants_agree(oracle, kernel, N, d, dtype):
     """The default path evaluates only the tiles on/below the diagonal and mirrors them (as the reference does); the
     full-square variant (option symmetric=0) sums every row independently.  Both must match the oracle and each other.
-    (fp64 on more than 256 features runs the v1 kernel, which has no symmetric variant: both settings then take the same path.  fp32 is
-    symmetric at any width: the linear kernel by passes over feature panels, rbf / polynomial by panels inside a tile.)"""
+    (fp64 rbf / polynomial on more than 256 features run the v1 kernel, which has no symmetric variant: both settings then take the same
+    path.  The linear kernel is symmetric at any width in both types -- passes over feature panels -- and so are fp32 rbf / polynomial, by
+    panels inside a tile.)"""
     X, y = make_blobs_pm1(N, d, seed=21, dtype=dtype)
     p = Parameter(kernel_type=kernel)
     rhs = np.random.default_rng(5).uniform(-1, 1, size=N - 1).astype(dtype)
@@ -682,7 +683,7 @@ def test_symmetric_and_full_square_variants_agree(oracle, kernel, N, d, dtype):
         finally:
             _capi.set_option("symmetric", 1)
     assert out[("sym", 0)] == 0
-    assert out[("sym", 1)] == (1 if dtype == np.float32 or d <= 256 else 0)
+    assert out[("sym", 1)] == (1 if dtype == np.float32 or d <= 256 or kernel == "linear" else 0)
     kw = dict(degree=3, gamma=1.0 / d, coef0=0.0)
     want = oracle.matvec(kernel, X, q, rhs, np.zeros(N - 1, dtype), QA, 1.0, 1.0, **kw)
     scale = np.max(np.abs(want))
@@ -926,9 +927,9 @@ def test_split_kernels_steady_state_at_every_chunk_count(oracle, kernel, d, mode
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_wide_data_at_the_reference_test_shape(oracle, kernel, dt):
     """The reference's own kernel tests run on 5000 x 2000 data (tests/CMakeLists.txt:36-69, generic_csvm_tests.hpp:372-493).  2000 features
-    are far beyond what the resident-row-panel kernels hold in registers (512 in fp32, 256 in fp64): in fp64 this shape runs the generic
-    tile kernels (both operands staged through LDS, full square), in fp32 the f16x3 kernels over feature panels of 128 (linear: one pass
-    per panel; rbf / polynomial: the panels inside a tile).  q and one implicit matvec against the float64 oracle at 1000 x 2000, with the
+    are far beyond what the resident-row-panel kernels hold in registers (512 in fp32, 256 in fp64): in fp64 rbf / polynomial run the
+    generic tile kernels (both operands staged through LDS, full square) and the linear kernel one pass per feature panel of 64, in fp32
+    the f16x3 kernels work over feature panels of 128 (linear: one pass per panel; rbf / polynomial: the panels inside a tile).  q and one implicit matvec against the float64 oracle at 1000 x 2000, with the
     reference's test parameters, on the scale of each row's summands."""
     N, d = 1000, 2000
     rng = np.random.default_rng(2000)
@@ -945,7 +946,7 @@ def test_wide_data_at_the_reference_test_shape(oracle, kernel, dt):
             # the panels walked inside a tile (lssvm_tile_f32_wide.hip.hpp)
             assert info["gram_mode"] == 2 and info["symmetric"] == 1
         else:
-            assert info["gram_mode"] == 0 and info["symmetric"] == 0   # the generic kernel
+            assert info["gram_mode"] == 0 and info["symmetric"] == (1 if kernel == "linear" else 0)   # fp64: linear over feature panels of 64, else the generic kernel
         q, QA = prob.q()
         got = prob.matvec(rhs, zero, 1.0).astype(np.float64)
     X64 = X.astype(np.float64)
