@@ -162,6 +162,13 @@ bool v2_eligible_f64(const Options &o, int ldx) {
 int f64_linear_panel(const Options &o) { return o.linear_panel_features == 64 ? 64 : 128; }
 constexpr int F64_ONE_PASS_FEATURES = 256;
 
+/* fp64 rbf / polynomial on more than 256 features: feature panels of 64 inside a sub-tile (lssvm_tile_f64_wide.hip.hpp; the data carries the
+   kernel's scale as on the one-pass v2 kernel, so gamma > 0 -- a precondition of the kernels anyway -- and a non-negative degree are required) */
+static bool wide_nonlinear_f64(const Options &o, const lssvm_params &p, size_t num_features) {
+    const bool nonlinear = p.kernel_type == LSSVM_KERNEL_RBF || (p.kernel_type == LSSVM_KERNEL_POLYNOMIAL && p.degree >= 0);
+    return nonlinear && p.gamma > 0.0 && o.tile_kernel != 1 && padded_features<double>(num_features) > F64_ONE_PASS_FEATURES;
+}
+
 /* fp32 rbf / polynomial beyond the feature count the one-pass split kernels take (row panel in registers): the panel kernel applies */
 static bool wide_nonlinear(const Options &o, const lssvm_params &p, bool rbf_direct, size_t num_features) {
     const bool nonlinear = (p.kernel_type == LSSVM_KERNEL_RBF && !rbf_direct) || (p.kernel_type == LSSVM_KERNEL_POLYNOMIAL && p.degree >= 0);
@@ -606,6 +613,8 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         if (params_.kernel_type == LSSVM_KERNEL_LINEAR && opt_.tile_kernel != 1 && opt_.symmetric != 0 && opt_.colslab_limit_mb != 0 && ldx_probe > F64_ONE_PASS_FEATURES) {
             v2_ok = wide_linear_ = true;
         }
+        // rbf / polynomial beyond 256 features: the panels inside a sub-tile, either variant
+        if (wide_nonlinear_f64(opt_, params_, num_features)) v2_ok = wide_nl_ = true;
     }
     if constexpr (std::is_same_v<T, float>) {
         // rbf / polynomial on more features than the row panel of the split kernels holds in registers (f16x3: 384 rbf, 512 polynomial; bf16x6:
@@ -673,14 +682,14 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     }
     // rbf on the matrix cores: centre the data, then c_i = -|x_i|^2 / 2
     if (params_.kernel_type == LSSVM_KERNEL_RBF && !rbf_direct_) {
-        center_columns<T>(X_, nullptr, rbf_prescale<T>(params_, v2_eligible_f64(opt_, X_.ldx)), st);
+        center_columns<T>(X_, nullptr, rbf_prescale<T>(params_, v2_eligible_f64(opt_, X_.ldx) || wide_nl_), st);
         half_neg_norms<T>(X_, c_, st);
     }
     // polynomial in fp64 on the v2 kernel: fold gamma into the data (x' = sqrt(gamma) x, after q was computed from the raw data), so
     // that the MFMA chain leaves gamma * <x_i, x_j> and the epilogue is the bare integer power -- every vector ALU instruction
     // beside v_mfma_f64 costs matrix-core time (gamma > 0 is a precondition of the kernel, parameter.hpp / csvm.cpp:77)
     if constexpr (std::is_same_v<T, double>) {
-        if (params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && v2_eligible_f64(opt_, X_.ldx) && params_.gamma > 0.0) {
+        if (params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && (v2_eligible_f64(opt_, X_.ldx) || wide_nl_) && params_.gamma > 0.0) {
             hipLaunchKernelGGL(k_center<T>, dim3((X_.dfeat + 255) / 256, X_.rows), dim3(256), 0, st, X_.data.p, X_.ldx, X_.dfeat, X_.rows,
                                static_cast<const T *>(nullptr), static_cast<T>(std::sqrt(params_.gamma)));
             LSSVM_HIP_CHECK(hipGetLastError());
@@ -695,7 +704,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         if (planes_.mode != 0) dc_folded_ = params_.kernel_type == LSSVM_KERNEL_RBF && opt_.rbf_fold != 0 && rbf_r2_ <= FOLD_MAX_R2;
     }
     interleave_features<T>(X_, st);
-    if ((std::is_same_v<T, float> && (v2_eligible(opt_, X_.ldx, rbf_direct_) || wide_linear_ || wide_nl_)) || (std::is_same_v<T, double> && (v2_eligible_f64(opt_, X_.ldx) || wide_linear_))) {
+    if ((std::is_same_v<T, float> && (v2_eligible(opt_, X_.ldx, rbf_direct_) || wide_linear_ || wide_nl_)) || (std::is_same_v<T, double> && (v2_eligible_f64(opt_, X_.ldx) || wide_linear_ || wide_nl_))) {
         dc_.alloc_zero(static_cast<size_t>(std::max(num_tiles_, 1)) * 256, st);  // (d_j | c_j) records: 256 reals per 128 columns
     }
     if (sym_) {
@@ -769,8 +778,8 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     if (poly_prescaled_) a.gamma = T(1);
     if constexpr (std::is_same_v<T, float>) {
         if (planes_.mode != 0) set_plane_args(a, params_, planes_, planes_, static_cast<size_t>(X_.rows_alloc), static_cast<size_t>(X_.rows_alloc));
-        a.wide_panels = wide_nl_ ? 1 : 0;
     }
+    a.wide_panels = wide_nl_ ? 1 : 0;
     set_launch_options(a, opt_);
     a.dc_folded = dc_folded_ ? 1 : 0;
     return a;
@@ -1451,12 +1460,16 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     const bool rbf_direct = rbf_wants_direct_form<T>(opt, params, S, &P, s, &rbf_r2);  // same rule as the training matvec (Problem<T>)
     int dc_folded = 0;
     if (params.kernel_type == LSSVM_KERNEL_RBF && !rbf_direct) {
-        center_columns<T>(S, &P, rbf_prescale<T>(params, v2_eligible_f64(opt, S.ldx)), s);
+        center_columns<T>(S, &P, rbf_prescale<T>(params, v2_eligible_f64(opt, S.ldx) || wide_nonlinear_f64(opt, params, nfeat)), s);
         half_neg_norms<T>(S, cS, s);
         half_neg_norms<T>(P, cP, s);
     }
-    bool wide = false;  // fp32 rbf / polynomial beyond the one-pass split kernels: feature panels inside a tile (full-square instance)
-    if constexpr (std::is_same_v<T, float>) wide = wide_nonlinear(opt, params, rbf_direct, nfeat);
+    bool wide = false;  // rbf / polynomial beyond the one-pass kernels: feature panels inside a tile (full-square instance)
+    if constexpr (std::is_same_v<T, float>) {
+        wide = wide_nonlinear(opt, params, rbf_direct, nfeat);
+    } else {
+        wide = wide_nonlinear_f64(opt, params, nfeat);
+    }
     const bool v2 = wide || (std::is_same_v<T, float> ? v2_eligible(opt, S.ldx, rbf_direct) : v2_eligible_f64(opt, S.ldx));
     bool poly_prescaled = false;
     if constexpr (std::is_same_v<T, double>) {
@@ -1528,8 +1541,8 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     if (poly_prescaled) ta.gamma = T(1);
     if constexpr (std::is_same_v<T, float>) {
         if (planesS.mode != 0) set_plane_args(ta, params, planesS, planesP, static_cast<size_t>(S.rows_alloc), static_cast<size_t>(P.rows_alloc));
-        ta.wide_panels = wide ? 1 : 0;
     }
+    ta.wide_panels = wide ? 1 : 0;
     set_launch_options(ta, opt);
     launch_tile_kernel<T>(ta, params.kernel_type, rbf_direct, num_jc, s);
     hipLaunchKernelGGL(k_reduce_partials<T>, dim3((P.rows_alloc + 255) / 256), dim3(256), 0, s, partial.p, ta.part_stride, num_jc, 0, P.rows_alloc, Kv.p);

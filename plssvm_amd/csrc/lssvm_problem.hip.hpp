@@ -146,6 +146,7 @@ template <typename T>
 inline int padded_features(size_t nfeat) {
     const int kc = kchunk_of<T>();
     const int ldx = round_up(static_cast<long>(nfeat), kc);
+    if (std::is_same_v<T, double> && ldx > 16 * kc) return round_up(static_cast<long>(nfeat), 64);  // fp64 beyond the one-pass kernels: whole feature panels of 64 (lssvm_tile_f64_wide.hip.hpp)
     return (ldx > 8 * kc && ldx <= 16 * kc) ? round_up(static_cast<long>(nfeat), 2 * kc) : ldx;
 }
 

@@ -34,6 +34,10 @@ void launch_tile_kernel<double>(TileArgs<double> &a, int kernel_type, bool /*rbf
     const dim3 block(TILE_THREADS);
     if (grid.x == 0) return;
     constexpr size_t lds = static_cast<size_t>(4) * TILE * F64_LS * sizeof(double);
+    if (a.dc != nullptr && a.wide_panels != 0) {
+        launch_wide_tile_kernel_f64(a, kernel_type, grid, s);
+        return;
+    }
     if (a.dc != nullptr) {  // the records exist only where the v2 kernel was chosen when the data was prepared; V2D_LDS_BYTES < 64 KiB
         if (a.items != nullptr) {
             const dim3 sgrid(static_cast<unsigned>(a.num_items));

@@ -233,15 +233,17 @@ def test_predict_values_on_the_bf16_matrix_cores(oracle, kernel, nsv, npts, d):
     assert not np.array_equal(out[0], out[2]) and not np.array_equal(out[0], out[1]) and not np.array_equal(out[1], out[2])  # three different kernels ran
 
 
+@pytest.mark.parametrize("d", [37, 300])
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("kernel", KERNELS)
-def test_predict_values_and_calculate_w_vs_oracle(oracle, kernel, dt):
+def test_predict_values_and_calculate_w_vs_oracle(oracle, kernel, dt, d):
+    """(300 features: beyond the one-pass fp64 kernels -- rbf / polynomial take the full-square instance of the panel kernel)"""
     rng = np.random.default_rng(3)
-    sv = rng.uniform(-1, 1, size=(301, 37)).astype(dt)
+    sv = rng.uniform(-1, 1, size=(301, d)).astype(dt)
     alpha = rng.uniform(-1, 1, size=301).astype(dt)
-    pts = rng.uniform(-1, 1, size=(157, 37)).astype(dt)
-    kw = dict(degree=3, gamma=1.0 / 37, coef0=0.5)
-    p = Parameter(kernel_type=kernel, degree=3, gamma=1.0 / 37, coef0=0.5)
+    pts = rng.uniform(-1, 1, size=(157, d)).astype(dt)
+    kw = dict(degree=3, gamma=1.0 / d, coef0=0.5)
+    p = Parameter(kernel_type=kernel, degree=3, gamma=1.0 / d, coef0=0.5)
     want, w_want = oracle.predict_values(kernel, sv, alpha, 0.125, pts, **kw)
     got, w = backend.predict_values(p, sv, alpha, 0.125, None, pts)
     scale = np.abs(alpha).sum()  # the sums cancel: compare on the scale of the summands
@@ -663,9 +665,7 @@ def test_predict_and_score_on_the_reference_fixture(kernel, dt):
 def test_symmetric_and_full_square_variants_agree(oracle, kernel, N, d, dtype):
     """The default path evaluates only the tiles on/below the diagonal and mirrors them (as the reference does); the
     full-square variant (option symmetric=0) sums every row independently.  Both must match the oracle and each other.
-    (fp64 rbf / polynomial on more than 256 features run the v1 kernel, which has no symmetric variant: both settings then take the same
-    path.  The linear kernel is symmetric at any width in both types -- passes over feature panels -- and so are fp32 rbf / polynomial, by
-    panels inside a tile.)"""
+    (Both types are symmetric at any width: the linear kernel by passes over feature panels, rbf / polynomial by panels inside a tile.)"""
     X, y = make_blobs_pm1(N, d, seed=21, dtype=dtype)
     p = Parameter(kernel_type=kernel)
     rhs = np.random.default_rng(5).uniform(-1, 1, size=N - 1).astype(dtype)
@@ -683,7 +683,7 @@ def test_symmetric_and_full_square_variants_agree(oracle, kernel, N, d, dtype):
         finally:
             _capi.set_option("symmetric", 1)
     assert out[("sym", 0)] == 0
-    assert out[("sym", 1)] == (1 if dtype == np.float32 or d <= 256 or kernel == "linear" else 0)
+    assert out[("sym", 1)] == 1
     kw = dict(degree=3, gamma=1.0 / d, coef0=0.0)
     want = oracle.matvec(kernel, X, q, rhs, np.zeros(N - 1, dtype), QA, 1.0, 1.0, **kw)
     scale = np.max(np.abs(want))
@@ -927,9 +927,9 @@ def test_split_kernels_steady_state_at_every_chunk_count(oracle, kernel, d, mode
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_wide_data_at_the_reference_test_shape(oracle, kernel, dt):
     """The reference's own kernel tests run on 5000 x 2000 data (tests/CMakeLists.txt:36-69, generic_csvm_tests.hpp:372-493).  2000 features
-    are far beyond what the resident-row-panel kernels hold in registers (512 in fp32, 256 in fp64): in fp64 rbf / polynomial run the
-    generic tile kernels (both operands staged through LDS, full square) and the linear kernel one pass per feature panel of 64, in fp32
-    the f16x3 kernels work over feature panels of 128 (linear: one pass per panel; rbf / polynomial: the panels inside a tile).  q and one implicit matvec against the float64 oracle at 1000 x 2000, with the
+    are far beyond what the resident-row-panel kernels hold in registers (512 in fp32, 256 in fp64): the linear kernel runs one pass per
+    feature panel (fp32: the f16x3 kernels over 128 features, fp64: 128), rbf / polynomial walk the panels inside a tile (fp32: 128
+    features, fp64: 64).  q and one implicit matvec against the float64 oracle at 1000 x 2000, with the
     reference's test parameters, on the scale of each row's summands."""
     N, d = 1000, 2000
     rng = np.random.default_rng(2000)
@@ -946,7 +946,7 @@ def test_wide_data_at_the_reference_test_shape(oracle, kernel, dt):
             # the panels walked inside a tile (lssvm_tile_f32_wide.hip.hpp)
             assert info["gram_mode"] == 2 and info["symmetric"] == 1
         else:
-            assert info["gram_mode"] == 0 and info["symmetric"] == (1 if kernel == "linear" else 0)   # fp64: linear over feature panels of 64, else the generic kernel
+            assert info["gram_mode"] == 0 and info["symmetric"] == 1   # fp64: linear over feature panels of 128, rbf / polynomial over panels of 64 inside a sub-tile
         q, QA = prob.q()
         got = prob.matvec(rhs, zero, 1.0).astype(np.float64)
     X64 = X.astype(np.float64)
@@ -966,6 +966,62 @@ def test_wide_data_at_the_reference_test_shape(oracle, kernel, dt):
     S = float(v64.sum())
     scale = np.abs(K) @ np.abs(v64) + np.abs(v64) / 0.1 + abs(float(QA) * S) + abs(float(q64 @ v64)) + np.abs(S * q64)
     assert np.max(np.abs(got - truth) / scale) < 16 * eps, float(np.max(np.abs(got - truth) / scale) / eps)
+
+
+@pytest.mark.parametrize("sym", [1, 0])
+@pytest.mark.parametrize("N, d, jct", [(700, 320, 0), (1500, 700, 2), (900, 2049, 0), (2700, 257, 5)])
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_fp64_on_more_than_256_features(oracle, kernel, N, d, jct, sym):
+    """fp64 beyond the widest resident row panel (256 features): the linear kernel as one pass of tile_matvec_f64_v2 per feature panel of
+    128, rbf / polynomial on tile_matvec_f64_wide (panels of 64 inside a sub-tile, lssvm_tile_f64_wide.hip.hpp), both variants; ragged
+    feature counts (the data is padded to whole panels), 1 ... 12 tiles per work item.  One implicit matvec against the float64 product
+    formed with numpy, on the scale of each row's summands, and a short solve against the same iterations in numpy."""
+    X, y = make_blobs_pm1(N, d, seed=13, dtype=np.float64)
+    P = dict(degree=3, gamma=1.0 / d, coef0=0.5, cost=2.0)
+    p = prm(kernel, P)
+    n = N - 1
+    v = np.random.default_rng(5).uniform(-1, 1, n)
+    zero = np.zeros(n)
+    _capi.set_option("j_chunk_tiles", jct)
+    _capi.set_option("symmetric", sym)
+    with backend.ResidentProblem(p, X) as prob:
+        # (the full-square linear fall-back is the generic kernel; everything else here is a panel path)
+        assert prob.info()["symmetric"] == sym
+        got = prob.matvec(v, zero, 1.0)
+        prob.cg_begin(y, 1e-30)
+        prob.cg_step(4)
+        a_panels = prob.cg_finish()[0]
+    G = X @ X.T
+    if kernel == "linear":
+        Ka = G
+    elif kernel == "polynomial":
+        Ka = (G / d + 0.5) ** 3
+    else:
+        sq = np.einsum("ij,ij->i", X, X)
+        Ka = np.exp(-np.maximum(sq[:, None] + sq[None, :] - 2.0 * G, 0.0) / d)
+    K, q, QA = Ka[:n, :n], Ka[:n, n], Ka[n, n] + 0.5
+    S = float(v.sum())
+    truth = K @ v + v * 0.5 + (QA * S - float(q @ v)) - S * q
+    scale = np.abs(K) @ np.abs(v) + np.abs(v) * 0.5 + abs(QA * S) + abs(float(q @ v)) + np.abs(S * q)
+    assert np.max(np.abs(got - truth) / scale) < 64 * np.finfo(np.float64).eps, float(np.max(np.abs(got - truth) / scale) / np.finfo(np.float64).eps)
+    # four CG iterations (x0 = 1, csvm.cpp:95-163) against the same iterations in numpy on the float64 matrix: the start from x0 = 1 amplifies
+    # rounding differences by ~1e8 (the generic full-square kernel is 3e-9 ... 2e-6 from it on these shapes, the panel kernels 6e-8 ... 2e-6:
+    # tests/tools/cg_check_f64_wide.py); alpha_N = -sum(alpha) is left out (a cancellation of n terms)
+    A = K + 0.5 * np.eye(n) + QA - q[:, None] - q[None, :]
+    b = y[:n] - y[n]
+    x = np.ones(n)
+    res = b - A @ x
+    dvec = res.copy()
+    delta = res @ res
+    for _ in range(4):
+        Ad = A @ dvec
+        alpha_cd = delta / (dvec @ Ad)
+        x = x + alpha_cd * dvec
+        res = res - alpha_cd * Ad
+        delta_new = res @ res
+        dvec = res + (delta_new / delta) * dvec
+        delta = delta_new
+    assert np.max(np.abs(a_panels[:n] - x)) / np.max(np.abs(x)) < 1e-5
 
 
 @pytest.mark.parametrize("mode", [3, 1])
