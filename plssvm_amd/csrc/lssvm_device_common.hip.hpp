@@ -282,21 +282,25 @@ __device__ __forceinline__ double sum_with_lane_xor16(double v) {
     return __builtin_bit_cast(double, (static_cast<unsigned long long>(ahi) << 32) | alo) + __builtin_bit_cast(double, (static_cast<unsigned long long>(bhi) << 32) | blo);
 }
 
-/* The paired butterfly for doubles (column sums of the fp64 sub-tile's four 16-column blocks).  A double is a register pair, which inline asm cannot
- * address by halves; the builtin form of the swaps can (the compiler swaps the sub-registers in place and pads the hazards itself) and is
- * correct as long as its two operands are DIFFERENT values, which they are here.  pair32(a, b) = [a summed over the wave's halves | b summed
- * over the halves]; pair16(a, b) = [a0 + a1, b0 + b1, a2 + a3, b2 + b3] over the 16-lane rows. */
+/* The paired butterfly for doubles (column sums of the fp64 sub-tile's four 16-column blocks).  A double is a register pair: the swaps work on
+ * its two dwords, passed to the asm as separate 32-bit operands (sub-registers of the pairs: no copies).  Inline asm with the wait states INSIDE
+ * the statement, not the builtin: the builtin leaves the "VALU write -> v_permlane*_swap read" hazard (2 wait states, cdna_hip_programming.md
+ * T21) to the compiler's hazard recognizer, which missed it where the value was written at the end of the previous basic block -- the
+ * generic-degree polynomial instantiation of tile_matvec_f64_wide, whose integer-power loop ends right in front of the butterfly, returned
+ * wrong column sums in a quarter of the lanes (found by tests/tools/wide_stress.py).
+ * pair32(a, b) = [a summed over the wave's halves | b summed over the halves]; pair16(a, b) = [a0 + a1, b0 + b1, a2 + a3, b2 + b3] over the
+ * 16-lane rows. */
 __device__ __forceinline__ double swap_halves_and_add(double a, double b, std::integral_constant<int, 32>) {
     const unsigned long long ab = __builtin_bit_cast(unsigned long long, a), bb = __builtin_bit_cast(unsigned long long, b);
-    const auto lo = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(ab), static_cast<unsigned>(bb), false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(ab >> 32), static_cast<unsigned>(bb >> 32), false, false);
-    return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi[0]) << 32) | lo[0]) + __builtin_bit_cast(double, (static_cast<unsigned long long>(hi[1]) << 32) | lo[1]);
+    unsigned alo = static_cast<unsigned>(ab), ahi = static_cast<unsigned>(ab >> 32), blo = static_cast<unsigned>(bb), bhi = static_cast<unsigned>(bb >> 32);
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3" : "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi));
+    return __builtin_bit_cast(double, (static_cast<unsigned long long>(ahi) << 32) | alo) + __builtin_bit_cast(double, (static_cast<unsigned long long>(bhi) << 32) | blo);
 }
 __device__ __forceinline__ double swap_halves_and_add(double a, double b, std::integral_constant<int, 16>) {
     const unsigned long long ab = __builtin_bit_cast(unsigned long long, a), bb = __builtin_bit_cast(unsigned long long, b);
-    const auto lo = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(ab), static_cast<unsigned>(bb), false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(ab >> 32), static_cast<unsigned>(bb >> 32), false, false);
-    return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi[0]) << 32) | lo[0]) + __builtin_bit_cast(double, (static_cast<unsigned long long>(hi[1]) << 32) | lo[1]);
+    unsigned alo = static_cast<unsigned>(ab), ahi = static_cast<unsigned>(ab >> 32), blo = static_cast<unsigned>(bb), bhi = static_cast<unsigned>(bb >> 32);
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3" : "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi));
+    return __builtin_bit_cast(double, (static_cast<unsigned long long>(ahi) << 32) | alo) + __builtin_bit_cast(double, (static_cast<unsigned long long>(bhi) << 32) | blo);
 }
 /* c[cb] = this lane group's rows of column 16 cb + r  ->  returns the finished sum of block q in lane group q (column = lane): 6 swaps + 3 adds
  * instead of 16 + 8 (+ the copies the one-value form needs).  Associates as sum_with_lane_xor16(sum_with_lane_xor32(v)) does in lane group 0. */

@@ -8,7 +8,8 @@
  * accumulators live across the panels, the epilogue runs after the last, and the row panel (64 features: 64 registers -- the budget of two
  * workgroups per CU) is re-loaded from L2 for every (sub-tile, panel), each 16-feature chunk requested as soon as the previous panel is through
  * with it.  The linear kernel does not come here: its Gram matrix is a sum over panels and runs one pass of the v2 kernel per panel
- * (lssvm_problem.hip).  The data is padded to whole panels (padded_features).  A negative polynomial degree stays on the generic kernel.
+ * (lssvm_problem.hip).  The data is padded to whole panels (padded_features).  Polynomial degrees other than 2 and 3 stay on the generic kernel
+ * (wide_nonlinear_f64 in lssvm_problem.hip says why).
  * Reference semantics: /root/reference/include/plssvm/backends/HIP/svm_kernel.hip.hpp:129-270 (one code path for any feature count).
  */
 #pragma once

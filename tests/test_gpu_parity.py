@@ -1024,6 +1024,27 @@ def test_fp64_on_more_than_256_features(oracle, kernel, N, d, jct, sym):
     assert np.max(np.abs(a_panels[:n] - x)) / np.max(np.abs(x)) < 1e-5
 
 
+@pytest.mark.parametrize("degree, coef0", [(4, 0.0), (1, 1.0), (5, 0.5)])
+def test_fp64_wide_polynomial_of_other_degrees_stays_on_the_generic_kernel(degree, coef0):
+    """The fp64 panel kernel takes polynomial degrees 2 and 3 (its run-time integer-power instantiation returned wrong sums for one row group of
+    every wave in tests/tools/wide_stress.py and is not shipped): other degrees on more than 256 features run the generic full-square kernel
+    and must be right -- the rows the broken form got wrong included."""
+    N, d = 513, 320
+    X, y = make_blobs_pm1(N, d, seed=166, dtype=np.float64)
+    p = Parameter(kernel_type="polynomial", gamma=0.3 / d, degree=degree, coef0=coef0, cost=1.0)
+    n = N - 1
+    v = np.ones(n)
+    with backend.ResidentProblem(p, X) as prob:
+        assert prob.info()["symmetric"] == 0
+        out = prob.matvec(v, np.zeros(n), 1.0)
+    Ka = (p.gamma * (X @ X.T) + coef0) ** degree
+    K, q, QA = Ka[:n, :n], Ka[:n, n], Ka[n, n] + 1.0
+    S = float(v.sum())
+    truth = K @ v + v + (QA * S - float(q @ v)) - S * q
+    scale = np.abs(K) @ np.abs(v) + np.abs(v) + abs(QA * S) + abs(float(q @ v)) + np.abs(S * q)
+    assert np.max(np.abs(out - truth) / scale) < 64 * np.finfo(np.float64).eps
+
+
 @pytest.mark.parametrize("mode", [3, 1])
 @pytest.mark.parametrize("N, d, jct", [(700, 520, 0), (1500, 640, 2), (1500, 1030, 0), (2700, 400, 5)])
 @pytest.mark.parametrize("kernel", ["rbf", "polynomial"])
