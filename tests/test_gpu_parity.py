@@ -1024,6 +1024,31 @@ def test_fp64_on_more_than_256_features(oracle, kernel, N, d, jct, sym):
     assert np.max(np.abs(a_panels[:n] - x)) / np.max(np.abs(x)) < 1e-5
 
 
+@pytest.mark.parametrize("mode", [3, 1])
+@pytest.mark.parametrize("sym", [1, 0])
+@pytest.mark.parametrize("degree, coef0", [(4, 0.0), (1, 1.0), (5, 0.5), (0, 1.0)])
+def test_fp32_wide_polynomial_with_the_run_time_integer_power(degree, coef0, sym, mode):
+    """The generic-degree instantiations of the fp32 panel kernel (every degree but 2 and 3; both plane kinds, both variants) on the shape and
+    the all-ones vector that exposed the broken fp64 counterpart: every row against the float64 product."""
+    N, d = 513, 640
+    X, y = make_blobs_pm1(N, d, seed=166, dtype=np.float32)
+    p = Parameter(kernel_type="polynomial", gamma=0.3 / d, degree=degree, coef0=coef0, cost=1.0)
+    n = N - 1
+    v = np.ones(n, np.float32)
+    _capi.set_option("gram_mode", mode)
+    _capi.set_option("symmetric", sym)
+    with backend.ResidentProblem(p, X) as prob:
+        assert prob.info()["symmetric"] == sym and prob.info()["gram_mode"] == (1 if mode == 1 else 2)
+        out = prob.matvec(v, np.zeros(n, np.float32), 1.0).astype(np.float64)
+    X64 = X.astype(np.float64)
+    Ka = (p.gamma * (X64 @ X64.T) + coef0) ** degree
+    K, q, QA = Ka[:n, :n], Ka[:n, n], Ka[n, n] + 1.0
+    S = float(n)
+    truth = K.sum(axis=1) + 1.0 + (QA * S - float(q.sum())) - S * q
+    scale = np.abs(K).sum(axis=1) + 1.0 + abs(QA * S) + abs(float(q.sum())) + np.abs(S * q)
+    assert np.max(np.abs(out - truth) / scale) < 16 * np.finfo(np.float32).eps
+
+
 @pytest.mark.parametrize("degree, coef0", [(4, 0.0), (1, 1.0), (5, 0.5)])
 def test_fp64_wide_polynomial_of_other_degrees_stays_on_the_generic_kernel(degree, coef0):
     """The fp64 panel kernel takes polynomial degrees 2 and 3 (its run-time integer-power instantiation returned wrong sums for one row group of
