@@ -254,10 +254,12 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *   "rbf_direct_above" threshold of rbf_form 0 (default 32: [-1,1]-scaled data with gamma = 1 / num_features has R2 <= 3)
  *   "j_chunk_tiles" number of 128-column tiles per work item; 0 = automatic (default: about 4096 work items per device, 2 ... 16 tiles each,
  *                   up to 64 for the split kernels)
- *   "symmetric"     1 = evaluate only the kernel-matrix tiles on/below the diagonal and mirror them (default; fp32 with the split Gram modes: any
- *                   num_features, otherwise <= 512 in fp32, <= 256 in fp64; a negative polynomial degree always runs the full square),
+ *   "symmetric"     1 = evaluate only the kernel-matrix tiles on/below the diagonal and mirror them (default; any num_features -- beyond 512 (fp32) /
+ *                   256 (fp64) features over feature panels -- except: fp32 with gram_mode = 0 beyond 512 features, fp64 polynomial degrees other
+ *                   than 2 and 3 beyond 256 features, and a negative polynomial degree, which run the full square),
  *                   0 = full square (row-owned sums, results independent of the GPU count)
- *   "tile_kernel"   0 = automatic: the "resident row panel" kernels for num_features <= 512 (fp32) / 256 (fp64) (default), 1 = always the generic kernel
+ *   "tile_kernel"   0 = automatic: the "resident row panel" kernels for num_features <= 512 (fp32) / 256 (fp64) and their feature-panel forms beyond
+ *                   (default), 1 = always the generic kernel
  *   "xcd_map"       1 = XCD-aware block -> work item mapping (8 x 8 super-tiles per XCD), 0 = linear (default)
  *   "item_order"    symmetric variant: 0 = work items in column-chunk major order, 1 = the same with the short items that end on the
  *                   diagonal moved to the end, longest first (default: shortens the last dispatch round), 2 = 1 with row blocks descending
