@@ -255,8 +255,8 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *   "j_chunk_tiles" number of 128-column tiles per work item; 0 = automatic (default: about 4096 work items per device, 2 ... 16 tiles each,
  *                   up to 64 for the split kernels)
  *   "symmetric"     1 = evaluate only the kernel-matrix tiles on/below the diagonal and mirror them (default; any num_features -- beyond 512 (fp32) /
- *                   256 (fp64) features over feature panels -- except: fp32 with gram_mode = 0 beyond 512 features, fp64 polynomial degrees other
- *                   than 2 and 3 beyond 256 features, and a negative polynomial degree, which run the full square),
+ *                   256 (fp64) features over feature panels -- except fp32 with gram_mode = 0 beyond 512 features and a negative polynomial
+ *                   degree, which run the full square),
  *                   0 = full square (row-owned sums, results independent of the GPU count)
  *   "tile_kernel"   0 = automatic: the "resident row panel" kernels for num_features <= 512 (fp32) / 256 (fp64) and their feature-panel forms beyond
  *                   (default), 1 = always the generic kernel

@@ -163,12 +163,9 @@ int f64_linear_panel(const Options &o) { return o.linear_panel_features == 64 ? 
 constexpr int F64_ONE_PASS_FEATURES = 256;
 
 /* fp64 rbf / polynomial on more than 256 features: feature panels of 64 inside a sub-tile (lssvm_tile_f64_wide.hip.hpp; the data carries the
-   kernel's scale as on the one-pass v2 kernel, so gamma > 0 -- a precondition of the kernels anyway -- is required).  Polynomial: degree 2 and 3
-   only -- the instantiation with the run-time integer power returned wrong sums for one row group of every wave (tests/tools/wide_stress.py
-   found it; the 32 power loops in front of the reductions are the only difference to the degree-2 / -3 forms, which are right, and the cause is
-   not understood), so other degrees keep the generic kernel. */
+   kernel's scale as on the one-pass v2 kernel, so gamma > 0 -- a precondition of the kernels anyway -- and a non-negative degree are required) */
 static bool wide_nonlinear_f64(const Options &o, const lssvm_params &p, size_t num_features) {
-    const bool nonlinear = p.kernel_type == LSSVM_KERNEL_RBF || (p.kernel_type == LSSVM_KERNEL_POLYNOMIAL && (p.degree == 2 || p.degree == 3));
+    const bool nonlinear = p.kernel_type == LSSVM_KERNEL_RBF || (p.kernel_type == LSSVM_KERNEL_POLYNOMIAL && p.degree >= 0);
     return nonlinear && p.gamma > 0.0 && o.tile_kernel != 1 && padded_features<double>(num_features) > F64_ONE_PASS_FEATURES;
 }
 

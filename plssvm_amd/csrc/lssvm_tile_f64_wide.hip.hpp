@@ -8,8 +8,7 @@
  * accumulators live across the panels, the epilogue runs after the last, and the row panel (64 features: 64 registers -- the budget of two
  * workgroups per CU) is re-loaded from L2 for every (sub-tile, panel), each 16-feature chunk requested as soon as the previous panel is through
  * with it.  The linear kernel does not come here: its Gram matrix is a sum over panels and runs one pass of the v2 kernel per panel
- * (lssvm_problem.hip).  The data is padded to whole panels (padded_features).  Polynomial degrees other than 2 and 3 stay on the generic kernel
- * (wide_nonlinear_f64 in lssvm_problem.hip says why).
+ * (lssvm_problem.hip).  The data is padded to whole panels (padded_features).  A negative polynomial degree stays on the generic kernel.
  * Reference semantics: /root/reference/include/plssvm/backends/HIP/svm_kernel.hip.hpp:129-270 (one code path for any feature count).
  */
 #pragma once
@@ -161,6 +160,13 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f64_wide(const Ti
         }
     };
 
+    // The two outer loops are kept as ROLLED loops: with the first iterations peeled off (what -O2 / -O3 do by themselves) the instantiation for
+    // a run-time polynomial degree returned wrong row sums -- the right ones plus a term identical in all four waves, i.e. column-side data in a
+    // register of the row sums -- deterministically, with or without the power loop, with SGPR spills in VGPR lanes or in scratch; -O1 and this
+    // pragma both give the right code, for that instantiation and (checked again: tests/tools/wide_stress.py) for all the others.  Whether the
+    // peeled copies trip the compiler's wait-count bookkeeping for the LDS reads that are carried across iterations, or an assumption of this
+    // file's inline asm, is not known.
+#pragma clang loop unroll(disable)
     for (int t = 0; t < nsub; ++t) {
         const double *dcr = reinterpret_cast<const double *>(dcs + (t % V2D_DC_SLOTS) * 1024);
         // start values of the chains: rbf c_i + c_j; polynomial coef0 (the data carries sqrt(gamma): the chain leaves gamma <x_i, x_j>)
@@ -184,6 +190,7 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f64_wide(const Ti
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[rb][cb][i] = a.coef0;
         }
+#pragma clang loop unroll(disable)  // (see above: no peeled copy of the panel loop either)
         for (int p = 0; p < panels; ++p) {
             const bool more_panels = t + 1 < nsub || p + 1 < panels;
             const int p_next = p + 1 < panels ? p + 1 : 0;  // (the row panel depends on the feature panel only, not on the sub-tile)

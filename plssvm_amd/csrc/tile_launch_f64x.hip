@@ -18,7 +18,7 @@ static void launch_wide_f64(const TileArgs<double> &a, int kernel_type, dim3 gri
             } else if (a.degree == 2) {
                 hipLaunchKernelGGL((tile_matvec_f64_wide<KT_POLY2, SYM>), grid, block, V2D_LDS_BYTES, s, a);
             } else {
-                throw Error(LSSVM_ERR_INTERNAL, "the wide fp64 tile kernel takes polynomial degrees 2 and 3 only");  // (see wide_nonlinear_f64)
+                hipLaunchKernelGGL((tile_matvec_f64_wide<KT_POLY, SYM>), grid, block, V2D_LDS_BYTES, s, a);
             }
             break;
         case KT_RBF: hipLaunchKernelGGL((tile_matvec_f64_wide<KT_RBF, SYM>), grid, block, V2D_LDS_BYTES, s, a); break;
@@ -29,6 +29,7 @@ static void launch_wide_f64(const TileArgs<double> &a, int kernel_type, dim3 gri
 /* `grid` is used by the full-square variant only (the symmetric variant runs one workgroup per listed work item) */
 void launch_wide_tile_kernel_f64(const TileArgs<double> &a, int kernel_type, dim3 grid, hipStream_t s) {
     if (a.kchunks < 8 || a.kchunks % 4 != 0) throw Error(LSSVM_ERR_INTERNAL, "the wide fp64 tile kernel needs data padded to a multiple of 64 features");
+    if (a.degree < 0 && kernel_type == KT_POLY) throw Error(LSSVM_ERR_INTERNAL, "the wide fp64 tile kernel does not take a negative polynomial degree");
     if (a.items != nullptr) {
         if (a.num_items > 0) launch_wide_f64<true>(a, kernel_type, dim3(static_cast<unsigned>(a.num_items)), s);
     } else {
