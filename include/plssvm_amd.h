@@ -284,7 +284,8 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *                   One process per GPU (lssvm_shard): 0 = RCCL when lssvm_mi355_comm_init was called in this process, else HIP IPC;
  *                   1 = RCCL; 2 = HIP IPC + the peer kernel (lssvm_mi355_problem_ipc_export / _connect)
  *   "linear_panel_features" fp32 linear kernel on the f16x3 kernels: K = sum over feature panels of X_p X_p^T, one pass of the tile kernel per panel of this
- *                   many features (multiple of 64, at most 512; default 128: two waves per SIMD and hand-scheduled groups in every pass), any width
+ *                   many features (multiple of 64, at most 512; default 128: two waves per SIMD and hand-scheduled groups in every pass), any width;
+ *                   fp64 linear kernel beyond 256 features: one pass of the fp64 kernel per panel of 128 features (64 if this option is 64)
  *   "ipc_timeout_s" one process per GPU over HIP IPC: seconds a rank waits for its peers at an exchange before it fails (default 600)
  *   "enqueue_ahead_below_us" CG loop: while an implicit matvec takes less than this many microseconds (default 5000), the direction update and
  *                   the NEXT matvec are enqueued before the host reads the stop test of the current iteration, so the device never waits for
