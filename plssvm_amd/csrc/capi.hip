@@ -338,8 +338,11 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
             LSSVM_REQUIRE(value >= 0 && value <= 3, "gram_mode must be 0 (v_mfma_f32), 1 (bf16x6), 2 (f16x3 unchecked) or 3 (f16x3 where the data allows, else bf16x6)");
             lssvm::options().gram_mode = value;
         } else if (n == "mfma_shape") {
-            LSSVM_REQUIRE(value >= 1 && value <= 3, "mfma_shape must be 1 (compiler-scheduled MFMA groups), 2 (hand-scheduled groups) or 3 (2 + the software-pipelined kernel where it exists)");
+            LSSVM_REQUIRE(value >= 1 && value <= 3, "mfma_shape must be 1 (compiler-scheduled MFMA groups), 2 (hand-scheduled groups) or 3 (2 + 256-row workgroups in the symmetric variant)");
             lssvm::options().mfma_shape = value;
+        } else if (n == "pair_lag") {
+            LSSVM_REQUIRE(value >= 0 && value <= 4, "pair_lag must be 0 ... 4");
+            lssvm::options().pair_lag = value;
         } else if (n == "colslab_band_mb") {
             LSSVM_REQUIRE(value >= 1, "colslab_band_mb must be positive");
             lssvm::options().colslab_band_mb = value;
@@ -398,6 +401,8 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             *value_out = lssvm::options().gram_mode;
         } else if (n == "mfma_shape") {
             *value_out = lssvm::options().mfma_shape;
+        } else if (n == "pair_lag") {
+            *value_out = lssvm::options().pair_lag;
         } else if (n == "colslab_band_mb") {
             *value_out = lssvm::options().colslab_band_mb;
         } else if (n == "colslab_limit_mb") {

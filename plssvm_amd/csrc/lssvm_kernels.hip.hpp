@@ -129,24 +129,26 @@ __global__ void k_reduce_partials(const T *__restrict__ partial, long part_strid
  * walk the row blocks with stride 1024 / W (four independent partial sums each, for memory-level parallelism), then the groups'
  * sums are added in group order -- the order depends only on the shape, never on timing. */
 template <typename T, int W>
-__global__ __launch_bounds__(1024) void k_reduce_colslab(const T *__restrict__ colslab, long pair_origin, int ib_begin, int ib_end, T *__restrict__ Kv) {
+__global__ __launch_bounds__(1024) void k_reduce_colslab(const T *__restrict__ colslab, long pair_origin, int ib_begin, int ib_end, int ib_step, T *__restrict__ Kv) {
     constexpr int SUB = TILE / W;
     constexpr int G = 1024 / W;
     __shared__ T red[G][W];
     const int c = blockIdx.x;
     const int l = threadIdx.x % W;
     const int g = threadIdx.x / W;
-    const int first = max(c / SUB + 1, ib_begin);
+    // ib_step 2 (256-row workgroups): the records of a block pair are those of its odd block; ib_begin is even
+    const int first = ib_step == 2 ? (max(c / SUB + 1, ib_begin) | 1) : max(c / SUB + 1, ib_begin);
     auto rec = [&](int ib) { return colslab[(SUB * (static_cast<long>(ib) * (ib - 1) / 2 - pair_origin) + c) * W + l]; };
     T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
-    int ib = first + g;
-    for (; ib + 3 * G < ib_end; ib += 4 * G) {
+    const int GS = G * ib_step;
+    int ib = first + g * ib_step;
+    for (; ib + 3 * GS < ib_end; ib += 4 * GS) {
         s0 += rec(ib);
-        s1 += rec(ib + G);
-        s2 += rec(ib + 2 * G);
-        s3 += rec(ib + 3 * G);
+        s1 += rec(ib + GS);
+        s2 += rec(ib + 2 * GS);
+        s3 += rec(ib + 3 * GS);
     }
-    for (; ib < ib_end; ib += G) s0 += rec(ib);
+    for (; ib < ib_end; ib += GS) s0 += rec(ib);
     red[g][l] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0) {

@@ -115,6 +115,8 @@ int select_device_checked(int device) {
 
 constexpr int MAX_LOCAL_DEVICES = 16;
 constexpr double FOLD_MAX_R2 = 200.0;    // folded rbf records (KT_RBFF) only while |c| = R2 / 2 <= 100: 2^c and 2^acc stay far inside the fp32 range
+constexpr double PAIR_FOLD_MAX_C = 32.0; // 256-row kernels, rbf: row AND column term folded (K = e_i 2^(x_i.x_j) e_j) only while |c| <= 32: the partial sums then carry at most 2^32 of
+                                         // extra scale (rbf_direct_above = 32 keeps the automatic choice at |c| <= 16)
 constexpr int SPLIT_MAX_FEATURES = 384;  // the bf16x6 kernels exist for 1 ... 6 chunks of 64 features (row panel = 3 planes in registers)
 constexpr int F16_MAX_FEATURES = 512;    // the f16x3 kernels exist for 1 ... 8 chunks of 64 features (row panel = 2 planes in registers)
 constexpr int F16_LINEAR_MAX_FEATURES = 1 << 20;
@@ -176,11 +178,13 @@ static bool wide_nonlinear(const Options &o, const lssvm_params &p, bool rbf_dir
     return nonlinear && o.gram_mode != 0 && o.tile_kernel != 1 && round_up(static_cast<long>(num_features), 64) > one_pass_limit;
 }
 
-/* first row block of rank r when the lower triangle is dealt by equal area: round(tiles * sqrt(r / world)) */
+/* first row block of rank r when the lower triangle is dealt by equal area: tiles * sqrt(r / world), rounded to an EVEN block index -- the
+ * 256-row workgroups of lssvm_tile_f32_pair.hip.hpp work on the block pairs (2p, 2p + 1), which must not straddle two devices (every symmetric
+ * partition follows the rule, whichever kernel runs: one partition per problem shape) */
 int sym_block_boundary(int num_tiles, int r, int world) {
     if (r <= 0) return 0;
     if (r >= world) return num_tiles;
-    const int b = static_cast<int>(std::llround(static_cast<double>(num_tiles) * std::sqrt(static_cast<double>(r) / static_cast<double>(world))));
+    const int b = 2 * static_cast<int>(std::llround(0.5 * static_cast<double>(num_tiles) * std::sqrt(static_cast<double>(r) / static_cast<double>(world))));
     return std::min(std::max(b, 0), num_tiles);
 }
 
@@ -224,6 +228,7 @@ static void set_launch_options(TileArgs<T> &a, const Options &o) {
     a.map_mode = o.xcd_map != 0 ? 1 : 0;
     a.lds_extra_kb = static_cast<int>(o.lds_extra_kb);
     a.mfma_shape = static_cast<int>(o.mfma_shape);
+    a.pair_lag = static_cast<int>(o.pair_lag);
 }
 
 /* rbf on the matrix cores: the data is scaled so that the MFMA chain leaves the exponent in the unit the epilogue wants:
@@ -536,7 +541,7 @@ static std::vector<int> band_edges(int ib_begin, int ib_end_all, size_t real_siz
     const double a0 = static_cast<double>(ib_begin) * ib_begin, a1 = static_cast<double>(ib_end_all) * ib_end_all;
     std::vector<int> edge(nbands + 1, ib_begin);
     for (int k = 1; k < nbands; ++k) {
-        const int e = static_cast<int>(std::llround(std::sqrt(a0 + (a1 - a0) * static_cast<double>(k) / nbands)));
+        const int e = 2 * static_cast<int>(std::llround(0.5 * std::sqrt(a0 + (a1 - a0) * static_cast<double>(k) / nbands)));  // even: a block pair stays in one band
         edge[k] = std::min<int>(std::max(e, edge[k - 1]), ib_end_all);
     }
     edge[nbands] = ib_end_all;
@@ -546,17 +551,20 @@ static std::vector<int> band_edges(int ib_begin, int ib_end_all, size_t real_siz
 /* The (row block, column chunk) work items of one band in DISPATCH order: column chunk major (concurrent workgroups share the chunk; the
    hardware dispatches workgroups in item order as CU slots free up).  item_order >= 1: the items cut short by the diagonal go last in
    their band, longest first, so that the final dispatch round is made of the shortest items.  .x = absolute row block, .y = chunk. */
-static std::vector<int2> band_items(int band_begin, int band_end, int jc_tiles, int num_jc, int order) {
+static std::vector<int2> band_items(int band_begin, int band_end, int jc_tiles, int num_jc, int order, bool pairs) {
     std::vector<int2> full, cut;
+    const int rows = pairs ? 2 : 1;  // row blocks per work item: block pairs (2p, 2p + 1) for the 256-row workgroups (.x = the even block; the band edges are even)
+    const int nrow_items = (band_end - band_begin + rows - 1) / rows;
     for (int jc = 0; jc < num_jc; ++jc) {
-        for (int kk = band_begin; kk < band_end; ++kk) {
-            const int ib = order == 2 ? band_end - 1 - (kk - band_begin) : kk;
-            if (jc * jc_tiles > ib) continue;
-            const bool is_cut = (jc + 1) * jc_tiles > ib + 1;  // fewer than jc_tiles tiles
+        for (int k = 0; k < nrow_items; ++k) {
+            const int ib = band_begin + rows * (order == 2 ? nrow_items - 1 - k : k);
+            const int last = ib + rows - 1;  // the item's tiles end at the diagonal of its LAST block
+            if (jc * jc_tiles > last) continue;
+            const bool is_cut = (jc + 1) * jc_tiles > last + 1;  // fewer than jc_tiles tiles
             (order >= 1 && is_cut ? cut : full).push_back(make_int2(ib, jc));
         }
     }
-    std::stable_sort(cut.begin(), cut.end(), [&](const int2 &x, const int2 &y) { return (x.x + 1 - x.y * jc_tiles) > (y.x + 1 - y.y * jc_tiles); });
+    std::stable_sort(cut.begin(), cut.end(), [&](const int2 &x, const int2 &y) { return (x.x + rows - x.y * jc_tiles) > (y.x + rows - y.y * jc_tiles); });
     full.insert(full.end(), cut.begin(), cut.end());
     return full;
 }
@@ -583,7 +591,8 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     ib_per_rank_ = (num_tiles_ + world_ - 1) / world_;
     nvec_ = ib_per_rank_ * world_ * TILE;
     // data matrix: all N points (the last one is row n; it takes part in q and QA_cost only)
-    X_.upload(X, mem_kind, num_points, num_features, static_cast<size_t>(nvec_), st);
+    // (+ TILE: an odd number of row blocks ends in a block pair whose second block is zero padding -- the 256-row workgroups read its rows, d_i and c_i)
+    X_.upload(X, mem_kind, num_points, num_features, static_cast<size_t>(nvec_) + TILE, st);
     // fp32 rbf: matrix cores (norm expansion) or the formula-exact vector-ALU kernel?  (every shard sees the same data: same decision)
     rbf_direct_ = rbf_wants_direct_form<T>(opt_, params_, X_, nullptr, st, &rbf_r2_);
     // symmetric variant: v2 kernels only; a negative polynomial degree can give inf on zero-padded rows -> full square
@@ -626,6 +635,16 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     // the symmetric variant keeps one 128-entry record per evaluated off-diagonal tile of the row-block BAND in flight (see the bands
     // below); colslab_limit_mb = 0 switches the variant off (a rule in the options only, so every rank of a sharded solve decides alike)
     if (sym_ && opt_.colslab_limit_mb == 0) sym_ = false;
+    if constexpr (std::is_same_v<T, float>) {
+        // 256-row workgroups on block pairs (lssvm_tile_f32_pair.hip.hpp): the symmetric variant of the split kernels on at most 128 features per
+        // pass with a hand-scheduled epilogue -- decided from the shape and the options alone (both plane kinds have the kernel), so that the
+        // geometry below does not wait for the planes and every rank of a sharded solve decides alike
+        const bool poly_generic = params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree != 2 && params_.degree != 3;
+        const bool narrow = wide_linear_ ? opt_.linear_panel_features <= 128 : (round_up(static_cast<long>(num_features), 64) <= 128 && v2_eligible(opt_, ldx_probe, rbf_direct_));
+        // (rbf: that kernel folds BOTH exponent terms out of the chain -- only while |c| = R2 / 2 stays small and the folded records are on)
+        const bool rbf_ok = params_.kernel_type != LSSVM_KERNEL_RBF || (opt_.rbf_fold != 0 && rbf_r2_ <= 2.0 * PAIR_FOLD_MAX_C);
+        pair_ = sym_ && opt_.gram_mode != 0 && opt_.mfma_shape >= 3 && !wide_nl_ && !poly_generic && narrow && rbf_ok;
+    }
     {
         int ib_end = 0;
         shard_blocks(num_tiles_, world_, rank_, sym_, ib_begin_, ib_end);
@@ -660,12 +679,12 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     QA_cost_ = static_cast<double>(host_self_kernel<T>(params_, last) + T(1) / static_cast<T>(params_.cost));
 
     // vectors (zero padded to nvec_)
-    for (DevBuf<T> *v : { &q_, &b_, &x_, &r_, &d_, &Ad_, &Kv_, &tmp_ }) v->alloc_zero(nvec_, st);
+    for (DevBuf<T> *v : { &q_, &b_, &x_, &r_, &d_, &Ad_, &Kv_, &tmp_ }) v->alloc_zero(static_cast<size_t>(nvec_) + TILE, st);
     Kres_ = Kv_.p;
     ylast_.alloc_zero(num_points, st);
     part_.alloc_zero(static_cast<size_t>(RED_BLOCKS) * 2, st);
     sc_.alloc_zero(SC_COUNT, st);
-    partial_.alloc_zero(static_cast<size_t>(std::max(num_jc_, 1)) * std::max(num_ib_, 1) * TILE, st);
+    partial_.alloc_zero(static_cast<size_t>(std::max(num_jc_, 1)) * part_blocks() * TILE, st);
     host_sc_.alloc(SC_COUNT);
 
     // q from the raw (un-centred) data: bit-compatible fma chains (q_kernel.cpp:18-55)
@@ -699,7 +718,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     if constexpr (std::is_same_v<T, float>) {
         // the (centred, scaled) data once more as operand planes of the split kernels (features in natural order): see make_planes
         if (!wide_linear_) make_planes(opt_, params_, rbf_direct_, X_, nullptr, planes_, nullptr, st, wide_nl_);
-        if (wide_nl_ && planes_.mode == 0) throw Error(LSSVM_ERR_INTERNAL, "no operand planes for the wide rbf / polynomial path");
+        if ((wide_nl_ || pair_) && planes_.mode == 0) throw Error(LSSVM_ERR_INTERNAL, "no operand planes for a path that was chosen from the shape alone");
         // rbf: folded records while the exponent terms stay small (rbf_r2_ = 2 max|c| in the exponent's unit)
         if (planes_.mode != 0) dc_folded_ = params_.kernel_type == LSSVM_KERNEL_RBF && opt_.rbf_fold != 0 && rbf_r2_ <= FOLD_MAX_R2;
     }
@@ -723,9 +742,10 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
             band.ib_end = edge[k + 1];
             band.item_begin = static_cast<int>(items.size());
             band.pair_origin = pairs_below(band.ib_begin);
-            for (const int2 &it : band_items(band.ib_begin, band.ib_end, jc_tiles_, num_jc_, static_cast<int>(opt_.item_order))) items.push_back(make_int2(it.x - ib_begin_, it.y));
+            for (const int2 &it : band_items(band.ib_begin, band.ib_end, jc_tiles_, num_jc_, static_cast<int>(opt_.item_order), pair_)) items.push_back(make_int2(it.x - ib_begin_, it.y));
             band.item_count = static_cast<int>(items.size()) - band.item_begin;
-            max_records = std::max(max_records, pairs_below(band.ib_end) - band.pair_origin);
+            // (block pairs: the records of the pair's SECOND block, which is padding behind an odd last block)
+            max_records = std::max(max_records, pairs_below(pair_ ? round_up(band.ib_end, 2) : band.ib_end) - band.pair_origin);
             if (band.ib_end > band.ib_begin) bands_.push_back(band);
         }
         num_items_ = static_cast<int>(items.size());
@@ -766,7 +786,7 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     a.colslab = colslab_.p;
     a.pair_origin = 0;
     a.partial = partial_.p;
-    a.part_stride = static_cast<long>(std::max(num_ib_, 1)) * TILE;
+    a.part_stride = static_cast<long>(part_blocks()) * TILE;
     a.ldx = X_.ldx;
     a.kchunks = X_.ldx / kchunk_of<T>();
     a.ib_begin = ib_begin_;
@@ -781,6 +801,7 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     }
     a.wide_panels = wide_nl_ ? 1 : 0;
     set_launch_options(a, opt_);
+    a.row_pair = pair_ ? 1 : 0;
     a.dc_folded = dc_folded_ ? 1 : 0;
     return a;
 }
@@ -865,9 +886,10 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
                 // fold the band's mirrored column sums into K*v before the next band re-uses the slab
                 if (band.ib_end > 1) {
                     if constexpr (std::is_same_v<T, float>) {
-                        hipLaunchKernelGGL((k_reduce_colslab<T, 128>), dim3(band.ib_end - 1), dim3(1024), 0, st, colslab_.p, band.pair_origin, band.ib_begin, band.ib_end, Kv_.p);
+                        // (block pairs: one record per pair and column tile, kept as the record of the pair's second -- odd -- block)
+                        hipLaunchKernelGGL((k_reduce_colslab<T, 128>), dim3(band.ib_end - 1), dim3(1024), 0, st, colslab_.p, band.pair_origin, band.ib_begin, pair_ ? round_up(band.ib_end, 2) : band.ib_end, pair_ ? 2 : 1, Kv_.p);
                     } else {  // fp64: records per 64-column sub-tile
-                        hipLaunchKernelGGL((k_reduce_colslab<T, 64>), dim3(2 * (band.ib_end - 1)), dim3(1024), 0, st, colslab_.p, band.pair_origin, band.ib_begin, band.ib_end, Kv_.p);
+                        hipLaunchKernelGGL((k_reduce_colslab<T, 64>), dim3(2 * (band.ib_end - 1)), dim3(1024), 0, st, colslab_.p, band.pair_origin, band.ib_begin, band.ib_end, 1, Kv_.p);
                     }
                 }
             }

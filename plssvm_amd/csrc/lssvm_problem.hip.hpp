@@ -71,8 +71,10 @@ struct Options {
     int64_t gram_mode = 3;         // fp32 Gram tiles: 0 = v_mfma_f32 chains; 1 = "bf16x6": exact 3-way bf16 split of the operands, six plane products on the bf16
                                    // MFMA (<= 384 features); 2 = "f16x3": two f16 planes of the pre-scaled operands, three plane products on the f16 MFMA (<= 512
                                    // features), without the representability check; 3 (default) = f16x3 where the data passes that check, else bf16x6
-    int64_t mfma_shape = 2;        // split kernels (v_mfma_f32_16x16x32_*): 1 = compiler-scheduled MFMA groups, 2 = hand-scheduled groups for <= 128 features
-                                   // (default; more features run as 1).  (0 was round 1's 32x32x16 form, retired)
+    int64_t mfma_shape = 3;        // split kernels (v_mfma_f32_16x16x32_*): 1 = compiler-scheduled MFMA groups, 2 = hand-scheduled groups for <= 128 features,
+                                   // 3 (default) = 2 with 256-row workgroups (eight waves on a block pair, one column stream) in the symmetric variant
+    int64_t pair_lag = 0;          // 256-row workgroups: plane-chunk steps waves 4-7 run behind waves 0-3 (0 = lock step: default and the only one the shipped library
+                                   // instantiates; 1, 3 in development builds -- measured slower)
     int64_t colslab_band_mb = 2048;    // symmetric variant: the column-sum records of ONE row-block band may take this many MiB; the tile kernel runs band by band
     int64_t colslab_limit_mb = 98304;  // symmetric variant only while its column slab (per device) stays below this many MiB (96 GiB of the 288 GB)
     int64_t force_collective = 0;  // testing aid: run the per-matvec collective even for a world of one (needs lssvm_mi355_comm_init(.., 0, 1, ..))
@@ -289,6 +291,8 @@ class Problem {
     bool rbf_direct_ = false;
     double rbf_r2_ = 0.0;  // fp32 rbf: 2 gamma log2(e) max|x - mean|^2
     bool dc_folded_ = false;  // the (d_j | c_j) records carry (2^c_j d_j | 2^c_j): rbf on the 16x16x32 bf16x6 kernels
+    bool pair_ = false;            // fp32 symmetric variant on the split kernels, <= 128 features per pass: 256-row workgroups on block pairs (lssvm_tile_f32_pair.hip.hpp)
+    int part_blocks() const { return pair_ ? round_up(std::max(num_ib_, 1), 2) : std::max(num_ib_, 1); }  // row blocks of a row slab (whole pairs)
     bool wide_nl_ = false;         // fp32 rbf / polynomial on more features than the one-pass split kernels take: feature panels inside a tile (lssvm_tile_f32_wide.hip.hpp)
     bool wide_linear_ = false;     // linear kernel over feature panels, one tile-kernel pass per panel: fp32 f16x3 beyond linear_panel_features, fp64 beyond 256 features
     bool poly_prescaled_ = false;  // fp64 polynomial on the v2 kernel: X_ carries sqrt(gamma), the kernel sees gamma = 1

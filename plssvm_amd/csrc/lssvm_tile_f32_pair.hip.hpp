@@ -1,0 +1,373 @@
+/*
+ * lssvm_tile_f32_pair.hip.hpp -- the split tile kernels (f16x3 / bf16x6, lssvm_tile_f32_split.hip.hpp) with 256-ROW WORKGROUPS: eight waves, two
+ * per SIMD, share ONE column stream (round 4; symmetric variant, num_features <= 128, hand-scheduled MFMA groups).
+ *
+ * Why.  In the 128-row kernels every wave issues 4 LDS-DMA instructions per plane-chunk (16 per 128 x 128 tile at 128 features) and a CU's two
+ * independent workgroups each pull their own copy of the column stream through L2 -> LDS.  Round 3's ablations priced the LDS-DMA at ~10 % of the
+ * kernel and showed that nothing beside the MFMAs hides on the 16x16x32 shape, so what is left is fewer instructions and fewer bytes per MFMA:
+ *   * a work item is a PAIR of row blocks (2p, 2p + 1) = 256 rows x a chunk of column tiles; wave w owns rows 32 w .. 32 w + 31 exactly as
+ *     before (same row panel in registers, same accumulators, same MFMA groups: lssvm_s6w_groups.inc) -- per MFMA the LDS-DMA instructions,
+ *     the L2 -> LDS bytes, the barriers and the column-sum records all halve;
+ *   * the two waves of a SIMD now belong to ONE workgroup and would run in lock step (both in their epilogues at the same time, the matrix
+ *     pipe idle).  Waves 4-7 therefore run LAG plane-chunk steps BEHIND waves 0-3 (MI355X_MICROARCH.md, "Two waves per SIMD", item 9: split
+ *     the roles by wave >= 4): with an odd lag one half's epilogue always meets the other half's MFMA step.  One workgroup per CU leaves room
+ *     for a ring of EIGHT 16 KiB slots, which is what lets a slot stay alive for the lagging half while the DMA runs three steps ahead;
+ *   * the diagonal: column tile J against the pair's blocks b = 2p (waves 0-3) and b = 2p + 1 (waves 4-7): J < b row and mirrored column
+ *     sums, J == b row sums only (the diagonal tile is evaluated in full), J > b nothing (tile 2p + 1 for the first half: one 128 x 128
+ *     sub-tile of idle MFMAs per row pair, 1 / n_tiles of the work).  One record of 128 column sums per (pair, J): record (2p + 1, J) of the
+ *     packed triangle, summed over the contributing waves in a fixed order; k_reduce_colslab walks the odd row blocks only.
+ * Everything else -- LDS image and swizzle, LDS-DMA with SGPR bases, counted waits, hand-over in mid-step, folded rbf records, shifted
+ * rbf planes, epilogue, butterflies -- is s6w_body's, statement by statement.  Shard and band boundaries are even block indices
+ * (sym_block_boundary, band_edges), so a pair never straddles two devices or two bands; an odd number of row blocks ends in a pair whose
+ * second block is zero padding (its row sums are never read, its column sums are exact zeros).
+ * Reference shape this replaces: include/plssvm/backends/HIP/svm_kernel.hip.hpp:208-270 (16 x 16 threads, 6 x 6 register tile, atomicAdd).
+ */
+#pragma once
+
+#include "lssvm_tile_f32_split.hip.hpp"
+
+namespace lssvm {
+
+constexpr int PR_WAVES = 8;
+constexpr int PR_THREADS = 64 * PR_WAVES;
+constexpr int PR_ROWS = 2 * TILE;
+constexpr int PR_RING = 8;  // 16 KiB slots (power of two)
+constexpr size_t PR_LDS_BYTES = static_cast<size_t>(PR_RING) * V2_SLOT_BYTES + V2_DC_SLOTS * 1024 + (2 * PR_ROWS + 2 * PR_WAVES * TILE) * sizeof(float);  // ring + records + cis, dis, colred
+
+/* HALF: 0 = waves 0-3 (row block 2p), 1 = waves 4-7 (row block 2p + 1, LAGT steps behind).  Both halves execute the same number of barriers. */
+template <int KT, int NK64, int PL, int HALF, int LAGT>
+__device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
+    static_assert(PL == 3 || PL == 2, "three bf16 planes (bf16x6) or two f16 planes (f16x3)");
+    static_assert(NK64 <= 2, "the hand-scheduled groups assume the 256-register budget of two waves per SIMD");
+    static_assert(KT != KT_RBF, "rbf runs here with BOTH exponent terms folded (KT_RBFF, see below); the unfolded form stays on the 128-row kernels");
+    static_assert(LAGT >= 0 && LAGT <= 4, "the ring holds the DMA's three steps ahead, the step in use and up to four steps of lag");
+    constexpr bool F16 = PL == 2;
+    constexpr int NKC = PL * NK64;
+    constexpr int LAG = HALF ? LAGT : 0;  // this half's distance behind the global step counter
+    constexpr int PLA = F16 ? ((KT == KT_RBF || KT == KT_RBFF) ? 3 : 2) : 3;
+    constexpr auto row_plane = [](int p, int q) constexpr { return (F16 && PLA == 3) ? (p == 0 ? (q == 0 ? 2 : 1) : 0) : q; };
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char *ring = smem_raw;                                               // [PR_RING][128 columns][128 B]
+    char *dcs = smem_raw + PR_RING * V2_SLOT_BYTES;                      // [V2_DC_SLOTS][256 floats]
+    float *cis = reinterpret_cast<float *>(dcs + V2_DC_SLOTS * 1024);    // [256] c_i of the row pair (rbf)
+    float *dis = cis + PR_ROWS;                                          // [256] d_i of the row pair
+    float *colred = dis + PR_ROWS;                                       // [2][8 waves][128] column sums of a tile
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0 .. 7
+    const int r = lane & 15;
+    const int g = lane >> 4;
+
+    const int2 it = a.items[blockIdx.x];
+    const int ibl = __builtin_amdgcn_readfirstlane(it.x);  // local index of the pair's FIRST block (even)
+    const int jc = __builtin_amdgcn_readfirstlane(it.y);
+    const int ib0 = a.ib_begin + ibl;
+    const int my_ib = ib0 + HALF;
+    const int row0 = ib0 * TILE;
+    const int jt_begin = jc * a.jc_tiles;
+    const int jt_end = min(min(jt_begin + a.jc_tiles, ib0 + 2), a.num_jt);
+    const int ntiles = jt_end - jt_begin;
+    if (ntiles <= 0) return;
+    const int nsteps = ntiles * NKC;
+    const long rec0 = static_cast<long>(ib0 + 1) * ib0 / 2 - a.pair_origin;  // records of row block ib0 + 1
+
+    // ---- the row panel (this wave's 32 rows, all features, all row planes) ----
+    bf16x8 afrag[PLA][2 * NK64][2];
+#pragma unroll
+    for (int p = 0; p < PLA; ++p) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const uint16_t *xr = a.Xr16 + p * a.plane_stride_r + static_cast<size_t>(row0 + wave * 32 + 16 * rb + r) * a.ldx16 + 8 * g;
+#pragma unroll
+            for (int kk = 0; kk < 2 * NK64; ++kk) afrag[p][kk][rb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(xr + 32 * kk));
+        }
+    }
+    // rbf: K_ij = 2^c_i 2^(x_i . x_j) 2^c_j with BOTH exponent terms folded out of the chain -- the column's as the record's factor e_j (k_pack_dc:
+    // (e_j d_j | e_j), as in s6w_body), the row's as e_i = 2^c_i: the mirrored column sums take e_i d_i in place of d_i, the finished row sums are
+    // multiplied by e_i once per work item, and the accumulators start from the constant 0 like every other kernel's.  (s6w_body starts them from
+    // c_i, eight registers that live across the whole tile loop: with the row panel of three planes, the accumulators and the private B fragments
+    // this kernel has none to spare, and a spilled row-panel fragment is re-loaded in front of every MFMA group.)  The host chooses this kernel
+    // only while |c| <= PAIR_FOLD_MAX_C keeps e and the partial sums inside the fp32 range.
+    if constexpr (HALF == 0) {
+        if constexpr (KT == KT_RBFF) cis[tid] = __builtin_amdgcn_exp2f(a.cr[row0 + tid]);
+    } else {
+        const float dv = a.dvec[row0 + tid - PR_ROWS];
+        if constexpr (KT == KT_RBFF) {
+            dis[tid - PR_ROWS] = dv * __builtin_amdgcn_exp2f(a.cr[row0 + tid - PR_ROWS]);
+        } else {
+            dis[tid - PR_ROWS] = dv;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PLA; ++p)
+#pragma unroll
+        for (int kk = 0; kk < 2 * NK64; ++kk)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) asm volatile("" : "+v"(afrag[p][kk][rb]));
+
+    // ---- LDS-DMA addressing: a slot is 16 pieces of 8 columns x 128 B; wave w moves pieces 2 w and 2 w + 1 ----
+    unsigned dma_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 8 * (2 * wave + i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        dma_off[i] = 2u * static_cast<unsigned>(row * a.ldx16 + 8 * c);
+    }
+    const unsigned ring_lds = static_cast<unsigned>(reinterpret_cast<size_t>(ring));
+    const unsigned dma_lds = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(ring_lds + static_cast<unsigned>(wave) * 2048u)));
+    const unsigned dc_lds = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(ring_lds + PR_RING * V2_SLOT_BYTES + static_cast<unsigned>(wave & 3) * 256u)));
+    auto issue_chunk = [&](int step) {  // generic form (prologue, last tiles)
+        const int t = step / NKC;
+        const int kc = step - t * NKC;
+        const char *base = sgpr_ptr(a.Xc16 + (kc % PL) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (kc / PL) * 64);
+        const unsigned slot = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(dma_lds + static_cast<unsigned>(step & (PR_RING - 1)) * V2_SLOT_BYTES)));
+        static_for<0, 2>([&](auto i_c) { lds_dma16<decltype(i_c)::value * 1024>(dma_off[decltype(i_c)::value], base, slot); });
+    };
+    const size_t tile_bytes = static_cast<size_t>(TILE) * a.ldx16 * 2;
+    const size_t plane_bytes = a.plane_stride * 2;
+    const char *xc_tile = reinterpret_cast<const char *>(a.Xc16) + static_cast<size_t>(jt_begin) * tile_bytes;
+    auto issue_part_static = [&](auto kc3_c, unsigned slot_idx, auto i_c) {  // kc3 = kc + 3 + LAG of the issuing (own) step
+        constexpr int KC3 = decltype(kc3_c)::value;
+        constexpr int KC = KC3 % NKC;
+        constexpr int i = decltype(i_c)::value;
+        if (LSSVM_DBG(a, 16)) return;  // ablation: no LDS-DMA after the prologue
+        const char *base = xc_tile + (KC3 / NKC) * tile_bytes + (KC % PL) * plane_bytes + (KC / PL) * 128;
+        lds_dma16<i * 1024>(dma_off[i], sgpr_ptr(base), dma_lds + slot_idx * V2_SLOT_BYTES);
+    };
+    auto issue_dc = [&](int t) {  // the record of column tile t: by the second half (four waves x 256 B)
+        if constexpr (HALF == 1) {
+            if (lane < 16) {
+                const char *src = sgpr_ptr(a.dc + static_cast<size_t>(jt_begin + t) * 256) + __builtin_amdgcn_readfirstlane((wave & 3) * 256);
+                lds_dma16<0>(16u * (lane_off(threadIdx.x) & 15u), sgpr_ptr(src), static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(dc_lds + static_cast<unsigned>(t % V2_DC_SLOTS) * 1024u))));
+            }
+        }
+    };
+
+    int rd_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) rd_off[kk] = r * 128 + (((4 * kk + g) ^ ((r >> 1) & 7)) << 4);
+
+    float rowpart[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rowpart[i] = 0.0f;
+    f32x4 acc[2][8];
+    const f32x4 civ0[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };  // (operands of the group dispatcher that no group of this kernel reads)
+
+    // hand-over in the middle of GLOBAL step gs (runtime form): the chunk of step gs + 1 becomes visible, the DMA of step gs + 3 starts.  The waves
+    // have at most the two pieces of step gs + 2 younger than what they wait for.  EVERY wave passes exactly one barrier per global step.
+    auto handover_checked = [&](int gs) {
+        if (gs + 2 < nsteps) {
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (gs + 3 < nsteps) {
+            if ((gs + 3) % NKC == 0) issue_dc((gs + 3) / NKC);
+            issue_chunk(gs + 3);
+        }
+    };
+
+    // ---- prologue: chunks 0, 1, 2 ----
+    issue_dc(0);
+    issue_chunk(0);
+#pragma unroll
+    for (int pre = 1; pre <= 2; ++pre) {
+        if (pre < nsteps) {
+            if (pre % NKC == 0) issue_dc(pre / NKC);
+            issue_chunk(pre);
+        }
+    }
+    if (nsteps >= 3) {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    } else if (nsteps == 2) {
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // the lagging half lets LAG global steps pass (hand-overs only)
+#pragma unroll
+    for (int gs = 0; gs < LAG; ++gs) handover_checked(gs);
+
+    const unsigned rdl[2] = { ring_lds + static_cast<unsigned>(rd_off[0]), ring_lds + static_cast<unsigned>(rd_off[1]) };
+    s6w_fill_b0<0, 2048, 4096, 6144>(rdl[0]);
+
+    auto flush_cols = [&](int t) {  // by waves 4 and 5: the eight waves' sums of a column in a fixed order -> record (ib0 + 1, J)
+        if constexpr (HALF == 1) {
+            if (tid < PR_ROWS + TILE) {
+                const int col = tid - PR_ROWS;
+                const float *cr_ = colred + (t & 1) * (PR_WAVES * TILE);
+                const float s03 = (cr_[col] + cr_[128 + col]) + (cr_[256 + col] + cr_[384 + col]);
+                const float s47 = (cr_[512 + col] + cr_[640 + col]) + (cr_[768 + col] + cr_[896 + col]);
+                auto *rec = (__attribute__((address_space(1))) float *) const_cast<char *>(sgpr_ptr(a.colslab + (rec0 + jt_begin + t) * TILE));
+                rec[lane_off(static_cast<unsigned>(col))] = s03 + s47;
+            }
+        }
+    };
+
+    auto tile_body = [&](int t, auto checked) {
+        const int s0 = t * NKC;
+        const int J = jt_begin + t;
+        const unsigned phase = static_cast<unsigned>(s0) & (PR_RING - 1);
+        static_for<0, NKC>([&](auto kc_c) {
+            constexpr int kc = decltype(kc_c)::value;
+            constexpr int chunk = kc / PL, plane = kc % PL;
+            const int step = s0 + kc;
+            const unsigned slot_off = ((phase + kc) & (PR_RING - 1)) * V2_SLOT_BYTES;
+            const unsigned slot_next_off = ((phase + kc + 1) & (PR_RING - 1)) * V2_SLOT_BYTES;
+            static_for<0, 4>([&](auto mm_c) {
+                constexpr int mm = decltype(mm_c)::value;
+                constexpr int kk = mm >> 1, cbh = mm & 1;
+                constexpr int NQ = PL - plane;
+                constexpr int Z = (kc == 0 && kk == 0) ? 1 : 0;  // first MFMA of every accumulator of this column half: C = 0
+                constexpr int CUR = mm & 1;
+                if constexpr (mm == 2) {
+                    if constexpr (HALF == 1) {
+                        if (kc == 0 && t > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    if constexpr (!decltype(checked)::value) {
+                        if (!LSSVM_DBG(a, 16)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        if (!LSSVM_DBG(a, 8)) __builtin_amdgcn_s_barrier();  // ablation bit 8: no hand-over barrier in the steady state
+                        asm volatile("" ::: "memory");
+                        if constexpr ((kc + 3 + LAG) % NKC == 0) issue_dc(t + (kc + 3 + LAG) / NKC);
+                    } else {
+                        handover_checked(step + LAG);
+                    }
+                    if constexpr (HALF == 1) {
+                        if (kc == 0 && t > 0 && J - 1 < ib0 + 1) flush_cols(t - 1);
+                    }
+                }
+                constexpr int NKK = (mm + 1) >> 1, NH = (mm + 1) & 1;
+                const unsigned paddr = mm < 3 ? rdl[NKK & 1] + slot_off : rdl[0] + slot_next_off;
+                constexpr int PO = mm < 3 ? 4 * NH * 2048 : 0;
+                f32x4 &c0 = acc[0][4 * cbh + 0], &c1 = acc[1][4 * cbh + 0], &c2 = acc[0][4 * cbh + 1], &c3 = acc[1][4 * cbh + 1];
+                f32x4 &c4 = acc[0][4 * cbh + 2], &c5 = acc[1][4 * cbh + 2], &c6 = acc[0][4 * cbh + 3], &c7 = acc[1][4 * cbh + 3];
+                constexpr int P0 = row_plane(plane, 0), P1 = NQ >= 2 ? row_plane(plane, 1) : P0, P2 = NQ >= 3 ? row_plane(plane, 2) : P0;
+                const bf16x8 &a00 = afrag[P0][2 * chunk + kk][0], &a01 = afrag[P0][2 * chunk + kk][1];
+                const bf16x8 &a10 = afrag[P1][2 * chunk + kk][0], &a11 = afrag[P1][2 * chunk + kk][1];
+                const bf16x8 &a20 = afrag[P2][2 * chunk + kk][0], &a21 = afrag[P2][2 * chunk + kk][1];
+                s6_group<F16, NQ, CUR, 1, Z, PO, PO + 2048, PO + 4096, PO + 6144>(c0, c1, c2, c3, c4, c5, c6, c7, a00, a01, a10, a11, a20, a21, civ0[0], civ0[1], paddr);
+                // the wave's two pieces of the chunk three global steps ahead: one behind each group of the step's second half
+                if constexpr (!decltype(checked)::value && mm >= 2) {
+                    issue_part_static(std::integral_constant<int, kc + 3 + LAG>{}, (phase + kc + 3 + LAG) & (PR_RING - 1), std::integral_constant<int, mm - 2>{});
+                }
+                if constexpr (kc == NKC - 1 && mm == 3) {
+                    // wait states between the last MFMAs and the epilogue's vector instructions (see s6w_body)
+                    asm volatile("s_nop 15\n\ts_nop 3"
+                                 : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[0][4]), "+v"(acc[0][5]), "+v"(acc[0][6]), "+v"(acc[0][7]),
+                                   "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]), "+v"(acc[1][4]), "+v"(acc[1][5]), "+v"(acc[1][6]), "+v"(acc[1][7])
+                                 :
+                                 : "memory");
+                }
+            });
+        });
+        xc_tile += tile_bytes;
+        // ONE epilogue per tile loop, without a branch: the steady-state tiles lie strictly below the pair's first block (rows and mirrored
+        // columns for every wave); the last tiles of a work item (MASKED) switch a wave's row sums off above its diagonal and its column sums off
+        // on and above it with two factors in {0, 1} -- the wave then adds exact zeros (K is finite), and the first half's zeros for tile
+        // (2p + 1, 2p), which the second half does flush, need no code of their own.  (With several epilogue variants behind branches in one
+        // loop the register allocator spills row-panel fragments for the whole kernel, and a scratch reload drains the LDS-DMA queue.)
+        constexpr bool MASKED = decltype(checked)::value;
+        if (!LSSVM_DBG(a, 4)) {  // ablation bit 4: no epilogue
+            f32x4 di[2];
+            using f32x2 = float __attribute__((ext_vector_type(2)));
+            float colacc[8];
+            f32x2 colacc2[8] = {};
+            f32x2 kvp = { 0.f, 0.f };
+            const float rowmask = (MASKED && J > my_ib) ? 0.0f : 1.0f, colmask = (MASKED && J >= my_ib) ? 0.0f : 1.0f;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                di[rb] = *reinterpret_cast<const f32x4 *>(dis + wave * 32 + 16 * rb + 4 * g);
+                if constexpr (MASKED) di[rb] *= colmask;
+            }
+            const float *dcr = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                float djv = dcr[cb * 16 + r];
+                if constexpr (MASKED) djv *= rowmask;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float kv = apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(acc[rb][cb][e], a);
+                        rowpart[4 * rb + e] = fmaf(kv, djv, rowpart[4 * rb + e]);
+                        kvp[e & 1] = kv;
+                        if (e & 1) {
+                            const f32x2 dip = { di[rb][e - 1], di[rb][e] };
+                            colacc2[cb] = __builtin_elementwise_fma(kvp, dip, colacc2[cb]);
+                        }
+                    }
+            }
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) colacc[cb] = colacc2[cb][0] + colacc2[cb][1];
+            float *cw = colred + (t & 1) * (PR_WAVES * TILE) + wave * TILE;
+            column_sums_of_8_blocks(colacc);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float v = colacc[4 * h];
+                if constexpr (KT == KT_RBFF) v *= dcr[128 + 64 * h + lane];
+                if constexpr (KT == KT_LINEAR && F16) v *= a.out_scale;
+                cw[64 * h + lane] = v;
+            }
+        }
+    };
+
+    constexpr int TAIL_TILES = (3 + LAG + NKC - 1) / NKC;
+    // steady-state tiles: the DMA three steps ahead needs no bounds AND the tile is strictly below the diagonal for both halves (J < ib0), so that
+    // the loop carries exactly one epilogue (with both variants in it the register allocator spills the row panel around the epilogues, and a
+    // scratch reload in the loop drains the LDS-DMA queue)
+    const int nmain = max(0, min(ntiles - TAIL_TILES, ib0 - jt_begin));
+    int t = 0;
+    for (; t < nmain; ++t) tile_body(t, std::false_type{});
+    for (; t < ntiles; ++t) tile_body(t, std::true_type{});
+    // the leading half accompanies the lagging half's last LAGT steps (hand-overs only)
+    if constexpr (HALF == 0) {
+#pragma unroll
+        for (int k = 0; k < LAGT; ++k) handover_checked(nsteps + k);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (jt_begin + ntiles - 1 < ib0 + 1) flush_cols(ntiles - 1);
+
+    // every lane group owns its rows: reduce over the 16 columns of the group and store
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float v = rowpart[i];
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 1);
+        if constexpr (KT == KT_LINEAR && F16) v *= a.out_scale;
+        rowpart[i] = v;
+    }
+    if constexpr (KT == KT_RBFF) {  // the row's folded factor e_i
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const f32x4 ei = *reinterpret_cast<const f32x4 *>(cis + wave * 32 + 16 * rb + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rowpart[4 * rb + e] *= ei[e];
+        }
+    }
+    if (r == 0) {
+        float *dst = a.partial + static_cast<size_t>(jc) * a.part_stride + ibl * TILE + wave * 32 + 4 * g;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[16 * (i >> 2) + (i & 3)] = rowpart[i];
+    }
+}
+
+/* PL = 2: f16x3 ("f3d"), PL = 3: bf16x6 ("s6d").  LAGT: steps the second half runs behind (0 = lock step). */
+template <int KT, int NK64, int PL, int LAGT>
+__global__ __launch_bounds__(PR_THREADS, 2) LSSVM_HAND_VGPR_CAP void tile_matvec_f32_pair(const TileArgs<float> a) {
+    if (__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6) < 4) {  // (a scalar branch: the halves are whole waves)
+        pair_body<KT, NK64, PL, 0, LAGT>(a);
+    } else {
+        pair_body<KT, NK64, PL, 1, LAGT>(a);
+    }
+}
+
+}  // namespace lssvm

@@ -44,11 +44,11 @@ static unsigned finish_mapping(TileArgs<T> &a, int num_jc) {
 void launch_split_tile_kernel(const TileArgs<float> &a, int kernel_type, dim3 grid, hipStream_t s);
 /* fp32 "f16x3" split kernel (tile_launch_f32h.hip) */
 void launch_f16_tile_kernel(const TileArgs<float> &a, int kernel_type, dim3 grid, hipStream_t s);
+/* both split kernels with 256-row workgroups on block pairs (tile_launch_f32d.hip): symmetric variant, <= 128 features per pass */
+void launch_pair_tile_kernel(const TileArgs<float> &a, int kernel_type, hipStream_t s);
 /* rbf / polynomial on more features than a row panel in registers holds (tile_launch_f32x.hip): feature panels inside a tile */
 void launch_wide_tile_kernel(const TileArgs<float> &a, int kernel_type, dim3 grid, hipStream_t s);
 /* fp64 rbf / polynomial on more than 256 features (tile_launch_f64x.hip): feature panels of 64 inside a sub-tile */
 void launch_wide_tile_kernel_f64(const TileArgs<double> &a, int kernel_type, dim3 grid, hipStream_t s);
-/* the software-pipelined f16x3 kernel (tile_launch_f32p.hip): false if none exists for this launch */
-bool launch_f3p_tile_kernel(const TileArgs<float> &a, int kernel_type, hipStream_t s);
 
 }  // namespace lssvm

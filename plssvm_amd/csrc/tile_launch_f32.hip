@@ -33,7 +33,9 @@ void launch_tile_kernel<float>(TileArgs<float> &a, int kernel_type, bool rbf_dir
     if (grid.x == 0) return;
     constexpr size_t lds = static_cast<size_t>(4) * TILE * F32_LS * sizeof(float) + TILE * sizeof(float);  // staging ring + c_i of the row block
     if (a.dc != nullptr && a.Xc16 != nullptr) {  // the data exists as planes: two f16 planes (f16x3) or three bf16 planes (bf16x6)
-        if (a.wide_panels != 0) {
+        if (a.row_pair != 0) {
+            launch_pair_tile_kernel(a, kernel_type, s);
+        } else if (a.wide_panels != 0) {
             launch_wide_tile_kernel(a, kernel_type, grid, s);
         } else if (a.planes_f16 != 0) {
             launch_f16_tile_kernel(a, kernel_type, grid, s);

@@ -134,7 +134,6 @@ static void launch_f3(const TileArgs<float> &a, int kernel_type, dim3 grid, hipS
 }
 
 void launch_f16_tile_kernel(const TileArgs<float> &a, int kernel_type, dim3 grid, hipStream_t s) {
-    if (a.mfma_shape >= 3 && launch_f3p_tile_kernel(a, kernel_type, s)) return;  // software-pipelined, one wave per SIMD, where such a kernel exists
     if (a.items != nullptr) {
         launch_f3<true>(a, kernel_type, dim3(static_cast<unsigned>(a.num_items)), s);
     } else {

@@ -36,12 +36,13 @@ def row_block_partition(n: int, world: int):
 
 def sym_block_partition(n: int, world: int):
     """Symmetric variant (only the tiles on/below the diagonal are evaluated): row block ``ib`` costs ``ib + 1`` tiles, so the
-    blocks are dealt by equal AREA -- boundary of rank r = round(tiles * sqrt(r / world)) (``sym_block_boundary`` in
-    plssvm_amd/csrc/lssvm_problem.hip).  Returns ``[(block_begin, block_end), ...]``."""
+    blocks are dealt by equal AREA -- boundary of rank r = tiles * sqrt(r / world) rounded to an EVEN block index (the 256-row
+    workgroups of the tile kernel work on block pairs; ``sym_block_boundary`` in plssvm_amd/csrc/lssvm_problem.hip).
+    Returns ``[(block_begin, block_end), ...]``."""
     import math
 
     tiles = (n + TILE - 1) // TILE
-    bounds = [0] + [min(max(int(math.floor(tiles * math.sqrt(r / world) + 0.5)), 0), tiles) for r in range(1, world)] + [tiles]
+    bounds = [0] + [min(max(2 * int(math.floor(0.5 * tiles * math.sqrt(r / world) + 0.5)), 0), tiles) for r in range(1, world)] + [tiles]
     return [(bounds[r], bounds[r + 1]) for r in range(world)]
 
 

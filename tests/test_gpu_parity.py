@@ -1135,20 +1135,3 @@ def test_wide_rbf_and_polynomial_on_the_split_kernels(oracle, kernel, N, d, jct,
     assert ol.rel_inf(a_sym[:-1], a64[:-1]) < 2 * ol.rel_inf(a_full[:-1], a64[:-1]) + 1e-4
 
 
-@pytest.mark.parametrize("N, jct", [(129, 0), (385, 0), (1500, 0), (1500, 1), (1500, 5), (4097, 0)])
-def test_software_pipelined_kernel_is_bit_identical(N, jct):
-    """Option mfma_shape = 3: the one-wave-per-SIMD kernel whose epilogue of tile t - 1 is interleaved by a generator with the MFMAs of tile t
-    (lssvm_tile_f32_pipe.hip.hpp, gen_f3p.py; rbf, folded records, 65 ... 128 features, symmetric).  Same arithmetic in the same order as
-    the hand-scheduled two-waves-per-SIMD kernel (including the even-rows / odd-rows pairs of the mirrored column sums): the results must
-    be EQUAL, bit for bit, at every work-item shape (1 ... 5 tiles, items that end on the diagonal, odd and even tile counts)."""
-    d = 128
-    X, _ = make_blobs_pm1(N, d, seed=3, dtype=np.float32)
-    v = np.random.default_rng(1).uniform(-1, 1, N - 1).astype(np.float32)
-    out = {}
-    _capi.set_option("gram_mode", 2)
-    _capi.set_option("j_chunk_tiles", jct)
-    for shape in (2, 3):
-        _capi.set_option("mfma_shape", shape)
-        with backend.ResidentProblem(Parameter(kernel_type="rbf", gamma=1.0 / d), X) as prob:
-            out[shape] = prob.matvec(v, np.zeros(N - 1, np.float32), 1.0)
-    assert np.all(np.isfinite(out[3])) and np.array_equal(out[2], out[3])
