@@ -117,6 +117,7 @@ constexpr int MAX_LOCAL_DEVICES = 16;
 constexpr double FOLD_MAX_R2 = 200.0;    // folded rbf records (KT_RBFF) only while |c| = R2 / 2 <= 100: 2^c and 2^acc stay far inside the fp32 range
 constexpr double PAIR_FOLD_MAX_C = 32.0; // 256-row kernels, rbf: row AND column term folded (K = e_i 2^(x_i.x_j) e_j) only while |c| <= 32: the partial sums then carry at most 2^32 of
                                          // extra scale (rbf_direct_above = 32 keeps the automatic choice at |c| <= 16)
+constexpr int PAIR_MIN_TILES = 64;       // 256-row workgroups from this many row blocks on (a rule on the global shape: every rank decides alike)
 constexpr int SPLIT_MAX_FEATURES = 384;  // the bf16x6 kernels exist for 1 ... 6 chunks of 64 features (row panel = 3 planes in registers)
 constexpr int F16_MAX_FEATURES = 512;    // the f16x3 kernels exist for 1 ... 8 chunks of 64 features (row panel = 2 planes in registers)
 constexpr int F16_LINEAR_MAX_FEATURES = 1 << 20;
@@ -569,6 +570,42 @@ static std::vector<int2> band_items(int band_begin, int band_end, int jc_tiles, 
     return full;
 }
 
+/* Chunk length of the 256-row workgroups (block pairs) when the launch is SMALL: one workgroup per CU means 256 slots, and a problem of 20 000
+ * points has only ~6 000 pair-tiles -- whether the items come out as 0.9 or 1.6 or 8 rounds over the slots decides the launch time (measured at
+ * 20 000 x 128: 0.186 ms with 3-tile items, 0.144 with 16, 0.136 with 32; 10 000 points: 0.070 / 0.049 with 2 / 8 tiles;
+ * profiles/r04_chunk_sweep_pair.log).  The host therefore replays the hardware's dispatch (items in list order onto the slot that frees up
+ * first) for a handful of candidate lengths with the cost model  item = tiles + 2.6  (the work-item prologue and tail in tile units, fitted to
+ * that sweep) and takes the shortest makespan.  Large launches (more than 64 items per slot at the longest chunk) keep the longest chunk. */
+static int choose_pair_chunk(int ib_begin, int ib_end, int num_tiles, size_t real_size, const Options &o, int slots) {
+    const int cap = 64;
+    const long area = (static_cast<long>(ib_end) * (ib_end + 1) - static_cast<long>(ib_begin) * (ib_begin + 1)) / 4;  // pair-tiles, about
+    if (area / cap > 64L * slots) return cap;
+    const std::vector<int> edge = band_edges(ib_begin, ib_end, real_size, o);
+    double best = 0.0;
+    int best_jc = 0;
+    for (const int jc : { 2, 3, 4, 6, 8, 10, 12, 16, 20, 24, 32, 40, 48, 64 }) {
+        const int num_jc = (num_tiles + jc - 1) / jc;
+        double total = 0.0;
+        for (size_t k = 0; k + 1 < edge.size(); ++k) {
+            if (edge[k + 1] <= edge[k]) continue;
+            std::vector<double> slot(static_cast<size_t>(slots), 0.0);  // a min-heap of the slots' finish times
+            auto later = [](double x, double y) { return x > y; };
+            for (const int2 &it : band_items(edge[k], edge[k + 1], jc, num_jc, static_cast<int>(o.item_order), true)) {
+                const int tiles = std::min(std::min((it.y + 1) * jc, it.x + 2), num_tiles) - it.y * jc;
+                std::pop_heap(slot.begin(), slot.end(), later);
+                slot.back() += static_cast<double>(std::max(tiles, 0)) + 2.6;
+                std::push_heap(slot.begin(), slot.end(), later);
+            }
+            total += *std::max_element(slot.begin(), slot.end());
+        }
+        if (best_jc == 0 || total < best) {
+            best = total;
+            best_jc = jc;
+        }
+    }
+    return best_jc;
+}
+
 /* ------------------------------------------------------------------ Problem: one device's shard ------------------------------------------------------------------ */
 template <typename T>
 Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *X, int mem_kind, size_t num_points, size_t num_features, int device, int rank, int world) :
@@ -643,7 +680,8 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         const bool narrow = wide_linear_ ? opt_.linear_panel_features <= 128 : (round_up(static_cast<long>(num_features), 64) <= 128 && v2_eligible(opt_, ldx_probe, rbf_direct_));
         // (rbf: that kernel folds BOTH exponent terms out of the chain -- only while |c| = R2 / 2 stays small and the folded records are on)
         const bool rbf_ok = params_.kernel_type != LSSVM_KERNEL_RBF || (opt_.rbf_fold != 0 && rbf_r2_ <= 2.0 * PAIR_FOLD_MAX_C);
-        pair_ = sym_ && opt_.gram_mode != 0 && opt_.mfma_shape >= 3 && !wide_nl_ && !poly_generic && narrow && rbf_ok;
+        // (below 64 row blocks -- 8 192 points -- the 128-row workgroups have more items to spread over the chip: 3 000 points 13.8 against 19.7 us)
+        pair_ = sym_ && opt_.gram_mode != 0 && opt_.mfma_shape >= 3 && !wide_nl_ && !poly_generic && narrow && rbf_ok && num_tiles_ >= PAIR_MIN_TILES;
     }
     {
         int ib_end = 0;
@@ -664,6 +702,11 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
                            && round_up(static_cast<long>(num_features), 64) <= ((opt_.gram_mode == 1 || params_.kernel_type == LSSVM_KERNEL_RBF) ? SPLIT_MAX_FEATURES : F16_MAX_FEATURES);
         const long cap = split ? 64 : 16;
         jc_tiles_ = static_cast<int>(std::min<long>(cap, std::max<long>(2, (area + 2048) / 4096)));
+        if (pair_) {
+            int cus = 256;  // one such workgroup per CU
+            LSSVM_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_));
+            jc_tiles_ = choose_pair_chunk(ib_begin_, static_cast<int>(ib_end), num_tiles_, sizeof(T), opt_, std::max(cus, 1));
+        }
     }
     num_jc_ = (num_tiles_ + jc_tiles_ - 1) / jc_tiles_;
     if (const char *dbg = std::getenv("LSSVM_MI355_DEBUG"); dbg != nullptr && dbg[0] == '1') {

@@ -1,0 +1,21 @@
+"""A seeded, bounded slice of the randomised kernel cross-checks on every `pytest -m gpu` run: 40 cases of the
+resident-row-panel kernels, 12 + 12 of the panels-inside-a-tile kernels in fp32 / fp64 -- shapes, chunk lengths, bands, shards, plane kinds,
+group forms (incl. the 256-row workgroups), degrees, both real types, both variants -- each against the float64 product and the generic kernel
+(tests/cross_check.py).  The long runs stay developer tools (tests/tools/narrow_stress.py, wide_stress.py: same generator, other seeds).
+Reference counterpart: the kernel tests every backend runs in every build, /root/reference/tests/backends/generic_csvm_tests.hpp:372-493."""
+
+import pytest
+
+import cross_check
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20261003
+CASES = ([cross_check.narrow_case(SEED, i) for i in range(40)] + [cross_check.wide_case(SEED, i, False) for i in range(12)]
+         + [cross_check.wide_case(SEED, i, True) for i in range(12)])
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"{c['family']}-{i}" for i, c in enumerate(CASES)])
+def test_random_case_agrees_with_the_float64_product(case):
+    res = cross_check.run_case(case)
+    assert res["ok"], f"{cross_check.describe(case)} -> (gram mode, symmetric) ({res['gram_mode']}, {res['symmetric']}): {res['err']:.2f} eps from float64 (generic kernel: {res['err_generic']:.2f})"
