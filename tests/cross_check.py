@@ -25,12 +25,28 @@ def narrow_case(seed: int, index: int) -> dict:
     rng = np.random.default_rng([seed, index, 1])
     dtype = ("float32", "float64")[int(rng.integers(2))]
     kernel = ("rbf", "polynomial", "linear")[int(rng.integers(3))]
-    N = int(rng.choice([2, 3, 100, 128, 129, 130, 257, 258, 385, 640, 1000, 1537, 2500, 4100]))
+    # (from 8 193 points on the narrow symmetric fp32 cases run the 256-row workgroups on block pairs: odd and even numbers of row blocks)
+    N = int(rng.choice([2, 3, 100, 128, 129, 130, 257, 258, 385, 640, 1000, 1537, 2500, 4100, 8322, 9001, 12290]))
     d = int(rng.choice([1, 3, 16, 31, 64, 65, 100, 128, 129, 192, 200, 256, 257, 300, 384, 385, 448, 512]))
+    if N > 8192 and rng.integers(3):
+        d = int(rng.choice([16, 64, 65, 100, 128, 200, 256]))  # mostly where the pair kernels apply (<= 128 features; the linear kernel's panel passes beyond)
     opts = dict(gram_mode=int(rng.choice([3, 3, 1, 0, 2])), j_chunk_tiles=int(rng.choice([0, 0, 1, 2, 3, 7])), symmetric=int(rng.choice([1, 1, 0])),
                 colslab_band_mb=int(rng.choice([2048, 1])), item_order=int(rng.choice([0, 1, 2])), rbf_fold=int(rng.choice([1, 0])), mfma_shape=int(rng.choice([3, 3, 2, 1])))
     return dict(family="narrow", dtype=dtype, kernel=kernel, N=N, d=d, opts=opts, shards=int(rng.choice([1, 1, 2, 3, 8])), degree=int(rng.choice([0, 1, 2, 3, 4])),
                 gamma=float(rng.choice([1.0, 0.3])) / d, coef0=float(rng.choice([0.0, 1.0])), data_seed=300 + index, v_seed=int(rng.integers(1 << 30)))
+
+
+def pair_case(seed: int, index: int) -> dict:
+    """the 256-row workgroups on block pairs (lssvm_tile_f32_pair.hip.hpp): fp32, symmetric, at most 128 features per pass (the linear kernel's panel
+    passes beyond), from 64 row blocks on -- odd and even block counts, chunk lengths from one tile, bands, shards, both plane kinds"""
+    rng = np.random.default_rng([seed, index, 4])
+    kernel = ("rbf", "polynomial", "linear")[int(rng.integers(3))]
+    N = int(rng.integers(8194, 13000))
+    d = int(rng.choice([1, 17, 64, 65, 100, 128])) if kernel != "linear" or rng.integers(2) else int(rng.choice([129, 200, 256, 300]))
+    opts = dict(gram_mode=int(rng.choice([3, 3, 2, 1])), j_chunk_tiles=int(rng.choice([0, 0, 1, 2, 3, 5, 7])), symmetric=1, colslab_band_mb=int(rng.choice([2048, 1])),
+                item_order=int(rng.choice([0, 1, 2])), rbf_fold=1, mfma_shape=3)
+    return dict(family="pair", dtype="float32", kernel=kernel, N=N, d=d, opts=opts, shards=int(rng.choice([1, 1, 2, 3, 8])), degree=int(rng.choice([2, 3])),
+                gamma=float(rng.choice([1.0, 0.3])) / d, coef0=float(rng.choice([0.0, 1.0])), data_seed=500 + index, v_seed=int(rng.integers(1 << 30)))
 
 
 def wide_case(seed: int, index: int, f64: bool) -> dict:

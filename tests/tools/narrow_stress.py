@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """Long randomised cross-check of the resident-row-panel tile kernels (generator and yardstick: tests/cross_check.py; a seeded slice of it runs
-in `pytest -m gpu`).  usage: narrow_stress.py [cases] [seed]"""
+in `pytest -m gpu`).  usage: narrow_stress.py [cases] [seed] [pair]   (pair: the 256-row workgroups on block pairs only)"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.dirname(TESTS), TESTS]
 import cross_check  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+make_case = cross_check.pair_case if len(sys.argv) > 3 and sys.argv[3] == "pair" else cross_check.narrow_case
 worst, flags = 0.0, 0
 for i in range(cases):
-    case = cross_check.narrow_case(seed, i)
+    case = make_case(seed, i)
     res = cross_check.run_case(case)
     worst = max(worst, res["err"])
     flags += 0 if res["ok"] else 1

@@ -4,7 +4,8 @@
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.dirname(TESTS), TESTS]
 import cross_check  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
