@@ -184,10 +184,6 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
         }
     };
 
-    // (both outer loops stay ROLLED: the fp64 counterpart of this kernel went wrong in one instantiation when the optimiser peeled their first
-    // iterations -- lssvm_tile_f64_wide.hip.hpp; every instantiation here was right with the peeled loops too, the
-    // pragma is the same precaution at no measurable cost)
-#pragma clang loop unroll(disable)
     for (int t = 0; t < ntiles; ++t) {
         const bool tile_sym = SYM && (jt_begin + t < ib);  // strictly below the diagonal
         const float *dcr = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);
@@ -207,7 +203,6 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) acc[rb][cb] = civ0[rb];  // (zero for the polynomial kernels)
         }
-#pragma clang loop unroll(disable)
         for (int p = 0; p < panels; ++p) {
             // (the row panel of this tile-panel was requested chunk by chunk while the previous one was being multiplied: see below)
             const bool more_panels = t + 1 < ntiles || p + 1 < panels;

@@ -160,13 +160,6 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f64_wide(const Ti
         }
     };
 
-    // The two outer loops are kept as ROLLED loops: with the first iterations peeled off (what -O2 / -O3 do by themselves) the instantiation for
-    // a run-time polynomial degree returned wrong row sums -- the right ones plus a term identical in all four waves, i.e. column-side data in a
-    // register of the row sums -- deterministically, with or without the power loop, with SGPR spills in VGPR lanes or in scratch; -O1 and this
-    // pragma both give the right code, for that instantiation and (checked again: tests/tools/wide_stress.py) for all the others.  Whether the
-    // peeled copies trip the compiler's wait-count bookkeeping for the LDS reads that are carried across iterations, or an assumption of this
-    // file's inline asm, is not known.
-#pragma clang loop unroll(disable)
     for (int t = 0; t < nsub; ++t) {
         const double *dcr = reinterpret_cast<const double *>(dcs + (t % V2D_DC_SLOTS) * 1024);
         // start values of the chains: rbf c_i + c_j; polynomial coef0 (the data carries sqrt(gamma): the chain leaves gamma <x_i, x_j>)
@@ -190,7 +183,20 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f64_wide(const Ti
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[rb][cb][i] = a.coef0;
         }
-#pragma clang loop unroll(disable)  // (see above: no peeled copy of the panel loop either)
+        // The start values must live in the accumulators' OWN registers (C == D for every MFMA of the chain).  Left alone, the optimiser peels the first
+        // panel, folds a splat start value (coef0) into ONE register quad that serves as the C operand of the first MFMA of all eight accumulators,
+        // and -- the quad being dead behind the eighth -- loads the next k-step's B fragments into it right there:
+        //       v_mfma_f64_16x16x4_f64 v[2:9], v[88:89], v[156:157], v[66:73]
+        //       ds_read_b64 v[66:67], v195 offset:512  ...  ds_read_b64 v[72:73], v195 offset:6656
+        // On gfx950 a load into the last register pair of C within five wait states of a v_mfma_f64_16x16x4_f64 corrupts the last rows of C (59 % of the
+        // lanes at three wait states, none from six on: tests/tools/repro/dgemm_srcc_war.hip; the 16-bit MFMAs are not affected), and ROCm 7.2's
+        // hazard recognizer has no rule for it.  That was round 3's wrong instantiation (run-time integer power, symmetric variant: accumulator element
+        // [1][3][3] started from a B-fragment value instead of coef0), "fixed" then by keeping the loops rolled; DESIGN.md section 4.1 has the trail.
+        // tests/tools/audit_hand_asm.py now checks EVERY kernel of the build for a load into the C operand of an in-flight v_mfma_f64.
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) asm volatile("" : "+v"(acc[rb][cb]));
         for (int p = 0; p < panels; ++p) {
             const bool more_panels = t + 1 < nsub || p + 1 < panels;
             const int p_next = p + 1 < panels ? p + 1 : 0;  // (the row panel depends on the feature panel only, not on the sub-tile)

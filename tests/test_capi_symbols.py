@@ -121,3 +121,23 @@ def test_cpp_adaptor_factory_and_loud_failure_without_gpu():
         pytest.skip("covered by the -m gpu run of the full driver")
     out = subprocess.run([exe, "--no-gpu"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_generated_code_of_the_shipped_library_passes_the_audit():
+    """The library is linked only if tests/tools/audit_hand_asm.py passes on the ISA its objects were assembled from (plssvm_amd/csrc/Makefile keeps it
+    under lib/asm): compiler code must stay out of the hand-scheduled kernels' private registers and away from accumulators in flight, must not touch
+    M0 where inline asm owns it, and no load may write the C operand of an in-flight v_mfma_f64 (gfx950 hazard without a compiler rule,
+    tests/tools/repro/dgemm_srcc_war.hip).  Re-run here so that the check is part of every test run where the build tree is present."""
+    import glob
+    import subprocess
+    import sys
+
+    asm = sorted(glob.glob(os.path.join(ROOT, "plssvm_amd", "lib", "asm", "*.s")))
+    if not asm:
+        pytest.skip("no build tree here (the ISA dumps do not travel to the GPU box)")
+    lib = os.path.join(ROOT, "plssvm_amd", "lib", "libplssvm_amd.so")
+    assert all(os.path.getmtime(a) <= os.path.getmtime(lib) + 1 for a in asm), "lib/asm is newer than the library: run make"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "audit_hand_asm.py")] + asm, capture_output=True, text=True)
+    last = res.stdout.strip().splitlines()[-1]
+    assert res.returncode == 0 and last.endswith(" 0 broken"), res.stdout[-2000:]
+    assert int(last.split()[0]) >= 40, last  # the hand-scheduled instantiations were found at all
