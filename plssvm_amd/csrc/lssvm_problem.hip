@@ -337,13 +337,16 @@ void half_neg_norms(const DeviceMatrix<T> &M, DevBuf<T> &c, hipStream_t s) {
  *   bf16x6 (mode 1): three bf16 planes, exact for every fp32 input (8 exponent bits), twice the matrix-core work.
  * option gram_mode: 0 = none (native v_mfma_f32 kernels), 1 = bf16x6, 2 = f16x3 without the check (A/B, tests), 3 = f16x3 if the data passes, else bf16x6. */
 static void make_planes(const Options &o, const lssvm_params &p, bool rbf_direct, const DeviceMatrix<float> &M, const DeviceMatrix<float> *M2, PlaneSet &out, PlaneSet *out2,
-                        hipStream_t s, bool wide_nl = false) {
+                        hipStream_t s, bool wide_nl = false, bool linear_panels = false, bool f16_known_bad = false) {
     out.mode = 0;
     if (out2 != nullptr) out2->mode = 0;
     // (wide_nl: rbf / polynomial beyond the register-resident row panel -- the kernel walks feature panels of 128 inside a tile and exists for
     // both plane kinds, so neither feature limit below applies; planes padded to whole panels)
     const int ldx16 = static_cast<int>(round_up(static_cast<long>(M.dfeat), wide_nl ? 128 : 64));
-    const bool wide_linear = p.kernel_type == LSSVM_KERNEL_LINEAR && ldx16 > static_cast<int>(o.linear_panel_features) && o.tile_kernel != 1;  // feature panels (f16x3 only)
+    // linear_panels: the CALLER says whether the linear kernel's panel passes will run (symmetric variant, f16x3 only) -- the decision is not
+    // re-derived here (a full-square problem of more than 512 features got planes that nobody read).  f16_known_bad: an earlier call
+    // on the same data has already seen the representability check fail.
+    const bool wide_linear = linear_panels && p.kernel_type == LSSVM_KERNEL_LINEAR && ldx16 > static_cast<int>(o.linear_panel_features) && o.tile_kernel != 1;
     if (o.gram_mode == 0 || rbf_direct || (!v2_eligible(o, M.ldx, false) && !wide_linear && !wide_nl)) return;
     auto alloc = [&](int nplanes) {
         out.ldx16 = ldx16;
@@ -354,8 +357,8 @@ static void make_planes(const Options &o, const lssvm_params &p, bool rbf_direct
         }
     };
     const bool rbf = p.kernel_type == LSSVM_KERNEL_RBF;
-    const int f16_limit = rbf ? F16_RBF_MAX_FEATURES : (p.kernel_type == LSSVM_KERNEL_LINEAR ? F16_LINEAR_MAX_FEATURES : F16_MAX_FEATURES);
-    if ((o.gram_mode == 2 || o.gram_mode == 3) && (ldx16 <= f16_limit || wide_nl)) {
+    const int f16_limit = rbf ? F16_RBF_MAX_FEATURES : (wide_linear ? F16_LINEAR_MAX_FEATURES : F16_MAX_FEATURES);
+    if ((o.gram_mode == 2 || o.gram_mode == 3) && (ldx16 <= f16_limit || wide_nl) && !(f16_known_bad && o.gram_mode == 3)) {
         DevBuf<unsigned> stats;
         stats.alloc_zero(4, s);
         int shift = 0;
@@ -641,12 +644,15 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         // (option linear_panel_features, default 512: narrower panels also for problems the one-pass kernels could hold)
         if (params_.kernel_type == LSSVM_KERNEL_LINEAR && opt_.gram_mode >= 2 && opt_.tile_kernel != 1
             && round_up(static_cast<long>(num_features), 64) > static_cast<long>(opt_.linear_panel_features)) {
-            make_planes(opt_, params_, false, X_, nullptr, planes_, nullptr, st);
-            if (planes_.mode == 2 && opt_.symmetric != 0 && opt_.colslab_limit_mb != 0) {  // (the panel passes exist for the symmetric variant)
-                v2_ok = wide_linear_ = true;
-            } else {
-                planes_.buf.release();
-                planes_.mode = 0;
+            if (opt_.symmetric != 0 && opt_.colslab_limit_mb != 0) {  // (the panel passes exist for the symmetric variant: no probe, no planes otherwise)
+                make_planes(opt_, params_, false, X_, nullptr, planes_, nullptr, st, false, true);
+                if (planes_.mode == 2) {
+                    v2_ok = wide_linear_ = true;
+                } else {
+                    f16_probe_failed_ = true;  // (the planes of the one-pass kernels below do not repeat the split and the check)
+                    planes_.buf.release();
+                    planes_.mode = 0;
+                }
             }
         }
     }
@@ -760,7 +766,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     }
     if constexpr (std::is_same_v<T, float>) {
         // the (centred, scaled) data once more as operand planes of the split kernels (features in natural order): see make_planes
-        if (!wide_linear_) make_planes(opt_, params_, rbf_direct_, X_, nullptr, planes_, nullptr, st, wide_nl_);
+        if (!wide_linear_) make_planes(opt_, params_, rbf_direct_, X_, nullptr, planes_, nullptr, st, wide_nl_, false, f16_probe_failed_);
         if ((wide_nl_ || pair_) && planes_.mode == 0) throw Error(LSSVM_ERR_INTERNAL, "no operand planes for a path that was chosen from the shape alone");
         // rbf: folded records while the exponent terms stay small (rbf_r2_ = 2 max|c| in the exponent's unit)
         if (planes_.mode != 0) dc_folded_ = params_.kernel_type == LSSVM_KERNEL_RBF && opt_.rbf_fold != 0 && rbf_r2_ <= FOLD_MAX_R2;
@@ -797,7 +803,9 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         colslab_.alloc_zero(static_cast<size_t>(max_records) * TILE, st);
         LSSVM_HIP_CHECK(hipStreamSynchronize(st));  // `items` goes out of scope
     }
-    events_.resize(4 * std::max<size_t>(bands_.size(), 1));
+    // (two matvecs can be in flight -- enqueue-ahead -- and each issues bands x feature-panel passes tile launches: ADVICE r03, the later panels of a wide
+    // linear problem went untimed and the reported kernel time came out too low)
+    events_.resize(4 * std::max<size_t>(bands_.size(), 1) * static_cast<size_t>(std::max(passes_per_matvec(), 1)));
     for (EvPair &e : events_) {
         e.a.create(true);
         e.b.create(true);
@@ -1360,10 +1368,11 @@ void Solver<T>::cg_step(uint64_t iterations, int *done_out) {
         // turns out to have converged is exactly where the reference stops (csvm.cpp:155-158), at the price of one discarded matvec.
         // The decision must be the same on every rank of a sharded solve (a rank that went ahead has one more collective in its queue than
         // one that did not: a hang at convergence, or every later collective paired one position off), so it is derived from the problem
-        // alone -- size, feature count, world -- never from this rank's own event timings: an implicit matvec is priced at 500 TFLOP/s of
-        // full-square work per device (the fp32 split kernels; slower paths then go ahead for somewhat longer matvecs, which is harmless).
+        // alone -- size, feature count, real type, kernel path, world -- never from this rank's own event timings: an implicit matvec is priced at
+        // the full-square rate of its path (one flat 500 TFLOP/s let the fp64 and generic kernels go ahead for matvecs ten times longer
+        // than the option says, each converged solve then paying one discarded matvec of that length).  Every input is the same on all ranks.
         const double n_d = static_cast<double>(p0.n_);
-        const double matvec_us = 2.0 * n_d * n_d * static_cast<double>(p0.X_.dfeat) / static_cast<double>(world_) / 500e12 * 1e6;
+        const double matvec_us = 2.0 * n_d * n_d * static_cast<double>(p0.X_.dfeat) / static_cast<double>(world_) / p0.nominal_full_square_rate() * 1e6;
         const bool ahead = opt_.enqueue_ahead_below_us > 0 && matvec_us < static_cast<double>(opt_.enqueue_ahead_below_us) && k + 1 < iterations
                            && exchange_ != Exchange::process_peer;
         if (ahead) {
@@ -1453,7 +1462,7 @@ void Solver<T>::fill_info(lssvm_cg_info *info) {
     info->devices_used = world_;
     info->converged = converged_ ? 1 : 0;
     info->symmetric = p0.sym_ ? 1 : 0;
-    info->gram_mode = p0.planes_.mode;
+    info->gram_mode = (p0.planes_.mode != 0 && p0.dc_.p != nullptr) ? p0.planes_.mode : 0;  // (a split kernel is dispatched only where both exist)
     info->local_devices = static_cast<int32_t>(shards_.size());
     info->rbf_direct = p0.rbf_direct_ ? 1 : 0;
     info->rbf_exponent_scale = p0.rbf_r2_;

@@ -272,6 +272,22 @@ class Problem {
         }
     }
 
+    /* full-square-equivalent rate (flop/s, 2 n^2 d per matvec) this shard's kernel path is expected to sustain -- a rule on the shape, the real type and
+     * the options only (never a measurement: every rank of a sharded solve must come to the same number).  Round numbers from profiles/r03 / r04:
+     * fp32 split kernels in the symmetric variant ~900 T (c5: 930, c3: 1 000), full square half of that; native fp32 v2 ~250 T (sym) / 125 T; panels
+     * inside a tile ~250 T; generic fp32 / direct rbf ~45 T; fp64 v2 ~130 T (sym, c4: 134) / 65 T; fp64 panels ~110 T; generic fp64 ~45 T. */
+    double nominal_full_square_rate() const {
+        const double sym = sym_ ? 1.0 : 0.5;
+        if constexpr (std::is_same_v<T, float>) {
+            if (rbf_direct_) return 45e12;
+            if (planes_.mode != 0 && dc_.p != nullptr) return (wide_nl_ ? 250e12 : 900e12) * sym;
+            return dc_.p != nullptr ? 250e12 * sym : 45e12;
+        } else {
+            if (wide_nl_) return 110e12 * sym;
+            return dc_.p != nullptr ? 130e12 * sym : 45e12;
+        }
+    }
+
   private:
     friend class Solver<T>;
     TileArgs<T> tile_args(const T *v_dev) const;
@@ -293,6 +309,7 @@ class Problem {
     bool dc_folded_ = false;  // the (d_j | c_j) records carry (2^c_j d_j | 2^c_j): rbf on the 16x16x32 bf16x6 kernels
     bool pair_ = false;            // fp32 symmetric variant on the split kernels, <= 128 features per pass: 256-row workgroups on block pairs (lssvm_tile_f32_pair.hip.hpp)
     int part_blocks() const { return pair_ ? round_up(std::max(num_ib_, 1), 2) : std::max(num_ib_, 1); }  // row blocks of a row slab (whole pairs)
+    bool f16_probe_failed_ = false;  // the probe for the linear kernel's panel passes found the data unfit for two f16 planes
     bool wide_nl_ = false;         // fp32 rbf / polynomial on more features than the one-pass split kernels take: feature panels inside a tile (lssvm_tile_f32_wide.hip.hpp)
     bool wide_linear_ = false;     // linear kernel over feature panels, one tile-kernel pass per panel: fp32 f16x3 beyond linear_panel_features, fp64 beyond 256 features
     bool poly_prescaled_ = false;  // fp64 polynomial on the v2 kernel: X_ carries sqrt(gamma), the kernel sees gamma = 1

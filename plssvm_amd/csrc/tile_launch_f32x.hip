@@ -53,6 +53,7 @@ void launch_wide_tile_kernel(const TileArgs<float> &a, int kernel_type, dim3 gri
     } else {
         launch_wide<false>(a, kernel_type, grid, s);
     }
+    LSSVM_HIP_CHECK(hipGetLastError());  // (a failed launch surfaces HERE, not at an unrelated later call)
 }
 
 }  // namespace lssvm

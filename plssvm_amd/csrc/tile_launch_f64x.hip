@@ -8,6 +8,8 @@
 
 namespace lssvm {
 
+static_assert(V2D_LDS_BYTES <= 64 * 1024, "the launches below do not opt into more dynamic LDS than the default limit");
+
 template <bool SYM>
 static void launch_wide_f64(const TileArgs<double> &a, int kernel_type, dim3 grid, hipStream_t s) {
     const dim3 block(TILE_THREADS);
@@ -35,6 +37,7 @@ void launch_wide_tile_kernel_f64(const TileArgs<double> &a, int kernel_type, dim
     } else {
         launch_wide_f64<false>(a, kernel_type, grid, s);
     }
+    LSSVM_HIP_CHECK(hipGetLastError());  // (a failed launch surfaces HERE, not at an unrelated later call)
 }
 
 }  // namespace lssvm

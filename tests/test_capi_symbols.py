@@ -141,3 +141,20 @@ def test_generated_code_of_the_shipped_library_passes_the_audit():
     last = res.stdout.strip().splitlines()[-1]
     assert res.returncode == 0 and last.endswith(" 0 broken"), res.stdout[-2000:]
     assert int(last.split()[0]) >= 40, last  # the hand-scheduled instantiations were found at all
+
+
+@pytest.mark.parametrize("exe_name, args", [("test_reader_sanitized", []), ("test_csvm_sanitized", ["--no-gpu"])])
+def test_host_side_under_address_and_undefined_behaviour_sanitizers(exe_name, args):
+    """CPU build only (GPU sanitizers are not available on this pool): the native LIBSVM reader on the shapes of the reference's
+    invalid fixtures, every truncation and single-byte corruption of a valid file, overflowing indices, CR / CRLF, NUL bytes ... and the host side of
+    the C++ adaptor (factory, named parameters, exceptions), both compiled with -fsanitize=address,undefined -fno-sanitize-recover.  The reader must
+    refuse what is not well formed without ever touching memory it does not own (/root/reference/include/plssvm/detail/io/libsvm_parsing.hpp:118-229
+    is the rule book; the reference-exact diagnosis stays with plssvm_amd/io_libsvm.py)."""
+    exe = os.path.join(ROOT, "tests", "cpp", exe_name)
+    if not os.path.isfile(exe):
+        subprocess.run(["make", "-C", os.path.dirname(exe), exe_name], check=True, capture_output=True)
+    if exe_name == "test_csvm_sanitized" and has_gpu:
+        pytest.skip("the --no-gpu subset is for boxes without a device")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")  # (leak checking: the HIP runtime's own start-up allocations)
+    out = subprocess.run([exe] + args, capture_output=True, text=True, env=env)
+    assert out.returncode == 0 and "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stdout[-1500:] + out.stderr[-3000:]

@@ -829,6 +829,32 @@ def test_bf16_split_gram_mode_is_fp32_accurate(oracle, kernel, N, d, sym):
     assert np.all(np.isfinite(out[("a", 1)])) and np.all(np.isfinite(out[("a", 2)]))
 
 
+@pytest.mark.parametrize("mode", [3, 2, 1])
+@pytest.mark.parametrize("sym", [1, 0])
+def test_linear_kernel_beyond_512_features_reports_the_kernel_that_ran(sym, mode):
+    """the linear kernel on more than 512 features runs the f16x3 panel passes in the SYMMETRIC variant only; the full-square variant (and
+    bf16x6) stays on the generic native kernel -- and must then neither build planes nobody reads nor report a split Gram mode (bench.py prices
+    `achieved` by it).  Results against the float64 product either way."""
+    N, d = 700, 600
+    X, _ = make_blobs_pm1(N, d, seed=31, dtype=np.float32)
+    v = np.random.default_rng(2).uniform(-1, 1, N - 1).astype(np.float32)
+    _capi.set_option("symmetric", sym)
+    _capi.set_option("gram_mode", mode)
+    with backend.ResidentProblem(Parameter(kernel_type="linear"), X) as prob:
+        info = prob.info()
+        q, QA = prob.q()
+        got = prob.matvec(v, np.zeros(N - 1, np.float32), 1.0).astype(np.float64)
+    assert info["symmetric"] == sym
+    assert info["gram_mode"] == (2 if sym == 1 and mode >= 2 else 0)
+    X64, v64 = X.astype(np.float64), v.astype(np.float64)
+    K = X64[:-1] @ X64[:-1].T
+    S = float(v64.sum())
+    q64 = X64[:-1] @ X64[-1]
+    truth = K @ v64 + v64 + ((float(X64[-1] @ X64[-1]) + 1.0) * S - float(q64 @ v64)) - S * q64
+    scale = np.abs(K) @ np.abs(v64) + np.abs(v64) + abs(QA * S) + abs(float(q64 @ v64)) + np.abs(S * q64)
+    assert np.max(np.abs(got - truth) / scale) < 16 * np.finfo(np.float32).eps
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_f16_planes_prescale_check_and_fallback(oracle, kernel):
     """The default Gram mode (3) decides ON THE DATA whether two f16 planes represent it as well as fp32 does (make_planes in
