@@ -829,6 +829,74 @@ def test_bf16_split_gram_mode_is_fp32_accurate(oracle, kernel, N, d, sym):
     assert np.all(np.isfinite(out[("a", 1)])) and np.all(np.isfinite(out[("a", 2)]))
 
 
+def _f16x2_row_statistic(X, shift):
+    """k_split_f16x2 (tile_launch_f32h.hip) in numpy for the pre-scaled planes of the linear / polynomial kernels: max over the rows of
+    |y - hi - mid|_2 / |y|_2 with y = 2^shift x, hi = f16(y), mid = f16(y - hi) (numpy's float16 conversion rounds to nearest even like v_cvt_f16_f32)."""
+    y = X.astype(np.float32) * np.float32(2.0 ** shift)
+    hi = y.astype(np.float16).astype(np.float32)
+    r1 = y - hi
+    r2 = r1 - r1.astype(np.float16).astype(np.float32)
+    sr, sx = np.sum(r2.astype(np.float64) ** 2, axis=1), np.sum(y.astype(np.float64) ** 2, axis=1)
+    return float(np.sqrt(np.max(sr[sx > 0] / sx[sx > 0])))
+
+
+def _data_at_the_f16_acceptance_edge(N, d, log2_target, seed):
+    """[-1, 1] data whose largest entry fixes the pre-scale (2^14 <= 2^k max|x| < 2^15) plus 64 rows of SMALL entries, s * (+-[0.5, 1]): their mid
+    plane is subnormal in f16 (absolute error ~2^-25 in the scaled domain), so their relative representation error grows as s shrinks -- s is
+    searched on a fine grid for the statistic closest to 2^log2_target."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1.0, 1.0, size=(N, d)).astype(np.float32)
+    X[0, 0] = 1.0
+    shift = 14  # ilogb(1.0) = 0
+    small = np.arange(N) % (N // 64) == 1
+    U = (rng.uniform(0.5, 1.0, size=(int(small.sum()), d)) * rng.choice([-1.0, 1.0], size=(int(small.sum()), d))).astype(np.float32)
+    best = None
+    for e in np.arange(-21.0, -14.0, 1.0 / 64):
+        X[small] = (U * np.float32(2.0 ** e)).astype(np.float32)
+        st = np.log2(_f16x2_row_statistic(X, shift))
+        if best is None or abs(st - log2_target) < abs(best[0] - log2_target):
+            best = (st, e)
+    X[small] = (U * np.float32(2.0 ** best[1])).astype(np.float32)
+    return X, small, np.log2(_f16x2_row_statistic(X, shift))
+
+
+@pytest.mark.parametrize("sym", [1, 0])
+@pytest.mark.parametrize("kernel", ["linear", "polynomial"])
+@pytest.mark.parametrize("N, d", [(1500, 96), (9000, 128)])
+def test_f16x3_at_its_acceptance_edge(kernel, N, d, sym):
+    """make_planes accepts two f16 planes while the largest relative representation error of a row stays <= 2^-22
+    (F16_REL2_MAX, lssvm_problem.hip), and every test so far sat at 2^-24.5.  Data constructed to land at 2^-22.1 (must be accepted and run f16x3)
+    and at 2^-21.9 (must be rejected and run bf16x6): on BOTH sides every row of A v stays within 16 eps of the float64 product on the scale of that
+    row's own summands -- the rows made of the small entries included, whose right-hand side is 1 on the small points only, so that they sum
+    small x small products and show what their planes are worth -- symmetric (9 000 points: the 256-row workgroups) and full-square variant.
+    Just beyond the edge the forced f16x3 kernel (gram_mode = 2) is still inside the bar: the threshold errs on the safe side."""
+    eps = np.finfo(np.float32).eps
+    for log2_target, want_mode in ((-22.1, 2), (-21.9, 1)):
+        X, small, got_stat = _data_at_the_f16_acceptance_edge(N, d, log2_target, seed=17)
+        assert abs(got_stat - log2_target) < 0.05, got_stat
+        rhs = np.where(small[:N - 1], 1.0, 0.0).astype(np.float32) * np.random.default_rng(3).uniform(0.5, 1.0, N - 1).astype(np.float32)
+        gamma = 1.0 / d
+        p = Parameter(kernel_type=kernel, degree=3, gamma=gamma, coef0=0.0)
+        X64, v64 = X.astype(np.float64)[:N - 1], rhs.astype(np.float64)
+        G = X64 @ X64.T
+        K = G if kernel == "linear" else (gamma * G) ** 3
+        for mode in ((3, 2) if want_mode == 1 else (3,)):
+            _capi.set_option("symmetric", sym)
+            _capi.set_option("gram_mode", mode)
+            with backend.ResidentProblem(p, X) as prob:
+                used = prob.info()["gram_mode"]
+                q, QA = prob.q()
+                got = prob.matvec(rhs, np.zeros(N - 1, np.float32), 1.0).astype(np.float64)
+            assert used == (want_mode if mode == 3 else 2), (log2_target, mode, used)
+            q64 = q.astype(np.float64)
+            S, qv = float(v64.sum()), float(q64 @ v64)
+            truth = K @ v64 + v64 + (float(QA) * S - qv) - S * q64
+            scale = np.abs(K) @ np.abs(v64) + np.abs(v64) + abs(float(QA) * S) + abs(qv) + np.abs(S * q64)
+            err = np.abs(got - truth) / scale / eps
+            print(f"\n{kernel} {N} x {d} sym {sym}: statistic 2^{got_stat:.2f}, gram_mode {mode} -> ran {used}: worst row {err.max():.2f} eps (rows of the small points: {err[small[:N - 1]].max():.2f})")
+            assert err.max() < 16.0, (log2_target, mode, float(err.max()))
+
+
 @pytest.mark.parametrize("mode", [3, 2, 1])
 @pytest.mark.parametrize("sym", [1, 0])
 def test_linear_kernel_beyond_512_features_reports_the_kernel_that_ran(sym, mode):

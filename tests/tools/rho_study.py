@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool (not a test): is the fp32 rho of the bf16x6 Gram mode systematically worse than that of the native v_mfma_f32 mode?
+"""Developer tool (not a test): is the fp32 rho of a split Gram mode (f16x3, the default; bf16x6) systematically worse than that of the native v_mfma_f32 mode?
 (16384 x 128 linear, eps 1e-6: |rho - rho64| / |rho64| = 6.9 for bf16x6, 0.31 native, 1.28 for the reference.)
 
 For several seeds: fp32 CG to eps on N x d data with both Gram modes and -- optionally -- the reference's OpenMP kernels, each against the
@@ -42,11 +42,11 @@ for kernel in ("linear", "rbf"):
         QA = (float(X64[-1] @ X64[-1]) if kernel == "linear" else 1.0) + 1.0
         scale = np.finfo(np.float32).eps * (abs(QA) * np.abs(a64[:-1]).sum() + np.abs(q * a64[:-1]).sum())
         line = f"{kernel:6s} {N}x{d} seed {seed}: fp64 {i64['iterations']:3d} its rho64 {float(r64):+.4e}  scale {scale:.2e} |"
-        for mode, name in ((1, "bf16x6"), (0, "native")):
+        for mode, name in ((3, "f16x3"), (1, "bf16x6"), (0, "native")):
             _capi.set_option("gram_mode", mode)
             a, r, info = backend.solve_system_of_linear_equations(p, X32, y32, eps, 400)
             line += f" {name}: its {info['iterations']:3d} alpha {rel_inf(a, a64):.2e} |drho| {abs(float(r) - float(r64)):.2e} |"
-        _capi.set_option("gram_mode", 1)
+        _capi.set_option("gram_mode", 3)
         if with_ref and oracle_lib.have_ref():
             a, r, info = oracle_lib.ref().solve(kernel, X32, y32, eps, 400, gamma=1.0 / d, degree=3, coef0=0.0, cost=1.0)
             line += f" reference fp32: its {int(info['iterations']):3d} alpha {rel_inf(a, a64):.2e} |drho| {abs(float(r) - float(r64)):.2e}"
