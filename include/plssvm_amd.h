@@ -243,26 +243,26 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
 
 /* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT).  set_option changes the process-wide DEFAULTS;
  * every problem / solve takes a snapshot of them when it is created, so later changes never affect a live problem.  The defaults can
- * be preset from the environment: LSSVM_MI355_OPTIONS="name=value,name=value" (read once when the library is loaded):
+ * be preset from the environment: LSSVM_MI355_OPTIONS="name=value,name=value" (read once when the library is loaded).  Twelve options here, two
+ * testing aids in plssvm_amd_testing.h -- who sets each besides the tests: DESIGN.md section 4.5 (round 4 retired xcd_map, lds_extra_kb, item_order,
+ * linear_panel_features, check_shards, rbf_direct_above and mfma_shape = 1: measured, decided, constants now):
  *   "rbf_form"      fp32 rbf: 0 = automatic (default): the norm expansion c_i + c_j + x_i'.x_j' on the matrix cores, unless
- *                   R2 = 2 gamma log2(e) max|x - mean|^2 exceeds "rbf_direct_above" -- the expansion's exponent carries an absolute error of
- *                   ~2^-24 R2 whatever the distance of the pair, which nearby pairs (K ~ 1) see as a relative error of K; then, and with
+ *                   R2 = 2 gamma log2(e) max|x - mean|^2 exceeds 32 -- the expansion's exponent carries an absolute error of
+ *                   ~2^-24 R2 whatever the distance of the pair, which nearby pairs (K ~ 1) see as a relative error of K
+ *                   ([-1,1]-scaled data with gamma = 1 / num_features has R2 <= 3); then, and with
  *                   1 = always, the formula-exact (x_i - x_j)^2 kernel on the vector ALU runs (5x slower); 2 = always the matrix cores
- *   "rbf_fold"      fp32 rbf on the 16x16x32 bf16x6 kernels: 1 (default) = the column records carry (2^c_j d_j | 2^c_j) and the accumulators start
- *                   from c_i as the C operand of their first MFMA -- no start-value instructions, K_ij = 2^acc 2^c_j (one more rounding than
- *                   2^(acc + c_j); used while the exponent scale R2 <= 200 keeps both factors far inside the fp32 range); 0 = start values c_i + c_j
- *   "rbf_direct_above" threshold of rbf_form 0 (default 32: [-1,1]-scaled data with gamma = 1 / num_features has R2 <= 3)
+ *   "rbf_fold"      fp32 rbf on the split kernels: 1 (default) = the column records carry (2^c_j d_j | 2^c_j) and the accumulators start
+ *                   from c_i as the C operand of their first MFMA (256-row workgroups: from 0, the row's term folded too) -- no start-value
+ *                   instructions, K_ij = 2^acc 2^c_j (one more rounding than 2^(acc + c_j); used while the exponent scale R2 <= 200 keeps both factors
+ *                   far inside the fp32 range); 0 = start values c_i + c_j
  *   "j_chunk_tiles" number of 128-column tiles per work item; 0 = automatic (default: about 4096 work items per device, 2 ... 16 tiles each,
- *                   up to 64 for the split kernels)
+ *                   up to 64 for the split kernels; 256-row workgroups: the length whose replayed dispatch over the CUs finishes first)
  *   "symmetric"     1 = evaluate only the kernel-matrix tiles on/below the diagonal and mirror them (default; any num_features -- beyond 512 (fp32) /
  *                   256 (fp64) features over feature panels -- except fp32 with gram_mode = 0 beyond 512 features and a negative polynomial
  *                   degree, which run the full square),
  *                   0 = full square (row-owned sums, results independent of the GPU count)
  *   "tile_kernel"   0 = automatic: the "resident row panel" kernels for num_features <= 512 (fp32) / 256 (fp64) and their feature-panel forms beyond
  *                   (default), 1 = always the generic kernel
- *   "xcd_map"       1 = XCD-aware block -> work item mapping (8 x 8 super-tiles per XCD), 0 = linear (default)
- *   "item_order"    symmetric variant: 0 = work items in column-chunk major order, 1 = the same with the short items that end on the
- *                   diagonal moved to the end, longest first (default: shortens the last dispatch round), 2 = 1 with row blocks descending
  *   "gram_mode"     fp32 Gram tiles on the 16-bit matrix cores with fp32 accumulation, at fp32-equivalent accuracy:
  *                   3 (default) = "f16x3" where the data allows, else "bf16x6"; 2 = "f16x3": every operand as TWO f16 planes (hi + mid; rbf: shifted by
  *                   2^-6 / 2^6, others pre-scaled by a power of two), three plane products on v_mfma_f32_16x16x32_f16; num_features <= 512 (rbf 384)
@@ -271,10 +271,10 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *                   1 = "bf16x6": exact split into THREE bf16 planes, six plane products on v_mfma_f32_16x16x32_bf16, num_features <= 384 in one
  *                   pass (rbf / polynomial beyond that: feature panels inside a tile);
  *                   0 = Gram tiles on v_mfma_f32_32x32x2_f32 (exact fmaf chains)
- *   "mfma_shape"    split kernels: 1 = MFMA groups scheduled by the compiler, 2 (default) = hand-scheduled MFMA groups (B fragments in registers the
- *                   compiler does not own) for num_features <= 128, 3 = 2 plus the software-pipelined one-wave-per-SIMD kernel where it exists
- *                   (f16x3 rbf, 65 ... 128 features, symmetric: bit-identical results, measured slower: DESIGN.md section 4.1)
- *   "colslab_band_mb" the symmetric variant leaves one record of 128 column sums per evaluated off-diagonal tile; the device's row blocks are
+ *   "mfma_shape"    split kernels, symmetric variant, at most 128 features per pass: 3 (default) = 256-row workgroups -- eight waves on a pair of row
+ *                   blocks share one column stream per CU -- from 64 row blocks (8 192 points) on; 2 = 128-row workgroups (four waves) throughout
+ *   "colslab_band_mb" the symmetric variant leaves one record of 128 column sums per evaluated off-diagonal tile (256-row workgroups: per pair of row
+ *                   blocks and column tile); the device's row blocks are
  *                   cut into bands of equal area whose records fit this many MiB (default 2048), the tile kernel runs band by band into one
  *                   slab and every band is folded into K*v before the next (1M points in fp32: 15.6 GB of records -> 8 bands, 2 GiB)
  *   "colslab_limit_mb" upper bound of the band slab (default 98304); 0 switches the symmetric variant off (full square)
@@ -283,15 +283,12 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *                   devices through its xGMI peer mappings in rank order (bit-equal on all devices, deterministic).
  *                   One process per GPU (lssvm_shard): 0 = RCCL when lssvm_mi355_comm_init was called in this process, else HIP IPC;
  *                   1 = RCCL; 2 = HIP IPC + the peer kernel (lssvm_mi355_problem_ipc_export / _connect)
- *   "linear_panel_features" fp32 linear kernel on the f16x3 kernels: K = sum over feature panels of X_p X_p^T, one pass of the tile kernel per panel of this
- *                   many features (multiple of 64, at most 512; default 128: two waves per SIMD and hand-scheduled groups in every pass), any width;
- *                   fp64 linear kernel beyond 256 features: one pass of the fp64 kernel per panel of 128 features (64 if this option is 64)
  *   "ipc_timeout_s" one process per GPU over HIP IPC: seconds a rank waits for its peers at an exchange before it fails (default 600)
- *   "enqueue_ahead_below_us" CG loop: while an implicit matvec takes less than this many microseconds (default 5000), the direction update and
+ *   "enqueue_ahead_below_us" CG loop: while an implicit matvec is expected to take less than this many microseconds (default 5000; the expectation is a rule
+ *                   on the shape, the real type and the kernel path -- never a measurement, every rank of a sharded solve must agree), the direction update and
  *                   the NEXT matvec are enqueued before the host reads the stop test of the current iteration, so the device never waits for
  *                   the host; they touch d and K*d only, so a converged solve ends exactly where the reference's does, one matvec is discarded.
  *                   0 = the host reads every stop test before it enqueues anything further
- *   "check_shards"  1 = cg_finish verifies that the CG scalars of all local shards are bit-equal (default), 0 = skip the check
  */
 int lssvm_mi355_set_option(const char *name, int64_t value);
 int lssvm_mi355_get_option(const char *name, int64_t *value_out);

@@ -20,12 +20,13 @@ extern "C" {
  * nominal peak -- is what a kernel on this device is up against; bench.py prints it beside roofline.frac. */
 int lssvm_mi355_measure_bf16_mfma_ceiling(int device, int b_from_lds, double settle_ms, double *tflops_out, double *clock_ghz_out, double *nominal_tflops_out);
 
-/* option names understood by lssvm_mi355_set_option / _get_option besides the ones documented in plssvm_amd.h:
- *   "lds_extra_kb"  experiment knob: extra dynamic LDS (KiB) per workgroup of the fp32 tile kernels (native and bf16x6), lowers the workgroups per CU
- *   "debug_ablate"  timing-only ablation bits of the fp32 tile kernel; effective only in -DLSSVM_ENABLE_ABLATION builds
+/* option names understood by lssvm_mi355_set_option / _get_option besides the twelve documented in plssvm_amd.h:
  *   "force_collective" 1 = run the per-matvec RCCL collective even with a world of 1 (testing aid; default 0)
  *   "skip_collective"  1 = problems created with world > 1 need no communicator and do NOT exchange their partial K*v (testing aid:
  *                      lets one GPU evaluate every rank's share in turn; default 0)
+ * and, accepted with the value 0 everywhere but effective in development builds only:
+ *   "debug_ablate"  timing-only ablation bits of the fp32 tile kernels (-DLSSVM_ENABLE_ABLATION; results are wrong when != 0)
+ *   "pair_lag"      256-row workgroups: plane-chunk steps waves 4-7 run behind waves 0-3 (make DEV=1: 0, 1, 3; the shipped library instantiates 0, lock step)
  */
 
 #ifdef __cplusplus

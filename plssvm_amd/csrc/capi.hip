@@ -314,9 +314,6 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
             lssvm::options().rbf_form = value;
         } else if (n == "rbf_fold") {
             lssvm::options().rbf_fold = value != 0 ? 1 : 0;
-        } else if (n == "rbf_direct_above") {
-            LSSVM_REQUIRE(value >= 0, "rbf_direct_above must not be negative");
-            lssvm::options().rbf_direct_above = value;
         } else if (n == "j_chunk_tiles") {
             LSSVM_REQUIRE(value >= 0 && value <= (1 << 20), "j_chunk_tiles out of range");
             lssvm::options().j_chunk_tiles = value;
@@ -325,24 +322,27 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
         } else if (n == "tile_kernel") {
             LSSVM_REQUIRE(value == 0 || value == 1, "tile_kernel must be 0 (automatic) or 1 (generic kernel)");
             lssvm::options().tile_kernel = value;
-        } else if (n == "lds_extra_kb") {
-            LSSVM_REQUIRE(value >= 0 && value <= 88, "lds_extra_kb out of range");
-            lssvm::options().lds_extra_kb = value;
         } else if (n == "debug_ablate") {
+#ifdef LSSVM_ENABLE_ABLATION
             lssvm::options().debug_ablate = value;
-        } else if (n == "xcd_map") {
-            lssvm::options().xcd_map = value != 0 ? 1 : 0;
+#else
+            LSSVM_REQUIRE(value == 0, "debug_ablate exists in builds with -DLSSVM_ENABLE_ABLATION only");
+#endif
         } else if (n == "force_collective") {
             lssvm::options().force_collective = value != 0 ? 1 : 0;
         } else if (n == "gram_mode") {
             LSSVM_REQUIRE(value >= 0 && value <= 3, "gram_mode must be 0 (v_mfma_f32), 1 (bf16x6), 2 (f16x3 unchecked) or 3 (f16x3 where the data allows, else bf16x6)");
             lssvm::options().gram_mode = value;
         } else if (n == "mfma_shape") {
-            LSSVM_REQUIRE(value >= 1 && value <= 3, "mfma_shape must be 1 (compiler-scheduled MFMA groups), 2 (hand-scheduled groups) or 3 (2 + 256-row workgroups in the symmetric variant)");
+            LSSVM_REQUIRE(value == 2 || value == 3, "mfma_shape must be 2 (128-row workgroups) or 3 (256-row workgroups in the symmetric variant where they apply)");
             lssvm::options().mfma_shape = value;
         } else if (n == "pair_lag") {
-            LSSVM_REQUIRE(value >= 0 && value <= 4, "pair_lag must be 0 ... 4");
+#ifdef LSSVM_DEV_SUBSET
+            LSSVM_REQUIRE(value == 0 || value == 1 || value == 3, "pair_lag must be 0, 1 or 3");
             lssvm::options().pair_lag = value;
+#else
+            LSSVM_REQUIRE(value == 0, "pair_lag exists in development builds (make DEV=1) only");
+#endif
         } else if (n == "colslab_band_mb") {
             LSSVM_REQUIRE(value >= 1, "colslab_band_mb must be positive");
             lssvm::options().colslab_band_mb = value;
@@ -354,20 +354,12 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
         } else if (n == "exchange") {
             LSSVM_REQUIRE(value >= 0 && value <= 2, "exchange must be 0 (automatic), 1 (RCCL) or 2 (peer kernels)");
             lssvm::options().exchange = value;
-        } else if (n == "check_shards") {
-            lssvm::options().check_shards = value != 0 ? 1 : 0;
-        } else if (n == "linear_panel_features") {
-            LSSVM_REQUIRE(value >= 64 && value <= 512 && value % 64 == 0, "linear_panel_features must be a multiple of 64 between 64 and 512");
-            lssvm::options().linear_panel_features = value;
         } else if (n == "ipc_timeout_s") {
             LSSVM_REQUIRE(value >= 1, "ipc_timeout_s must be at least 1");
             lssvm::options().ipc_timeout_s = value;
         } else if (n == "enqueue_ahead_below_us") {
             LSSVM_REQUIRE(value >= 0, "enqueue_ahead_below_us must not be negative");
             lssvm::options().enqueue_ahead_below_us = value;
-        } else if (n == "item_order") {
-            LSSVM_REQUIRE(value >= 0 && value <= 2, "item_order must be 0, 1 or 2");
-            lssvm::options().item_order = value;
         } else {
             throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "unknown option '" + n + "'");
         }
@@ -381,20 +373,14 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             *value_out = lssvm::options().rbf_form;
         } else if (n == "rbf_fold") {
             *value_out = lssvm::options().rbf_fold;
-        } else if (n == "rbf_direct_above") {
-            *value_out = lssvm::options().rbf_direct_above;
         } else if (n == "j_chunk_tiles") {
             *value_out = lssvm::options().j_chunk_tiles;
         } else if (n == "symmetric") {
             *value_out = lssvm::options().symmetric;
         } else if (n == "tile_kernel") {
             *value_out = lssvm::options().tile_kernel;
-        } else if (n == "lds_extra_kb") {
-            *value_out = lssvm::options().lds_extra_kb;
         } else if (n == "debug_ablate") {
             *value_out = lssvm::options().debug_ablate;
-        } else if (n == "xcd_map") {
-            *value_out = lssvm::options().xcd_map;
         } else if (n == "force_collective") {
             *value_out = lssvm::options().force_collective;
         } else if (n == "gram_mode") {
@@ -411,16 +397,10 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             *value_out = lssvm::options().skip_collective;
         } else if (n == "exchange") {
             *value_out = lssvm::options().exchange;
-        } else if (n == "check_shards") {
-            *value_out = lssvm::options().check_shards;
-        } else if (n == "linear_panel_features") {
-            *value_out = lssvm::options().linear_panel_features;
         } else if (n == "ipc_timeout_s") {
             *value_out = lssvm::options().ipc_timeout_s;
         } else if (n == "enqueue_ahead_below_us") {
             *value_out = lssvm::options().enqueue_ahead_below_us;
-        } else if (n == "item_order") {
-            *value_out = lssvm::options().item_order;
         } else {
             throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "unknown option '" + n + "'");
         }

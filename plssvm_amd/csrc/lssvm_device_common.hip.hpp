@@ -41,30 +41,14 @@ __device__ __forceinline__ T ipow(T base, int degree) {
     return degree < 0 ? T(1) / result : result;
 }
 
-/* blockIdx.x -> (local row block, column chunk).
- * map_mode 0: consecutive blocks walk the row blocks of one column chunk.
- * map_mode 1 (XCD aware): the hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with a private
- *   4 MiB L2 (placement is a speed matter only, never correctness).  The ids that land on one XCD are grouped into 8 x 8
- *   super-tiles (8 row blocks x 8 column chunks), so that the ~64 workgroups resident on an XCD at a time re-read only 8
- *   row panels (8 x d x 128 x s bytes) and share every column tile 8 ways -- instead of 64 distinct row panels that alone
- *   overflow the L2. */
+/* blockIdx.x -> (local row block, column chunk) of the full-square variant: consecutive workgroups walk the row blocks of one column chunk.
+ * (An XCD-aware 8 x 8 super-tile map was measured equal at every size in round 2 -- the launch is neither tail- nor L2-bound -- and retired in round 4.) */
 template <typename T>
 __device__ __forceinline__ bool decode_work_item(const TileArgs<T> &a, int &ibl, int &jc) {
     const int id = blockIdx.x;
-    if (a.map_mode == 0) {
-        ibl = id % a.num_ib;
-        jc = id / a.num_ib;
-        return true;
-    }
-    const int x = id & 7;
-    const int k = id >> 3;
-    const int l = k & 63;
-    const int S = (k >> 6) * 8 + x;  // super-tile index
-    const int si = S % a.super_i;
-    const int sj = S / a.super_i;
-    ibl = si * 8 + (l & 7);
-    jc = sj * 8 + (l >> 3);
-    return ibl < a.num_ib && jc < a.num_jc;
+    ibl = id % a.num_ib;
+    jc = id / a.num_ib;
+    return true;
 }
 
 /* exp(x) in double for the rbf epilogue: 2^k * p(r), k = rint(x log2 e), r = x - k ln2 (two-part ln2), p = degree-13 Taylor

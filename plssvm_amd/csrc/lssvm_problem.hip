@@ -116,7 +116,7 @@ int select_device_checked(int device) {
 constexpr int MAX_LOCAL_DEVICES = 16;
 constexpr double FOLD_MAX_R2 = 200.0;    // folded rbf records (KT_RBFF) only while |c| = R2 / 2 <= 100: 2^c and 2^acc stay far inside the fp32 range
 constexpr double PAIR_FOLD_MAX_C = 32.0; // 256-row kernels, rbf: row AND column term folded (K = e_i 2^(x_i.x_j) e_j) only while |c| <= 32: the partial sums then carry at most 2^32 of
-                                         // extra scale (rbf_direct_above = 32 keeps the automatic choice at |c| <= 16)
+                                         // extra scale (RBF_DIRECT_ABOVE = 32 keeps the automatic choice at |c| <= 16)
 constexpr int PAIR_MIN_TILES = 64;       // 256-row workgroups from this many row blocks on (a rule on the global shape: every rank decides alike)
 constexpr int SPLIT_MAX_FEATURES = 384;  // the bf16x6 kernels exist for 1 ... 6 chunks of 64 features (row panel = 3 planes in registers)
 constexpr int F16_MAX_FEATURES = 512;    // the f16x3 kernels exist for 1 ... 8 chunks of 64 features (row panel = 2 planes in registers)
@@ -151,18 +151,16 @@ std::vector<int> resolve_devices(const int *devices, int num_devices, size_t num
 
 /* ------------------------------------------------------------------ tile kernel selection ------------------------------------------------------------------ */
 /* the v2 kernels exist for 1..8 and 10, 12, 14, 16 k-chunks (padded_features() never produces an odd count above 8) */
-static bool v2_chunk_count_ok(int kchunks) {
-    return kchunks <= 8 || (kchunks <= 16 && kchunks % 2 == 0);
+static bool v2_chunk_count_ok(int kchunks, int single_up_to = 8) {
+    return kchunks <= single_up_to || (kchunks <= 16 && kchunks % 2 == 0);
 }
 bool v2_eligible(const Options &o, int ldx, bool rbf_direct) {
-    return !rbf_direct && v2_chunk_count_ok(ldx / F32_KC) && o.tile_kernel != 1;
+    return !rbf_direct && v2_chunk_count_ok(ldx / F32_KC, 4) && o.tile_kernel != 1;
 }
 bool v2_eligible_f64(const Options &o, int ldx) {
     return v2_chunk_count_ok(ldx / F64_KC) && o.tile_kernel != 1;
 }
 
-/* features per pass of the fp64 linear kernel (see Problem<double>'s constructor) */
-int f64_linear_panel(const Options &o) { return o.linear_panel_features == 64 ? 64 : 128; }
 constexpr int F64_ONE_PASS_FEATURES = 256;
 
 /* fp64 rbf / polynomial on more than 256 features: feature panels of 64 inside a sub-tile (lssvm_tile_f64_wide.hip.hpp; the data carries the
@@ -226,8 +224,6 @@ static void set_kernel_scalars(TileArgs<T> &a, const lssvm_params &p, bool rbf_d
 template <typename T>
 static void set_launch_options(TileArgs<T> &a, const Options &o) {
     a.dbg = static_cast<int>(o.debug_ablate);
-    a.map_mode = o.xcd_map != 0 ? 1 : 0;
-    a.lds_extra_kb = static_cast<int>(o.lds_extra_kb);
     a.mfma_shape = static_cast<int>(o.mfma_shape);
     a.pair_lag = static_cast<int>(o.pair_lag);
 }
@@ -289,7 +285,7 @@ void center_columns(DeviceMatrix<T> &M, DeviceMatrix<T> *M2, T scale, hipStream_
  * sqrt(2 gamma log2 e), so its ABSOLUTE error is about 2^-24 times the size of the terms that cancel, R2 = 2 gamma log2(e) max |x - mean|^2,
  * whatever the distance of the pair -- for nearby points (K close to 1) that is a relative error of K of ~R2 * 2^-24, where the reference's
  * direct (x_i - x_j)^2 chain keeps all its digits.  [-1, 1]-scaled data with gamma = 1 / num_features has R2 <= 3; gamma = 1 at 128
- * features has R2 ~ 100.  Above `rbf_direct_above` the formula-exact vector-ALU kernel is used instead (5x slower, same accuracy class as
+ * features has R2 ~ 100.  Above RBF_DIRECT_ABOVE the formula-exact vector-ALU kernel is used instead (5x slower, same accuracy class as
  * the reference).  Returns true for the direct form.  `M2` (predict: the points beside the support vectors) may be NULL. */
 template <typename T>
 static bool rbf_wants_direct_form(const Options &o, const lssvm_params &p, const DeviceMatrix<T> &M, const DeviceMatrix<T> *M2, hipStream_t s, double *r2_out) {
@@ -303,7 +299,7 @@ static bool rbf_wants_direct_form(const Options &o, const lssvm_params &p, const
     const double r2 = 2.0 * static_cast<double>(static_cast<T>(p.gamma)) * 1.4426950408889634 * sq;
     if (r2_out != nullptr) *r2_out = r2;
     if (o.rbf_form == 2) return false;  // matrix cores whatever the scale (r2 is still reported: it decides the record form)
-    return r2 > static_cast<double>(o.rbf_direct_above);
+    return r2 > RBF_DIRECT_ABOVE;
 }
 
 /* fp32: reorder the features of every group of 8 to 0,2,4,6,1,3,5,7 (the operand order of the MFMA kernels); fp64: nothing */
@@ -330,7 +326,7 @@ void half_neg_norms(const DeviceMatrix<T> &M, DevBuf<T> &c, hipStream_t s) {
  *     so that mid stays a NORMAL f16 for entries down to 2^-17 of it -- undone exactly on the finished sums (TileArgs::out_scale) or inside
  *     gamma.  rbf cannot pre-scale (the chain must leave the exponent itself, and a multiply per element in the epilogue costs matrix-core
  *     time): it uses the SHIFTED planes (2^-6 hi, 2^6 mid, 2^6 hi) -- every product of a row plane and a column plane carries the net scale 1,
- *     mid is normal for |x| in [2^-8, 2^10), which covers everything the exponent scale allows (|x| <= sqrt(rbf_direct_above)); the price is a
+ *     mid is normal for |x| in [2^-8, 2^10), which covers everything the exponent scale allows (|x| <= sqrt(RBF_DIRECT_ABOVE)); the price is a
  *     third row plane in registers, none in the column stream.  Whether the planes carry THIS data as well as fp32 does is measured, not
  *     assumed: k_split_f16x2 returns the largest relative representation error of a row; above 2^-22 (data with a dynamic range beyond the
  *     planes', or planes that overflow) the answer is no -- for rbf an absolute bound on the exponent's error is accepted as well.
@@ -346,7 +342,7 @@ static void make_planes(const Options &o, const lssvm_params &p, bool rbf_direct
     // linear_panels: the CALLER says whether the linear kernel's panel passes will run (symmetric variant, f16x3 only) -- the decision is not
     // re-derived here (a full-square problem of more than 512 features got planes that nobody read).  f16_known_bad: an earlier call
     // on the same data has already seen the representability check fail.
-    const bool wide_linear = linear_panels && p.kernel_type == LSSVM_KERNEL_LINEAR && ldx16 > static_cast<int>(o.linear_panel_features) && o.tile_kernel != 1;
+    const bool wide_linear = linear_panels && p.kernel_type == LSSVM_KERNEL_LINEAR && ldx16 > LINEAR_PANEL_FEATURES && o.tile_kernel != 1;
     if (o.gram_mode == 0 || rbf_direct || (!v2_eligible(o, M.ldx, false) && !wide_linear && !wide_nl)) return;
     auto alloc = [&](int nplanes) {
         out.ldx16 = ldx16;
@@ -553,7 +549,7 @@ static std::vector<int> band_edges(int ib_begin, int ib_end_all, size_t real_siz
 }
 
 /* The (row block, column chunk) work items of one band in DISPATCH order: column chunk major (concurrent workgroups share the chunk; the
-   hardware dispatches workgroups in item order as CU slots free up).  item_order >= 1: the items cut short by the diagonal go last in
+   hardware dispatches workgroups in item order as CU slots free up).  order >= 1 (ITEM_ORDER): the items cut short by the diagonal go last in
    their band, longest first, so that the final dispatch round is made of the shortest items.  .x = absolute row block, .y = chunk. */
 static std::vector<int2> band_items(int band_begin, int band_end, int jc_tiles, int num_jc, int order, bool pairs) {
     std::vector<int2> full, cut;
@@ -593,7 +589,7 @@ static int choose_pair_chunk(int ib_begin, int ib_end, int num_tiles, size_t rea
             if (edge[k + 1] <= edge[k]) continue;
             std::vector<double> slot(static_cast<size_t>(slots), 0.0);  // a min-heap of the slots' finish times
             auto later = [](double x, double y) { return x > y; };
-            for (const int2 &it : band_items(edge[k], edge[k + 1], jc, num_jc, static_cast<int>(o.item_order), true)) {
+            for (const int2 &it : band_items(edge[k], edge[k + 1], jc, num_jc, ITEM_ORDER, true)) {
                 const int tiles = std::min(std::min((it.y + 1) * jc, it.x + 2), num_tiles) - it.y * jc;
                 std::pop_heap(slot.begin(), slot.end(), later);
                 slot.back() += static_cast<double>(std::max(tiles, 0)) + 2.6;
@@ -641,9 +637,8 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     if constexpr (std::is_same_v<T, float>) {
         // linear kernel on more than 512 features: K*v = sum over feature panels of (X_p X_p^T) v, every panel one launch of the f16x3 kernels
         // (enqueue_apply_K_local).  Whether the data allows f16 planes decides it, so the planes are built HERE (the linear kernel needs the raw data).
-        // (option linear_panel_features, default 512: narrower panels also for problems the one-pass kernels could hold)
         if (params_.kernel_type == LSSVM_KERNEL_LINEAR && opt_.gram_mode >= 2 && opt_.tile_kernel != 1
-            && round_up(static_cast<long>(num_features), 64) > static_cast<long>(opt_.linear_panel_features)) {
+            && round_up(static_cast<long>(num_features), 64) > LINEAR_PANEL_FEATURES) {
             if (opt_.symmetric != 0 && opt_.colslab_limit_mb != 0) {  // (the panel passes exist for the symmetric variant: no probe, no planes otherwise)
                 make_planes(opt_, params_, false, X_, nullptr, planes_, nullptr, st, false, true);
                 if (planes_.mode == 2) {
@@ -683,7 +678,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         // pass with a hand-scheduled epilogue -- decided from the shape and the options alone (both plane kinds have the kernel), so that the
         // geometry below does not wait for the planes and every rank of a sharded solve decides alike
         const bool poly_generic = params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree != 2 && params_.degree != 3;
-        const bool narrow = wide_linear_ ? opt_.linear_panel_features <= 128 : (round_up(static_cast<long>(num_features), 64) <= 128 && v2_eligible(opt_, ldx_probe, rbf_direct_));
+        const bool narrow = wide_linear_ ? true : (round_up(static_cast<long>(num_features), 64) <= 128 && v2_eligible(opt_, ldx_probe, rbf_direct_));
         // (rbf: that kernel folds BOTH exponent terms out of the chain -- only while |c| = R2 / 2 stays small and the folded records are on)
         const bool rbf_ok = params_.kernel_type != LSSVM_KERNEL_RBF || (opt_.rbf_fold != 0 && rbf_r2_ <= 2.0 * PAIR_FOLD_MAX_C);
         // (below 64 row blocks -- 8 192 points -- the 128-row workgroups have more items to spread over the chip: 3 000 points 13.8 against 19.7 us)
@@ -791,7 +786,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
             band.ib_end = edge[k + 1];
             band.item_begin = static_cast<int>(items.size());
             band.pair_origin = pairs_below(band.ib_begin);
-            for (const int2 &it : band_items(band.ib_begin, band.ib_end, jc_tiles_, num_jc_, static_cast<int>(opt_.item_order), pair_)) items.push_back(make_int2(it.x - ib_begin_, it.y));
+            for (const int2 &it : band_items(band.ib_begin, band.ib_end, jc_tiles_, num_jc_, ITEM_ORDER, pair_)) items.push_back(make_int2(it.x - ib_begin_, it.y));
             band.item_count = static_cast<int>(items.size()) - band.item_begin;
             // (block pairs: the records of the pair's SECOND block, which is padding behind an odd last block)
             max_records = std::max(max_records, pairs_below(pair_ ? round_up(band.ib_end, 2) : band.ib_end) - band.pair_origin);
@@ -902,7 +897,7 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
     const int nrows = num_ib_ * TILE;
     // wide linear problems: one pass per panel of 512 features, every pass ADDS its K_p * v (rows and mirrored columns) into K*v
     const int npanels = passes_per_matvec();
-    const int panel_features = std::is_same_v<T, float> ? static_cast<int>(opt_.linear_panel_features) : f64_linear_panel(opt_);
+    const int panel_features = LINEAR_PANEL_FEATURES;
     if (sym_) {
         bool first = true;
         for (int panel = 0; panel < npanels; ++panel) {
@@ -1405,7 +1400,7 @@ void Solver<T>::cg_finish(void *alpha_out, double *rho_out, lssvm_cg_info *info)
     LSSVM_REQUIRE(alpha_out != nullptr && rho_out != nullptr, "alpha_out / rho_out must not be NULL");
     const double t0 = now_ms();
     // bias = y_last + QA_cost * sum(x) - q^T x ; alpha_N = -sum(x) ; rho = -bias   (csvm.cpp:179-182)
-    const bool check = shards_.size() > 1 && opt_.check_shards != 0 && exchange_ != Exchange::none;
+    const bool check = shards_.size() > 1 && exchange_ != Exchange::none;
     for (auto &p : shards_) {
         if (p.get() != shards_[0].get() && !check) continue;
         p->activate();

@@ -56,37 +56,37 @@ struct Error : std::runtime_error {
 
 /* ------------------------------------------------------------------ options ------------------------------------------------------------------ */
 struct Options {
-    int64_t rbf_form = 0;        // fp32 rbf: 0 automatic (matrix cores unless the exponent scale of the data exceeds rbf_direct_above), 1 always the direct
+    // the 14 options of the product (lssvm_mi355_set_option; include/plssvm_amd.h documents them; round 4 retired xcd_map, lds_extra_kb, item_order,
+    // linear_panel_features, check_shards, rbf_direct_above and mfma_shape = 1 -- measured, decided, now constants below)
+    int64_t rbf_form = 0;        // fp32 rbf: 0 automatic (matrix cores unless the exponent scale of the data exceeds RBF_DIRECT_ABOVE), 1 always the direct
                                  // (x_i - x_j)^2 kernel on the vector ALU, 2 always the norm expansion on the matrix cores
-    int64_t rbf_fold = 1;        // fp32 rbf on the 16x16x32 bf16x6 kernels: 1 = folded column records (2^c_j d_j | 2^c_j), accumulators start from c_i as the C
+    int64_t rbf_fold = 1;        // fp32 rbf on the split kernels: 1 = folded column records (2^c_j d_j | 2^c_j), accumulators start from c_i as the C
                                  // operand of their first MFMA (default, while the exponent scale stays below 200); 0 = start values c_i + c_j by vector adds
-    int64_t rbf_direct_above = 32;  // rbf_form 0: threshold on 2 gamma log2(e) max|x - mean|^2 (absolute error of the matrix-core exponent ~ 2^-24 x that)
-    int64_t j_chunk_tiles = 0;   // 128-column tiles per work item; 0 = automatic (2 ... 16, about 4096 work items per device)
-    int64_t symmetric = 1;         // 1: evaluate only the tiles on/below the diagonal and mirror them (fp32 v2 kernel), 0: full square
-    int64_t tile_kernel = 0;       // 0: automatic (v2 'resident row panel' kernels when num_features <= 512 in fp32 / 256 in fp64), 1: always the generic v1 kernel
-    int64_t xcd_map = 0;           // 1: XCD-aware work item mapping (8 x 8 super-tiles per XCD), 0: linear (default: measured equal, better balanced)
-    int64_t lds_extra_kb = 0;      // experiment knob: extra dynamic LDS per workgroup of the fp32 v2 kernel (lowers workgroups per CU)
-    int64_t debug_ablate = 0;      // diagnostic timing ablations of the fp32 tile kernel (results are wrong when != 0)
-    int64_t item_order = 1;        // symmetric variant, order of the work items: 0 column-chunk major, 1 = 0 with the short (diagonal) items moved to the end, longest first
-    int64_t gram_mode = 3;         // fp32 Gram tiles: 0 = v_mfma_f32 chains; 1 = "bf16x6": exact 3-way bf16 split of the operands, six plane products on the bf16
-                                   // MFMA (<= 384 features); 2 = "f16x3": two f16 planes of the pre-scaled operands, three plane products on the f16 MFMA (<= 512
-                                   // features), without the representability check; 3 (default) = f16x3 where the data passes that check, else bf16x6
-    int64_t mfma_shape = 3;        // split kernels (v_mfma_f32_16x16x32_*): 1 = compiler-scheduled MFMA groups, 2 = hand-scheduled groups for <= 128 features,
-                                   // 3 (default) = 2 with 256-row workgroups (eight waves on a block pair, one column stream) in the symmetric variant
-    int64_t pair_lag = 0;          // 256-row workgroups: plane-chunk steps waves 4-7 run behind waves 0-3 (0 = lock step: default and the only one the shipped library
-                                   // instantiates; 1, 3 in development builds -- measured slower)
+    int64_t j_chunk_tiles = 0;   // 128-column tiles per work item; 0 = automatic (see Problem<T>'s constructor)
+    int64_t symmetric = 1;         // 1: evaluate only the tiles on/below the diagonal and mirror them, 0: full square
+    int64_t tile_kernel = 0;       // 0: automatic (resident-row-panel kernels where they exist), 1: always the generic v1 kernel (the cross-checks' yardstick)
+    int64_t gram_mode = 3;         // fp32 Gram tiles: 0 = v_mfma_f32 chains; 1 = "bf16x6"; 2 = "f16x3" without the representability check; 3 (default) = f16x3
+                                   // where the data passes that check, else bf16x6
+    int64_t mfma_shape = 3;        // split kernels, symmetric variant, <= 128 features per pass: 2 = 128-row workgroups (four waves), 3 (default) = 256-row
+                                   // workgroups on block pairs (eight waves, one column stream per CU) from 64 row blocks on
     int64_t colslab_band_mb = 2048;    // symmetric variant: the column-sum records of ONE row-block band may take this many MiB; the tile kernel runs band by band
-    int64_t colslab_limit_mb = 98304;  // symmetric variant only while its column slab (per device) stays below this many MiB (96 GiB of the 288 GB)
+    int64_t colslab_limit_mb = 98304;  // symmetric variant only while its column slab (per device) stays below this many MiB (96 GiB of the 288 GB); 0 = off
     int64_t force_collective = 0;  // testing aid: run the per-matvec collective even for a world of one (needs lssvm_mi355_comm_init(.., 0, 1, ..))
     int64_t skip_collective = 0;   // testing aid: sharded problems (world > 1) need no communicator and leave their PARTIAL K*v un-exchanged
     int64_t exchange = 0;          // several devices in ONE process: 0 = automatic (RCCL when the devices are distinct, else peer kernels), 1 = RCCL all-reduce / all-gather
                                    // (ncclCommInitAll), 2 = peer kernels: every device sums the partial vectors of all devices over xGMI in rank order
     int64_t enqueue_ahead_below_us = 5000;  // CG: implicit matvecs shorter than this are enqueued ahead of the previous iteration's stop test (0 = never)
-    int64_t linear_panel_features = 128;  // fp32 linear kernel on the f16x3 kernels: features per pass (multiple of 64, <= 512); more features run as several passes.
-                                          // 128: the hand-scheduled two-waves kernel per pass beats the wider one-wave kernels at every width measured (5 ... 12 %)
     int64_t ipc_timeout_s = 600;   // one process per GPU over HIP IPC: how long a rank waits for its peers at an exchange before it gives up
-    int64_t check_shards = 1;      // several devices in ONE process: cg_finish verifies that the CG scalars of all shards are bit-equal
+    // development builds only (the setter refuses them elsewhere)
+    int64_t debug_ablate = 0;      // -DLSSVM_ENABLE_ABLATION: timing ablations of the fp32 tile kernels (results are wrong when != 0)
+    int64_t pair_lag = 0;          // make DEV=1: plane-chunk steps waves 4-7 of a 256-row workgroup run behind waves 0-3 (0 = lock step: the shipped form; 1, 3
+                                   // measured slower)
 };
+constexpr double RBF_DIRECT_ABOVE = 32.0;     // rbf_form 0: the formula-exact kernel above this exponent scale 2 gamma log2(e) max|x - mean|^2 (absolute error of the
+                                              // matrix-core exponent ~ 2^-24 x that; [-1, 1]-scaled data with gamma = 1 / num_features has <= 3)
+constexpr int LINEAR_PANEL_FEATURES = 128;    // linear kernel beyond this many features: one pass of the <= 128-feature kernels per feature panel (fp32 f16x3: beats the
+                                              // wider one-wave kernels by 5 ... 12 % at every width measured; fp64: 64- and 256-feature panels within 2 %)
+constexpr int ITEM_ORDER = 1;                 // symmetric variant: work items in column-chunk major order, the items cut short by the diagonal last, longest first
 /* process-wide DEFAULTS (lssvm_mi355_set_option); every problem takes a snapshot when it is created */
 Options &options();
 
@@ -142,14 +142,16 @@ constexpr int kchunk_of() {
     return std::is_same_v<T, float> ? F32_KC : F64_KC;
 }
 
-/* Padded feature count: a multiple of the k-chunk; between 8 and 16 chunks a multiple of TWO chunks, so that the v2 tile kernels
- * (instantiated for 1..8 and 10, 12, 14, 16 chunks) cover num_features <= 512 in fp32 / <= 256 in fp64. */
+/* Padded feature count: a multiple of the k-chunk; between 8 (fp32: 4) and 16 chunks a multiple of TWO chunks, so that the v2 tile kernels
+ * (fp64: instantiated for 1..8 and 10, 12, 14, 16 chunks; fp32: 1..4, 6, 8, 10, 12, 14, 16) cover num_features <= 512 in fp32 / <= 256 in fp64. */
 template <typename T>
 inline int padded_features(size_t nfeat) {
     const int kc = kchunk_of<T>();
     const int ldx = round_up(static_cast<long>(nfeat), kc);
     if (std::is_same_v<T, double> && ldx > 16 * kc) return round_up(static_cast<long>(nfeat), 64);  // fp64 beyond the one-pass kernels: whole feature panels of 64 (lssvm_tile_f64_wide.hip.hpp)
-    return (ldx > 8 * kc && ldx <= 16 * kc) ? round_up(static_cast<long>(nfeat), 2 * kc) : ldx;
+    // fp32: whole pairs of chunks already beyond 4 (the native v2 kernel -- the rare path without operand planes -- is instantiated for 1 ... 4, 6, 8 ... 16)
+    const int single_up_to = std::is_same_v<T, float> ? 4 : 8;
+    return (ldx > single_up_to * kc && ldx <= 16 * kc) ? round_up(static_cast<long>(nfeat), 2 * kc) : ldx;
 }
 
 /* A dense row-major point set in HBM: rows padded to a multiple of 128, features padded to a multiple of the k-chunk
@@ -229,7 +231,6 @@ void split_bf16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx1
 void split_f16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, float scale, int shift, uint16_t *planes, size_t plane_stride, unsigned *stats, hipStream_t s);  // tile_launch_f32h.hip
 void absmax_f32(const float *X, int ldx, int dfeat, size_t rows, unsigned *out, hipStream_t s);  // tile_launch_f32h.hip
 bool v2_eligible_f64(const Options &o, int ldx);
-int f64_linear_panel(const Options &o);  // features per pass of the fp64 linear kernel
 int sym_block_boundary(int num_tiles, int r, int world);
 void shard_blocks(int num_tiles, int world, int rank, bool symmetric, int &begin, int &end);
 
@@ -266,9 +267,9 @@ class Problem {
     int passes_per_matvec() const {  // feature panels of a wide linear problem: fp32 over the planes, fp64 over the row-major data
         if (!wide_linear_) return 1;
         if constexpr (std::is_same_v<T, float>) {
-            return (planes_.ldx16 + static_cast<int>(opt_.linear_panel_features) - 1) / static_cast<int>(opt_.linear_panel_features);
+            return (planes_.ldx16 + LINEAR_PANEL_FEATURES - 1) / LINEAR_PANEL_FEATURES;
         } else {
-            return (X_.ldx + f64_linear_panel(opt_) - 1) / f64_linear_panel(opt_);
+            return (X_.ldx + LINEAR_PANEL_FEATURES - 1) / LINEAR_PANEL_FEATURES;
         }
     }
 

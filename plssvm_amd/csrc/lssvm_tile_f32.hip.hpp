@@ -578,6 +578,7 @@ __global__ __launch_bounds__(TILE_THREADS, (NKC <= 4 ? 2 : 1)) void tile_matvec_
 constexpr int DIR_KC = 32;
 constexpr int DIR_LS = 33;
 
+template <bool ONE_INSTANCE = true>  // (a template so that only the translation unit that launches it carries it)
 __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_rbf_direct_f32(const TileArgs<float> a) {
     __shared__ float As[TILE * DIR_LS];
     __shared__ float Bs[TILE * DIR_LS];

@@ -64,12 +64,9 @@ struct TileArgs {
     int num_jt;       // number of column tiles in total
     int jc_tiles;     // column tiles per work item
     int num_jc;       // number of column chunks = ceil(num_jt / jc_tiles)
-    int map_mode;     // 0: linear block -> item map, 1: XCD-aware 8 x 8 super-tiles (see decode_work_item)
-    int super_i;      // map_mode 1: ceil(num_ib / 8)
     int row_pair;     // host side only: != 0 selects the 256-row-workgroup kernels (items = block pairs, lssvm_tile_f32_pair.hip.hpp)
     int pair_lag;     // host side only: steps the second half of such a workgroup runs behind the first
-    int mfma_shape;   // host side only: bf16x6 kernel on 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16
-    int lds_extra_kb; // host side only: extra dynamic LDS per workgroup of the fp32 v2 kernel (experiment knob, lowers the workgroups per CU)
+    int mfma_shape;   // host side only: option mfma_shape (2 = 128-row workgroups, 3 = 256-row workgroups where they apply)
     int dbg;          // diagnostic ablations (timing only, results wrong): 1 = no global re-loads, 2 = no kernel function in the epilogue
     int ncols_valid;  // columns >= this are padding (used only where a padded column could produce inf/nan)
     int degree;       // polynomial

@@ -33,11 +33,8 @@ static void ensure_dynamic_lds(K kernel, size_t bytes) {
 /* fills the block -> work item mapping fields and returns the grid size */
 template <typename T>
 static unsigned finish_mapping(TileArgs<T> &a, int num_jc) {
-    a.num_jc = num_jc;  // (dbg, map_mode and lds_extra_kb were filled in by the caller from ITS options: set_launch_options)
-    a.super_i = (a.num_ib + 7) / 8;
-    if (a.map_mode == 0) return static_cast<unsigned>(a.num_ib) * static_cast<unsigned>(num_jc);
-    const long supers = static_cast<long>(a.super_i) * ((num_jc + 7) / 8);
-    return static_cast<unsigned>(((supers + 7) / 8) * 8 * 64);
+    a.num_jc = num_jc;  // (dbg and mfma_shape were filled in by the caller from ITS options: set_launch_options)
+    return static_cast<unsigned>(a.num_ib) * static_cast<unsigned>(num_jc);
 }
 
 /* fp32 "bf16x6" split kernel (tile_launch_f32s.hip); `grid` is used by the full-square variant only */

@@ -7,8 +7,15 @@
 
 #include "lssvm_tile_f32_split.hip.hpp"
 
+/* compiled as TWO translation units (LSSVM_TU_HALF 1: *_sym.hip, the symmetric instantiations; 2: *_full.hip, the full-square ones, the set-up kernels of
+ * the planes and the entry point) so that the build spreads over more cores */
+#ifndef LSSVM_TU_HALF
+#error "compile the _sym / _full wrapper of this file"
+#endif
+
 namespace lssvm {
 
+#if LSSVM_TU_HALF != 1  // (the set-up kernels of the planes: in the full-square half only)
 /* "f16x3" planes of y = scale * x (scale = 2^k, exact).  One wave per row.
  *   shift = 0 (linear, polynomial):  hi = f16(y), mid = f16(y - hi); planes [2][rows][ldx16] = (hi, mid).
  *   shift = s > 0 (rbf):             P0 = f16(2^-s y), P1 = f16(2^s (y - 2^s P0)), P2 = 2^(2s) P0 (exact); planes [3][rows][ldx16] = (P0, P1, P2).
@@ -77,24 +84,27 @@ __global__ void k_absmax(const float *__restrict__ X, int ldx, int dfeat, size_t
     }
     if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
 }
+#endif
 
 
 template <int KT, bool SYM>
 static void launch_f3_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
     const dim3 block(TILE_THREADS);
-    const size_t V2_LDS_BYTES = lssvm::V2_LDS_BYTES + static_cast<size_t>(a.lds_extra_kb) * 1024;  // experiment knob: limits workgroups per CU
+    // ONE kernel per (kernel function, feature count, variant) -- the instantiations no default path reaches were retired in round 4:
+    //   <= 128 features: the hand-scheduled groups (tile_matvec_f32_f3h); the run-time integer power, whose epilogue does not fit their capped
+    //                    register budget without spills, stays on the compiler-scheduled groups (tile_matvec_f32_f3w) at every width;
+    //   beyond:          tile_matvec_f32_f3w -- except the linear kernel in the symmetric variant, which runs one pass of the 128-feature kernels
+    //                    per feature panel (Problem<float>: wide_linear_) and never comes here with more.
 #define LSSVM_F3_CASE(N)                                                                                  \
     case N:                                                                                               \
         if constexpr (N > f16_max_nk64(KT)) {                                                             \
             throw Error(LSSVM_ERR_INTERNAL, "no f16x3 rbf tile kernel for this number of features");       \
-        } else if (a.mfma_shape >= 2) {                                                                          \
-            if constexpr (KT != KT_POLY && N <= F16_HAND_MAX_NK64) { /* (generic integer power: its epilogue does not fit the capped register budget without spills) */                                                       \
-                ensure_dynamic_lds(tile_matvec_f32_f3h<KT, N, SYM>, V2_LDS_BYTES);                        \
-                hipLaunchKernelGGL((tile_matvec_f32_f3h<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);   \
-                break;                                                                                    \
-            }                                                                                             \
-        }                                                                                                 \
-        if constexpr (N <= f16_max_nk64(KT)) {                                                            \
+        } else if constexpr (KT != KT_POLY && N <= F16_HAND_MAX_NK64) {                                   \
+            ensure_dynamic_lds(tile_matvec_f32_f3h<KT, N, SYM>, V2_LDS_BYTES);                            \
+            hipLaunchKernelGGL((tile_matvec_f32_f3h<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);       \
+        } else if constexpr (KT == KT_LINEAR && SYM) {                                                    \
+            throw Error(LSSVM_ERR_INTERNAL, "the symmetric linear kernel takes feature-panel passes beyond 128 features"); \
+        } else {                                                                                          \
             ensure_dynamic_lds(tile_matvec_f32_f3w<KT, N, SYM>, V2_LDS_BYTES);                            \
             hipLaunchKernelGGL((tile_matvec_f32_f3w<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);       \
         }                                                                                                 \
@@ -133,9 +143,16 @@ static void launch_f3(const TileArgs<float> &a, int kernel_type, dim3 grid, hipS
     }
 }
 
+void launch_f16_tile_kernel_sym(const TileArgs<float> &a, int kernel_type, hipStream_t s);  // tile_launch_f32h_sym.hip
+
+#if LSSVM_TU_HALF == 1
+void launch_f16_tile_kernel_sym(const TileArgs<float> &a, int kernel_type, hipStream_t s) {
+    launch_f3<true>(a, kernel_type, dim3(static_cast<unsigned>(a.num_items)), s);
+}
+#else
 void launch_f16_tile_kernel(const TileArgs<float> &a, int kernel_type, dim3 grid, hipStream_t s) {
     if (a.items != nullptr) {
-        launch_f3<true>(a, kernel_type, dim3(static_cast<unsigned>(a.num_items)), s);
+        launch_f16_tile_kernel_sym(a, kernel_type, s);
     } else {
         launch_f3<false>(a, kernel_type, grid, s);
     }
@@ -151,5 +168,7 @@ void absmax_f32(const float *X, int ldx, int dfeat, size_t rows, unsigned *out, 
     hipLaunchKernelGGL(k_absmax, dim3(1024), dim3(256), 0, s, X, ldx, dfeat, rows, out);
     LSSVM_HIP_CHECK(hipGetLastError());
 }
+
+#endif
 
 }  // namespace lssvm

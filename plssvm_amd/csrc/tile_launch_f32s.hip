@@ -6,8 +6,15 @@
 
 #include "lssvm_tile_f32_split.hip.hpp"
 
+/* compiled as TWO translation units (LSSVM_TU_HALF 1: *_sym.hip, the symmetric instantiations; 2: *_full.hip, the full-square ones, the set-up kernels of
+ * the planes and the entry point) so that the build spreads over more cores */
+#ifndef LSSVM_TU_HALF
+#error "compile the _sym / _full wrapper of this file"
+#endif
+
 namespace lssvm {
 
+#if LSSVM_TU_HALF != 1  // (the set-up kernels of the planes: in the full-square half only)
 /* x = hi + mid + lo, each rounded to nearest-even bf16 of the remainder (exact: the remainders are representable in fp32).
  * X: [rows][ldx] fp32, features in natural order; planes: [3][rows][ldx16] bf16, zero padded. */
 __global__ void k_split_bf16x3(const float *__restrict__ X, int ldx, int dfeat, size_t rows, int ldx16, uint16_t *__restrict__ planes, size_t plane_stride) {
@@ -26,23 +33,23 @@ __global__ void k_split_bf16x3(const float *__restrict__ X, int ldx, int dfeat, 
     planes[plane_stride + idx] = __builtin_bit_cast(uint16_t, mid);
     planes[2 * plane_stride + idx] = __builtin_bit_cast(uint16_t, lo);
 }
+#endif
 
 
 template <int KT, bool SYM>
 static void launch_s6_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
     const dim3 block(TILE_THREADS);
-    const size_t V2_LDS_BYTES = lssvm::V2_LDS_BYTES + static_cast<size_t>(a.lds_extra_kb) * 1024;  // experiment knob: limits workgroups per CU
+    // (<= 128 features: the hand-scheduled groups; the run-time integer power and everything wider: the compiler-scheduled groups -- one kernel per
+    // case, see tile_launch_f32h.hip)
 #define LSSVM_S6_CASE(N)                                                                                  \
     case N:                                                                                               \
-        if (a.mfma_shape >= 2) {                                                                          \
-            if constexpr (KT != KT_POLY && N <= 2) { /* (generic integer power: its epilogue does not fit the capped register budget without spills) */                                                                       \
-                ensure_dynamic_lds(tile_matvec_f32_s6h<KT, N, SYM>, V2_LDS_BYTES);                        \
-                hipLaunchKernelGGL((tile_matvec_f32_s6h<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);   \
-                break;                                                                                    \
-            }                                                                                             \
+        if constexpr (KT != KT_POLY && N <= 2) {                                                          \
+            ensure_dynamic_lds(tile_matvec_f32_s6h<KT, N, SYM>, V2_LDS_BYTES);                            \
+            hipLaunchKernelGGL((tile_matvec_f32_s6h<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);       \
+        } else {                                                                                          \
+            ensure_dynamic_lds(tile_matvec_f32_s6w<KT, N, SYM>, V2_LDS_BYTES);                            \
+            hipLaunchKernelGGL((tile_matvec_f32_s6w<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);       \
         }                                                                                                 \
-        ensure_dynamic_lds(tile_matvec_f32_s6w<KT, N, SYM>, V2_LDS_BYTES);                                \
-        hipLaunchKernelGGL((tile_matvec_f32_s6w<KT, N, SYM>), grid, block, V2_LDS_BYTES, s, a);           \
         break;
     switch (a.nk64) {
 #ifdef LSSVM_DEV_SUBSET  // development builds (make DEV=1): 128 and 256 features only
@@ -78,9 +85,16 @@ static void launch_s6(const TileArgs<float> &a, int kernel_type, dim3 grid, hipS
     }
 }
 
+void launch_split_tile_kernel_sym(const TileArgs<float> &a, int kernel_type, hipStream_t s);  // tile_launch_f32s_sym.hip
+
+#if LSSVM_TU_HALF == 1
+void launch_split_tile_kernel_sym(const TileArgs<float> &a, int kernel_type, hipStream_t s) {
+    launch_s6<true>(a, kernel_type, dim3(static_cast<unsigned>(a.num_items)), s);
+}
+#else
 void launch_split_tile_kernel(const TileArgs<float> &a, int kernel_type, dim3 grid, hipStream_t s) {
     if (a.items != nullptr) {
-        launch_s6<true>(a, kernel_type, dim3(static_cast<unsigned>(a.num_items)), s);
+        launch_split_tile_kernel_sym(a, kernel_type, s);
     } else {
         launch_s6<false>(a, kernel_type, grid, s);
     }
@@ -92,5 +106,7 @@ void split_bf16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx1
     hipLaunchKernelGGL(k_split_bf16x3, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, X, ldx, dfeat, rows, ldx16, planes, plane_stride);
     LSSVM_HIP_CHECK(hipGetLastError());
 }
+
+#endif
 
 }  // namespace lssvm

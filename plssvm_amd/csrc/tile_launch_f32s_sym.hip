@@ -1,0 +1,3 @@
+/* one half of tile_launch_f32s.hip as a translation unit of its own (see there) */
+#define LSSVM_TU_HALF 1
+#include "tile_launch_f32s.hip"

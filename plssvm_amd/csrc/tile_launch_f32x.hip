@@ -11,7 +11,7 @@ namespace lssvm {
 template <int KT, bool SYM>
 static void launch_wide_kt(const TileArgs<float> &a, dim3 grid, hipStream_t s) {
     const dim3 block(TILE_THREADS);
-    const size_t lds = lssvm::V2_LDS_BYTES + static_cast<size_t>(a.lds_extra_kb) * 1024;
+    const size_t lds = lssvm::V2_LDS_BYTES;
     if (a.planes_f16 != 0) {
         ensure_dynamic_lds(tile_matvec_f32_wide<KT, 2, SYM>, lds);
         hipLaunchKernelGGL((tile_matvec_f32_wide<KT, 2, SYM>), grid, block, lds, s, a);

@@ -6,6 +6,12 @@
 
 #include "lssvm_tile_f64.hip.hpp"
 
+/* This source is compiled as TWO translation units (tile_launch_f64_sym.hip: LSSVM_TU_HALF 1 = the symmetric instantiations, tile_launch_f64_full.hip:
+ * LSSVM_TU_HALF 2 = the full-square ones, the generic kernel and the entry point), so that the build spreads over more cores. */
+#ifndef LSSVM_TU_HALF
+#error "compile tile_launch_f64_sym.hip / tile_launch_f64_full.hip"
+#endif
+
 namespace lssvm {
 
 template <int KT, bool SYM>
@@ -28,6 +34,26 @@ static void launch_v2d_kt(const TileArgs<double> &a, dim3 grid, hipStream_t s) {
     }
 }
 
+void launch_v2d_sym(const TileArgs<double> &a, int kernel_type, hipStream_t s);  // tile_launch_f64_sym.hip
+
+#if LSSVM_TU_HALF == 1
+void launch_v2d_sym(const TileArgs<double> &a, int kernel_type, hipStream_t s) {
+    const dim3 sgrid(static_cast<unsigned>(a.num_items));
+    switch (kernel_type) {
+        case KT_LINEAR: launch_v2d_kt<KT_LINEAR, true>(a, sgrid, s); break;
+        case KT_POLY:
+            if (a.degree == 3) {
+                launch_v2d_kt<KT_POLY3, true>(a, sgrid, s);
+            } else if (a.degree == 2) {
+                launch_v2d_kt<KT_POLY2, true>(a, sgrid, s);
+            } else {
+                launch_v2d_kt<KT_POLY, true>(a, sgrid, s);
+            }
+            break;
+        default: launch_v2d_kt<KT_RBF, true>(a, sgrid, s); break;
+    }
+}
+#else
 template <>
 void launch_tile_kernel<double>(TileArgs<double> &a, int kernel_type, bool /*rbf_direct*/, int num_jc, hipStream_t s) {
     const dim3 grid(a.num_ib > 0 && num_jc > 0 ? finish_mapping(a, num_jc) : 0u);
@@ -40,20 +66,7 @@ void launch_tile_kernel<double>(TileArgs<double> &a, int kernel_type, bool /*rbf
     }
     if (a.dc != nullptr) {  // the records exist only where the v2 kernel was chosen when the data was prepared; V2D_LDS_BYTES < 64 KiB
         if (a.items != nullptr) {
-            const dim3 sgrid(static_cast<unsigned>(a.num_items));
-            switch (kernel_type) {
-                case KT_LINEAR: launch_v2d_kt<KT_LINEAR, true>(a, sgrid, s); break;
-                case KT_POLY:
-                    if (a.degree == 3) {
-                        launch_v2d_kt<KT_POLY3, true>(a, sgrid, s);
-                    } else if (a.degree == 2) {
-                        launch_v2d_kt<KT_POLY2, true>(a, sgrid, s);
-                    } else {
-                        launch_v2d_kt<KT_POLY, true>(a, sgrid, s);
-                    }
-                    break;
-                default: launch_v2d_kt<KT_RBF, true>(a, sgrid, s); break;
-            }
+            launch_v2d_sym(a, kernel_type, s);
         } else {
             switch (kernel_type) {
                 case KT_LINEAR: launch_v2d_kt<KT_LINEAR, false>(a, grid, s); break;
@@ -88,5 +101,6 @@ void launch_tile_kernel<double>(TileArgs<double> &a, int kernel_type, bool /*rbf
     }
     LSSVM_HIP_CHECK(hipGetLastError());
 }
+#endif
 
 }  // namespace lssvm

@@ -17,7 +17,7 @@ from plssvm_amd import _capi, backend
 from plssvm_amd.datagen import make_blobs_pm1
 from plssvm_amd.parameter import Parameter
 
-OPTION_KEYS = ("gram_mode", "tile_kernel", "j_chunk_tiles", "symmetric", "colslab_band_mb", "item_order", "rbf_fold", "mfma_shape")
+OPTION_KEYS = ("gram_mode", "tile_kernel", "j_chunk_tiles", "symmetric", "colslab_band_mb", "rbf_fold", "mfma_shape")
 
 
 def narrow_case(seed: int, index: int) -> dict:
@@ -31,7 +31,7 @@ def narrow_case(seed: int, index: int) -> dict:
     if N > 8192 and rng.integers(3):
         d = int(rng.choice([16, 64, 65, 100, 128, 200, 256]))  # mostly where the pair kernels apply (<= 128 features; the linear kernel's panel passes beyond)
     opts = dict(gram_mode=int(rng.choice([3, 3, 1, 0, 2])), j_chunk_tiles=int(rng.choice([0, 0, 1, 2, 3, 7])), symmetric=int(rng.choice([1, 1, 0])),
-                colslab_band_mb=int(rng.choice([2048, 1])), item_order=int(rng.choice([0, 1, 2])), rbf_fold=int(rng.choice([1, 0])), mfma_shape=int(rng.choice([3, 3, 2, 1])))
+                colslab_band_mb=int(rng.choice([2048, 1])), rbf_fold=int(rng.choice([1, 0])), mfma_shape=int(rng.choice([3, 3, 2])))
     return dict(family="narrow", dtype=dtype, kernel=kernel, N=N, d=d, opts=opts, shards=int(rng.choice([1, 1, 2, 3, 8])), degree=int(rng.choice([0, 1, 2, 3, 4])),
                 gamma=float(rng.choice([1.0, 0.3])) / d, coef0=float(rng.choice([0.0, 1.0])), data_seed=300 + index, v_seed=int(rng.integers(1 << 30)))
 
@@ -44,7 +44,7 @@ def pair_case(seed: int, index: int) -> dict:
     N = int(rng.integers(8194, 13000))
     d = int(rng.choice([1, 17, 64, 65, 100, 128])) if kernel != "linear" or rng.integers(2) else int(rng.choice([129, 200, 256, 300]))
     opts = dict(gram_mode=int(rng.choice([3, 3, 2, 1])), j_chunk_tiles=int(rng.choice([0, 0, 1, 2, 3, 5, 7])), symmetric=1, colslab_band_mb=int(rng.choice([2048, 1])),
-                item_order=int(rng.choice([0, 1, 2])), rbf_fold=1, mfma_shape=3)
+                rbf_fold=1, mfma_shape=3)
     return dict(family="pair", dtype="float32", kernel=kernel, N=N, d=d, opts=opts, shards=int(rng.choice([1, 1, 2, 3, 8])), degree=int(rng.choice([2, 3])),
                 gamma=float(rng.choice([1.0, 0.3])) / d, coef0=float(rng.choice([0.0, 1.0])), data_seed=500 + index, v_seed=int(rng.integers(1 << 30)))
 
@@ -58,7 +58,7 @@ def wide_case(seed: int, index: int, f64: bool) -> dict:
     if not f64 and kernel == "polynomial" and d <= 512 and rng.integers(2):
         d += 256
     opts = dict(gram_mode=int(rng.choice([3, 1])), j_chunk_tiles=int(rng.choice([0, 1, 2, 3, 7])), symmetric=int(rng.choice([1, 1, 0])),
-                colslab_band_mb=int(rng.choice([2048, 1])), item_order=int(rng.choice([0, 1, 2])), rbf_fold=int(rng.choice([1, 0])))
+                colslab_band_mb=int(rng.choice([2048, 1])), rbf_fold=int(rng.choice([1, 0])))
     return dict(family="wide_f64" if f64 else "wide_f32", dtype="float64" if f64 else "float32", kernel=kernel, N=N, d=d, opts=opts, shards=int(rng.choice([1, 1, 2, 3, 8])),
                 degree=int(rng.choice([1, 2, 3, 4])), gamma=float(rng.choice([1.0, 0.3])) / d, coef0=float(rng.choice([0.0, 1.0])), data_seed=100 + index, v_seed=int(rng.integers(1 << 30)))
 

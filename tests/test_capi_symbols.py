@@ -32,8 +32,16 @@ def test_header_and_binding_agree():
     # the public header carries no measurement / test entry point and documents no test knob
     assert "lssvm_mi355_measure_bf16_mfma_ceiling" not in declared_symbols((HEADER,))
     public = open(HEADER).read()
-    for knob in ("debug_ablate", "lds_extra_kb", "skip_collective", "force_collective"):
+    for knob in ("debug_ablate", "pair_lag", "skip_collective", "force_collective"):
         assert knob not in public, knob
+    # twelve documented options + two testing aids = the fourteen the library accepts (+ two that exist in development builds only)
+    documented = re.findall(r'^ \*   "(\w+)"', public, flags=re.M)
+    assert sorted(documented + ["force_collective", "skip_collective"]) == sorted(_capi.OPTION_NAMES) and len(_capi.OPTION_NAMES) == 14
+    for name in _capi.OPTION_NAMES + _capi.DEV_OPTION_NAMES:
+        _capi.get_option(name)
+    for retired in ("xcd_map", "lds_extra_kb", "item_order", "linear_panel_features", "check_shards", "rbf_direct_above"):
+        with pytest.raises(InvalidParameterError):
+            _capi.get_option(retired)
 
 
 def test_library_exports_every_declared_symbol():
