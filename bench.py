@@ -48,8 +48,11 @@ WORKLOADS = {
 PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6, "bf16": 16 * 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md (bf16 = 16 x the f32 MFMA rate, ~2.5 PF)
 
 # the sources that decide how many bytes the tile kernel moves: profiles/hbm_traffic.json carries their hash, a stale entry is dropped
-TRAFFIC_SOURCES = ["plssvm_amd/csrc/lssvm_tile_f32_split.hip.hpp", "plssvm_amd/csrc/lssvm_s6w_groups.inc", "plssvm_amd/csrc/lssvm_tile_f32.hip.hpp", "plssvm_amd/csrc/lssvm_tile_f64.hip.hpp",
-                   "plssvm_amd/csrc/lssvm_device_common.hip.hpp", "plssvm_amd/csrc/lssvm_problem.hip"]
+TRAFFIC_SOURCES = ["plssvm_amd/csrc/lssvm_tile_f32_split.hip.hpp", "plssvm_amd/csrc/lssvm_tile_f32_pair.hip.hpp", "plssvm_amd/csrc/lssvm_s6w_groups.inc", "plssvm_amd/csrc/lssvm_tile_f32.hip.hpp",
+                   "plssvm_amd/csrc/lssvm_tile_f32_wide.hip.hpp", "plssvm_amd/csrc/lssvm_tile_f64.hip.hpp", "plssvm_amd/csrc/lssvm_tile_f64_wide.hip.hpp", "plssvm_amd/csrc/lssvm_device_common.hip.hpp",
+                   "plssvm_amd/csrc/lssvm_kernels.hip.hpp", "plssvm_amd/csrc/lssvm_problem.hip", "plssvm_amd/csrc/lssvm_problem.hip.hpp", "plssvm_amd/csrc/lssvm_types.hpp",
+                   "plssvm_amd/csrc/tile_launch_f32.hip", "plssvm_amd/csrc/tile_launch_f32h.hip", "plssvm_amd/csrc/tile_launch_f32s.hip", "plssvm_amd/csrc/tile_launch_f32d.hip",
+                   "plssvm_amd/csrc/tile_launch_f32x.hip", "plssvm_amd/csrc/tile_launch_f64.hip", "plssvm_amd/csrc/tile_launch_f64x.hip"]  # (the launch and split sources belong here too)
 
 
 def kernel_source_hash() -> str:
@@ -80,6 +83,30 @@ def measured_traffic(key: str):
     return None, "unstamped entry (taken before the kernel-source stamp existed)"
 
 
+def physical_cores() -> int:
+    """Physical cores of the box (distinct (package, core) pairs of /proc/cpuinfo) -- `cpu_baseline.cores`; os.cpu_count() counts hardware threads
+    (256 on the 2 x 64-core host of the GPU box)."""
+    try:
+        pairs, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        pairs.add((phys, core))
+                    phys = core = None
+        if phys is not None and core is not None:
+            pairs.add((phys, core))
+        if pairs:
+            return len(pairs)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_model() -> str:
     try:
         with open("/proc/cpuinfo") as f:
@@ -100,7 +127,8 @@ def cpu_baseline(X, y, kernel, sample_rows, iters):
 
     ns = min(sample_rows, X.shape[0])
     Xs, ys = X[:ns], y[:ns]
-    cores = os.cpu_count() if oracle_lib.have_ref() else oracle_lib.oracle().num_threads()
+    threads = os.cpu_count() if oracle_lib.have_ref() else oracle_lib.oracle().num_threads()  # OpenMP's default: one thread per hardware thread
+    cores = min(physical_cores(), threads)
 
     def run(impl, kind, flags):
         t0 = time.perf_counter()
@@ -110,7 +138,7 @@ def cpu_baseline(X, y, kernel, sample_rows, iters):
         # the solve runs its + 1 implicit matvecs (one for the initial residual); price an iteration as wall / (its + 1)
         t_iter = wall / (its + 1)
         flop = 2.0 * (ns - 1) ** 2 * X.shape[1]
-        return {"value": flop / t_iter / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": kind, "cpu_model": cpu_model(), "build_flags": flags,
+        return {"value": flop / t_iter / 1e9, "unit": "GFLOP/s", "cores": cores, "threads": threads, "kind": kind, "cpu_model": cpu_model(), "build_flags": flags,
                 "sample": f"first {ns} rows of the workload, {its} CG iterations + initial residual ({its + 1} implicit matvecs), "
                           f"{t_iter * 1e3:.1f} ms per matvec; effective GFLOP/s = 2*n^2*d / t is size independent",
                 "ms_per_step_at_sample": t_iter * 1e3}
