@@ -124,7 +124,7 @@ LSSVM_IPC_BLOB_BYTES = 256
 OPTION_NAMES = ["rbf_form", "rbf_fold", "j_chunk_tiles", "symmetric", "tile_kernel", "gram_mode", "mfma_shape", "colslab_band_mb", "colslab_limit_mb", "force_collective", "skip_collective",
                 "exchange", "ipc_timeout_s", "enqueue_ahead_below_us"]
 # accepted with the value 0 everywhere, with other values in development builds only (make DEV=1 / -DLSSVM_ENABLE_ABLATION)
-DEV_OPTION_NAMES = ["pair_lag", "debug_ablate"]
+DEV_OPTION_NAMES = ["pair_lag", "debug_ablate", "item_order_dev"]
 
 
 def int_array(values):

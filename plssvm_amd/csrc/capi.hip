@@ -336,6 +336,13 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
         } else if (n == "mfma_shape") {
             LSSVM_REQUIRE(value == 2 || value == 3, "mfma_shape must be 2 (128-row workgroups) or 3 (256-row workgroups in the symmetric variant where they apply)");
             lssvm::options().mfma_shape = value;
+        } else if (n == "item_order_dev") {
+#ifdef LSSVM_DEV_SUBSET
+            LSSVM_REQUIRE(value >= 0 && value <= 3, "item_order_dev must be 0 ... 3");
+            lssvm::options().item_order_dev = value;
+#else
+            LSSVM_REQUIRE(value == 0, "item_order_dev exists in development builds (make DEV=1) only");
+#endif
         } else if (n == "pair_lag") {
 #ifdef LSSVM_DEV_SUBSET
             LSSVM_REQUIRE(value == 0 || value == 1 || value == 3, "pair_lag must be 0, 1 or 3");
@@ -387,6 +394,8 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             *value_out = lssvm::options().gram_mode;
         } else if (n == "mfma_shape") {
             *value_out = lssvm::options().mfma_shape;
+        } else if (n == "item_order_dev") {
+            *value_out = lssvm::options().item_order_dev;
         } else if (n == "pair_lag") {
             *value_out = lssvm::options().pair_lag;
         } else if (n == "colslab_band_mb") {

@@ -565,6 +565,36 @@ static std::vector<int2> band_items(int band_begin, int band_end, int jc_tiles, 
         }
     }
     std::stable_sort(cut.begin(), cut.end(), [&](const int2 &x, const int2 &y) { return (x.x + rows - x.y * jc_tiles) > (y.x + rows - y.y * jc_tiles); });
+    if (order == 3) {
+        // XCD-aware: the hardware deals consecutive workgroups round-robin over the 8 XCDs (observed, a speed matter only), each with an L2 of its own.
+        // In column-chunk major order the workgroups that stream one chunk are spread over all eight L2s, which each fetch it from the fabric; here list
+        // position 8 k + x belongs to "lane" x, and a lane works through ONE column chunk at a time (the chunks dealt to the lanes as they run dry),
+        // so that an XCD's workgroups share their column stream in ITS L2.
+        std::vector<std::vector<int2>> by_chunk(static_cast<size_t>(num_jc));
+        for (const int2 &it : full) by_chunk[static_cast<size_t>(it.y)].push_back(it);
+        std::vector<int2> out;
+        out.reserve(full.size());
+        int next_chunk = 0;
+        std::vector<int> lane_chunk(8, -1);
+        std::vector<size_t> lane_pos(8, 0);
+        size_t emitted = 0;
+        while (emitted < full.size()) {
+            for (int x = 0; x < 8 && emitted < full.size(); ++x) {
+                while (lane_chunk[x] < 0 || lane_pos[x] >= by_chunk[static_cast<size_t>(lane_chunk[x])].size()) {
+                    if (next_chunk >= num_jc) {
+                        lane_chunk[x] = -2;
+                        break;
+                    }
+                    lane_chunk[x] = next_chunk++;
+                    lane_pos[x] = 0;
+                }
+                if (lane_chunk[x] == -2) continue;  // (this lane has run out of chunks: its positions go to the others)
+                out.push_back(by_chunk[static_cast<size_t>(lane_chunk[x])][lane_pos[x]++]);
+                ++emitted;
+            }
+        }
+        full.swap(out);
+    }
     full.insert(full.end(), cut.begin(), cut.end());
     return full;
 }
@@ -786,7 +816,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
             band.ib_end = edge[k + 1];
             band.item_begin = static_cast<int>(items.size());
             band.pair_origin = pairs_below(band.ib_begin);
-            for (const int2 &it : band_items(band.ib_begin, band.ib_end, jc_tiles_, num_jc_, ITEM_ORDER, pair_)) items.push_back(make_int2(it.x - ib_begin_, it.y));
+            for (const int2 &it : band_items(band.ib_begin, band.ib_end, jc_tiles_, num_jc_, opt_.item_order_dev != 0 ? static_cast<int>(opt_.item_order_dev) : ITEM_ORDER, pair_)) items.push_back(make_int2(it.x - ib_begin_, it.y));
             band.item_count = static_cast<int>(items.size()) - band.item_begin;
             // (block pairs: the records of the pair's SECOND block, which is padding behind an odd last block)
             max_records = std::max(max_records, pairs_below(pair_ ? round_up(band.ib_end, 2) : band.ib_end) - band.pair_origin);

@@ -79,6 +79,7 @@ struct Options {
     int64_t ipc_timeout_s = 600;   // one process per GPU over HIP IPC: how long a rank waits for its peers at an exchange before it gives up
     // development builds only (the setter refuses them elsewhere)
     int64_t debug_ablate = 0;      // -DLSSVM_ENABLE_ABLATION: timing ablations of the fp32 tile kernels (results are wrong when != 0)
+    int64_t item_order_dev = 0;    // make DEV=1: order of the work items of the symmetric variant (0 = ITEM_ORDER; 3 = XCD-aware lanes)
     int64_t pair_lag = 0;          // make DEV=1: plane-chunk steps waves 4-7 of a 256-row workgroup run behind waves 0-3 (0 = lock step: the shipped form; 1, 3
                                    // measured slower)
 };
@@ -86,7 +87,10 @@ constexpr double RBF_DIRECT_ABOVE = 32.0;     // rbf_form 0: the formula-exact k
                                               // matrix-core exponent ~ 2^-24 x that; [-1, 1]-scaled data with gamma = 1 / num_features has <= 3)
 constexpr int LINEAR_PANEL_FEATURES = 128;    // linear kernel beyond this many features: one pass of the <= 128-feature kernels per feature panel (fp32 f16x3: beats the
                                               // wider one-wave kernels by 5 ... 12 % at every width measured; fp64: 64- and 256-feature panels within 2 %)
-constexpr int ITEM_ORDER = 1;                 // symmetric variant: work items in column-chunk major order, the items cut short by the diagonal last, longest first
+constexpr int ITEM_ORDER = 3;                 // symmetric variant: the work items of a column chunk on ONE XCD at a time (list position 8 k + x = lane x; the hardware deals
+                                              // workgroups round-robin over the 8 XCDs), the items cut short by the diagonal last, longest first.  Against plain
+                                              // column-chunk major order (1): bit-identical results, fabric traffic 116 -> 97 GB per matvec at 1 000 000 x 128, time -0.3 %
+                                              // (profiles/r04_ab_xcd_item_order.log)
 /* process-wide DEFAULTS (lssvm_mi355_set_option); every problem takes a snapshot when it is created */
 Options &options();
 

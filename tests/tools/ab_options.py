@@ -40,7 +40,7 @@ def main():
     dt = np.dtype(args.dtype)
     X, y = make_blobs_pm1(args.points, args.features, seed=42, dtype=dt)
     p = Parameter(kernel_type=args.kernel)
-    defaults = {n: _capi.get_option(n) for n in _capi.OPTION_NAMES}
+    defaults = {n: _capi.get_option(n) for n in _capi.OPTION_NAMES + _capi.DEV_OPTION_NAMES}
     ref = None
     v = np.random.default_rng(1).uniform(-1, 1, size=args.points - 1).astype(dt)
     print(f"# {args.points} x {args.features} {args.kernel} {args.dtype}, {args.steps} steps, device {_capi.device_name(0)}", flush=True)
