@@ -72,40 +72,6 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
     const int nsteps = ntiles * NKC;
     const long rec0 = static_cast<long>(ib0 + 1) * ib0 / 2 - a.pair_origin;  // records of row block ib0 + 1
 
-    // ---- the row panel (this wave's 32 rows, all features, all row planes) ----
-    bf16x8 afrag[PLA][2 * NK64][2];
-#pragma unroll
-    for (int p = 0; p < PLA; ++p) {
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const uint16_t *xr = a.Xr16 + p * a.plane_stride_r + static_cast<size_t>(row0 + wave * 32 + 16 * rb + r) * a.ldx16 + 8 * g;
-#pragma unroll
-            for (int kk = 0; kk < 2 * NK64; ++kk) afrag[p][kk][rb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(xr + 32 * kk));
-        }
-    }
-    // rbf: K_ij = 2^c_i 2^(x_i . x_j) 2^c_j with BOTH exponent terms folded out of the chain -- the column's as the record's factor e_j (k_pack_dc:
-    // (e_j d_j | e_j), as in s6w_body), the row's as e_i = 2^c_i: the mirrored column sums take e_i d_i in place of d_i, the finished row sums are
-    // multiplied by e_i once per work item, and the accumulators start from the constant 0 like every other kernel's.  (s6w_body starts them from
-    // c_i, eight registers that live across the whole tile loop: with the row panel of three planes, the accumulators and the private B fragments
-    // this kernel has none to spare, and a spilled row-panel fragment is re-loaded in front of every MFMA group.)  The host chooses this kernel
-    // only while |c| <= PAIR_FOLD_MAX_C keeps e and the partial sums inside the fp32 range.
-    if constexpr (HALF == 0) {
-        if constexpr (KT == KT_RBFF) cis[tid] = __builtin_amdgcn_exp2f(a.cr[row0 + tid]);
-    } else {
-        const float dv = a.dvec[row0 + tid - PR_ROWS];
-        if constexpr (KT == KT_RBFF) {
-            dis[tid - PR_ROWS] = dv * __builtin_amdgcn_exp2f(a.cr[row0 + tid - PR_ROWS]);
-        } else {
-            dis[tid - PR_ROWS] = dv;
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < PLA; ++p)
-#pragma unroll
-        for (int kk = 0; kk < 2 * NK64; ++kk)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) asm volatile("" : "+v"(afrag[p][kk][rb]));
-
     // ---- LDS-DMA addressing: a slot is 16 pieces of 8 columns x 128 B; wave w moves pieces 2 w and 2 w + 1 ----
     unsigned dma_off[2];
 #pragma unroll
@@ -170,7 +136,8 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
         }
     };
 
-    // ---- prologue: chunks 0, 1, 2 ----
+    // ---- prologue: the LDS-DMA of chunks 0, 1, 2 goes out FIRST, the row panel (ordinary loads) behind it -- one memory latency per work item instead
+    // of two; with one workgroup per CU nothing else covers a work item's start.  One wait for all of it: the row panel is needed at once anyway. ----
     issue_dc(0);
     issue_chunk(0);
 #pragma unroll
@@ -180,13 +147,42 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
             issue_chunk(pre);
         }
     }
-    if (nsteps >= 3) {
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    } else if (nsteps == 2) {
-        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // ---- the row panel (this wave's 32 rows, all features, all row planes) ----
+    bf16x8 afrag[PLA][2 * NK64][2];
+#pragma unroll
+    for (int p = 0; p < PLA; ++p) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const uint16_t *xr = a.Xr16 + p * a.plane_stride_r + static_cast<size_t>(row0 + wave * 32 + 16 * rb + r) * a.ldx16 + 8 * g;
+#pragma unroll
+            for (int kk = 0; kk < 2 * NK64; ++kk) afrag[p][kk][rb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(xr + 32 * kk));
+        }
     }
+    // rbf: K_ij = 2^c_i 2^(x_i . x_j) 2^c_j with BOTH exponent terms folded out of the chain -- the column's as the record's factor e_j (k_pack_dc:
+    // (e_j d_j | e_j), as in s6w_body), the row's as e_i = 2^c_i: the mirrored column sums take e_i d_i in place of d_i, the finished row sums are
+    // multiplied by e_i once per work item, and the accumulators start from the constant 0 like every other kernel's.  (s6w_body starts them from
+    // c_i, eight registers that live across the whole tile loop: with the row panel of three planes, the accumulators and the private B fragments
+    // this kernel has none to spare, and a spilled row-panel fragment is re-loaded in front of every MFMA group.)  The host chooses this kernel
+    // only while |c| <= PAIR_FOLD_MAX_C keeps e and the partial sums inside the fp32 range.
+    if constexpr (HALF == 0) {
+        if constexpr (KT == KT_RBFF) cis[tid] = __builtin_amdgcn_exp2f(a.cr[row0 + tid]);
+    } else {
+        const float dv = a.dvec[row0 + tid - PR_ROWS];
+        if constexpr (KT == KT_RBFF) {
+            dis[tid - PR_ROWS] = dv * __builtin_amdgcn_exp2f(a.cr[row0 + tid - PR_ROWS]);
+        } else {
+            dis[tid - PR_ROWS] = dv;
+        }
+    }
+    // (retire the ordinary loads HERE: none may be outstanding once the counted waits of the hand-overs begin)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int p = 0; p < PLA; ++p)
+#pragma unroll
+        for (int kk = 0; kk < 2 * NK64; ++kk)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) asm volatile("" : "+v"(afrag[p][kk][rb]));
+
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     // the lagging half lets LAG global steps pass (hand-overs only)
@@ -337,11 +333,13 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
     // every lane group owns its rows: reduce over the 16 columns of the group and store
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+        // sum over the 16 columns of the lane group on the vector ALU (DPP: xor 1, xor 2 inside the quads, then the mirrored half row and the
+        // mirrored row, which pair quads / halves whose sums are already uniform) -- no LDS round trips at the end of a work item
         float v = rowpart[i];
-        v += __shfl_xor(v, 8);
-        v += __shfl_xor(v, 4);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 1);
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1, 0, 3, 2]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2, 3, 0, 1]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
         if constexpr (KT == KT_LINEAR && F16) v *= a.out_scale;
         rowpart[i] = v;
     }
