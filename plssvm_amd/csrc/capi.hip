@@ -345,7 +345,7 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
 #endif
         } else if (n == "pair_lag") {
 #ifdef LSSVM_DEV_SUBSET
-            LSSVM_REQUIRE(value == 0 || value == 1 || value == 3, "pair_lag must be 0, 1 or 3");
+            LSSVM_REQUIRE(value >= 0 && value <= 7 && value != 2, "pair_lag must be 0, 1, 3 (steps of lag) or 4 ... 7 (priority experiments)");
             lssvm::options().pair_lag = value;
 #else
             LSSVM_REQUIRE(value == 0, "pair_lag exists in development builds (make DEV=1) only");

@@ -40,10 +40,16 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
     static_assert(PL == 3 || PL == 2, "three bf16 planes (bf16x6) or two f16 planes (f16x3)");
     static_assert(NK64 <= 2, "the hand-scheduled groups assume the 256-register budget of two waves per SIMD");
     static_assert(KT != KT_RBF, "rbf runs here with BOTH exponent terms folded (KT_RBFF, see below); the unfolded form stays on the 128-row kernels");
-    static_assert(LAGT >= 0 && LAGT <= 4, "the ring holds the DMA's three steps ahead, the step in use and up to four steps of lag");
+    static_assert(LAGT >= 0 && LAGT <= 7, "0 ... 3: steps of lag; 4 ... 7: priority experiments of the development builds");
     constexpr bool F16 = PL == 2;
     constexpr int NKC = PL * NK64;
-    constexpr int LAG = HALF ? LAGT : 0;  // this half's distance behind the global step counter
+    // LAGT = 0, the shipped form: lock step, and the second-dispatched half of the workgroup (waves 4-7, the loser of the SIMD's issue arbitration by age) at
+    // s_setprio 1 for the whole kernel (MI355X_MICROARCH.md, Two waves per SIMD, item 4): 265.0 -> 262.1 ms at 1 000 000 x 128 rbf, neutral for the linear
+    // kernel (profiles/r04_ab_pair_priority.log).  Development builds also carry 1, 3 = steps of lag (no priority); 4 = lock step WITHOUT the priority;
+    // 5 = priority 3; 6 = one step of lag + priority 1; 7 = priority 1 for waves 0-3 instead -- all measured slower than 0.
+    constexpr int PRIO = (LAGT == 0 || LAGT == 6) ? (HALF == 1 ? 1 : 0) : (LAGT == 5 ? (HALF == 1 ? 3 : 0) : (LAGT == 7 ? (HALF == 0 ? 1 : 0) : 0));
+    constexpr int LAGE = LAGT == 6 ? 1 : (LAGT >= 4 ? 0 : LAGT);
+    constexpr int LAG = HALF ? LAGE : 0;  // this half's distance behind the global step counter
     constexpr int PLA = F16 ? ((KT == KT_RBF || KT == KT_RBFF) ? 3 : 2) : 3;
     constexpr auto row_plane = [](int p, int q) constexpr { return (F16 && PLA == 3) ? (p == 0 ? (q == 0 ? 2 : 1) : 0) : q; };
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -59,6 +65,8 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
     const int r = lane & 15;
     const int g = lane >> 4;
 
+    if constexpr (PRIO == 1) asm volatile("s_setprio 1");
+    if constexpr (PRIO == 3) asm volatile("s_setprio 3");
     const int2 it = a.items[blockIdx.x];
     const int ibl = __builtin_amdgcn_readfirstlane(it.x);  // local index of the pair's FIRST block (even)
     const int jc = __builtin_amdgcn_readfirstlane(it.y);
@@ -323,7 +331,7 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
     // the leading half accompanies the lagging half's last LAGT steps (hand-overs only)
     if constexpr (HALF == 0) {
 #pragma unroll
-        for (int k = 0; k < LAGT; ++k) handover_checked(nsteps + k);
+        for (int k = 0; k < LAGE; ++k) handover_checked(nsteps + k);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

@@ -19,7 +19,7 @@ static void launch_pair_lag(const TileArgs<float> &a, hipStream_t s) {
         break;
     switch (a.pair_lag) {
 #ifdef LSSVM_DEV_SUBSET  // development builds: the lag as a run-time choice (A/B; measured: every lag is SLOWER than lock step)
-        LSSVM_PAIR_LAG(1) LSSVM_PAIR_LAG(3)
+        LSSVM_PAIR_LAG(1) LSSVM_PAIR_LAG(3) LSSVM_PAIR_LAG(4) LSSVM_PAIR_LAG(5) LSSVM_PAIR_LAG(6) LSSVM_PAIR_LAG(7)
 #endif
         LSSVM_PAIR_LAG(0)
         default: throw Error(LSSVM_ERR_INTERNAL, "no 256-row tile kernel for this lag");
