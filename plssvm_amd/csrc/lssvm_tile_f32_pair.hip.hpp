@@ -369,6 +369,10 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
 /* PL = 2: f16x3 ("f3d"), PL = 3: bf16x6 ("s6d").  LAGT: steps the second half runs behind (0 = lock step). */
 template <int KT, int NK64, int PL, int LAGT>
 __global__ __launch_bounds__(PR_THREADS, 2) LSSVM_HAND_VGPR_CAP void tile_matvec_f32_pair(const TileArgs<float> a) {
+#ifdef LSSVM_CODE_SHIFT  // placement experiment (cdna_hip_programming.md section 5.4, rule 27): shift the instruction stream by 4 x LSSVM_CODE_SHIFT bytes
+#pragma unroll
+    for (int i = 0; i < LSSVM_CODE_SHIFT; ++i) asm volatile("s_nop 0");
+#endif
     if (__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6) < 4) {  // (a scalar branch: the halves are whole waves)
         pair_body<KT, NK64, PL, 0, LAGT>(a);
     } else {

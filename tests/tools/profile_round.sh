@@ -8,7 +8,8 @@ export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
 for wl in c2 c3 c4 c5; do
-  st=10; [ $wl = c5 ] && st=5
+  # (short launches need enough timed steps for the chip to settle: 10 steps of the 0.7 ms c2 iteration measure 0.79 ms per launch, 200 steps 0.705)
+  st=20; [ $wl = c5 ] && st=5; [ $wl = c2 ] && st=200
   python3 bench.py --workload $wl --steps $st --warmup 2 > $O/${TAG}_bench_${wl}_n1.json 2> $O/${TAG}_bench_${wl}.err
 done
 # what a BARE bf16 MFMA loop sustains on THIS box (the chip lowers its clock under matrix-core load): the practical ceiling beside the bench lines
@@ -16,12 +17,14 @@ done
 python3 bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline --no-native-reference > $O/${TAG}_bench_c5_n1_after_microbench.json 2>/dev/null
 # the native v_mfma_f32 path and the bf16x6 split of the fp32 workloads, same box, for reference (the library default is f16x3 where the data allows)
 for wl in c2 c3 c5; do
-  python3 bench.py --workload $wl --steps 5 --warmup 2 --gram-mode 0 --no-cpu-baseline > $O/${TAG}_bench_${wl}_n1_native_f32_mfma.json 2> $O/${TAG}_bench_${wl}_native.err
-  python3 bench.py --workload $wl --steps 5 --warmup 2 --gram-mode 1 --no-cpu-baseline --no-native-reference > $O/${TAG}_bench_${wl}_n1_bf16x6.json 2> $O/${TAG}_bench_${wl}_bf16x6.err
+  st=5; [ $wl = c2 ] && st=100
+  python3 bench.py --workload $wl --steps $st --warmup 2 --gram-mode 0 --no-cpu-baseline > $O/${TAG}_bench_${wl}_n1_native_f32_mfma.json 2> $O/${TAG}_bench_${wl}_native.err
+  python3 bench.py --workload $wl --steps $st --warmup 2 --gram-mode 1 --no-cpu-baseline --no-native-reference > $O/${TAG}_bench_${wl}_n1_bf16x6.json 2> $O/${TAG}_bench_${wl}_bf16x6.err
 done
 for wl in c2 c3 c4 c5; do
   rm -rf $O/prof_$wl
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -- python3 bench.py --workload $wl --steps 5 --warmup 1 --no-cpu-baseline --no-native-reference --no-ceiling > $O/prof_$wl.log 2>&1
+  st=5; [ $wl = c2 ] && st=100
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -- python3 bench.py --workload $wl --steps $st --warmup 1 --no-cpu-baseline --no-native-reference --no-ceiling > $O/prof_$wl.log 2>&1
   f=$(find $O/prof_$wl -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" $O/${TAG}_rocprofv3_kernel_stats_bench_${wl}.csv
   grep "^{" $O/prof_$wl.log | tail -1 > $O/${TAG}_rocprofv3_bench_line_${wl}.json
