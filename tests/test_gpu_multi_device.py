@@ -80,7 +80,7 @@ def test_sharded_matvec_and_cg_equal_the_single_device_run(kernel, dtype, N, d, 
             got = prob.matvec(v, zero, 1.0)
             prob.cg_begin(y, 1e-30)
             prob.cg_step(3)
-            a, rho, info = prob.cg_finish()  # also asserts (check_shards) that all shards hold bit-equal CG scalars
+            a, rho, info = prob.cg_finish()  # also asserts (the shard check of cg_finish) that all shards hold bit-equal CG scalars
         assert info["devices_used"] == len(devices) and info["local_devices"] == len(devices) and info["symmetric"] == info1["symmetric"]
         assert info["exchange"] == (2 if len(set(devices)) < len(devices) else 1)
         if info["symmetric"]:

@@ -314,7 +314,7 @@ def test_rbf_direct_form_agrees_with_matrix_core_form(oracle):
 def test_rbf_large_exponent_scale_switches_to_the_direct_kernel(oracle, case):
     """the matrix-core rbf form evaluates the exponent as c_i + c_j + x_i'.x_j'; its absolute error is ~2^-24 R2 with
     R2 = 2 gamma log2(e) max|x - mean|^2, which pairs of NEARBY points (K ~ 1) see as a relative error of K.  With rbf_form = 0 the
-    library measures R2 and runs the formula-exact (x_i - x_j)^2 kernel above rbf_direct_above (default 32).  Cases: gamma = 1 and 10 at
+    library measures R2 and runs the formula-exact (x_i - x_j)^2 kernel above RBF_DIRECT_ABOVE = 32 (lssvm_problem.hip.hpp).  Cases: gamma = 1 and 10 at
     128 features on [-1,1]-scaled data (gamma = 1 lands just BELOW the threshold and stays on the matrix cores), and unscaled data (features of order 30) at gamma = 1/d.  Every data set carries near-duplicate
     points, the pairs that lose digits.  Asserted against the float64 oracle on the scale of each row's summands: the automatic choice
     stays below 16 eps; the forced matrix-core form (rbf_form = 2) is measurably worse by roughly R2 / 32 -- the reason for the switch --

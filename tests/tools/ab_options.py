@@ -2,7 +2,7 @@
 """Developer tool (not a test): same-box A/B of library options on one workload shape.
 
     python tests/tools/ab_options.py --points 300000 --features 128 --kernel rbf --steps 6 --repeat 2 \
-        --variant mfma_shape=0 --variant mfma_shape=1 --variant "mfma_shape=1,j_chunk_tiles=32"
+        --variant mfma_shape=2 --variant mfma_shape=3 --variant "mfma_shape=3,j_chunk_tiles=32"
 
 Every variant creates a fresh resident problem (the options are snapshotted then), runs `steps` CG iterations after a warm-up and
 prints the average tile-kernel time (HIP events on the solver stream) and the wall time per iteration; the variants are interleaved

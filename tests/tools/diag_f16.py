@@ -27,7 +27,7 @@ for (N, d) in cases:
     v = np.random.default_rng(1).uniform(-1, 1, N - 1).astype(np.float32)
     for kernel in ("rbf", "linear"):
         Kv, scale = truth(kernel, X, v, 1.0 / d)
-        for gm, shape, sym, fold in itertools.product((2, 1), (2, 1), (1, 0), (1, 0)):
+        for gm, shape, sym, fold in itertools.product((2, 1), (3, 2), (1, 0), (1, 0)):
             if kernel != "rbf" and fold == 0:
                 continue
             for k, val in (("gram_mode", gm), ("mfma_shape", shape), ("symmetric", sym), ("rbf_fold", fold)):

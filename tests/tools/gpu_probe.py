@@ -106,46 +106,11 @@ if __name__ == "__main__":
                 print(f"debug_ablate={dbg}: ", end="")
                 perf(100000, 64, kern, np.float64, iters=4)
         _capi.set_option("debug_ablate", 0)
-    elif "--sched" in sys.argv:
-        # scheduling experiments on the symmetric kernels: item order, items per column chunk
-        for N in (50000, 100000):
-            for order in (0, 1, 2):
-                for jt in (8, 16, 32):
-                    _capi.set_option("item_order", order)
-                    _capi.set_option("j_chunk_tiles", jt)
-                    print(f"N={N} item_order={order} j_chunk_tiles={jt}: ", end="")
-                    perf(N, 128, "rbf", np.float32, iters=6)
-            _capi.set_option("item_order", 1)
-            _capi.set_option("j_chunk_tiles", 0)
-        for jt in (8, 16, 32):
-            _capi.set_option("j_chunk_tiles", jt)
-            print(f"j_chunk_tiles={jt}: ", end="")
-            perf(100000, 64, "polynomial", np.float64, iters=6)
-            print(f"j_chunk_tiles={jt}: ", end="")
-            perf(100000, 64, "rbf", np.float64, iters=6)
-        _capi.set_option("j_chunk_tiles", 0)
     elif "--ablate2" in sys.argv:
         for dbg in (0, 1, 4, 5, 16, 20, 28):
             _capi.set_option("debug_ablate", dbg)
             print(f"debug_ablate={dbg}: ", end="")
             perf(100000, 128, "rbf", np.float32, iters=4)
-        _capi.set_option("debug_ablate", 0)
-    elif "--occ" in sys.argv:
-        for extra in (0, 20, 88):
-            for kern in ("linear", "rbf"):
-                _capi.set_option("lds_extra_kb", extra)
-                print(f"lds_extra_kb={extra}: ", end="")
-                perf(100000, 128, kern, np.float32, iters=4)
-        _capi.set_option("lds_extra_kb", 0)
-    elif "--items" in sys.argv:
-        for dbg in (13, 0):
-            for xm in (0, 1):
-                for jt in (16, 64, 391):
-                    _capi.set_option("debug_ablate", dbg)
-                    _capi.set_option("xcd_map", xm)
-                    _capi.set_option("j_chunk_tiles", jt)
-                    print(f"dbg={dbg} xcd_map={xm} j_chunk_tiles={jt}: ", end="")
-                    perf(50000, 128, "rbf", np.float32, iters=8)
         _capi.set_option("debug_ablate", 0)
     elif "--ablate" in sys.argv:
         for dbg in (0, 1, 5, 9, 13, 4, 8):
@@ -153,16 +118,6 @@ if __name__ == "__main__":
             print(f"debug_ablate={dbg}: ", end="")
             perf(50000, 128, "rbf", np.float32, iters=8)
         _capi.set_option("debug_ablate", 0)
-    elif "--map" in sys.argv:
-        for N in (50000, 200000):
-            for xm in (0, 1):
-                for jt in (8, 16, 32):
-                    _capi.set_option("xcd_map", xm)
-                    _capi.set_option("j_chunk_tiles", jt)
-                    print(f"xcd_map={xm} j_chunk_tiles={jt}: ", end="")
-                    perf(N, 128, "rbf", np.float32, iters=3 if N > 100000 else 8)
-        _capi.set_option("xcd_map", 1)
-        _capi.set_option("j_chunk_tiles", 0)
     elif "--perf" in sys.argv:
         perf(50000, 128, "rbf", np.float32)
         perf(50000, 128, "linear", np.float32)
