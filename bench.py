@@ -364,13 +364,33 @@ def main():
         prob.cg_step(args.warmup)
     prob.synchronize()
     i0 = prob.info()
+    # board power and shader clock of this rank's device while the timed steps run (a host thread reading two sysfs files every 20 ms: the
+    # 16-bit tile kernels sit at the board's power cap, DESIGN.md 4.1.0 -- the line should say so for the box it was taken on)
+    sampler = None
+    if rank == 0 and devices is None:
+        from plssvm_amd.hwmon import PowerSampler
+
+        sampler = PowerSampler(local_rank)
+        if sampler.available:
+            sampler.start()
     barrier()
     t0 = time.perf_counter()
+    w0 = time.time()
     prob.cg_step(args.steps)
     prob.synchronize()
     barrier()
     t1 = time.perf_counter()
+    w1 = time.time()
     i1 = prob.info()
+    board_power = None
+    if sampler is not None and sampler.available:
+        from plssvm_amd.hwmon import median
+
+        sampler.stop()
+        watts, ghz = sampler.window(w0, w1)
+        if watts:
+            board_power = {"median_w": median(watts), "max_w": max(watts), "cap_w": sampler.cap_watts(), "shader_clock_ghz_median": median(ghz), "samples": len(watts),
+                           "source": f"amdgpu hwmon of PCI {sampler.bus}, every 20 ms over the last 70 % of the timed region"}
 
     elapsed = t1 - t0
     if dist is not None:
@@ -454,6 +474,7 @@ def main():
                          "hbm": {"algorithmic_bytes_per_launch": float(n) * d * dt.itemsize + 4.0 * n * dt.itemsize,
                                  "traffic_rate_TBps": (traffic / kern_s / 1e12) if (traffic is not None and kern_ms > 0) else None,
                                  "traffic_frac_of_hbm_peak": (traffic / kern_s / 1e12 / 8.0) if (traffic is not None and kern_ms > 0) else None},
+                         "board_power": board_power,
                          "kernel": "lssvm::tile_matvec (implicit K*d tile kernel)", "launches": launches, "avg_launch_ms": kern_ms,
                          "tile_launches_per_matvec": bands,
                          "launch_note": "a 'launch' here is ONE implicit matvec = the sum of its row-block band launches of the tile kernel (rocprofv3 lists the bands one by one)",

@@ -11,10 +11,8 @@ Phases (each sampled at ~50 Hz, the first 30 % of every phase dropped as settlin
 
 import argparse
 import ctypes as C
-import glob
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -24,51 +22,8 @@ sys.path.insert(0, ROOT)
 
 from plssvm_amd import _capi, backend  # noqa: E402
 from plssvm_amd.datagen import make_blobs_pm1  # noqa: E402
+from plssvm_amd.hwmon import PowerSampler  # noqa: E402
 from plssvm_amd.parameter import Parameter  # noqa: E402
-
-
-def read_num(path):
-    try:
-        with open(path) as f:
-            return float(f.read().split()[0])
-    except (OSError, ValueError, IndexError):
-        return None
-
-
-def hwmon_of_hip_device(device=0):
-    """The hwmon directory of HIP device `device`, found through its PCI bus id (a box of the pool shows the cards of all its GPUs in /sys;
-    only the one this container was given runs our kernels)."""
-    hip = C.CDLL("libamdhip64.so")
-    buf = C.create_string_buffer(64)
-    if hip.hipDeviceGetPCIBusId(buf, C.c_int(64), C.c_int(device)) != 0:
-        return None, None
-    bus = buf.value.decode().lower()
-    for cand in (bus, bus if bus.count(":") == 2 else "0000:" + bus):
-        found = sorted(glob.glob(f"/sys/bus/pci/devices/{cand}/hwmon/hwmon*"))
-        if found:
-            return found[0], cand
-    return None, bus
-
-
-class Sampler(threading.Thread):
-    def __init__(self, hw, period=0.02):
-        super().__init__(daemon=True)
-        self.hw, self.period, self.rows, self.stop_flag = hw, period, [], False
-        self.pfile = next((os.path.join(hw, f) for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw, f))), None)
-        self.ffile = os.path.join(hw, "freq1_input")
-
-    def run(self):
-        while not self.stop_flag:
-            p = read_num(self.pfile) if self.pfile else None
-            f = read_num(self.ffile)
-            self.rows.append((time.time(), None if p is None else p * 1e-6, None if f is None else f * 1e-9))
-            time.sleep(self.period)
-
-    def window(self, t0, t1):
-        rows = [r for r in self.rows if t0 + 0.3 * (t1 - t0) <= r[0] <= t1]
-        pw = np.array([r[1] for r in rows if r[1] is not None])
-        fq = np.array([r[2] for r in rows if r[2] is not None])
-        return pw, fq
 
 
 def fmt(a, unit):
@@ -82,15 +37,13 @@ def main():
     ap.add_argument("--steps", type=int, default=12)
     a = ap.parse_args()
 
-    hw, bus = hwmon_of_hip_device(0)
-    if hw is None:
-        print(f"no hwmon directory for HIP device 0 (PCI {bus}) is visible to this user")
+    smp = PowerSampler(0)
+    if not smp.available:
+        print(f"no hwmon power reading for HIP device 0 (PCI {smp.bus}) is visible to this user")
         return 1
-    cap = read_num(os.path.join(hw, "power1_cap"))
-    cap_max = read_num(os.path.join(hw, "power1_cap_max"))
-    print(f"device: {_capi.device_name(0)}   PCI {bus}   hwmon: {hw}: {sorted(os.listdir(hw))}")
-    print(f"power cap: {'n/a' if cap is None else f'{cap * 1e-6:.0f} W'}   (maximum cap: {'n/a' if cap_max is None else f'{cap_max * 1e-6:.0f} W'})")
-    smp = Sampler(hw)
+    cap = smp.cap_watts()
+    print(f"device: {_capi.device_name(0)}   PCI {smp.bus}   hwmon: {smp.hwmon}")
+    print(f"power cap: {'n/a' if cap is None else f'{cap:.0f} W'}")
     smp.start()
     phases = []
 
@@ -165,10 +118,9 @@ def main():
     timed_phase("fp64 polynomial 100 000 x 64 (v_mfma_f64)", fp64)
     phase("idle again", lambda: time.sleep(1.0))
 
-    smp.stop_flag = True
-    smp.join()
+    smp.stop()
     for name, t0, t1, extra in phases:
-        pw, fq = smp.window(t0, t1)
+        pw, fq = (np.array(x) for x in smp.window(t0, t1))
         print(f"{name:46s} {t1 - t0:6.1f} s | power {fmt(pw, 'W')} | sclk {fmt(fq, 'GHz')} | {extra}")
     return 0
 
