@@ -55,11 +55,29 @@ TRAFFIC_SOURCES = ["plssvm_amd/csrc/lssvm_tile_f32_split.hip.hpp", "plssvm_amd/c
                    "plssvm_amd/csrc/tile_launch_f32x.hip", "plssvm_amd/csrc/tile_launch_f64.hip", "plssvm_amd/csrc/tile_launch_f64x.hip"]  # (the launch and split sources belong here too)
 
 
-def kernel_source_hash() -> str:
+_C_TOKENS = None
+
+
+def strip_comments(text: str) -> str:
+    """C / C++ source without comments and with every run of white space collapsed (string and character literals are kept as they are)."""
+    import re
+
+    global _C_TOKENS
+    if _C_TOKENS is None:
+        _C_TOKENS = re.compile(r'//[^\n]*|/\*.*?\*/|"(?:\\.|[^"\\])*"|\'(?:\\.|[^\'\\])*\'', re.S)
+    code = _C_TOKENS.sub(lambda m: " " if m.group(0).startswith("/") else m.group(0), text)
+    return " ".join(code.split())
+
+
+def kernel_source_hash(code_only: bool = True) -> str:
+    """sha256 (16 hex digits) over the kernel and launch sources: of the CODE (comments and white space stripped), so that a stamp in
+    profiles/hbm_traffic.json stays valid across comment-only edits and goes stale with the first changed token; code_only=False: of the raw bytes
+    (the stamp of the entries written before this distinction existed, kept beside the new one)."""
     h = hashlib.sha256()
     for rel in TRAFFIC_SOURCES:
         with open(os.path.join(ROOT, rel), "rb") as f:
-            h.update(f.read())
+            raw = f.read()
+        h.update(strip_comments(raw.decode("utf-8", errors="replace")).encode() if code_only else raw)
     return h.hexdigest()[:16]
 
 
@@ -77,8 +95,12 @@ def measured_traffic(key: str):
     if entry is None:
         return None, f"no PMC pass committed for {key}"
     if isinstance(entry, dict):
-        if entry.get("kernel_sha") != kernel_source_hash():
-            return None, f"stale: PMC pass was taken on kernel sources {entry.get('kernel_sha')}, these are {kernel_source_hash()}"
+        if "code_sha" in entry:  # (comments and white space do not count)
+            if entry["code_sha"] != kernel_source_hash():
+                return None, f"stale: PMC pass was taken on kernel code {entry['code_sha']}, this is {kernel_source_hash()}"
+            return entry.get("bytes"), f"{entry.get('profile', 'profiles/')} (kernel code {entry['code_sha']}, comments and white space stripped)"
+        if entry.get("kernel_sha") != kernel_source_hash(code_only=False):
+            return None, f"stale: PMC pass was taken on kernel sources {entry.get('kernel_sha')}, these are {kernel_source_hash(code_only=False)}"
         return entry.get("bytes"), f"{entry.get('profile', 'profiles/')} (kernel sources {entry.get('kernel_sha')})"
     return None, "unstamped entry (taken before the kernel-source stamp existed)"
 

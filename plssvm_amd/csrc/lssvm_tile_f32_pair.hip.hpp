@@ -8,10 +8,12 @@
  *   * a work item is a PAIR of row blocks (2p, 2p + 1) = 256 rows x a chunk of column tiles; wave w owns rows 32 w .. 32 w + 31 exactly as
  *     before (same row panel in registers, same accumulators, same MFMA groups: lssvm_s6w_groups.inc) -- per MFMA the LDS-DMA instructions,
  *     the L2 -> LDS bytes, the barriers and the column-sum records all halve;
- *   * the two waves of a SIMD now belong to ONE workgroup and would run in lock step (both in their epilogues at the same time, the matrix
- *     pipe idle).  Waves 4-7 therefore run LAG plane-chunk steps BEHIND waves 0-3 (MI355X_MICROARCH.md, "Two waves per SIMD", item 9: split
- *     the roles by wave >= 4): with an odd lag one half's epilogue always meets the other half's MFMA step.  One workgroup per CU leaves room
- *     for a ring of EIGHT 16 KiB slots, which is what lets a slot stay alive for the lagging half while the DMA runs three steps ahead;
+ *   * the two waves of a SIMD now belong to ONE workgroup and run in LOCK STEP (one barrier per plane-chunk step for all eight waves), the
+ *     second-dispatched half (waves 4-7) at s_setprio 1.  The stagger of MI355X_MICROARCH.md, "Two waves per SIMD", item 9 -- waves 4-7 LAG
+ *     plane-chunk steps behind waves 0-3 so that one half's epilogue meets the other half's MFMA step; the ring of EIGHT 16 KiB slots exists for
+ *     it -- was built and measured SLOWER at every lag (template parameter LAGT, development builds only): the 16-bit
+ *     MFMA stream runs at the board's power cap, where cycles left idle come back as clock and instructions moved under the MFMAs still cost
+ *     their energy;
  *   * the diagonal: column tile J against the pair's blocks b = 2p (waves 0-3) and b = 2p + 1 (waves 4-7): J < b row and mirrored column
  *     sums, J == b row sums only (the diagonal tile is evaluated in full), J > b nothing (tile 2p + 1 for the first half: one 128 x 128
  *     sub-tile of idle MFMAs per row pair, 1 / n_tiles of the work).  One record of 128 column sums per (pair, J): record (2p + 1, J) of the
@@ -34,7 +36,8 @@ constexpr int PR_ROWS = 2 * TILE;
 constexpr int PR_RING = 8;  // 16 KiB slots (power of two)
 constexpr size_t PR_LDS_BYTES = static_cast<size_t>(PR_RING) * V2_SLOT_BYTES + V2_DC_SLOTS * 1024 + (2 * PR_ROWS + 2 * PR_WAVES * TILE) * sizeof(float);  // ring + records + cis, dis, colred
 
-/* HALF: 0 = waves 0-3 (row block 2p), 1 = waves 4-7 (row block 2p + 1, LAGT steps behind).  Both halves execute the same number of barriers. */
+/* HALF: 0 = waves 0-3 (row block 2p), 1 = waves 4-7 (row block 2p + 1; LAGT = 0, the shipped form: in lock step with the first half).  Both halves
+ * execute the same number of barriers. */
 template <int KT, int NK64, int PL, int HALF, int LAGT>
 __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
     static_assert(PL == 3 || PL == 2, "three bf16 planes (bf16x6) or two f16 planes (f16x3)");

@@ -1,6 +1,6 @@
 /*
  * tile_launch_f32d.hip -- instantiates and launches the split tile kernels with 256-row workgroups (lssvm_tile_f32_pair.hip.hpp: eight waves on a
- * block pair, one column stream, the second half of the waves a step behind the first).  Symmetric variant, at most 128 features per pass, both
+ * block pair, one column stream, in lock step).  Symmetric variant, at most 128 features per pass, both
  * plane kinds (f16x3, bf16x6).  Compiled for gfx950 only.
  */
 #include "tile_launch.hip.hpp"

@@ -1,5 +1,5 @@
-"""CPU: plssvm_amd/hwmon.py, the reader behind bench.py's `roofline.board_power` -- absent files mean "not available", never an error; a fake
-hwmon directory yields the readings in watts / GHz."""
+"""CPU: the measurement aids of bench.py -- plssvm_amd/hwmon.py, the reader behind `roofline.board_power` (absent files mean "not available", never an
+error; a fake hwmon directory yields the readings in watts / GHz), and the stamp that ties profiles/hbm_traffic.json to the kernel sources."""
 
 import time
 
@@ -34,3 +34,20 @@ def test_sampler_reads_a_hwmon_directory(tmp_path, monkeypatch):
     s.stop()
     watts, ghz = s.window(t0, time.time(), settle=0.0)
     assert len(watts) >= 5 and set(watts) == {1364.0} and set(ghz) == {2.0}
+
+
+def test_traffic_stamp_ignores_comments_and_white_space_only():
+    """bench.kernel_source_hash: the stamp that ties profiles/hbm_traffic.json to the kernel sources hashes the CODE -- a comment edit keeps it,
+    a changed token does not."""
+    import sys
+
+    from conftest import ROOT
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    a = 'int a = 1; // one\n/* two\n lines */ const char *s = "// kept /* too */";\n\tchar c = \'"\';'
+    b = 'int a = 1;\nconst char *s = "// kept /* too */"; char c = \'"\';  // other words'
+    assert bench.strip_comments(a) == bench.strip_comments(b) == 'int a = 1; const char *s = "// kept /* too */"; char c = \'"\';'
+    assert bench.strip_comments(a) != bench.strip_comments(a.replace("a = 1", "a = 2"))
+    assert len(bench.kernel_source_hash()) == 16 and bench.kernel_source_hash() != bench.kernel_source_hash(code_only=False)

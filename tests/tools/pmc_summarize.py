@@ -68,7 +68,7 @@ def main():
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
         from bench import kernel_source_hash  # the stamp bench.py checks before it reports `traffic`
 
-        data[args.key] = {"bytes": rd + wr, "read_bytes": rd, "write_bytes": wr, "kernel_sha": kernel_source_hash(), "profile": args.profile or args.outdir,
+        data[args.key] = {"bytes": rd + wr, "read_bytes": rd, "write_bytes": wr, "kernel_sha": kernel_source_hash(code_only=False), "code_sha": kernel_source_hash(), "profile": args.profile or args.outdir,
                           "launches_per_matvec_note": "bytes are per tile-kernel LAUNCH as rocprofv3 counts them; bench.py multiplies by tile_launches_per_matvec"}
         with open(args.json, "w") as fh:
             json.dump(data, fh, indent=1, sort_keys=True)
