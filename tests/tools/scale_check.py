@@ -31,5 +31,11 @@ with backend.ResidentProblem(p, X) as prob:
 rows = np.random.default_rng(1).choice(N - 1, 64, replace=False)
 X64, v64, q64 = X.astype(np.float64), v.astype(np.float64), q.astype(np.float64)
 S, qv = v64.sum(), q64 @ v64
-want = np.array([np.exp(-((X64[: N - 1] - X64[r]) ** 2).sum(1) / d) @ v64 + v64[r] + float(QA) * S - qv - S * q64[r] for r in rows])
-print(f"64 sampled rows of A-bar v against float64: max rel err {np.max(np.abs(out[rows] - want)) / np.max(np.abs(want)):.3e}", flush=True)
+want, scale = [], []
+for r in rows:
+    k = np.exp(-((X64[: N - 1] - X64[r]) ** 2).sum(1) / d)
+    want.append(k @ v64 + v64[r] + float(QA) * S - qv - S * q64[r])
+    scale.append(k @ np.abs(v64) + abs(v64[r]) + abs(float(QA) * S) + abs(qv) + abs(S * q64[r]))
+want, scale = np.array(want), np.array(scale)
+print(f"64 sampled rows of A-bar v against float64: max rel err {np.max(np.abs(out[rows] - want)) / np.max(np.abs(want)):.3e}; "
+      f"worst row {np.max(np.abs(out[rows] - want) / scale) / 2.0 ** -24:.2f} eps of the row's summands", flush=True)
