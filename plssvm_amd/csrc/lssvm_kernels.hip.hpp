@@ -24,8 +24,9 @@ namespace lssvm {
 /* folded != 0 (rbf on the 16x16x32 bf16x6 kernels): dc[jt][0..127] = 2^c_j * d_j, dc[jt][128..255] = 2^c_j -- the tile kernel then starts its
  * accumulators from c_i alone (as the C operand of the first MFMA) and evaluates K_ij d_j = 2^acc * (2^c_j d_j); used only while
  * |c| <= 100, so neither factor leaves the fp32 range */
-__global__ void k_pack_dc(const float *__restrict__ dvec, const float *__restrict__ cc, int ncols_padded, float *__restrict__ dc, int folded) {
+__global__ void k_pack_dc(const float *__restrict__ dvec, const float *__restrict__ cc, int ncols_padded, float *__restrict__ dc, int folded, float *__restrict__ zero, int nzero) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nzero) zero[j] = 0.0f;  // (the symmetric variant ADDS into K*v: the vector is cleared here instead of by a memset of its own)
     if (j >= ncols_padded) return;
     const int jt = j >> 7, l = j & 127;
     const float c = (cc != nullptr) ? cc[j] : 0.0f;
@@ -51,8 +52,9 @@ __global__ void k_interleave_features(float *__restrict__ X, size_t ngroups) {
 
 
 /* fp64 records of the v2 kernel: per 64-column sub-tile st: dc[st][0..63] = d, dc[st][64..127] = c */
-__global__ void k_pack_dc_f64(const double *__restrict__ dvec, const double *__restrict__ cc, int ncols_padded, double *__restrict__ dc) {
+__global__ void k_pack_dc_f64(const double *__restrict__ dvec, const double *__restrict__ cc, int ncols_padded, double *__restrict__ dc, double *__restrict__ zero, int nzero) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nzero) zero[j] = 0.0;
     if (j >= ncols_padded) return;
     const int st = j >> 6, l = j & 63;
     dc[static_cast<size_t>(st) * 128 + l] = dvec[j];
@@ -82,6 +84,21 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], double *lds /* [NV
 #pragma unroll
         for (int k = 0; k < NV; ++k) v[k] = (lds[k * 4 + 0] + lds[k * 4 + 1]) + (lds[k * 4 + 2] + lds[k * 4 + 3]);
     }
+}
+
+/* The two sums a PREVIOUS kernel left as RED_BLOCKS x 2 partials, reduced by every block of the consuming kernel for itself, in the fixed tree
+ * order of k_finish2 (bit-identical to it, whichever block asks): the single-block launch that used to stand between the two kernels -- 5 us of
+ * a 50 000-point CG iteration each, and there were three per iteration -- is gone, and no block ever waits for another. */
+__device__ __forceinline__ void finish2_in_block(const double *__restrict__ part, double *lds /* [8] */, double *tot /* [2] */, double &s0, double &s1) {
+    double acc[2] = { part[threadIdx.x * 2 + 0], part[threadIdx.x * 2 + 1] };
+    block_reduce<2>(acc, lds);
+    if (threadIdx.x == 0) {
+        tot[0] = acc[0];
+        tot[1] = acc[1];
+    }
+    __syncthreads();
+    s0 = tot[0];
+    s1 = tot[1];
 }
 
 /* part[b][0] = sum v, part[b][1] = sum q*v over the block's grid-stride slice */
@@ -190,13 +207,19 @@ __global__ void k_apply_ret(const T *__restrict__ Kv, const T *__restrict__ v, c
     }
 }
 
-/* Ad_i = (Abar d)_i ; part[b][0] = sum d_i Ad_i     (csvm.cpp:131-135) */
+/* Ad_i = (Abar d)_i ; part[b][0] = sum d_i Ad_i     (csvm.cpp:131-135).  S = sum d and q.d come as k_update_d's partials (`part_d`). */
 template <typename T>
 __global__ __launch_bounds__(RED_THREADS) void k_Ad_and_dAd(const T *__restrict__ Kv, const T *__restrict__ d, const T *__restrict__ q,
-                                                            const double *__restrict__ sc, int n, double inv_cost, double QA_cost,
+                                                            const double *__restrict__ part_d, double *__restrict__ sc, int n, double inv_cost, double QA_cost,
                                                             T *__restrict__ Ad, double *__restrict__ part) {
     __shared__ double lds[8];
-    const double S = sc[SC_S], QD = sc[SC_QD];
+    __shared__ double tot[2];
+    double S, QD;
+    finish2_in_block(part_d, lds, tot, S, QD);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // (for the record: cg_finish compares the shards' scalars)
+        sc[SC_S] = S;
+        sc[SC_QD] = QD;
+    }
     double acc[2] = { 0.0, 0.0 };
     for (int i = blockIdx.x * RED_THREADS + threadIdx.x; i < n; i += RED_BLOCKS * RED_THREADS) {
         const T adi = static_cast<T>(abar_row(Kv, d, q, i, inv_cost, QA_cost, S, QD));
@@ -210,24 +233,21 @@ __global__ __launch_bounds__(RED_THREADS) void k_Ad_and_dAd(const T *__restrict_
     }
 }
 
-/* alpha_cd = delta / (d^T Ad)      (csvm.cpp:135) */
-__global__ __launch_bounds__(RED_THREADS) void k_finish_alpha(const double *__restrict__ part, double *__restrict__ sc) {
-    __shared__ double lds[8];
-    double acc[2] = { part[threadIdx.x * 2 + 0], 0.0 };
-    block_reduce<2>(acc, lds);
-    if (threadIdx.x == 0) {
-        sc[SC_DAD] = acc[0];
-        sc[SC_ALPHA] = sc[SC_DELTA] / acc[0];
-    }
-}
-
-/* x += alpha_cd d ; r -= alpha_cd Ad ; part = sum r^2      (csvm.cpp:138, :148, :153).  The scalar is rounded to T first,
- * as the reference's real_type alpha_cd is. */
+/* alpha_cd = delta / (d^T Ad) from k_Ad_and_dAd's partials (`part_dad`; csvm.cpp:135) ; x += alpha_cd d ; r -= alpha_cd Ad ; part = sum r^2
+ * (csvm.cpp:138, :148, :153).  The scalar is rounded to T first, as the reference's real_type alpha_cd is. */
 template <typename T>
 __global__ __launch_bounds__(RED_THREADS) void k_update_x_r(T *__restrict__ x, T *__restrict__ r, const T *__restrict__ d, const T *__restrict__ Ad,
-                                                            const double *__restrict__ sc, int n, int update_r, double *__restrict__ part) {
+                                                            const double *__restrict__ part_dad, double *__restrict__ sc, int n, int update_r, double *__restrict__ part) {
     __shared__ double lds[8];
-    const T alpha = static_cast<T>(sc[SC_ALPHA]);
+    __shared__ double tot[2];
+    double dAd, unused;
+    finish2_in_block(part_dad, lds, tot, dAd, unused);
+    const double alpha_cd = sc[SC_DELTA] / dAd;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc[SC_DAD] = dAd;
+        sc[SC_ALPHA] = alpha_cd;
+    }
+    const T alpha = static_cast<T>(alpha_cd);
     double acc[2] = { 0.0, 0.0 };
     for (int i = blockIdx.x * RED_THREADS + threadIdx.x; i < n; i += RED_BLOCKS * RED_THREADS) {
         x[i] += alpha * d[i];

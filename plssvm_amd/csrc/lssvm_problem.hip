@@ -756,10 +756,11 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     for (DevBuf<T> *v : { &q_, &b_, &x_, &r_, &d_, &Ad_, &Kv_, &tmp_ }) v->alloc_zero(static_cast<size_t>(nvec_) + TILE, st);
     Kres_ = Kv_.p;
     ylast_.alloc_zero(num_points, st);
-    part_.alloc_zero(static_cast<size_t>(RED_BLOCKS) * 2, st);
+    part_.alloc_zero(static_cast<size_t>(PART_REGIONS) * RED_BLOCKS * 2, st);  // (four sets of partial sums: a kernel reduces its predecessor's while it writes its own)
     sc_.alloc_zero(SC_COUNT, st);
     partial_.alloc_zero(static_cast<size_t>(std::max(num_jc_, 1)) * part_blocks() * TILE, st);
     host_sc_.alloc(SC_COUNT);
+    host_delta_.alloc_mapped(1);
 
     // q from the raw (un-centred) data: bit-compatible fma chains (q_kernel.cpp:18-55)
     {
@@ -909,19 +910,21 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
         }
         return nullptr;
     };
-    if (zero_first || sym_) {
-        // symmetric variant: row sums of the device's blocks and the mirrored column sums of every band are ADDED into K*v (and, sharded,
-        // every rank adds into all earlier rows): start from zero
-        LSSVM_HIP_CHECK(hipMemsetAsync(Kv_.p, 0, static_cast<size_t>(nvec_) * sizeof(T), st));
-    }
+    // symmetric variant: row sums of the device's blocks and the mirrored column sums of every band are ADDED into K*v (and, sharded, every rank
+    // adds into all earlier rows): start from zero -- by the kernel that packs the records where there is one, by a memset otherwise
+    const bool clear = zero_first || sym_;
+    const bool pack = dc_.p != nullptr && num_ib_ > 0;
+    if (clear && !pack) LSSVM_HIP_CHECK(hipMemsetAsync(Kv_.p, 0, static_cast<size_t>(nvec_) * sizeof(T), st));
     if (num_ib_ <= 0) return;
     TileArgs<T> a = tile_args(v_dev);
-    if (dc_.p != nullptr) {  // v2 kernels: pack (d_j | c_j) records for the LDS-DMA
+    if (pack) {  // v2 kernels: pack (d_j | c_j) records for the LDS-DMA
         const int ncols = num_tiles_ * TILE;
+        const int nzero = clear ? static_cast<int>(nvec_) : 0;
+        const int nthreads = std::max(ncols, nzero);
         if constexpr (std::is_same_v<T, float>) {
-            hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, st, v_dev, c_.p, ncols, dc_.p, a.dc_folded);
+            hipLaunchKernelGGL(k_pack_dc, dim3((nthreads + 255) / 256), dim3(256), 0, st, v_dev, c_.p, ncols, dc_.p, a.dc_folded, Kv_.p, nzero);
         } else {
-            hipLaunchKernelGGL(k_pack_dc_f64, dim3((ncols + 255) / 256), dim3(256), 0, st, v_dev, c_.p, ncols, dc_.p);
+            hipLaunchKernelGGL(k_pack_dc_f64, dim3((nthreads + 255) / 256), dim3(256), 0, st, v_dev, c_.p, ncols, dc_.p, Kv_.p, nzero);
         }
     }
     const int nrows = num_ib_ * TILE;
@@ -988,8 +991,8 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
 
 template <typename T>
 void Problem<T>::enqueue_sum_and_qdot(const T *v_dev, int slot_sum, int slot_q) {
-    hipLaunchKernelGGL(k_sum_and_qdot<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_.s, v_dev, q_.p, n_, part_.p);
-    hipLaunchKernelGGL(k_finish2, dim3(1), dim3(RED_THREADS), 0, stream_.s, part_.p, sc_.p, slot_sum, slot_q);
+    hipLaunchKernelGGL(k_sum_and_qdot<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream_.s, v_dev, q_.p, n_, part(PART_SUMS));
+    hipLaunchKernelGGL(k_finish2, dim3(1), dim3(RED_THREADS), 0, stream_.s, part(PART_SUMS), sc_.p, slot_sum, slot_q);
     LSSVM_HIP_CHECK(hipGetLastError());
 }
 
@@ -1322,11 +1325,10 @@ void Solver<T>::cg_begin(const void *y, double eps) {
     for (auto &p : shards_) {
         p->activate();
         hipStream_t st = p->stream();
-        hipLaunchKernelGGL(k_residual<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->Kres_, p->x_.p, p->q_.p, p->b_.p, p->sc_.p, p->n_, p->inv_cost_, p->QA_cost_, p->r_.p, p->part_.p);
-        hipLaunchKernelGGL(k_finish_delta, dim3(1), dim3(RED_THREADS), 0, st, p->part_.p, p->sc_.p, p->sc_.p + SC_COUNT - 1, 1);  // csvm.cpp:107-108
-        // d = r   (csvm.cpp:111), and the sums the next matvec needs
-        hipLaunchKernelGGL(k_update_d<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->d_.p, p->r_.p, p->q_.p, p->sc_.p, p->n_, 1, p->part_.p);
-        hipLaunchKernelGGL(k_finish2, dim3(1), dim3(RED_THREADS), 0, st, p->part_.p, p->sc_.p, static_cast<int>(SC_S), static_cast<int>(SC_QD));
+        hipLaunchKernelGGL(k_residual<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->Kres_, p->x_.p, p->q_.p, p->b_.p, p->sc_.p, p->n_, p->inv_cost_, p->QA_cost_, p->r_.p, p->part(PART_RR));
+        hipLaunchKernelGGL(k_finish_delta, dim3(1), dim3(RED_THREADS), 0, st, p->part(PART_RR), p->sc_.p, p->sc_.p + SC_COUNT - 1, 1);  // csvm.cpp:107-108
+        // d = r   (csvm.cpp:111), and -- as partial sums that k_Ad_and_dAd finishes for itself -- the sums the next matvec's rank-1 terms need
+        hipLaunchKernelGGL(k_update_d<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->d_.p, p->r_.p, p->q_.p, p->sc_.p, p->n_, 1, p->part(PART_D));
         LSSVM_HIP_CHECK(hipGetLastError());
     }
     Problem<T> &p0 = *shards_[0];
@@ -1350,8 +1352,7 @@ void Solver<T>::cg_step(uint64_t iterations, int *done_out) {
         for (auto &p : shards_) {
             p->activate();
             hipStream_t st = p->stream();
-            hipLaunchKernelGGL(k_update_d<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->d_.p, p->r_.p, p->q_.p, p->sc_.p, p->n_, 0, p->part_.p);
-            hipLaunchKernelGGL(k_finish2, dim3(1), dim3(RED_THREADS), 0, st, p->part_.p, p->sc_.p, static_cast<int>(SC_S), static_cast<int>(SC_QD));
+            hipLaunchKernelGGL(k_update_d<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->d_.p, p->r_.p, p->q_.p, p->sc_.p, p->n_, 0, p->part(PART_D));
             LSSVM_HIP_CHECK(hipGetLastError());
         }
     };
@@ -1364,10 +1365,10 @@ void Solver<T>::cg_step(uint64_t iterations, int *done_out) {
         for (auto &p : shards_) {
             p->activate();
             hipStream_t st = p->stream();
-            hipLaunchKernelGGL(k_Ad_and_dAd<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->Kres_, p->d_.p, p->q_.p, p->sc_.p, p->n_, p->inv_cost_, p->QA_cost_, p->Ad_.p, p->part_.p);
-            hipLaunchKernelGGL(k_finish_alpha, dim3(1), dim3(RED_THREADS), 0, st, p->part_.p, p->sc_.p);  // csvm.cpp:135
-            // x += alpha d ; r -= alpha Ad   (csvm.cpp:138, :148) -- or, every 50th iteration, x only and r = b - A x below (csvm.cpp:140-145)
-            hipLaunchKernelGGL(k_update_x_r<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->x_.p, p->r_.p, p->d_.p, p->Ad_.p, p->sc_.p, p->n_, refresh ? 0 : 1, p->part_.p);
+            // (every kernel of the chain reduces its predecessor's partial sums for itself -- finish2_in_block -- so no single-block kernel stands between them)
+            hipLaunchKernelGGL(k_Ad_and_dAd<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->Kres_, p->d_.p, p->q_.p, p->part(PART_D), p->sc_.p, p->n_, p->inv_cost_, p->QA_cost_, p->Ad_.p, p->part(PART_DAD));
+            // alpha = delta / d.Ad (csvm.cpp:135) ; x += alpha d ; r -= alpha Ad   (csvm.cpp:138, :148) -- or, every 50th iteration, x only and r = b - A x below (csvm.cpp:140-145)
+            hipLaunchKernelGGL(k_update_x_r<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->x_.p, p->r_.p, p->d_.p, p->Ad_.p, p->part(PART_DAD), p->sc_.p, p->n_, refresh ? 0 : 1, p->part(PART_RR));
             if (refresh) p->enqueue_sum_and_qdot(p->x_.p, SC_SUMX, SC_QX);
             LSSVM_HIP_CHECK(hipGetLastError());
         }
@@ -1375,17 +1376,17 @@ void Solver<T>::cg_step(uint64_t iterations, int *done_out) {
             apply_K(Vec::x);
             for (auto &p : shards_) {
                 p->activate();
-                hipLaunchKernelGGL(k_residual<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, p->stream(), p->Kres_, p->x_.p, p->q_.p, p->b_.p, p->sc_.p, p->n_, p->inv_cost_, p->QA_cost_, p->r_.p, p->part_.p);
+                hipLaunchKernelGGL(k_residual<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, p->stream(), p->Kres_, p->x_.p, p->q_.p, p->b_.p, p->sc_.p, p->n_, p->inv_cost_, p->QA_cost_, p->r_.p, p->part(PART_RR));
             }
         }
         for (auto &p : shards_) {
             p->activate();
-            hipLaunchKernelGGL(k_finish_delta, dim3(1), dim3(RED_THREADS), 0, p->stream(), p->part_.p, p->sc_.p, p->sc_.p + SC_COUNT - 1, 0);  // csvm.cpp:152-153
+            // the stop test needs delta on the host: shard 0's kernel stores its 8 bytes straight into mapped host memory (all shards hold the same
+            // bits); the others publish into a spare device word
+            hipLaunchKernelGGL(k_finish_delta, dim3(1), dim3(RED_THREADS), 0, p->stream(), p->part(PART_RR), p->sc_.p, p.get() == &p0 ? p0.host_delta_.dev : p->sc_.p + SC_COUNT - 1, 0);  // csvm.cpp:152-153
             LSSVM_HIP_CHECK(hipGetLastError());
         }
-        // the stop test needs delta on the host: 8 bytes from shard 0 (all shards hold the same bits)
         p0.activate();
-        LSSVM_HIP_CHECK(hipMemcpyAsync(p0.host_sc_.p + SC_DELTA, p0.sc_.p + SC_DELTA, sizeof(double), hipMemcpyDeviceToHost, p0.stream()));
         LSSVM_HIP_CHECK(hipEventRecord(ev_delta_.e, p0.stream()));
         // Short matvecs (option enqueue_ahead_below_us): waiting for delta here would leave the device idle while the host wakes up and
         // launches the next kernels (about 4 % of a 50 000-point iteration).  So the direction update and the NEXT implicit matvec go
@@ -1408,7 +1409,7 @@ void Solver<T>::cg_step(uint64_t iterations, int *done_out) {
         LSSVM_HIP_CHECK(hipEventSynchronize(ev_delta_.e));
         for (auto &p : shards_) p->drain_events();
         ++iter_;
-        delta_ = static_cast<double>(static_cast<T>(p0.host_sc_.p[SC_DELTA]));
+        delta_ = static_cast<double>(static_cast<T>(*static_cast<volatile double *>(p0.host_delta_.p)));
         if (static_cast<T>(delta_) <= target) {  // csvm.cpp:155-158: tested BEFORE the direction update
             converged_ = true;
             if (ahead) sync_all();  // let the discarded work drain
@@ -1619,9 +1620,9 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
         dc.alloc_zero(static_cast<size_t>(num_jt) * 256, s);
         const int ncols = num_jt * TILE;
         if constexpr (std::is_same_v<T, float>) {
-            hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, s, a.p, cS.p, ncols, dc.p, dc_folded);
+            hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, s, a.p, cS.p, ncols, dc.p, dc_folded, static_cast<float *>(nullptr), 0);
         } else {
-            hipLaunchKernelGGL(k_pack_dc_f64, dim3((ncols + 255) / 256), dim3(256), 0, s, a.p, cS.p, ncols, dc.p);
+            hipLaunchKernelGGL(k_pack_dc_f64, dim3((ncols + 255) / 256), dim3(256), 0, s, a.p, cS.p, ncols, dc.p, static_cast<double *>(nullptr), 0);
         }
         LSSVM_HIP_CHECK(hipGetLastError());
     }

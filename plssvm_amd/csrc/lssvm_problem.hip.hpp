@@ -211,6 +211,12 @@ struct PinnedBuf {
         if (p != nullptr) (void) hipHostFree(p);
     }
     void alloc(size_t n) { LSSVM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p), n * sizeof(U), hipHostMallocDefault)); }
+    /* host memory a KERNEL writes (fine-grained, mapped): `dev` is the address the device uses; the host reads `p` behind an event of the stream */
+    U *dev = nullptr;
+    void alloc_mapped(size_t n) {
+        LSSVM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p), n * sizeof(U), hipHostMallocMapped | hipHostMallocCoherent));
+        LSSVM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), p, 0));
+    }
 };
 
 /* ------------------------------------------------------------------ tile kernel launch ------------------------------------------------------------------ */
@@ -338,7 +344,9 @@ class Problem {
     };
     std::vector<Band> bands_;
     DevBuf<double> part_, sc_;
+    double *part(PartSet s) const { return part_.p + static_cast<size_t>(s) * RED_BLOCKS * 2; }  // (lssvm_types.hpp)
     PinnedBuf<double> host_sc_;  // SC_COUNT doubles
+    PinnedBuf<double> host_delta_;  // one word: k_finish_delta stores the iteration's delta straight into host memory (no copy kernel per iteration)
     double QA_cost_ = 0.0;
     double inv_cost_ = 1.0;
     double setup_ms_ = 0.0;

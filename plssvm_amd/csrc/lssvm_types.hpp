@@ -84,5 +84,8 @@ constexpr int RED_THREADS = 256;
 
 /* device-resident scalars of the CG recursion (all double) */
 enum ScalarSlot : int { SC_S = 0, SC_QD = 1, SC_DAD = 2, SC_DELTA = 3, SC_DELTA_OLD = 4, SC_ALPHA = 5, SC_BETA = 6, SC_DELTA0 = 7, SC_SUMX = 8, SC_QX = 9, SC_COUNT = 16 };
+/* the partial sums of the reductions, RED_BLOCKS x 2 doubles per set: sum d | q.d (k_update_d), d.Ad (k_Ad_and_dAd), r.r (k_update_x_r, k_residual),
+ * sum v | q.v (enqueue_sum_and_qdot) -- separate sets, because a kernel finishes its predecessor's sums while its own blocks write theirs */
+enum PartSet : int { PART_D = 0, PART_DAD = 1, PART_RR = 2, PART_SUMS = 3, PART_REGIONS = 4 };
 
 }  // namespace lssvm
