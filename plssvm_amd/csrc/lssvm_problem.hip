@@ -890,7 +890,7 @@ void Problem<T>::drain_events() {
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, e.a.e, e.b.e) == hipSuccess) {
                 matvec_ms_ += ms;  // the band launches of one matvec add up; the matvec is counted once
-                if (e.first_of_matvec) ++matvec_launches_;
+                if (e.first_of_matvec) ++matvec_timed_;
             }
             e.pending = false;
         }
@@ -901,7 +901,10 @@ template <typename T>
 void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
     // this shard's part of the implicit K * v: tile kernel over its row blocks (band by band), slabs added in a fixed order
     hipStream_t st = stream_.s;
+    const bool timed = matvec_launches_ % static_cast<uint64_t>(event_stride()) == 0;
+    ++matvec_launches_;
     auto free_event = [&]() -> EvPair * {
+        if (!timed) return nullptr;
         for (int attempt = 0; attempt < 2; ++attempt) {
             for (EvPair &e : events_) {
                 if (!e.pending) return &e;
@@ -1313,6 +1316,7 @@ void Solver<T>::cg_begin(const void *y, double eps) {
         p->activate();
         p->matvec_ms_ = 0.0;
         p->matvec_launches_ = 0;
+        p->matvec_timed_ = 0;
         hipStream_t st = p->stream();
         LSSVM_HIP_CHECK(hipMemcpyAsync(p->ylast_.p, y, N * sizeof(T), hipMemcpyHostToDevice, st));
         const dim3 gn((p->n_ + 255) / 256), bn(256);
@@ -1481,7 +1485,7 @@ void Solver<T>::fill_info(lssvm_cg_info *info) {
     info->setup_ms = setup_ms_;
     // the tile kernel of the slowest shard sets the pace of a sharded matvec
     for (const auto &p : shards_) {
-        const double avg = p->matvec_launches_ > 0 ? p->matvec_ms_ / static_cast<double>(p->matvec_launches_) : 0.0;
+        const double avg = p->matvec_timed_ > 0 ? p->matvec_ms_ / static_cast<double>(p->matvec_timed_) : 0.0;
         info->matvec_kernel_ms = std::max(info->matvec_kernel_ms, avg);
     }
     info->matvec_launches = p0.matvec_launches_;

@@ -352,8 +352,15 @@ class Problem {
     double setup_ms_ = 0.0;
 
     // statistics: HIP events around the tile kernel
-    double matvec_ms_ = 0.0;
-    uint64_t matvec_launches_ = 0;
+    double matvec_ms_ = 0.0;       // tile-kernel time of the TIMED matvecs (HIP events around the band launches)
+    uint64_t matvec_launches_ = 0; // matvecs enqueued
+    uint64_t matvec_timed_ = 0;    // ... of which timed: all of them where a matvec is long, every 8th where it is short (two event records cost ~6 us per
+                                   // matvec on the stream: 9 % of a 10 000-point CG iteration, profiles/r04_event_record_cost.log)
+    /* a rule on the shape only, like the enqueue-ahead decision: below ~1 ms per matvec the events are sampled */
+    int event_stride() const {
+        const double n_d = static_cast<double>(n_);
+        return 2.0 * n_d * n_d * static_cast<double>(X_.dfeat) / static_cast<double>(world_) / nominal_full_square_rate() < 1e-3 ? 8 : 1;
+    }
     struct EvPair {
         Event a, b;
         bool pending = false;
