@@ -1,0 +1,331 @@
+/*
+ * lssvm_tile_f32_wide_pair.hip.hpp -- the panels-inside-a-tile kernel (lssvm_tile_f32_wide.hip.hpp: rbf / polynomial on more features than a row
+ * panel in registers holds) with 256-ROW WORKGROUPS on block pairs, as lssvm_tile_f32_pair.hip.hpp does for the narrow kernels: eight waves, two
+ * per SIMD, ONE column stream per CU (end of round 4; symmetric variant).
+ *
+ * Why.  That kernel re-loads a wave's row fragments at every tile-panel, so a CU's two 128-row workgroups pull 2 x (4 x 16-24 KiB of rows + 64 KiB of
+ * columns) = 256-320 KiB through L2 -> CU per 2 x 4 x 192 MFMAs -- at 64 B per cycle that is 4 100-5 100 of the 6 144 cycles the MFMAs take: the kernel
+ * runs at the L2 port, at half the matrix-core rate of the 128-feature kernels.  Eight waves on a pair of row blocks share the columns: 192-256 KiB
+ * for the same MFMAs, and half the LDS-DMA instructions, hand-over barriers and column-sum records per MFMA.
+ * Everything else is s6x_body's, statement by statement (compiler-scheduled MFMA groups, the row fragments of a 64-feature chunk requested into
+ * the same registers as soon as the previous tile-panel is through with them); the diagonal is pair_body's: column tile J against block
+ * b = 2p (waves 0-3) or 2p + 1 (waves 4-7): J < b row and mirrored column sums, J == b row sums only, J > b nothing, here as two factors in {0, 1}
+ * on every tile (the epilogue is a small part of a tile of >= 768 MFMAs per wave); one record of 128 column sums per (pair, J), kept as record
+ * (2p + 1, J).  Reference semantics: include/plssvm/backends/HIP/svm_kernel.hip.hpp:129-270 (one code path for any feature count).
+ */
+#pragma once
+
+#include "lssvm_tile_f32_wide.hip.hpp"
+
+namespace lssvm {
+
+constexpr int XP_WAVES = 8;
+constexpr int XP_THREADS = 64 * XP_WAVES;
+constexpr int XP_ROWS = 2 * TILE;
+constexpr size_t XP_LDS_BYTES = static_cast<size_t>(V2_RING) * V2_SLOT_BYTES + V2_DC_SLOTS * 1024 + (2 * XP_ROWS + 2 * XP_WAVES * TILE) * sizeof(float);  // ring + records + cis, dis, colred
+
+template <int KT, int PL>
+__device__ __forceinline__ void s6x_pair_body(const TileArgs<float> &a) {
+    static_assert(PL == 3 || PL == 2, "three bf16 planes (bf16x6) or two f16 planes (f16x3)");
+    static_assert(KT != KT_LINEAR, "the linear kernel takes feature-panel passes of the 128-feature kernels");
+    constexpr bool F16 = PL == 2;
+    constexpr int NK64 = 2;          // 64-feature chunks per panel
+    constexpr int NKC = PL * NK64;   // plane-chunks (steps) per tile-panel
+    constexpr int PLA = F16 ? ((KT == KT_RBF || KT == KT_RBFF) ? 3 : 2) : 3;  // row planes in registers (s6w_body: the shifted rbf planes)
+    constexpr auto row_plane = [](int p, int q) constexpr { return (F16 && PLA == 3) ? (p == 0 ? (q == 0 ? 2 : 1) : 0) : q; };
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char *ring = smem_raw;                                                          // [V2_RING][128 columns][128 B]
+    char *dcs = smem_raw + V2_RING * V2_SLOT_BYTES;                                 // [V2_DC_SLOTS][256 floats]
+    float *cis = reinterpret_cast<float *>(dcs + V2_DC_SLOTS * 1024);               // [256] c_i of the row pair (rbf)
+    float *dis = cis + XP_ROWS;                                                     // [256] d_i of the row pair
+    float *colred = dis + XP_ROWS;                                                  // [2][8 waves][128] column sums of a tile
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0 .. 7: rows 32 wave .. 32 wave + 31 of the pair's 256
+    const int r = lane & 15;
+    const int g = lane >> 4;
+
+    const int2 it = a.items[blockIdx.x];
+    const int ibl = __builtin_amdgcn_readfirstlane(it.x);  // local index of the pair's FIRST block (even)
+    const int jc = __builtin_amdgcn_readfirstlane(it.y);
+    const int ib0 = a.ib_begin + ibl;
+    const int my_ib = ib0 + (wave >> 2);  // waves 0-3: block 2p, waves 4-7: block 2p + 1
+    const int row0 = ib0 * TILE;
+    const int jt_begin = jc * a.jc_tiles;
+    const int jt_end = min(min(jt_begin + a.jc_tiles, ib0 + 2), a.num_jt);
+    const int ntiles = jt_end - jt_begin;
+    if (ntiles <= 0) return;
+    const int panels = a.nk64 / NK64;          // (uniform; the planes are padded to a multiple of 128 features)
+    const int steps_per_tile = panels * NKC;
+    const int nsteps = ntiles * steps_per_tile;
+    const long rec0 = static_cast<long>(ib0 + 1) * ib0 / 2 - a.pair_origin;  // records of row block ib0 + 1 (one record per pair and column tile)
+
+    // ---- the row panel of ONE feature panel: lane (r, g) holds features 128 p + 32 kk + 8 g .. + 7 of row 16 rb + r ----
+    bf16x8 afrag[PLA][2 * NK64][2];
+    // (uniform base in SGPRs + ONE 32-bit lane offset: per-lane 64-bit row pointers for every plane and row block would live across the whole
+    // work item and spill)
+    const unsigned row_lane_off = 2u * static_cast<unsigned>(r * a.ldx16 + 8 * g);
+    auto load_row_chunk = [&](int p, auto chunk_c) {  // the 64-feature chunk `chunk` of panel p: k32 steps 2 chunk, 2 chunk + 1
+        constexpr int chunk = decltype(chunk_c)::value;
+#pragma unroll
+        for (int pl = 0; pl < PLA; ++pl) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const char *base = sgpr_ptr(a.Xr16 + pl * a.plane_stride_r + static_cast<size_t>(row0 + wave * 32 + 16 * rb) * a.ldx16 + p * (64 * NK64) + 64 * chunk);
+                const auto *xr = (const __attribute__((address_space(1))) char *) base + lane_off(row_lane_off);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) afrag[pl][2 * chunk + kk][rb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(xr + 64 * kk));
+            }
+        }
+    };
+    auto load_row_panel = [&](int p) { static_for<0, NK64>([&](auto c) { load_row_chunk(p, c); }); };
+    load_row_panel(0);
+    if (tid < XP_ROWS) {
+        if constexpr (KT == KT_RBF || KT == KT_RBFF) cis[tid] = a.cr[row0 + tid];
+    } else {
+        dis[tid - XP_ROWS] = a.dvec[row0 + tid - XP_ROWS];
+    }
+    // make the compiler retire these ordinary loads HERE, before any LDS-DMA is in flight
+#pragma unroll
+    for (int pl = 0; pl < PLA; ++pl)
+#pragma unroll
+        for (int kk = 0; kk < 2 * NK64; ++kk)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) asm volatile("" : "+v"(afrag[pl][kk][rb]));
+
+    // ---- LDS-DMA addressing (the LDS image of a plane-chunk is that of s6w_body) ----
+    unsigned dma_off[2];  // a slot is 16 pieces of 8 columns x 128 B; wave w moves pieces 2 w and 2 w + 1
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 8 * (2 * wave + i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        dma_off[i] = 2u * static_cast<unsigned>(row * a.ldx16 + 8 * c);
+    }
+    const unsigned ring_lds = static_cast<unsigned>(reinterpret_cast<size_t>(ring));
+    const unsigned dma_lds = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(ring_lds + static_cast<unsigned>(wave) * 2048u)));
+    const unsigned dc_lds = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(ring_lds + V2_RING * V2_SLOT_BYTES + static_cast<unsigned>(wave & 3) * 256u)));
+    auto issue_chunk = [&](int step) {  // step = (tile t, panel p, plane-chunk kc): plane kc % PL of the 64-feature chunk kc / PL of panel p
+        const int t = step / steps_per_tile;
+        const int in_tile = step - t * steps_per_tile;
+        const int p = in_tile / NKC;
+        const int kc = in_tile - p * NKC;
+        const char *base = sgpr_ptr(a.Xc16 + (kc % PL) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (p * NK64 + kc / PL) * 64);
+        const unsigned slot = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(dma_lds + static_cast<unsigned>(step % V2_RING) * V2_SLOT_BYTES)));
+        static_for<0, 2>([&](auto i_c) { lds_dma16<decltype(i_c)::value * 1024>(dma_off[decltype(i_c)::value], base, slot); });
+    };
+    auto issue_dc = [&](int t) {  // the record of column tile t: by the second half (four waves x 256 B)
+        if (wave >= 4 && lane < 16) {
+            const char *src = sgpr_ptr(a.dc + static_cast<size_t>(jt_begin + t) * 256) + __builtin_amdgcn_readfirstlane((wave & 3) * 256);
+            lds_dma16<0>(16u * (lane_off(threadIdx.x) & 15u), sgpr_ptr(src), static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(dc_lds + static_cast<unsigned>(t % V2_DC_SLOTS) * 1024u))));
+        }
+    };
+
+    int rd_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) rd_off[kk] = r * 128 + (((4 * kk + g) ^ ((r >> 1) & 7)) << 4);
+
+    float rowpart[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rowpart[i] = 0.0f;
+    f32x4 acc[2][8];
+
+    // ---- prologue: chunks 0, 1, 2 (a tile has at least 2 x NKC >= 8 steps here: only the record of tile 0 falls into it) ----
+    issue_dc(0);
+    issue_chunk(0);
+    issue_chunk(1);
+    issue_chunk(2);
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");  // (two pieces per wave and chunk: all but the four youngest = chunk 0 and the record)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    f32x4 civ0[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
+    if constexpr (KT == KT_RBF || KT == KT_RBFF) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) civ0[rb] = *reinterpret_cast<const f32x4 *>(cis + wave * 32 + 16 * rb + 4 * g);
+    }
+    f32x4 bbuf[2][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bbuf[0][c] = *reinterpret_cast<const f32x4 *>(ring + c * 2048 + rd_off[0]);
+
+    // hand-over of the next chunk in the middle of a step (s6w_body's checked form): this wave's two pieces of chunk step + 1 are complete once
+    // all but its 2 youngest DMA instructions (chunk step + 2) are; the barrier publishes every wave's pieces; the DMA issued here (chunk
+    // step + 3) overwrites the slot of chunk step - 1, which every wave finished before this barrier.  (The row-panel re-loads are ordinary
+    // loads the compiler waits for itself with vmcnt(0) -- which also lands the chunks in flight, early but in order: the counted waits that
+    // follow are then trivially met.)
+    auto handover = [&](int step) {
+        if (step + 1 < nsteps) {
+            if (step + 2 < nsteps) {
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (step + 3 < nsteps) {
+                const int s3 = step + 3;
+                const int t3 = s3 / steps_per_tile;
+                if (s3 - t3 * steps_per_tile == 0) issue_dc(t3);
+                issue_chunk(s3);
+            }
+        }
+    };
+
+    auto flush_cols = [&](int t) {  // the eight waves' sums of a column in a fixed order -> record (ib0 + 1, J)
+        if (tid < TILE) {
+            const float *cr_ = colred + (t & 1) * (XP_WAVES * TILE);
+            const float s03 = (cr_[tid] + cr_[128 + tid]) + (cr_[256 + tid] + cr_[384 + tid]);
+            const float s47 = (cr_[512 + tid] + cr_[640 + tid]) + (cr_[768 + tid] + cr_[896 + tid]);
+            auto *rec = (__attribute__((address_space(1))) float *) const_cast<char *>(sgpr_ptr(a.colslab + (rec0 + jt_begin + t) * TILE));
+            rec[lane_off(static_cast<unsigned>(tid))] = s03 + s47;
+        }
+    };
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int J = jt_begin + t;
+        // this wave's part in the tile: J < its block: row and mirrored column sums; J == its block: row sums only (the diagonal tile in full);
+        // J > its block (tile 2p + 1 for the first half): nothing -- switched with two factors in {0, 1}; the wave then adds exact zeros (K is
+        // finite), and the zeros the first half contributes to record (2p + 1, 2p) need no code of their own
+        const float rowmask = J > my_ib ? 0.0f : 1.0f, colmask = J >= my_ib ? 0.0f : 1.0f;
+        const float *dcr = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);
+        // start values of the chain: rbf c_i + c_j, rbf with folded records c_i (c_j is the factor 2^c_j of the record), polynomial 0
+        if constexpr (KT == KT_RBF) {
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                const float cjv = dcr[128 + cb * 16 + r];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[rb][cb][e] = civ0[rb][e] + cjv;
+            }
+        } else {
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) acc[rb][cb] = civ0[rb];  // (zero for the polynomial kernels)
+        }
+        for (int p = 0; p < panels; ++p) {
+            // (the row panel of this tile-panel was requested chunk by chunk while the previous one was being multiplied: see below)
+            const bool more_panels = t + 1 < ntiles || p + 1 < panels;
+            const int p_next = p + 1 < panels ? p + 1 : 0;  // (the row panel depends on the feature panel only, not on the tile)
+            const int s0 = t * steps_per_tile + p * NKC;
+            const unsigned phase = static_cast<unsigned>(s0) & (V2_RING - 1);
+            static_for<0, NKC>([&](auto kc_c) {
+                constexpr int kc = decltype(kc_c)::value;
+                constexpr int chunk = kc / PL, plane = kc % PL;
+                const int step = s0 + kc;
+                const unsigned slot_off = ((phase + kc) & (V2_RING - 1)) * V2_SLOT_BYTES;
+                const unsigned slot_next_off = ((phase + kc + 1) & (V2_RING - 1)) * V2_SLOT_BYTES;
+                const char *slot = ring + slot_off;
+                const char *slot_next = ring + slot_next_off;
+                static_for<0, 4>([&](auto mm_c) {
+                    constexpr int mm = decltype(mm_c)::value;
+                    constexpr int kk = mm >> 1, cbh = mm & 1;
+                    f32x4(&bcur)[4] = bbuf[mm & 1];
+                    f32x4(&bnext)[4] = bbuf[(mm + 1) & 1];
+                    if constexpr (mm < 3) {  // next group of this chunk
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) bnext[c] = *reinterpret_cast<const f32x4 *>(slot + (4 * ((mm + 1) & 1) + c) * 2048 + rd_off[(mm + 1) >> 1]);
+                        if constexpr (mm != 2) LSSVM_SCHED_BARRIER();
+                    }
+                    if constexpr (mm == 2) {
+                        // (the colred writes of the previous tile's epilogue must have completed before the barrier publishes them)
+                        if (kc == 0 && p == 0 && t > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        handover(step);
+                        if (kc == 0 && p == 0 && t > 0 && J - 1 < ib0 + 1) flush_cols(t - 1);
+                        LSSVM_SCHED_BARRIER();
+                    }
+                    if constexpr (mm == 3) {  // first group of the next chunk: visible since this step's hand-over
+                        if (step + 1 < nsteps) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) bnext[c] = *reinterpret_cast<const f32x4 *>(slot_next + c * 2048 + rd_off[0]);
+                        }
+                        LSSVM_SCHED_BARRIER();
+                    }
+#pragma unroll
+                    for (int q = 0; q < PL; ++q) {
+                        if (q + plane > PL - 1) continue;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int cb = 4 * cbh + c;
+                            const bf16x8 bv = __builtin_bit_cast(bf16x8, bcur[c]);
+#pragma unroll
+                            for (int rb = 0; rb < 2; ++rb) acc[rb][cb] = plane_mfma<F16>(afrag[row_plane(plane, q)][2 * chunk + kk][rb], bv, acc[rb][cb]);
+                        }
+                    }
+                });
+                // the last plane of a 64-feature chunk is through: its row fragments are dead, the registers take the same chunk of the NEXT
+                // tile-panel -- requested half a tile-panel or more before its first use instead of in front of it
+                if constexpr (plane == PL - 1) {
+                    if (more_panels) load_row_chunk(p_next, std::integral_constant<int, chunk>{});
+                }
+            });
+        }
+        // ---- epilogue of the tile (s6w_body's; ONE form, the masks above switch a wave's contributions) ----
+        {
+            using f32x2 = float __attribute__((ext_vector_type(2)));
+            f32x4 di[2];
+            float colacc[8];
+            f32x2 colacc2[8] = {};
+            f32x2 kvp = { 0.f, 0.f };
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) di[rb] = *reinterpret_cast<const f32x4 *>(dis + wave * 32 + 16 * rb + 4 * g) * colmask;
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                const float djv = dcr[cb * 16 + r] * rowmask;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float kv = apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(acc[rb][cb][e], a);
+                        rowpart[4 * rb + e] = fmaf(kv, djv, rowpart[4 * rb + e]);
+                        kvp[e & 1] = kv;
+                        if (e & 1) {
+                            const f32x2 dip = { di[rb][e - 1], di[rb][e] };
+                            colacc2[cb] = __builtin_elementwise_fma(kvp, dip, colacc2[cb]);
+                        }
+                    }
+            }
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) colacc[cb] = colacc2[cb][0] + colacc2[cb][1];
+            float *cw = colred + (t & 1) * (XP_WAVES * TILE) + wave * TILE;
+            column_sums_of_8_blocks(colacc);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float v = colacc[4 * h];
+                if constexpr (KT == KT_RBFF) v *= dcr[128 + 64 * h + lane];
+                cw[64 * h + lane] = v;
+            }
+        }
+    }
+    if (jt_begin + ntiles - 1 < ib0 + 1) {  // (uniform over the workgroup)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        flush_cols(ntiles - 1);
+    }
+
+    // every lane group owns its rows: reduce over the 16 columns of the group and store
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float v = rowpart[i];
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 1);
+        rowpart[i] = v;
+    }
+    if (r == 0) {
+        float *dst = a.partial + static_cast<size_t>(jc) * a.part_stride + ibl * TILE + wave * 32 + 4 * g;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[16 * (i >> 2) + (i & 3)] = rowpart[i];
+    }
+}
+
+/* PL = 2: f16x3 (two f16 column planes), PL = 3: bf16x6 (three bf16 planes).  Two waves per SIMD, one workgroup per CU. */
+template <int KT, int PL>
+__global__ __launch_bounds__(XP_THREADS, 1) void tile_matvec_f32_wide_pair(const TileArgs<float> a) {
+    s6x_pair_body<KT, PL>(a);
+}
+
+}  // namespace lssvm
