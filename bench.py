@@ -192,7 +192,7 @@ def spawn_ranks(n: int) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+                                      stdout=(_RESULT_FD if r == 0 else subprocess.DEVNULL)))  # (rank 0 writes the result line: it gets the ORIGINAL stdout)
     # poll ALL children: a rank that dies leaves its siblings blocked in the exchange (RCCL, or the IPC wait with its 600 s default), so
     # on the first non-zero exit the others get SIGTERM, a short grace period, then SIGKILL -- these are children this parent started itself
     worst = 0
@@ -562,7 +562,7 @@ def main():
             out["cpu_baseline"] = line_a
             if line_b is not None:
                 out["cpu_baseline_release"] = line_b
-        print(json.dumps(out), flush=True)
+        emit_result_line(json.dumps(out))
 
     if dist is not None:
         dist.barrier()  # (HIP IPC: a rank's partial vector stays mapped by its peers until every rank is done)
@@ -574,5 +574,26 @@ def main():
         dist.destroy_process_group()
 
 
+_RESULT_FD = None
+
+
+def keep_stdout_for_the_result_line():
+    """The contract is ONE JSON line on stdout.  Libraries underneath write there too (gloo: "[Gloo] Rank 0 is connected to 3 peer ranks ..." in front of
+    the line of a multi-rank run), so file descriptor 1 is pointed at stderr for the whole run and the original is kept for the result line alone."""
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit_result_line(line: str):
+    sys.stdout.flush()
+    if _RESULT_FD is None:
+        print(line, flush=True)
+    else:
+        os.write(_RESULT_FD, (line + "\n").encode())
+
+
 if __name__ == "__main__":
+    keep_stdout_for_the_result_line()
     main()
