@@ -499,7 +499,8 @@ def main():
                          "board_power": board_power,
                          "kernel": "lssvm::tile_matvec (implicit K*d tile kernel)", "launches": launches, "avg_launch_ms": kern_ms,
                          "tile_launches_per_matvec": bands,
-                         "launch_note": "a 'launch' here is ONE implicit matvec = the sum of its row-block band launches of the tile kernel (rocprofv3 lists the bands one by one)",
+                         "launch_note": "a 'launch' here is ONE implicit matvec = the sum of its row-block band launches of the tile kernel (rocprofv3 lists the bands one by one); "
+                                        "where a matvec is short (< 1 ms by the library's shape rule) the HIP events bracket every 8th matvec only -- avg_launch_ms is their average",
                          "algorithmic_flop_per_launch": useful_launch * plane_products, "symmetric": symmetric,
                          "executed_flop_per_launch": exec_launch * plane_products, "executed": executed, "executed_frac": executed / peak,
                          "gram_mode": gram_name, "plane_products": plane_products, "fp32_equivalent": fp32_equivalent, "fp32_mfma_peak": PEAK_TFLOPS["float32"],
