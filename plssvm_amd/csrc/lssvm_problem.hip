@@ -664,13 +664,29 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     // symmetric variant: v2 kernels only; a negative polynomial degree can give inf on zero-padded rows -> full square
     const int ldx_probe = padded_features<T>(num_features);
     bool v2_ok = std::is_same_v<T, float> ? v2_eligible(opt_, ldx_probe, rbf_direct_) : v2_eligible_f64(opt_, ldx_probe);
+    // FEW points, many features, linear kernel (fp32): the feature-panel passes below are launch-bound there -- 3 000 x 16 384: 128 passes 4.75 ms, the
+    // polynomial kernel's ONE launch over the same panels 2.89 (profiles/r04_very_wide_probe.log).  Below LINEAR_IN_TILE_BELOW points and beyond 256
+    // features the tile kernels therefore run the linear kernel AS the polynomial kernel of degree 1 with gamma = 1, coef0 = 0: K_ij = (1 * acc + 0)^1,
+    // bit for bit the linear kernel's value (the planes' power-of-two pre-scale is undone inside gamma, exactly); above, the passes win (twice the
+    // matrix-core rate of the panels-inside-a-tile kernels).  q, QA_cost and the data preparation keep the caller's kernel (params_); a rule on the
+    // shape and the options only, so every rank of a sharded solve decides alike.
+    tile_params_ = params_;
+    if constexpr (std::is_same_v<T, float>) {
+        if (params_.kernel_type == LSSVM_KERNEL_LINEAR && opt_.gram_mode != 0 && opt_.tile_kernel != 1 && round_up(static_cast<long>(num_features), 64) > 256
+            && n_ < LINEAR_IN_TILE_BELOW) {
+            tile_params_.kernel_type = LSSVM_KERNEL_POLYNOMIAL;
+            tile_params_.degree = 1;
+            tile_params_.gamma = 1.0;
+            tile_params_.coef0 = 0.0;
+        }
+    }
     if constexpr (std::is_same_v<T, float>) {
         // linear kernel on more than 512 features: K*v = sum over feature panels of (X_p X_p^T) v, every panel one launch of the f16x3 kernels
         // (enqueue_apply_K_local).  Whether the data allows f16 planes decides it, so the planes are built HERE (the linear kernel needs the raw data).
-        if (params_.kernel_type == LSSVM_KERNEL_LINEAR && opt_.gram_mode >= 2 && opt_.tile_kernel != 1
+        if (tile_params_.kernel_type == LSSVM_KERNEL_LINEAR && opt_.gram_mode >= 2 && opt_.tile_kernel != 1
             && round_up(static_cast<long>(num_features), 64) > LINEAR_PANEL_FEATURES) {
             if (opt_.symmetric != 0 && opt_.colslab_limit_mb != 0) {  // (the panel passes exist for the symmetric variant: no probe, no planes otherwise)
-                make_planes(opt_, params_, false, X_, nullptr, planes_, nullptr, st, false, true);
+                make_planes(opt_, tile_params_, false, X_, nullptr, planes_, nullptr, st, false, true);
                 if (planes_.mode == 2) {
                     v2_ok = wide_linear_ = true;
                 } else {
@@ -697,9 +713,9 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         // rbf / polynomial on more features than the row panel of the split kernels holds in registers (f16x3: 384 rbf, 512 polynomial; bf16x6:
         // 384): feature panels of 128 walked inside a tile (lssvm_tile_f32_wide.hip.hpp), either variant, either plane kind -- decided from
         // the shape and the options alone, so every rank of a sharded solve decides alike.  (The linear kernel has its panel passes above.)
-        if (wide_nonlinear(opt_, params_, rbf_direct_, num_features)) v2_ok = wide_nl_ = true;
+        if (wide_nonlinear(opt_, tile_params_, rbf_direct_, num_features)) v2_ok = wide_nl_ = true;
     }
-    sym_ = opt_.symmetric != 0 && v2_ok && !(params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree < 0);
+    sym_ = opt_.symmetric != 0 && v2_ok && !(tile_params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && tile_params_.degree < 0);
     // the symmetric variant keeps one 128-entry record per evaluated off-diagonal tile of the row-block BAND in flight (see the bands
     // below); colslab_limit_mb = 0 switches the variant off (a rule in the options only, so every rank of a sharded solve decides alike)
     if (sym_ && opt_.colslab_limit_mb == 0) sym_ = false;
@@ -707,10 +723,10 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         // 256-row workgroups on block pairs (lssvm_tile_f32_pair.hip.hpp): the symmetric variant of the split kernels on at most 128 features per
         // pass with a hand-scheduled epilogue -- decided from the shape and the options alone (both plane kinds have the kernel), so that the
         // geometry below does not wait for the planes and every rank of a sharded solve decides alike
-        const bool poly_generic = params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree != 2 && params_.degree != 3;
+        const bool poly_generic = tile_params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && tile_params_.degree != 2 && tile_params_.degree != 3;
         const bool narrow = wide_linear_ ? true : (round_up(static_cast<long>(num_features), 64) <= 128 && v2_eligible(opt_, ldx_probe, rbf_direct_));
         // (rbf: that kernel folds BOTH exponent terms out of the chain -- only while |c| = R2 / 2 stays small and the folded records are on)
-        const bool rbf_ok = params_.kernel_type != LSSVM_KERNEL_RBF || (opt_.rbf_fold != 0 && rbf_r2_ <= 2.0 * PAIR_FOLD_MAX_C);
+        const bool rbf_ok = tile_params_.kernel_type != LSSVM_KERNEL_RBF || (opt_.rbf_fold != 0 && rbf_r2_ <= 2.0 * PAIR_FOLD_MAX_C);
         // (below 64 row blocks -- 8 192 points -- the 128-row workgroups have more items to spread over the chip: 3 000 points 13.8 against 19.7 us)
         pair_ = sym_ && opt_.gram_mode != 0 && opt_.mfma_shape >= 3 && !wide_nl_ && !poly_generic && narrow && rbf_ok && num_tiles_ >= PAIR_MIN_TILES;
     }
@@ -730,7 +746,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         // the bf16x6 kernel has the costlier work-item prologue (three planes of the row panel) and the faster tiles: longer chunks
         // (measured 16 -> 64 tiles: +1.5 % at 100 000 points, +2 % at 300 000; the native kernels are flat or lose beyond 16)
         const bool split = wide_linear_ || wide_nl_ || std::is_same_v<T, float> && opt_.gram_mode != 0 && v2_eligible(opt_, ldx_probe, rbf_direct_)
-                           && round_up(static_cast<long>(num_features), 64) <= ((opt_.gram_mode == 1 || params_.kernel_type == LSSVM_KERNEL_RBF) ? SPLIT_MAX_FEATURES : F16_MAX_FEATURES);
+                           && round_up(static_cast<long>(num_features), 64) <= ((opt_.gram_mode == 1 || tile_params_.kernel_type == LSSVM_KERNEL_RBF) ? SPLIT_MAX_FEATURES : F16_MAX_FEATURES);
         const long cap = split ? 64 : 16;
         jc_tiles_ = static_cast<int>(std::min<long>(cap, std::max<long>(2, (area + 2048) / 4096)));
         if (pair_) {
@@ -792,10 +808,10 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     }
     if constexpr (std::is_same_v<T, float>) {
         // the (centred, scaled) data once more as operand planes of the split kernels (features in natural order): see make_planes
-        if (!wide_linear_) make_planes(opt_, params_, rbf_direct_, X_, nullptr, planes_, nullptr, st, wide_nl_, false, f16_probe_failed_);
+        if (!wide_linear_) make_planes(opt_, tile_params_, rbf_direct_, X_, nullptr, planes_, nullptr, st, wide_nl_, false, f16_probe_failed_);
         if ((wide_nl_ || pair_) && planes_.mode == 0) throw Error(LSSVM_ERR_INTERNAL, "no operand planes for a path that was chosen from the shape alone");
         // rbf: folded records while the exponent terms stay small (rbf_r2_ = 2 max|c| in the exponent's unit)
-        if (planes_.mode != 0) dc_folded_ = params_.kernel_type == LSSVM_KERNEL_RBF && opt_.rbf_fold != 0 && rbf_r2_ <= FOLD_MAX_R2;
+        if (planes_.mode != 0) dc_folded_ = tile_params_.kernel_type == LSSVM_KERNEL_RBF && opt_.rbf_fold != 0 && rbf_r2_ <= FOLD_MAX_R2;
     }
     interleave_features<T>(X_, st);
     if ((std::is_same_v<T, float> && (v2_eligible(opt_, X_.ldx, rbf_direct_) || wide_linear_ || wide_nl_)) || (std::is_same_v<T, double> && (v2_eligible_f64(opt_, X_.ldx) || wide_linear_ || wide_nl_))) {
@@ -871,10 +887,10 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     a.num_jt = num_tiles_;
     a.jc_tiles = jc_tiles_;
     a.ncols_valid = n_;
-    set_kernel_scalars(a, params_, rbf_direct_);
+    set_kernel_scalars(a, tile_params_, rbf_direct_);
     if (poly_prescaled_) a.gamma = T(1);
     if constexpr (std::is_same_v<T, float>) {
-        if (planes_.mode != 0) set_plane_args(a, params_, planes_, planes_, static_cast<size_t>(X_.rows_alloc), static_cast<size_t>(X_.rows_alloc));
+        if (planes_.mode != 0) set_plane_args(a, tile_params_, planes_, planes_, static_cast<size_t>(X_.rows_alloc), static_cast<size_t>(X_.rows_alloc));
     }
     a.wide_panels = wide_nl_ ? 1 : 0;
     set_launch_options(a, opt_);
@@ -958,7 +974,7 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
                 ab.pair_origin = band.pair_origin;
                 EvPair *ev = free_event();
                 if (ev != nullptr) LSSVM_HIP_CHECK(hipEventRecord(ev->a.e, st));
-                launch_tile_kernel<T>(ab, params_.kernel_type, rbf_direct_, num_jc_, st);
+                launch_tile_kernel<T>(ab, tile_params_.kernel_type, rbf_direct_, num_jc_, st);
                 if (ev != nullptr) {
                     LSSVM_HIP_CHECK(hipEventRecord(ev->b.e, st));
                     ev->pending = true;
@@ -981,7 +997,7 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
     } else {
         EvPair *ev = free_event();
         if (ev != nullptr) LSSVM_HIP_CHECK(hipEventRecord(ev->a.e, st));
-        launch_tile_kernel<T>(a, params_.kernel_type, rbf_direct_, num_jc_, st);
+        launch_tile_kernel<T>(a, tile_params_.kernel_type, rbf_direct_, num_jc_, st);
         if (ev != nullptr) {
             LSSVM_HIP_CHECK(hipEventRecord(ev->b.e, st));
             ev->pending = true;

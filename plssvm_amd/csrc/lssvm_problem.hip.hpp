@@ -85,6 +85,8 @@ struct Options {
 };
 constexpr double RBF_DIRECT_ABOVE = 32.0;     // rbf_form 0: the formula-exact kernel above this exponent scale 2 gamma log2(e) max|x - mean|^2 (absolute error of the
                                               // matrix-core exponent ~ 2^-24 x that; [-1, 1]-scaled data with gamma = 1 / num_features has <= 3)
+constexpr int LINEAR_IN_TILE_BELOW = 10000;   // fp32 linear kernel on more than 256 features and fewer points than this: ONE launch of the polynomial tile kernels with degree 1
+                                              // instead of launch-bound feature-panel passes (Problem<float>::tile_params_)
 constexpr int LINEAR_PANEL_FEATURES = 128;    // linear kernel beyond this many features: one pass of the <= 128-feature kernels per feature panel (fp32 f16x3: beats the
                                               // wider one-wave kernels by 5 ... 12 % at every width measured; fp64: 64- and 256-feature panels within 2 %)
 constexpr int ITEM_ORDER = 3;                 // symmetric variant: the work items of a column chunk on ONE XCD at a time (list position 8 k + x = lane x; the hardware deals
@@ -305,6 +307,8 @@ class Problem {
 
     Options opt_{};
     lssvm_params params_{};
+    lssvm_params tile_params_{};   // what the TILE kernels evaluate: params_, except that a linear kernel on few points and many features runs as the polynomial
+                                   // kernel of degree 1 (constructor; same values, one launch instead of feature-panel passes)
     int device_ = 0;
     int rank_ = 0, world_ = 1;
     Stream stream_;

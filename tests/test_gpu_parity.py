@@ -809,7 +809,9 @@ def test_bf16_split_gram_mode_is_fp32_accurate(oracle, kernel, N, d, sym):
             with backend.ResidentProblem(p, X) as prob:
                 q, QA = prob.q()
                 f16_limit = 384 if kernel == "rbf" else 512  # rbf holds three row planes in registers (the shifted planes)
-                panels = kernel != "linear"                   # beyond the one-pass kernels: feature panels inside a tile (either variant, either plane kind)
+                # beyond the one-pass kernels: feature panels inside a tile (either variant, either plane kind) -- the linear kernel too where it runs as the
+                # polynomial kernel of degree 1 (more than 256 features, fewer than 10 000 points: every shape of this test with d > 256)
+                panels = kernel != "linear" or d > 256
                 assert prob.info()["gram_mode"] == {0: 0, 1: 1 if d <= 384 or panels else 0, 2: 2 if d <= f16_limit or panels else 0, 3: 2 if d <= f16_limit or panels else 0}[mode]
                 out[mode] = prob.matvec(rhs, zero, 1.0)
                 prob.cg_begin(y, 1e-30)
@@ -897,13 +899,14 @@ def test_f16x3_at_its_acceptance_edge(kernel, N, d, sym):
             assert err.max() < 16.0, (log2_target, mode, float(err.max()))
 
 
-@pytest.mark.parametrize("mode", [3, 2, 1])
-@pytest.mark.parametrize("sym", [1, 0])
-def test_linear_kernel_beyond_512_features_reports_the_kernel_that_ran(sym, mode):
-    """the linear kernel on more than 512 features runs the f16x3 panel passes in the SYMMETRIC variant only; the full-square variant (and
-    bf16x6) stays on the generic native kernel -- and must then neither build planes nobody reads nor report a split Gram mode (bench.py prices
-    `achieved` by it).  Results against the float64 product either way."""
-    N, d = 700, 600
+@pytest.mark.parametrize("N, sym, mode", [(700, s, m) for s in (1, 0) for m in (3, 2, 1)] + [(10100, 1, 3), (10100, 0, 3), (10100, 1, 1)])
+def test_linear_kernel_beyond_512_features_reports_the_kernel_that_ran(N, sym, mode):
+    """From 10 000 points on: the linear kernel on more than 512 features runs the f16x3 panel passes in the SYMMETRIC variant only; the
+    full-square variant (and bf16x6) stays on the generic native kernel -- and must then neither build planes nobody reads nor report a split Gram mode
+    (bench.py prices `achieved` by it).  Below 10 000 points (round 4: the panel passes are launch-bound there) the tile kernels evaluate the linear
+    kernel as the polynomial kernel of degree 1 -- one launch of the panels-inside-a-tile kernels, which exist for both variants and both plane kinds.
+    Results against the float64 product either way."""
+    d = 600
     X, _ = make_blobs_pm1(N, d, seed=31, dtype=np.float32)
     v = np.random.default_rng(2).uniform(-1, 1, N - 1).astype(np.float32)
     _capi.set_option("symmetric", sym)
@@ -912,9 +915,13 @@ def test_linear_kernel_beyond_512_features_reports_the_kernel_that_ran(sym, mode
         info = prob.info()
         q, QA = prob.q()
         got = prob.matvec(v, np.zeros(N - 1, np.float32), 1.0).astype(np.float64)
-    panels = sym == 1 and mode >= 2  # (the panel passes are f16x3 kernels of the symmetric variant; everything else runs the generic full-square kernel)
-    assert info["symmetric"] == (1 if panels else 0)
-    assert info["gram_mode"] == (2 if panels else 0)
+    if N >= 10000:
+        panels = sym == 1 and mode >= 2  # (the panel passes are f16x3 kernels of the symmetric variant; everything else runs the generic full-square kernel)
+        assert info["symmetric"] == (1 if panels else 0)
+        assert info["gram_mode"] == (2 if panels else 0)
+    else:
+        assert info["symmetric"] == sym
+        assert info["gram_mode"] == (2 if mode >= 2 else 1)
     X64, v64 = X.astype(np.float64), v.astype(np.float64)
     K = X64[:-1] @ X64[:-1].T
     S = float(v64.sum())
