@@ -40,6 +40,24 @@ __global__ void k_pack_dc(const float *__restrict__ dvec, const float *__restric
     }
 }
 
+/* operand planes [nplanes][rows][ldx16] (row-major, rows a multiple of 16, ldx16 of 64) -> the same data with every block of 16 rows x 32 features stored
+ * as ONE MFMA A fragment (64 lanes x 8 halfs, lane 16 g + r holding features 8 g .. 8 g + 7 of row r), ordered
+ * [plane][ldx16 / 64 chunks][rows / 16 blocks][2 k32 steps][64 lanes][8]: the 64-feature chunk OUTERMOST, so that the sixteen row blocks a workgroup
+ * loads for one chunk are 32 KiB contiguous (with the row block outermost they lay a power of two apart whenever ldx16 is one: every wave on the same
+ * L2 channels -- 100 000 x 385 measured 16 % slower that way).  One thread per 16-byte piece. */
+__global__ void k_planes_fragment_major(const uint16_t *__restrict__ src, size_t plane_elems, int rows, int ldx16, int nplanes, uint16_t *__restrict__ dst) {
+    const size_t piece = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t per_plane = static_cast<size_t>(rows) * (ldx16 / 8);
+    if (piece >= per_plane * nplanes) return;
+    const size_t pl = piece / per_plane;
+    const size_t in_plane = piece - pl * per_plane;
+    const int row = static_cast<int>(in_plane / (ldx16 / 8));
+    const int f8 = static_cast<int>(in_plane - static_cast<size_t>(row) * (ldx16 / 8));
+    const int rb = row >> 4, r = row & 15, c64 = f8 >> 3, kk = (f8 >> 2) & 1, g = f8 & 3;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(src + pl * plane_elems + static_cast<size_t>(row) * ldx16 + 8 * f8);
+    *reinterpret_cast<f32x4 *>(dst + pl * plane_elems + (static_cast<size_t>(c64) * (rows / 16) + rb) * 1024 + kk * 512 + (16 * g + r) * 8) = v;
+}
+
 /* in place: the features of every aligned group of 8 are reordered to 0,2,4,6,1,3,5,7 (fp32 HBM layout, see above) */
 __global__ void k_interleave_features(float *__restrict__ X, size_t ngroups) {
     const size_t g = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;

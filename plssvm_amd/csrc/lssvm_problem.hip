@@ -346,6 +346,8 @@ static void make_planes(const Options &o, const lssvm_params &p, bool rbf_direct
     if (o.gram_mode == 0 || rbf_direct || (!v2_eligible(o, M.ldx, false) && !wide_linear && !wide_nl)) return;
     auto alloc = [&](int nplanes) {
         out.ldx16 = ldx16;
+        out.nplanes = nplanes;
+        if (out2 != nullptr) out2->nplanes = nplanes;
         out.buf.alloc_zero(static_cast<size_t>(nplanes) * M.rows_alloc * ldx16, s);
         if (M2 != nullptr) {
             out2->ldx16 = ldx16;
@@ -810,6 +812,16 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         // the (centred, scaled) data once more as operand planes of the split kernels (features in natural order): see make_planes
         if (!wide_linear_) make_planes(opt_, tile_params_, rbf_direct_, X_, nullptr, planes_, nullptr, st, wide_nl_, false, f16_probe_failed_);
         if ((wide_nl_ || pair_) && planes_.mode == 0) throw Error(LSSVM_ERR_INTERNAL, "no operand planes for a path that was chosen from the shape alone");
+        if (wide_nl_ && sym_) {
+            // the row side of the panels-inside-a-tile kernel: the planes once more, every 16 x 32 block stored as the A fragment a wave loads
+            // (lssvm_tile_f32_wide.hip.hpp: the row fragments are re-loaded at every tile-panel -- whole cache lines instead of half lines)
+            const size_t plane_elems = static_cast<size_t>(X_.rows_alloc) * planes_.ldx16;
+            planes_frag_.alloc_zero(static_cast<size_t>(planes_.nplanes) * plane_elems, st);
+            const size_t pieces = static_cast<size_t>(planes_.nplanes) * X_.rows_alloc * (planes_.ldx16 / 8);
+            hipLaunchKernelGGL(k_planes_fragment_major, dim3(static_cast<unsigned>((pieces + 255) / 256)), dim3(256), 0, st, planes_.buf.p, plane_elems, static_cast<int>(X_.rows_alloc), planes_.ldx16,
+                               planes_.nplanes, planes_frag_.p);
+            LSSVM_HIP_CHECK(hipGetLastError());
+        }
         // rbf: folded records while the exponent terms stay small (rbf_r2_ = 2 max|c| in the exponent's unit)
         if (planes_.mode != 0) dc_folded_ = tile_params_.kernel_type == LSSVM_KERNEL_RBF && opt_.rbf_fold != 0 && rbf_r2_ <= FOLD_MAX_R2;
     }
@@ -890,6 +902,7 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     set_kernel_scalars(a, tile_params_, rbf_direct_);
     if (poly_prescaled_) a.gamma = T(1);
     if constexpr (std::is_same_v<T, float>) {
+        a.Xr16f = planes_frag_.p;
         if (planes_.mode != 0) set_plane_args(a, tile_params_, planes_, planes_, static_cast<size_t>(X_.rows_alloc), static_cast<size_t>(X_.rows_alloc));
     }
     a.wide_panels = wide_nl_ ? 1 : 0;

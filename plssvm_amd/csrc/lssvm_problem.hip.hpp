@@ -252,6 +252,7 @@ struct PlaneSet {
     int ldx16 = 0;
     int mode = 0;   // 0 none, 1 bf16x6 (three bf16 planes), 2 f16x3 (two f16 planes)
     int shift = 0;  // f16x3: the planes carry 2^shift x
+    int nplanes = 0;  // planes in `buf` (f16x3: 2, rbf 3 -- the shifted planes; bf16x6: 3)
 };
 
 /* ------------------------------------------------------------------ one device's share of the problem ------------------------------------------------------------------ */
@@ -307,6 +308,7 @@ class Problem {
 
     Options opt_{};
     lssvm_params params_{};
+    DevBuf<uint16_t> planes_frag_;  // panels-inside-a-tile kernel, symmetric variant: the planes once more, fragment-major, for the row side (TileArgs::Xr16f)
     lssvm_params tile_params_{};   // what the TILE kernels evaluate: params_, except that a linear kernel on few points and many features runs as the polynomial
                                    // kernel of degree 1 (constructor; same values, one launch instead of feature-panel passes)
     int device_ = 0;

@@ -68,17 +68,29 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
     bf16x8 afrag[PLA][2 * NK64][2];
     // (uniform base in SGPRs + ONE 32-bit lane offset: per-lane 64-bit row pointers for every plane and row block would live across the whole
     // work item and spill)
-    const unsigned row_lane_off = 2u * static_cast<unsigned>(r * a.ldx16 + 8 * g);
+    // Symmetric variant (training): the row side comes from a FRAGMENT-MAJOR copy of the planes (TileArgs::Xr16f, k_planes_fragment_major) -- every
+    // block of 16 rows x 32 features stored as the 1 KiB a wave loads as one A fragment (64-feature chunk outermost, then the row block, then the
+    // chunk's two k32 steps), so a load instruction touches 8 whole 128-byte lines instead of 16 half lines.  The re-loads are what this kernel waits for (ablation: without them 8.6 -> 4.7 ms at 60 000 x 640 rbf,
+    // profiles/r04_ablation_wide.log), and the vector memory path they share with the column stream counts line requests, not bytes.
+    const unsigned row_lane_off = SYM ? 16u * static_cast<unsigned>(lane) : 2u * static_cast<unsigned>(r * a.ldx16 + 8 * g);
+    const size_t frag_rows16 = SYM ? a.plane_stride_r / static_cast<size_t>(a.ldx16) / 16 : 0;  // 16-row blocks of a plane (uniform; once per work item)
     auto load_row_chunk = [&](int p, auto chunk_c) {  // the 64-feature chunk `chunk` of panel p: k32 steps 2 chunk, 2 chunk + 1
         constexpr int chunk = decltype(chunk_c)::value;
 #pragma unroll
         for (int pl = 0; pl < PLA; ++pl) {
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
-                const char *base = sgpr_ptr(a.Xr16 + pl * a.plane_stride_r + static_cast<size_t>(row0 + wave * 32 + 16 * rb) * a.ldx16 + p * (64 * NK64) + 64 * chunk);
-                const auto *xr = (const __attribute__((address_space(1))) char *) base + lane_off(row_lane_off);
+                if constexpr (SYM) {
+                    const char *base = sgpr_ptr(a.Xr16f + pl * a.plane_stride_r + (static_cast<size_t>(p * NK64 + chunk) * frag_rows16 + static_cast<size_t>(row0 / 16 + wave * 2 + rb)) * 1024);
+                    const auto *xr = (const __attribute__((address_space(1))) char *) base + lane_off(row_lane_off);
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) afrag[pl][2 * chunk + kk][rb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(xr + 64 * kk));
+                    for (int kk = 0; kk < 2; ++kk) afrag[pl][2 * chunk + kk][rb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(xr + 1024 * kk));
+                } else {
+                    const char *base = sgpr_ptr(a.Xr16 + pl * a.plane_stride_r + static_cast<size_t>(row0 + wave * 32 + 16 * rb) * a.ldx16 + p * (64 * NK64) + 64 * chunk);
+                    const auto *xr = (const __attribute__((address_space(1))) char *) base + lane_off(row_lane_off);
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) afrag[pl][2 * chunk + kk][rb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(xr + 64 * kk));
+                }
             }
         }
     };
@@ -166,7 +178,7 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
             }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (step + 3 < nsteps) {
+            if (step + 3 < nsteps && !LSSVM_DBG(a, 16)) {
                 const int s3 = step + 3;
                 const int t3 = s3 / steps_per_tile;
                 if (s3 - t3 * steps_per_tile == 0) issue_dc(t3);
@@ -260,7 +272,7 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
                 // the last plane of a 64-feature chunk is through: its row fragments are dead, the registers take the same chunk of the NEXT
                 // tile-panel -- requested half a tile-panel or more before its first use instead of in front of it
                 if constexpr (plane == PL - 1) {
-                    if (more_panels) load_row_chunk(p_next, std::integral_constant<int, chunk>{});
+                    if (more_panels && !LSSVM_DBG(a, 1)) load_row_chunk(p_next, std::integral_constant<int, chunk>{});  // ablation bit 1: no row-panel re-loads
                 }
             });
         }
@@ -307,10 +319,12 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
                 }
             }
         };
-        if (tile_sym) {
-            epilogue(std::true_type{});
-        } else {
-            epilogue(std::false_type{});
+        if (!LSSVM_DBG(a, 4)) {
+            if (tile_sym) {
+                epilogue(std::true_type{});
+            } else {
+                epilogue(std::false_type{});
+            }
         }
     }
     if constexpr (SYM) {

@@ -42,6 +42,8 @@ struct TileArgs {
     int dc_folded;    // host side only: 1 if the records carry the folded form (rbf on the 16x16x32 bf16x6 kernels while |c| stays small)
     const uint16_t *Xr16;  // fp32 split kernels: the row side as three bf16 planes [3][rows][ldx16] (hi, mid, lo: x = hi + mid + lo exactly; "bf16x6")
                            // or as two f16 planes [2][rows][ldx16] (hi, mid of 2^k x; "f16x3")
+    const uint16_t *Xr16f; // panels-inside-a-tile kernel, symmetric variant: the row side FRAGMENT-MAJOR -- [plane][ldx16 / 64][rows / 16][2][64 lanes][8], lane 16 g + r
+                           // = features 8 g .. 8 g + 7 of row r of the block (k_planes_fragment_major); same plane stride as Xr16
     const uint16_t *Xc16;  // fp32 split kernels: the column side, same layout
     int planes_f16;        // host side only: 1 if the planes are the two f16 planes (f16x3 kernels), 0 for the three bf16 planes
     T out_scale;           // f16x3, linear kernel: 2^(-2k), undoes the power-of-two pre-scale of the planes on the finished sums (exact);

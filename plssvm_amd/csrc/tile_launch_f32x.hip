@@ -49,6 +49,7 @@ void launch_wide_tile_kernel(const TileArgs<float> &a, int kernel_type, dim3 gri
     if (a.nk64 < 4 || a.nk64 % 2 != 0) throw Error(LSSVM_ERR_INTERNAL, "the wide split tile kernel needs planes padded to a multiple of 128 features");
     if (a.degree < 0 && kernel_type == KT_POLY) throw Error(LSSVM_ERR_INTERNAL, "the wide split tile kernel does not take a negative polynomial degree");
     if (a.items != nullptr) {
+        if (a.Xr16f == nullptr) throw Error(LSSVM_ERR_INTERNAL, "the symmetric wide split tile kernel needs the fragment-major row planes");
         if (a.num_items > 0) launch_wide<true>(a, kernel_type, dim3(static_cast<unsigned>(a.num_items)), s);
     } else {
         launch_wide<false>(a, kernel_type, grid, s);
