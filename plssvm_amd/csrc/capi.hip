@@ -338,7 +338,7 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
             lssvm::options().mfma_shape = value;
         } else if (n == "item_order_dev") {
 #ifdef LSSVM_DEV_SUBSET
-            LSSVM_REQUIRE(value >= 0 && value <= 3, "item_order_dev must be 0 ... 3");
+            LSSVM_REQUIRE(value >= 0 && value <= 7, "item_order_dev must be 0 ... 7");
             lssvm::options().item_order_dev = value;
 #else
             LSSVM_REQUIRE(value == 0, "item_order_dev exists in development builds (make DEV=1) only");

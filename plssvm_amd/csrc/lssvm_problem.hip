@@ -557,6 +557,35 @@ static std::vector<int2> band_items(int band_begin, int band_end, int jc_tiles, 
     std::vector<int2> full, cut;
     const int rows = pairs ? 2 : 1;  // row blocks per work item: block pairs (2p, 2p + 1) for the 256-row workgroups (.x = the even block; the band edges are even)
     const int nrow_items = (band_end - band_begin + rows - 1) / rows;
+    if (order >= 4) {
+        // ROW-GROUP major, for the kernels that re-load their row panel at every tile (panels inside a tile): the 64 workgroups an XCD runs at a time
+        // are the items of a GROUP of row blocks x their column chunks, so that the row panels they keep re-reading fit that XCD's L2 (with the
+        // column-chunk major orders every concurrent workgroup has a row panel of its own: 60 000 x 640 rbf re-read 54 GB of row planes per matvec
+        // from beyond L2) and a column tile is streamed for the whole group at once.  List position 8 k + x belongs to XCD x: runs of 64 consecutive items of the
+        // sequence go to one lane.
+        std::vector<int2> seq;
+        const int GROUP = order == 4 ? 4 : (order == 5 ? 2 : (order == 6 ? 8 : 1));  // (4 and 5 ship; 6, 7: development builds, item_order_dev)
+        for (int g0 = 0; g0 < nrow_items; g0 += GROUP) {
+            for (int jc = 0; jc < num_jc; ++jc) {
+                for (int k = g0; k < std::min(g0 + GROUP, nrow_items); ++k) {
+                    const int ib = band_begin + rows * k;
+                    if (jc * jc_tiles > ib + rows - 1) continue;
+                    seq.push_back(make_int2(ib, jc));
+                }
+            }
+        }
+        std::vector<std::vector<int2>> lane(8);
+        for (size_t i = 0; i < seq.size(); ++i) lane[(i / 64) % 8].push_back(seq[i]);
+        std::vector<int2> out;
+        out.reserve(seq.size());
+        std::vector<size_t> pos(8, 0);
+        while (out.size() < seq.size()) {
+            for (int x = 0; x < 8; ++x) {
+                if (pos[x] < lane[x].size()) out.push_back(lane[x][pos[x]++]);
+            }
+        }
+        return out;
+    }
     for (int jc = 0; jc < num_jc; ++jc) {
         for (int k = 0; k < nrow_items; ++k) {
             const int ib = band_begin + rows * (order == 2 ? nrow_items - 1 - k : k);
@@ -756,6 +785,21 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
             LSSVM_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_));
             jc_tiles_ = choose_pair_chunk(ib_begin_, static_cast<int>(ib_end), num_tiles_, sizeof(T), opt_, std::max(cus, 1));
         }
+        // panels inside a tile, symmetric variant: SHORT items in row-group major order (wide_order_ below) -- the shorter the better at every shape
+        // (12 > 8 > 4 > 2 tiles, profiles/r04_ab_wide_item_order_groups.log, r04_ab_wide_final.log); longer only where the partial slabs would grow
+        // beyond 256 per row
+        if (wide_nl_ && sym_) jc_tiles_ = static_cast<int>(std::min<long>(64, std::max<long>(2, (num_tiles_ + 255) / 256)));
+    }
+    if (wide_nl_ && sym_) {
+        // These kernels re-load a work item's row panel at EVERY column tile.  In the column-chunk major orders each of the 64 workgroups an XCD runs
+        // at a time has a row panel of its own -- 64 x 0.4 ... 1.6 MB against 4 MB of L2: the re-loads came from beyond L2 at HBM rate (60 000 x 640
+        // rbf: 54 GB of row planes per matvec, 6 TB/s).  Row-group major (band_items, order 4 / 5): an XCD works on FOUR (two, where a panel is
+        // beyond 640 KB) row blocks x their column chunks at a time, so their panels stay in its L2 and every column tile is streamed for the
+        // whole group: 60 000 x 640 rbf 8.5 -> 6.2 ms, 100 000 x 385 rbf 19.4 -> 12.4 ms.  Results do not depend on the order.
+        const double panel_bytes = std::is_same_v<T, float>
+                                       ? 128.0 * static_cast<double>(round_up(static_cast<long>(num_features), 128)) * ((tile_params_.kernel_type == LSSVM_KERNEL_RBF || opt_.gram_mode == 1) ? 3.0 : 2.0) * 2.0
+                                       : 128.0 * static_cast<double>(ldx_probe) * 8.0;
+        wide_order_ = panel_bytes <= 640e3 ? 4 : 5;
     }
     num_jc_ = (num_tiles_ + jc_tiles_ - 1) / jc_tiles_;
     if (const char *dbg = std::getenv("LSSVM_MI355_DEBUG"); dbg != nullptr && dbg[0] == '1') {
@@ -845,7 +889,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
             band.ib_end = edge[k + 1];
             band.item_begin = static_cast<int>(items.size());
             band.pair_origin = pairs_below(band.ib_begin);
-            for (const int2 &it : band_items(band.ib_begin, band.ib_end, jc_tiles_, num_jc_, opt_.item_order_dev != 0 ? static_cast<int>(opt_.item_order_dev) : ITEM_ORDER, pair_)) items.push_back(make_int2(it.x - ib_begin_, it.y));
+            for (const int2 &it : band_items(band.ib_begin, band.ib_end, jc_tiles_, num_jc_, opt_.item_order_dev != 0 ? static_cast<int>(opt_.item_order_dev) : (wide_order_ != 0 ? wide_order_ : ITEM_ORDER), pair_)) items.push_back(make_int2(it.x - ib_begin_, it.y));
             band.item_count = static_cast<int>(items.size()) - band.item_begin;
             // (block pairs: the records of the pair's SECOND block, which is padding behind an odd last block)
             max_records = std::max(max_records, pairs_below(pair_ ? round_up(band.ib_end, 2) : band.ib_end) - band.pair_origin);

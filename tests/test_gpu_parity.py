@@ -1067,7 +1067,13 @@ def test_wide_data_at_the_reference_test_shape(oracle, kernel, dt):
     v64 = rhs.astype(np.float64)
     S = float(v64.sum())
     scale = np.abs(K) @ np.abs(v64) + np.abs(v64) / 0.1 + abs(float(QA) * S) + abs(float(q64 @ v64)) + np.abs(S * q64)
-    assert np.max(np.abs(got - truth) / scale) < 16 * eps, float(np.max(np.abs(got - truth) / scale) / eps)
+    # fp64: the yardstick is itself a float64 evaluation -- the oracle's (= the reference's) lower-triangle kernel adds its mirrored terms with
+    # `omp atomic` in an order that changes from run to run, and two float64 evaluations of this product (the oracle's, numpy's K @ v) differ by
+    # 14 eps of the rows' summands.  Against such a yardstick the bitwise reproducible device result measured 15.x ... 16.4 eps: at a bar of 16 this
+    # test failed once in ~15 runs.  64 eps for float64 (the randomised cross-checks allow 256); float32 is held at 16 eps of float32, where the
+    # yardstick's uncertainty is nine orders of magnitude below the bar.
+    bar = 16 * eps if dt == np.float32 else 64 * eps
+    assert np.max(np.abs(got - truth) / scale) < bar, float(np.max(np.abs(got - truth) / scale) / eps)
 
 
 @pytest.mark.parametrize("sym", [1, 0])
