@@ -58,6 +58,19 @@ __global__ void k_planes_fragment_major(const uint16_t *__restrict__ src, size_t
     *reinterpret_cast<f32x4 *>(dst + pl * plane_elems + (static_cast<size_t>(c64) * (rows / 16) + rb) * 1024 + kk * 512 + (16 * g + r) * 8) = v;
 }
 
+/* fp64 data [rows][ldx] (row-major, rows a multiple of 16, ldx of 16) -> the same data with every block of 16 rows x 4 features stored as ONE A fragment of
+ * v_mfma_f64_16x16x4 (64 lanes, lane 16 q + r = row r, feature q), ordered [ldx / 16 chunks][rows / 16 blocks][4 k-steps][64 lanes]: the 16-feature
+ * chunk outermost, so that the eight row blocks a workgroup loads for one chunk are 16 KiB contiguous.  One thread per element.  (The
+ * panels-inside-a-sub-tile kernel re-loads its row fragments at every sub-tile and panel -- 22 % of its time, row-major: 32 bytes of each of 16 lines
+ * per load instruction.) */
+__global__ void k_rows_fragment_major_f64(const double *__restrict__ src, int rows, int ldx, double *__restrict__ dst) {
+    const size_t e = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e >= static_cast<size_t>(rows) * ldx) return;
+    const int row = static_cast<int>(e / ldx), f = static_cast<int>(e - static_cast<size_t>(row) * ldx);
+    const int rb = row >> 4, r = row & 15, chunk = f >> 4, s = (f >> 2) & 3, q = f & 3;
+    dst[((static_cast<size_t>(chunk) * (rows / 16) + rb) * 4 + s) * 64 + 16 * q + r] = src[e];
+}
+
 /* in place: the features of every aligned group of 8 are reordered to 0,2,4,6,1,3,5,7 (fp32 HBM layout, see above) */
 __global__ void k_interleave_features(float *__restrict__ X, size_t ngroups) {
     const size_t g = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;

@@ -870,6 +870,16 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         if (planes_.mode != 0) dc_folded_ = tile_params_.kernel_type == LSSVM_KERNEL_RBF && opt_.rbf_fold != 0 && rbf_r2_ <= FOLD_MAX_R2;
     }
     interleave_features<T>(X_, st);
+    if constexpr (std::is_same_v<T, double>) {
+        if (wide_nl_ && sym_) {
+            // the row side of the fp64 panels-inside-a-sub-tile kernel: the (prepared) data once more, every 16 x 4 block stored as the A fragment a wave
+            // loads (lssvm_tile_f64_wide.hip.hpp) -- after every in-place transformation of X_ above
+            Xfrag_.alloc_zero(static_cast<size_t>(X_.rows_alloc) * X_.ldx, st);
+            const size_t elems = static_cast<size_t>(X_.rows_alloc) * X_.ldx;
+            hipLaunchKernelGGL(k_rows_fragment_major_f64, dim3(static_cast<unsigned>((elems + 255) / 256)), dim3(256), 0, st, X_.data.p, static_cast<int>(X_.rows_alloc), X_.ldx, Xfrag_.p);
+            LSSVM_HIP_CHECK(hipGetLastError());
+        }
+    }
     if ((std::is_same_v<T, float> && (v2_eligible(opt_, X_.ldx, rbf_direct_) || wide_linear_ || wide_nl_)) || (std::is_same_v<T, double> && (v2_eligible_f64(opt_, X_.ldx) || wide_linear_ || wide_nl_))) {
         dc_.alloc_zero(static_cast<size_t>(std::max(num_tiles_, 1)) * 256, st);  // (d_j | c_j) records: 256 reals per 128 columns
     }
@@ -925,6 +935,8 @@ template <typename T>
 TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     TileArgs<T> a{};
     a.Xr = X_.data.p;
+    a.Xrf = Xfrag_.p;
+    a.frag_rows16 = static_cast<int>(X_.rows_alloc / 16);
     a.Xc = X_.data.p;
     a.cr = c_.p;
     a.cc = c_.p;

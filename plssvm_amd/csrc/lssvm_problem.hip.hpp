@@ -309,6 +309,7 @@ class Problem {
     Options opt_{};
     lssvm_params params_{};
     int wide_order_ = 0;            // panels inside a tile, symmetric variant: the row-group major item order (band_items 4 / 5: groups of four / two row blocks); 0 elsewhere
+    DevBuf<T> Xfrag_;               // fp64 panels-inside-a-sub-tile kernel, symmetric variant: the data once more, fragment-major, for the row side (TileArgs::Xrf)
     DevBuf<uint16_t> planes_frag_;  // panels-inside-a-tile kernel, symmetric variant: the planes once more, fragment-major, for the row side (TileArgs::Xr16f)
     lssvm_params tile_params_{};   // what the TILE kernels evaluate: params_, except that a linear kernel on few points and many features runs as the polynomial
                                    // kernel of degree 1 (constructor; same values, one launch instead of feature-panel passes)

@@ -57,15 +57,25 @@ __global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f64_wide(const Ti
     // row panel of ONE feature panel: A operand of lane (r, q) for k-step s of chunk c is X[row][64 p + 16 c + 4 s + q]
     // (uniform base in SGPRs + one 32-bit lane offset: no per-lane 64-bit row pointers across the work item)
     double afrag[2][4 * NKC];
-    const unsigned row_lane_off = 8u * static_cast<unsigned>(r * a.ldx + q);
+    // Symmetric variant (training): from the FRAGMENT-MAJOR copy of the data (TileArgs::Xrf, k_rows_fragment_major_f64) -- a load instruction reads the
+    // 512 contiguous bytes of one A fragment instead of 32 bytes of each of 16 lines.  The re-loads are what this kernel loses against the one-pass
+    // kernels (ablation: without them 21.6 -> 16.9 ms at 60 000 x 320 rbf = the one-pass rate).
+    const unsigned row_lane_off = SYM ? 8u * static_cast<unsigned>(lane) : 8u * static_cast<unsigned>(r * a.ldx + q);
     auto load_row_chunk = [&](int p, auto chunk_c) {
         constexpr int chunk = decltype(chunk_c)::value;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-            const char *base = sgpr_ptr(a.Xr + static_cast<size_t>(row0 + wave * 32 + rb * 16) * a.ldx + p * (16 * NKC) + 16 * chunk);
-            const auto *xr = (const __attribute__((address_space(1))) char *) base + lane_off(row_lane_off);
+            if constexpr (SYM) {
+                const char *base = sgpr_ptr(a.Xrf + ((static_cast<size_t>(p * NKC + chunk) * a.frag_rows16 + static_cast<size_t>(row0 / 16 + wave * 2 + rb)) * 4) * 64);
+                const auto *xr = (const __attribute__((address_space(1))) char *) base + lane_off(row_lane_off);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) afrag[rb][4 * chunk + s] = *reinterpret_cast<const __attribute__((address_space(1))) double *>(xr + 32 * s);
+                for (int s = 0; s < 4; ++s) afrag[rb][4 * chunk + s] = *reinterpret_cast<const __attribute__((address_space(1))) double *>(xr + 512 * s);
+            } else {
+                const char *base = sgpr_ptr(a.Xr + static_cast<size_t>(row0 + wave * 32 + rb * 16) * a.ldx + p * (16 * NKC) + 16 * chunk);
+                const auto *xr = (const __attribute__((address_space(1))) char *) base + lane_off(row_lane_off);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) afrag[rb][4 * chunk + s] = *reinterpret_cast<const __attribute__((address_space(1))) double *>(xr + 32 * s);
+            }
         }
     };
     static_for<0, NKC>([&](auto c) { load_row_chunk(0, c); });

@@ -34,6 +34,9 @@ using f64x4 = double __attribute__((ext_vector_type(4)));
 template <typename T>
 struct TileArgs {
     const T *Xr;      // [>= (ib_begin+num_ib)*TILE][ldx] row side, zero padded
+    const T *Xrf;     // fp64 panels-inside-a-sub-tile kernel, symmetric variant: the row side FRAGMENT-MAJOR -- [ldx / 16][rows / 16][4 k-steps][64 lanes], lane 16 q + r
+                      // = X[16 block + r][16 chunk + 4 step + q] (k_rows_fragment_major_f64): 512 contiguous bytes per A fragment of v_mfma_f64_16x16x4
+    int frag_rows16;  // 16-row blocks of Xrf (rows_alloc / 16)
     const T *Xc;      // [>= num_jt*TILE][ldx]            column side, zero padded
     const T *cr;      // rbf: -0.5 * |x_i|^2 per row-side point
     const T *cc;      // rbf: -0.5 * |x_j|^2 per column-side point

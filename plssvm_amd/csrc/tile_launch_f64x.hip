@@ -33,6 +33,7 @@ void launch_wide_tile_kernel_f64(const TileArgs<double> &a, int kernel_type, dim
     if (a.kchunks < 8 || a.kchunks % 4 != 0) throw Error(LSSVM_ERR_INTERNAL, "the wide fp64 tile kernel needs data padded to a multiple of 64 features");
     if (a.degree < 0 && kernel_type == KT_POLY) throw Error(LSSVM_ERR_INTERNAL, "the wide fp64 tile kernel does not take a negative polynomial degree");
     if (a.items != nullptr) {
+        if (a.Xrf == nullptr || a.frag_rows16 <= 0) throw Error(LSSVM_ERR_INTERNAL, "the symmetric wide fp64 tile kernel needs the fragment-major rows");
         if (a.num_items > 0) launch_wide_f64<true>(a, kernel_type, dim3(static_cast<unsigned>(a.num_items)), s);
     } else {
         launch_wide_f64<false>(a, kernel_type, grid, s);
