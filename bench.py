@@ -176,6 +176,63 @@ def cpu_baseline(X, y, kernel, sample_rows, iters):
     return a, b
 
 
+def kernel_ms_between(i0, i1):
+    """(matvecs enqueued, matvecs timed, average tile-kernel time of ONE implicit matvec in ms) between two lssvm_mi355_problem_info snapshots.  Short
+    matvecs are event-bracketed by sampling (every 8th); the average is over the TIMED ones only -- their summed time over their count (the
+    earlier form weighted the samples with the count of all matvecs)."""
+    launches = int(i1["matvec_launches"] - i0["matvec_launches"])
+    timed = int(i1["matvec_timed"] - i0["matvec_timed"])
+    total = float(i1["matvec_kernel_ms_total"] - i0["matvec_kernel_ms_total"])
+    return launches, timed, (total / timed if timed > 0 else 0.0)
+
+
+def plane_products_of(gram_mode: int) -> float:
+    return {0: 1.0, 1: 6.0, 2: 3.0}[gram_mode]
+
+
+def short_leg(name, steps, warmup, seed, device):
+    """One short leg of another BASELINE workload on the same device (reported as other_workloads.<name>): the same timed region as the
+    headline -- `steps` CG iterations after `warmup`, data resident -- and the same pricing of the tile kernel (`frac` = algorithmic flop of the kernel as
+    executed on the matrix cores / its peak)."""
+    import numpy as np
+
+    from plssvm_amd import backend
+    from plssvm_amd.datagen import make_blobs_pm1
+    from plssvm_amd.parameter import Parameter
+    from plssvm_amd.sharding import triangle_share, work_share
+
+    wl = WORKLOADS[name]
+    N, d = wl["n"], wl["d"]
+    dt = np.dtype(wl["dtype"])
+    X, y = make_blobs_pm1(N, d, seed=seed, dtype=dt)
+    prm = Parameter(kernel_type=wl["kernel"], degree=3, gamma=None, coef0=0.0, cost=1.0)
+    with backend.ResidentProblem(prm, X, device=device) as prob:
+        prob.cg_begin(y, 1e-30)
+        prob.cg_step(warmup)
+        prob.synchronize()
+        i0 = prob.info()
+        t0 = time.perf_counter()
+        prob.cg_step(steps)
+        prob.synchronize()
+        elapsed = time.perf_counter() - t0
+        i1 = prob.info()
+    done = int(i1["iterations"] - i0["iterations"])
+    launches, timed, kern_ms = kernel_ms_between(i0, i1)
+    n = N - 1
+    symmetric = bool(i1.get("symmetric", 0))
+    sq_mac, exe_mac = work_share(n, 1, 0, symmetric)
+    use_mac = triangle_share(n, 1, 0) if symmetric else sq_mac
+    gram_mode = int(i1.get("gram_mode", 0))
+    pp = plane_products_of(gram_mode)
+    peak = PEAK_TFLOPS["bf16"] if gram_mode != 0 else PEAK_TFLOPS[wl["dtype"]]
+    kern_s = kern_ms * 1e-3
+    return {"workload": wl["desc"], "steps": done, "warmup": warmup, "ms_per_step": elapsed / max(done, 1) * 1e3, "value": 2.0 * n * n * d * done / elapsed / 1e9, "unit": "GFLOP/s",
+            "avg_launch_ms": kern_ms, "launches": launches, "launches_timed": timed, "tile_launches_per_matvec": int(i1.get("tile_launches_per_matvec", 1)),
+            "frac": (2.0 * use_mac * d * pp / kern_s / 1e12 / peak) if kern_ms > 0 else None,
+            "executed_frac": (2.0 * exe_mac * d * pp / kern_s / 1e12 / peak) if kern_ms > 0 else None, "peak": peak,
+            "gram_mode": {0: "native", 1: "bf16x6", 2: "f16x3"}[gram_mode], "dtype": "f32" if wl["dtype"] == "float32" else "f64", "symmetric": symmetric}
+
+
 def free_port() -> int:
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
@@ -240,7 +297,12 @@ def main():
                          "seen on single-GPU boxes of this pool)")
     ap.add_argument("--rank-devices", default=None,
                     help="one process per GPU: comma separated HIP ordinal per local rank (default: the local rank).  Repeats put several ranks on one device "
-                         "-- a functional check of the rank path on a one-GPU box (needs --exchange 2 --dist-backend gloo: RCCL refuses two ranks on one device)")
+                         "-- a functional check of the rank path on a one-GPU box (needs --exchange 2, or --rccl-stand-in: the real RCCL refuses two ranks on one device)")
+    ap.add_argument("--rccl-stand-in", default=None, metavar="PATH",
+                    help="TESTING AID for one-GPU boxes: load this library (tests/tools/fake_rccl/librccl.so.1, a stand-in with RCCL's SONAME that accepts several "
+                         "ranks per device) into the process before torch and the product library, so that the product's own dlopen(\"librccl.so.1\") resolves to it.  "
+                         "The line then names it in config.rccl_library; such a line is a functional check of the RCCL exchange path, never a scaling number")
+    ap.add_argument("--no-other-workloads", action="store_true", help="default run (c5, one GPU): skip the short legs of c2 / c3 / c4 reported as other_workloads")
     ap.add_argument("--gram-mode", type=int, default=None, choices=[0, 1, 2, 3],
                     help="fp32 only: 3 (library default) = f16x3 where the data passes the representability check, else bf16x6; 2 = f16x3 unchecked; "
                          "1 = bf16x6; 0 = native v_mfma_f32 chains")
@@ -270,6 +332,15 @@ def main():
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # (the side channel: a container's hostname need not resolve)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    stand_in = None
+    if args.rccl_stand_in:
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location("fake_rccl_preload", os.path.join(os.path.dirname(os.path.abspath(args.rccl_stand_in)), "preload.py"))
+        preload = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(preload)
+        stand_in = preload.load(args.rccl_stand_in)  # ahead of torch (which keeps its own RCCL): the product's dlopen("librccl.so.1") finds this one by SONAME
 
     import numpy as np
     import torch  # plumbing only: device selection, synchronisation, torch.distributed (RCCL) for the barrier / id exchange
@@ -427,9 +498,7 @@ def main():
 
     # roofline of the dominant kernel (the tile kernel of the implicit matvec), from HIP events on the solver stream(s); a process
     # that drives several shards reports the slowest shard's average launch
-    launches = int(i1["matvec_launches"] - i0["matvec_launches"])
-    kern_ms_total = i1["matvec_kernel_ms"] * i1["matvec_launches"] - i0["matvec_kernel_ms"] * i0["matvec_launches"]
-    kern_ms = kern_ms_total / max(launches, 1)
+    launches, timed, kern_ms = kernel_ms_between(i0, i1)
     from plssvm_amd.sharding import triangle_share, work_share
 
     # Three flop counts of one tile-kernel launch of one shard:
@@ -454,7 +523,7 @@ def main():
     gram_mode = int(i1.get("gram_mode", 0))
     gram_name = {0: "native", 1: "bf16x6", 2: "f16x3"}[gram_mode]
     bf16x6 = gram_mode != 0  # (a split mode on the 16-bit matrix cores)
-    plane_products = {0: 1.0, 1: 6.0, 2: 3.0}[gram_mode]
+    plane_products = plane_products_of(gram_mode)
     fp32_equivalent = achieved
     if bf16x6:
         peak = PEAK_TFLOPS["bf16"]
@@ -488,7 +557,12 @@ def main():
                               "accumulated in fp32 on the f16 matrix cores"}.get(gram_mode, "native " + wl["dtype"] + " matrix-core fma chains"),
             "config": {"workload": wl["desc"], "num_points": N, "num_features": d, "kernel": wl["kernel"], "gamma": 1.0 / d, "cost": 1.0,
                        "seed": args.seed, "library_options": args.option, "parallelism": parallelism, "shards": shards, "exchange": exchange_names.get(int(i1.get("exchange", 0)), "?"),
-                       "residuum_after_timed_steps": i1["residuum"]},
+                       "residuum_after_timed_steps": i1["residuum"],
+                       # what RCCL itself reports for the communicator the partial vectors travelled over (ncclCommCount / ncclCommCuDevice on rank 0), and the
+                       # file its entry points were resolved from -- null / 0 when no RCCL exchange ran
+                       "rccl_nranks": int(i1.get("rccl_nranks", 0)), "rccl_rank0_device": (int(i1["rccl_device"]) if int(i1.get("rccl_nranks", 0)) > 0 else None),
+                       "rccl_library": (backend.comm_library_path() if int(i1.get("rccl_nranks", 0)) > 0 else None),
+                       "rccl_is_stand_in": stand_in is not None},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_source": traffic_source,
                          # the HBM side of the same launch (SURVEY.md 8d asks for both fractions): algorithmic bytes n*d*s + 4*n*s, the measured
@@ -497,10 +571,10 @@ def main():
                                  "traffic_rate_TBps": (traffic / kern_s / 1e12) if (traffic is not None and kern_ms > 0) else None,
                                  "traffic_frac_of_hbm_peak": (traffic / kern_s / 1e12 / 8.0) if (traffic is not None and kern_ms > 0) else None},
                          "board_power": board_power,
-                         "kernel": "lssvm::tile_matvec (implicit K*d tile kernel)", "launches": launches, "avg_launch_ms": kern_ms,
+                         "kernel": "lssvm::tile_matvec (implicit K*d tile kernel)", "launches": launches, "launches_timed": timed, "avg_launch_ms": kern_ms,
                          "tile_launches_per_matvec": bands,
                          "launch_note": "a 'launch' here is ONE implicit matvec = the sum of its row-block band launches of the tile kernel (rocprofv3 lists the bands one by one); "
-                                        "where a matvec is short (< 1 ms by the library's shape rule) the HIP events bracket every 8th matvec only -- avg_launch_ms is their average",
+                                        "where a matvec is short (< 1 ms by the library's shape rule) the HIP events bracket every 8th matvec only (never the first after cg_begin) -- avg_launch_ms is the summed time of the launches_timed bracketed matvecs over their count",
                          "algorithmic_flop_per_launch": useful_launch * plane_products, "symmetric": symmetric,
                          "executed_flop_per_launch": exec_launch * plane_products, "executed": executed, "executed_frac": executed / peak,
                          "gram_mode": gram_name, "plane_products": plane_products, "fp32_equivalent": fp32_equivalent, "fp32_mfma_peak": PEAK_TFLOPS["float32"],
@@ -522,8 +596,7 @@ def main():
             tn = time.perf_counter() - tn
             j1 = nat.info()
             nsteps = int(j1["iterations"] - j0["iterations"])
-            nl = int(j1["matvec_launches"] - j0["matvec_launches"])
-            nk_ms = (j1["matvec_kernel_ms"] * j1["matvec_launches"] - j0["matvec_kernel_ms"] * j0["matvec_launches"]) / max(nl, 1)
+            _, _, nk_ms = kernel_ms_between(j0, j1)
             out["native_f32_path"] = {"ms_per_step": tn / max(nsteps, 1) * 1e3, "value": flop_step * nsteps / tn / 1e9, "unit": "GFLOP/s", "steps": nsteps,
                                       "tile_kernel_ms": nk_ms, "useful_tflops": useful_launch / (nk_ms * 1e-3) / 1e12 if nk_ms > 0 else 0.0,
                                       "frac_of_f32_mfma_peak": useful_launch / (nk_ms * 1e-3) / 1e12 / PEAK_TFLOPS["float32"] if nk_ms > 0 else 0.0}
@@ -556,6 +629,18 @@ def main():
                 "kernel_vs_bare_register_loop": achieved / regs_tf if regs_tf > 0 else None,
                 "kernel_vs_bare_lds_fed_loop": achieved / lds_tf if lds_tf > 0 else None,
             }
+        if args.workload == "c5" and shards == 1 and not args.no_other_workloads:
+            # BASELINE's other single-GPU configs, driver-observed: short legs on the same device after the headline's legs
+            if prob is not None:
+                prob.close()
+                prob = None
+            legs = {}
+            for name, k, w in (("c2", 200, 20), ("c3", 20, 3), ("c4", 20, 3)):
+                try:
+                    legs[name] = short_leg(name, k, w, args.seed, local_rank)
+                except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
+                    legs[name] = {"error": f"{type(e).__name__}: {e}"}
+            out["other_workloads"] = legs
         # the CPU legs come LAST: the OpenMP runtime's workers keep spinning after a parallel region and would slow the host side of
         # the GPU legs down (measured: 16 ms instead of 2.6 ms per c2 iteration in a native leg that followed them)
         if not args.no_cpu_baseline and shards == 1:

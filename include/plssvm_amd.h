@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define PLSSVM_AMD_ABI_VERSION 2 /* 2: multi-device entry points (_multi), lssvm_cg_info grew local_devices / exchange */
+#define PLSSVM_AMD_ABI_VERSION 3 /* 2: multi-device entry points (_multi), lssvm_cg_info grew local_devices / exchange; 3: lssvm_cg_info grew matvec_timed /
+                                  * matvec_kernel_ms_total / rccl_nranks / rccl_rank / rccl_device */
 
 typedef enum lssvm_status {
     LSSVM_SUCCESS = 0,
@@ -69,17 +70,25 @@ typedef struct lssvm_cg_info {
     double avg_iteration_ms; /* host wall clock per CG iteration */
     double total_ms;         /* host wall clock of begin + all steps + finish */
     double setup_ms;         /* host->device transfer of the data matrix, q vector, norms */
-    double matvec_kernel_ms; /* average device time of the tile-kernel launches of ONE implicit matvec (HIP events on the solver stream) */
-    uint64_t matvec_launches;
+    double matvec_kernel_ms; /* average device time of the tile-kernel launches of ONE implicit matvec (HIP events on the solver stream): matvec_kernel_ms_total / matvec_timed */
+    uint64_t matvec_launches; /* implicit matvecs enqueued since cg_begin */
     int32_t devices_used;    /* world size of the row-block sharding (1 = single GPU) */
     int32_t converged;       /* 1 if the stop test delta <= eps^2 * delta0 fired */
     int32_t symmetric;       /* 1 if the implicit matvec evaluated only the tiles on/below the diagonal (half the multiply-adds) */
-    int32_t gram_mode;       /* fp32: 1 if the Gram tiles ran as the exact 3-way bf16 split on the bf16 matrix cores ("bf16x6"), else 0 */
+    int32_t gram_mode;       /* fp32: how the Gram tiles ran: 0 = native v_mfma_f32 chains, 1 = "bf16x6" (exact 3-way bf16 split), 2 = "f16x3" (two f16 planes per operand) */
     int32_t local_devices;   /* devices driven by THIS process (1 for a single GPU and for one process per GPU) */
     int32_t exchange;        /* how the partial K*v vectors were combined per matvec: 0 none, 1 RCCL (all-reduce / all-gather), 2 peer kernels over xGMI */
     int32_t tile_launches_per_matvec; /* tile-kernel launches per implicit matvec: row-block bands (option colslab_band_mb) x feature panels of a wide linear problem; matvec_kernel_ms is their SUM */
     int32_t rbf_direct;      /* fp32 rbf: 1 if the formula-exact (x_i - x_j)^2 kernel ran instead of the matrix-core norm expansion (option rbf_form) */
     double rbf_exponent_scale; /* fp32 rbf, rbf_form 0: 2 gamma log2(e) max|x - mean|^2, the quantity compared with rbf_direct_above */
+    uint64_t matvec_timed;   /* of matvec_launches, the matvecs whose tile-kernel launches were bracketed by HIP events AND have been read back (short matvecs
+                              * are sampled: every 8th, never the first after cg_begin) */
+    double matvec_kernel_ms_total; /* summed device time of the tile-kernel launches of those matvec_timed matvecs (slowest shard of this process): differences of
+                                    * (matvec_kernel_ms_total, matvec_timed) between two lssvm_mi355_problem_info calls give the average over the steps between them */
+    int32_t rccl_nranks;     /* exchange == 1: ncclCommCount of the communicator the partial vectors travel over (what RCCL itself says, not what was asked for); else 0 */
+    int32_t rccl_rank;       /* exchange == 1: ncclCommUserRank of this process's (first) communicator; else -1 */
+    int32_t rccl_device;     /* exchange == 1: ncclCommCuDevice of that communicator; else -1 */
+    int32_t reserved_;
 } lssvm_cg_info;
 
 /* ------------------------------------------------------------------------------------------------------------------ */

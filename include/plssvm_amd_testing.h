@@ -20,6 +20,11 @@ extern "C" {
  * nominal peak -- is what a kernel on this device is up against; bench.py prints it beside roofline.frac. */
 int lssvm_mi355_measure_bf16_mfma_ceiling(int device, int b_from_lds, double settle_ms, double *tflops_out, double *clock_ghz_out, double *nominal_tflops_out);
 
+/* The file the library's RCCL entry points were resolved from (dladdr of ncclAllReduce after the lazy dlopen of "librccl.so.1"): a bench line or a
+ * test can then say WHICH library carried the exchange -- the process's RCCL (PyTorch's or /opt/rocm's), or a stand-in with that SONAME which a test
+ * harness loaded into the process first (tests/tools/; the library itself never looks for one). */
+int lssvm_mi355_comm_library_path(char *buf, size_t buf_len);
+
 /* option names understood by lssvm_mi355_set_option / _get_option besides the twelve documented in plssvm_amd.h:
  *   "force_collective" 1 = run the per-matvec RCCL collective even with a world of 1 (testing aid; default 0)
  *   "skip_collective"  1 = problems created with world > 1 need no communicator and do NOT exchange their partial K*v (testing aid:

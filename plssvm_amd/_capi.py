@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "lssvm_mi355_shard_blocks", "lssvm_mi355_comm_get_unique_id", "lssvm_mi355_comm_init", "lssvm_mi355_comm_destroy",
     "lssvm_mi355_problem_create", "lssvm_mi355_problem_create_multi", "lssvm_mi355_problem_ipc_export", "lssvm_mi355_problem_ipc_connect", "lssvm_mi355_problem_destroy", "lssvm_mi355_problem_get_q", "lssvm_mi355_problem_matvec",
     "lssvm_mi355_cg_begin", "lssvm_mi355_cg_step", "lssvm_mi355_cg_finish", "lssvm_mi355_problem_synchronize", "lssvm_mi355_problem_info",
-    "lssvm_mi355_measure_bf16_mfma_ceiling", "lssvm_mi355_set_option", "lssvm_mi355_get_option",
+    "lssvm_mi355_measure_bf16_mfma_ceiling", "lssvm_mi355_comm_library_path", "lssvm_mi355_set_option", "lssvm_mi355_get_option",
     "lssvm_mi355_libsvm_open", "lssvm_mi355_libsvm_fill_f32", "lssvm_mi355_libsvm_fill_f64", "lssvm_mi355_libsvm_close",
 ]
 
@@ -48,7 +48,8 @@ class LssvmCgInfo(C.Structure):
     _fields_ = [("iterations", C.c_uint64), ("max_iterations", C.c_uint64), ("residuum", C.c_double), ("initial_residuum", C.c_double),
                 ("target_residuum", C.c_double), ("epsilon", C.c_double), ("avg_iteration_ms", C.c_double), ("total_ms", C.c_double),
                 ("setup_ms", C.c_double), ("matvec_kernel_ms", C.c_double), ("matvec_launches", C.c_uint64), ("devices_used", C.c_int32),
-                ("converged", C.c_int32), ("symmetric", C.c_int32), ("gram_mode", C.c_int32), ("local_devices", C.c_int32), ("exchange", C.c_int32), ("tile_launches_per_matvec", C.c_int32), ("rbf_direct", C.c_int32), ("rbf_exponent_scale", C.c_double)]
+                ("converged", C.c_int32), ("symmetric", C.c_int32), ("gram_mode", C.c_int32), ("local_devices", C.c_int32), ("exchange", C.c_int32), ("tile_launches_per_matvec", C.c_int32), ("rbf_direct", C.c_int32), ("rbf_exponent_scale", C.c_double),
+                ("matvec_timed", C.c_uint64), ("matvec_kernel_ms_total", C.c_double), ("rccl_nranks", C.c_int32), ("rccl_rank", C.c_int32), ("rccl_device", C.c_int32), ("reserved_", C.c_int32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -118,7 +119,7 @@ def device_name(device: int = 0) -> str:
     return buf.value.decode()
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 LSSVM_IPC_BLOB_BYTES = 256
 # every tuning knob of lssvm_mi355_set_option (include/plssvm_amd.h)
 OPTION_NAMES = ["rbf_form", "rbf_fold", "j_chunk_tiles", "symmetric", "tile_kernel", "gram_mode", "mfma_shape", "colslab_band_mb", "colslab_limit_mb", "force_collective", "skip_collective",

@@ -151,6 +151,13 @@ def comm_init(device: int, rank: int, world: int, unique_id: bytes) -> None:
     check(lib.lssvm_mi355_comm_init(C.c_int(device), C.c_int(rank), C.c_int(world), buf))
 
 
+def comm_library_path() -> str:
+    """The file the library resolved its RCCL entry points from (a measurement / test aid, include/plssvm_amd_testing.h)."""
+    buf = C.create_string_buffer(4096)
+    check(lib.lssvm_mi355_comm_library_path(buf, C.c_size_t(4096)))
+    return buf.value.decode()
+
+
 def comm_destroy() -> None:
     check(lib.lssvm_mi355_comm_destroy())
 

@@ -7,6 +7,7 @@
 
 #include "libsvm_reader.hpp"
 
+#include <dlfcn.h>
 #include <cstdlib>
 #include <memory>
 #include <new>
@@ -77,6 +78,7 @@ void generate_q_one_shot(const lssvm_params *params, const T *X, size_t N, size_
 
 extern "C" {
 
+static_assert(sizeof(lssvm_cg_info) == 160, "lssvm_cg_info changed: bump PLSSVM_AMD_ABI_VERSION and plssvm_amd/_capi.py (LssvmCgInfo) with it");
 int lssvm_mi355_abi_version(void) { return PLSSVM_AMD_ABI_VERSION; }
 
 const char *lssvm_mi355_last_error(void) { return g_last_error.c_str(); }
@@ -213,6 +215,15 @@ int lssvm_mi355_comm_init(int device, int rank, int world, const unsigned char i
         c.rank = rank;
         c.world = world;
         c.device = device;
+    });
+}
+int lssvm_mi355_comm_library_path(char *buf, size_t buf_len) {
+    return guarded([&] {
+        LSSVM_REQUIRE(buf != nullptr && buf_len > 0, "buf must not be NULL");
+        lssvm::comm_load();
+        Dl_info di{};
+        const char *path = dladdr(reinterpret_cast<void *>(lssvm::comm().pAllReduce), &di) != 0 && di.dli_fname != nullptr ? di.dli_fname : "";
+        std::snprintf(buf, buf_len, "%s", path);
     });
 }
 int lssvm_mi355_comm_destroy(void) {

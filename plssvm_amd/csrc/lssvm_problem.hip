@@ -50,7 +50,10 @@ void comm_load() {
     c.pGroupStart = reinterpret_cast<decltype(c.pGroupStart)>(dlsym(lib, "ncclGroupStart"));
     c.pGroupEnd = reinterpret_cast<decltype(c.pGroupEnd)>(dlsym(lib, "ncclGroupEnd"));
     c.pGetErrorString = reinterpret_cast<decltype(c.pGetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-    if (!c.pGetUniqueId || !c.pCommInitRank || !c.pCommInitAll || !c.pCommDestroy || !c.pAllGather || !c.pAllReduce || !c.pGroupStart || !c.pGroupEnd || !c.pGetErrorString) {
+    c.pCommCount = reinterpret_cast<decltype(c.pCommCount)>(dlsym(lib, "ncclCommCount"));
+    c.pCommCuDevice = reinterpret_cast<decltype(c.pCommCuDevice)>(dlsym(lib, "ncclCommCuDevice"));
+    c.pCommUserRank = reinterpret_cast<decltype(c.pCommUserRank)>(dlsym(lib, "ncclCommUserRank"));
+    if (!c.pCommCount || !c.pCommCuDevice || !c.pCommUserRank || !c.pGetUniqueId || !c.pCommInitRank || !c.pCommInitAll || !c.pCommDestroy || !c.pAllGather || !c.pAllReduce || !c.pGroupStart || !c.pGroupEnd || !c.pGetErrorString) {
         throw Error(LSSVM_ERR_COMM, "the loaded RCCL library lacks a required symbol");
     }
     c.lib = lib;
@@ -986,7 +989,10 @@ template <typename T>
 void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
     // this shard's part of the implicit K * v: tile kernel over its row blocks (band by band), slabs added in a fixed order
     hipStream_t st = stream_.s;
-    const bool timed = matvec_launches_ % static_cast<uint64_t>(event_stride()) == 0;
+    // sampled matvecs: every `stride`-th, starting with the LAST of each run of `stride` -- never launch 0, the cold first matvec of cg_begin, which
+    // would otherwise carry `stride` times its weight in the average
+    const uint64_t stride = static_cast<uint64_t>(event_stride());
+    const bool timed = matvec_launches_ % stride == stride - 1;
     ++matvec_launches_;
     auto free_event = [&]() -> EvPair * {
         if (!timed) return nullptr;
@@ -1142,7 +1148,7 @@ Solver<T>::Solver(const lssvm_params &params, const void *X, int mem_kind, size_
         std::vector<int> sorted(devices);
         std::sort(sorted.begin(), sorted.end());
         const bool distinct = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
-        LSSVM_REQUIRE(opt_.exchange != 1 || distinct, "RCCL needs distinct devices (option exchange = 1)");
+        // (exchange = 1 with a repeated ordinal: RCCL's own ncclCommInitAll refuses the list -- "duplicate GPU detected" -- and its message comes back)
         exchange_ = (opt_.exchange == 1 || (opt_.exchange == 0 && distinct)) ? Exchange::local_rccl : Exchange::peer;
         if (opt_.skip_collective != 0) exchange_ = Exchange::none;
     }
@@ -1571,7 +1577,11 @@ void Solver<T>::fill_info(lssvm_cg_info *info) {
     // the tile kernel of the slowest shard sets the pace of a sharded matvec
     for (const auto &p : shards_) {
         const double avg = p->matvec_timed_ > 0 ? p->matvec_ms_ / static_cast<double>(p->matvec_timed_) : 0.0;
-        info->matvec_kernel_ms = std::max(info->matvec_kernel_ms, avg);
+        if (avg >= info->matvec_kernel_ms) {
+            info->matvec_kernel_ms = avg;
+            info->matvec_timed = p->matvec_timed_;
+            info->matvec_kernel_ms_total = p->matvec_ms_;
+        }
     }
     info->matvec_launches = p0.matvec_launches_;
     info->devices_used = world_;
@@ -1583,6 +1593,16 @@ void Solver<T>::fill_info(lssvm_cg_info *info) {
     info->rbf_exponent_scale = p0.rbf_r2_;
     info->tile_launches_per_matvec = static_cast<int32_t>(std::max<size_t>(p0.bands_.size(), 1)) * p0.passes_per_matvec();  // bands x feature panels
     info->exchange = exchange_ == Exchange::none ? 0 : ((exchange_ == Exchange::peer || exchange_ == Exchange::process_peer) ? 2 : 1);
+    // what RCCL itself says about the communicator the partial vectors travel over (a bench line can then prove that N ranks met)
+    info->rccl_nranks = 0;
+    info->rccl_rank = info->rccl_device = -1;
+    ncclComm_t used = exchange_ == Exchange::process_rccl ? comm().comm : (exchange_ == Exchange::local_rccl && local_comms_ ? local_comms_->comms[0] : nullptr);
+    if (used != nullptr) {
+        int v = 0;
+        if (comm().pCommCount(used, &v) == ncclSuccess) info->rccl_nranks = v;
+        if (comm().pCommUserRank(used, &v) == ncclSuccess) info->rccl_rank = v;
+        if (comm().pCommCuDevice(used, &v) == ncclSuccess) info->rccl_device = v;
+    }
 }
 
 template class Solver<float>;

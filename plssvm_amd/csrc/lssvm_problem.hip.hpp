@@ -110,6 +110,9 @@ struct Comm {  // the RCCL entry points (dlopen'ed once) + the communicator of a
     decltype(&ncclGroupStart) pGroupStart = nullptr;
     decltype(&ncclGroupEnd) pGroupEnd = nullptr;
     decltype(&ncclGetErrorString) pGetErrorString = nullptr;
+    decltype(&ncclCommCount) pCommCount = nullptr;
+    decltype(&ncclCommCuDevice) pCommCuDevice = nullptr;
+    decltype(&ncclCommUserRank) pCommUserRank = nullptr;
 };
 Comm &comm();
 void comm_load();

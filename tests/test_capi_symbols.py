@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -69,7 +70,7 @@ def test_abi_version_and_struct_layout():
     assert _capi.lib.lssvm_mi355_abi_version() == _capi.ABI_VERSION
     assert C.sizeof(_capi.LssvmParams) == 32
     assert C.sizeof(_capi.LssvmShard) == 8
-    assert C.sizeof(_capi.LssvmCgInfo) == 128
+    assert C.sizeof(_capi.LssvmCgInfo) == 160  # ABI 3 (static_assert in capi.hip)
 
 
 has_gpu = _capi.device_count() > 0
@@ -166,3 +167,47 @@ def test_host_side_under_address_and_undefined_behaviour_sanitizers(exe_name, ar
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")  # (leak checking: the HIP runtime's own start-up allocations)
     out = subprocess.run([exe] + args, capture_output=True, text=True, env=env)
     assert out.returncode == 0 and "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+FAKE_RCCL = os.path.join(ROOT, "tests", "tools", "fake_rccl", "librccl.so.1")
+
+
+def test_rccl_stand_in_exports_what_the_product_binds_and_is_unknown_to_the_product():
+    """tests/tools/fake_rccl/librccl.so.1 (test infrastructure for tests/test_gpu_fake_rccl.py) must offer every RCCL entry point the product resolves
+    with dlsym -- and the product must not know about it: no file of the package or of include/ and no string of the shipped library names it."""
+    src = open(os.path.join(ROOT, "plssvm_amd", "csrc", "lssvm_problem.hip")).read()
+    bound = set(re.findall(r'dlsym\(lib, "(nccl\w+)"\)', src))
+    assert {"ncclAllReduce", "ncclAllGather", "ncclCommInitRank", "ncclCommInitAll", "ncclGroupStart", "ncclGroupEnd", "ncclCommCount"} <= bound
+    assert os.path.isfile(FAKE_RCCL), "build it: python -c 'import __graft_entry__ as g; g.build()'"
+    out = subprocess.run(["nm", "-D", "--defined-only", FAKE_RCCL], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (\w+)", out))
+    assert bound <= exported and "fake_rccl_marker" in exported
+    soname = subprocess.run(["readelf", "-d", FAKE_RCCL], capture_output=True, text=True, check=True).stdout
+    assert "librccl.so.1" in soname
+    for base in (os.path.join(ROOT, "plssvm_amd"), os.path.join(ROOT, "include")):
+        for dirpath, _, files in os.walk(base):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".inc", "Makefile")):
+                    assert "fake_rccl" not in open(os.path.join(dirpath, f), errors="replace").read(), f"{f} names the RCCL stand-in"
+    assert b"fake_rccl" not in open(_capi.LIB_PATH, "rb").read()
+    # the only libraries the product ever dlopens are RCCL's own names
+    assert set(re.findall(r'"((?:/opt/rocm/lib/)?librccl[^"]*)"', src)) == {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}
+
+
+def test_rccl_stand_in_wins_the_soname_lookup_only_when_a_harness_loads_it_first():
+    """How the stand-in reaches a process: a harness loads it BEFORE anything else; the product's dlopen("librccl.so.1") then returns the already-loaded
+    object with that SONAME.  In a process that did not do so, the same dlopen finds a real RCCL (checked in a child: no GPU is touched)."""
+    code = ("import ctypes, os, sys\n"
+            "if len(sys.argv) > 1:\n"
+            "    sys.path.insert(0, os.path.dirname(sys.argv[1]))\n"
+            "    import preload\n"
+            "    first = preload.load(sys.argv[1])\n"
+            "import torch\n"
+            "h = ctypes.CDLL('librccl.so.1')\n"
+            "hip = [l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l]\n"
+            "print('stand-in' if hasattr(h, 'fake_rccl_marker') else 'real', torch.cuda.nccl.version()[0], len(set(hip)))\n")
+    with_it = subprocess.run([sys.executable, "-c", code, FAKE_RCCL], capture_output=True, text=True, check=True).stdout.split()
+    without = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.split()
+    assert with_it[0] == "stand-in" and without[0] == "real"
+    assert with_it[1] == without[1] == "2"  # torch keeps its own RCCL either way (the stand-in reports version 0)
+    assert with_it[2] == without[2] == "1"  # ONE HIP runtime in the process (a second one finds no device)

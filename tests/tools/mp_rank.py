@@ -4,9 +4,15 @@ processes; it also runs under torchrun).  RANK / LOCAL_RANK / WORLD_SIZE / MASTE
 unique id is handed over through a gloo process group (CPU), so the only RCCL user in the process is libplssvm_amd.so itself;
 --exchange 2: no RCCL at all, the ranks map each other's partial vectors with HIP IPC (works with several ranks on ONE device).  Rank r runs
 ResidentProblem(rank=r, world=W): one implicit matvec and a few CG iterations; rank 0 also runs the single-GPU problem and writes
-the distances.  Every rank writes a hash of its alpha: all ranks must hold the same bits."""
+the distances.  Every rank writes a hash of its alpha: all ranks must hold the same bits.
+
+--rccl-stand-in PATH: load the tests' single-device stand-in for RCCL (tests/tools/fake_rccl/librccl.so.1) into THIS process before anything
+else, so that the product library's own dlopen("librccl.so.1") resolves to it by SONAME -- the product's RCCL exchange then runs with several ranks
+on ONE device (the real RCCL refuses that).  With it and --exchange 1 every rank ALSO repeats the run over HIP IPC + the peer kernel (the same
+fixed rank-order sum) and reports whether the two exchanges agree bit for bit."""
 
 import argparse
+import ctypes
 import hashlib
 import json
 import os
@@ -28,7 +34,14 @@ def main():
     ap.add_argument("--points", type=int, default=6000)
     ap.add_argument("--features", type=int, default=128)
     ap.add_argument("--out", required=True)
+    ap.add_argument("--rccl-stand-in", default=None)
     args = ap.parse_args()
+    stand_in = None
+    if args.rccl_stand_in:  # BEFORE torch and the product library
+        sys.path.insert(0, os.path.dirname(os.path.abspath(args.rccl_stand_in)))
+        import preload
+
+        stand_in = preload.load(args.rccl_stand_in)
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
 
     import numpy as np
@@ -63,7 +76,25 @@ def main():
             alpha, rho, info = prob.cg_finish()
             dist.barrier()  # (IPC: a rank's vector stays mapped by its peers until they are done)
         out = {"rank": rank, "alpha_sha": hashlib.sha256(alpha.tobytes()).hexdigest(), "rho": float(rho), "devices_used": int(info["devices_used"]),
-               "exchange": int(info["exchange"]), "symmetric": int(info["symmetric"])}
+               "exchange": int(info["exchange"]), "symmetric": int(info["symmetric"]), "rccl_nranks": int(info["rccl_nranks"]), "rccl_rank": int(info["rccl_rank"]),
+               "rccl_device": int(info["rccl_device"]), "iterations": int(info["iterations"])}
+        if args.exchange == 1:
+            out["rccl_library"] = backend.comm_library_path()
+            out["stand_in_loaded"] = bool(stand_in is not None and hasattr(ctypes.CDLL(out["rccl_library"]), "fake_rccl_marker"))
+        if args.exchange == 1 and stand_in is not None:
+            # the same problem over HIP IPC + the peer kernel: the stand-in sums in rank order like k_peer_sum, so the two exchanges must agree bit for bit
+            _capi.set_option("exchange", 2)
+            with backend.ResidentProblem(p, X, device=local, rank=rank, world=world) as prob2:
+                connect_peers(dist, prob2)
+                got2 = prob2.matvec(v, zero, 1.0)
+                prob2.cg_begin(y, 1e-30)
+                prob2.cg_step(args.steps)
+                alpha2, rho2, info2 = prob2.cg_finish()
+                dist.barrier()
+            _capi.set_option("exchange", 1)
+            out["peer_exchange_matvec_equal_bits"] = bool(np.array_equal(got, got2))
+            out["peer_exchange_alpha_equal_bits"] = bool(np.array_equal(alpha, alpha2) and float(rho) == float(rho2))
+            out["peer_exchange"] = int(info2["exchange"])
         if rank == 0:
             with backend.ResidentProblem(p, X, device=local) as single:
                 want = single.matvec(v, zero, 1.0)
