@@ -410,7 +410,10 @@ def _sampled_rows_vs_oracle_gamma(oracle, prob, X, rows, gamma):
     K = np.exp(-gamma * np.maximum(sq[rows, None] + sq[None, :n] - 2.0 * (X64[rows] @ X64[:n].T), 0.0))
     absd = np.abs(rhs64)
     scale = K @ absd + (abs(float(QA)) + np.abs(q64[rows])) * absd.sum() + np.abs(q64) @ absd + absd[rows]
-    return float(np.max(np.abs(got[rows] - want[rows]) / scale)), got, rhs
+    err = float(np.max(np.abs(got[rows] - want[rows]) / scale))
+    if with_abs:  # also the largest absolute deviation of a sampled row
+        return err, got, rhs, float(np.max(np.abs(got[rows] - want[rows])))
+    return err, got, rhs
 
 
 def test_rbf_uncentred_data_with_large_offset(oracle):
@@ -515,7 +518,7 @@ def test_sub_sampled_rows_of_a_large_matvec_vs_oracle(oracle):
     assert np.max(np.abs(got[rows] - want[rows])) < 16 * np.finfo(np.float32).eps * scale
 
 
-def _sampled_rows_vs_oracle(oracle, prob, kernel, X, rows, seed=0):
+def _sampled_rows_vs_oracle(oracle, prob, kernel, X, rows, seed=0, with_abs=False):
     """one implicit matvec of a resident problem against the float64 oracle on `rows` (row-owned sums, svm_kernel.cpp:33-54)"""
     N, d = X.shape
     n = N - 1
@@ -539,7 +542,10 @@ def _sampled_rows_vs_oracle(oracle, prob, kernel, X, rows, seed=0):
         K = G
     absd = np.abs(rhs64)
     scale = np.abs(K) @ absd + (abs(float(QA)) + np.abs(q64[rows])) * absd.sum() + np.abs(q64) @ absd + absd[rows]
-    return float(np.max(np.abs(got[rows] - want[rows]) / scale)), got, rhs
+    err = float(np.max(np.abs(got[rows] - want[rows]) / scale))
+    if with_abs:  # also the largest absolute deviation of a sampled row
+        return err, got, rhs, float(np.max(np.abs(got[rows] - want[rows])))
+    return err, got, rhs
 
 
 @pytest.mark.parametrize("cfg, kernel, dt, N, d", [("configs[2]", "linear", np.float32, 200_000, 256), ("configs[3]", "polynomial", np.float64, 100_000, 64),
@@ -556,8 +562,11 @@ def test_baseline_configs_at_full_size(oracle, cfg, kernel, dt, N, d):
     rows[0], rows[-1] = 0, n - 1  # first row (longest mirrored column) and last row (longest row of the triangle)
     with backend.ResidentProblem(p, X) as prob:
         assert prob.info()["symmetric"] == 1 and prob.info()["gram_mode"] == (2 if dt == np.float32 else 0)  # fp32: f16x3 (the data passes the check)
-        err, Au, u = _sampled_rows_vs_oracle(oracle, prob, kernel, X, rows)
-        assert err < 16 * eps, (cfg, err / eps)
+        err, Au, u, abs_err = _sampled_rows_vs_oracle(oracle, prob, kernel, X, rows, with_abs=True)
+        # on the scale of a row's SUMMANDS (the rank-1 terms are 1e3 x the result at configs[4]): measured 0.01 ... 0.03 eps (profiles/r04_scale_check_*.log); the bar
+        # was 16 eps until round 4 -- and on the scale of the RESULT itself
+        assert err < 1 * eps, (cfg, err / eps)
+        assert abs_err <= (4e-6 if dt == np.float32 else 4e-14) * np.max(np.abs(Au)), (cfg, abs_err / np.max(np.abs(Au)))
         v = np.random.default_rng(1).uniform(-1, 1, size=n).astype(dt)
         z = np.zeros(n, dt)
         Av = prob.matvec(v, z)
@@ -579,8 +588,9 @@ def test_baseline_config4_row_sharded_over_eight_shards(oracle):
     with backend.ResidentProblem(Parameter(kernel_type="rbf"), X, devices=devices) as prob:
         info = prob.info()
         assert info["devices_used"] == 8 and info["local_devices"] == 8 and info["symmetric"] == 1
-        err, _, _ = _sampled_rows_vs_oracle(oracle, prob, "rbf", X, rows)
-    assert err < 16 * np.finfo(np.float32).eps, err / np.finfo(np.float32).eps
+        err, Au, _, abs_err = _sampled_rows_vs_oracle(oracle, prob, "rbf", X, rows, with_abs=True)
+    assert err < 1 * np.finfo(np.float32).eps, err / np.finfo(np.float32).eps  # (16 eps until round 4; measured 0.01 eps)
+    assert abs_err <= 4e-6 * np.max(np.abs(Au)), abs_err / np.max(np.abs(Au))
 
 
 def test_baseline_config0_500x4_linear_fp64_through_the_libsvm_files(tmp_path):
@@ -1305,3 +1315,93 @@ def test_fp32_alpha_against_the_reference_as_the_north_star_writes_it(inputs, na
     assert e_gpu64 <= max(2.0 * e_ref64, 1e-4), (e_gpu64, e_ref64)
     if e_self <= 1e-4 and e_ref64 <= 1e-4:
         assert e_gpu <= 1e-4, (e_gpu, e_self, e_ref64)
+
+
+FP32_CG_FIXED = None
+
+
+@pytest.mark.parametrize("mode", [3, 1, 0])
+@pytest.mark.parametrize("pname", ["ref", "def"])
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("name", ["500x200", "blobs263x37", "blobs2000x64"])
+def test_fp32_alpha_after_one_two_and_three_iterations_against_the_reference(inputs, name, kernel, pname, mode):
+    """"alpha within 1e-4 rel-inf of OpenMP" (BASELINE.json north_star) asserted where it is ATTAINABLE in fp32 -- after a FIXED number of CG
+    iterations k = 1, 2, 3 (eps = 1e-30), before the recursion has amplified rounding differences -- against the reference's own kernels run with one thread
+    (tests/golden/fp32_cg_fixed.npz, generator tests/golden/make_golden_r05.py; recipe src/plssvm/backends/OpenMP/csvm.cpp:125-166).  The fixture also holds
+    the reference's float64 run of the same k iterations: with the reference's start vector x0 = 1 the first residual r0 = b - A 1 is a difference of row sums
+    over n terms, and the reference's sequential fp32 sums miss their own float64 result by 2e-7 ... 2e-2 after ONE iteration (and by up to 27 after two: the
+    generator prints the table).  So, for every k and all three Gram modes:
+      * where the reference's fp32 run agrees with its float64 run to 5e-5 (9 of the 18 systems at k = 1), alpha_gpu is within 1e-4 rel-inf of the reference's
+        fp32 alpha -- the north_star sentence as written;
+      * everywhere, alpha_gpu is no farther from the float64 run than twice the reference's fp32 run is (or 1e-4): the distance to the reference is the
+        reference's own rounding, not the GPU's."""
+    global FP32_CG_FIXED
+    if FP32_CG_FIXED is None:
+        FP32_CG_FIXED = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp32_cg_fixed.npz"))
+    G = FP32_CG_FIXED
+    X, y = _fp32_cg_inputs(inputs, name)
+    P = dict(PARAM_SETS[pname])
+    if P["gamma"] is None:
+        P["gamma"] = 1.0 / X.shape[1]
+    _capi.set_option("gram_mode", mode)
+    asserted_as_written = 0
+    with backend.ResidentProblem(prm(kernel, P), X) as prob:
+        for k in (1, 2, 3):
+            key = f"{name}/{kernel}/{pname}/k{k}"
+            a_ref, a64 = G[key + "/alpha"], G[key + "/alpha64"]
+            prob.cg_begin(y, 1e-30)
+            prob.cg_step(k)
+            a, rho, info = prob.cg_finish()
+            assert info["iterations"] == k
+            e_gpu, e_gpu64, e_ref64 = ol.rel_inf(a, a_ref), ol.rel_inf(a, a64), ol.rel_inf(a_ref, a64)
+            print(f"\n{key:36s} gram mode {mode}: alpha vs the reference's fp32 run {e_gpu:.2e}   vs its float64 run {e_gpu64:.2e} [the reference's fp32 run: {e_ref64:.2e}]"
+                  f"   rho {abs(float(rho) - float(G[key + '/rho64'])):.2e} [{abs(float(G[key + '/rho']) - float(G[key + '/rho64'])):.2e}]")
+            assert e_gpu64 <= max(2.0 * e_ref64, 1e-4), (key, e_gpu64, e_ref64)
+            if e_ref64 <= 5e-5:
+                assert e_gpu <= 1e-4, (key, e_gpu, e_ref64)
+                asserted_as_written += 1
+    if (name, kernel, pname) in {("500x200", "linear", "ref"), ("500x200", "rbf", "def"), ("blobs263x37", "linear", "def"), ("blobs2000x64", "linear", "def"), ("blobs2000x64", "rbf", "def")}:
+        assert asserted_as_written >= 1  # (these systems meet the sentence at k = 1 in the fixture: the branch above is not vacuous)
+
+
+PAIR_MATVEC = None
+
+
+@pytest.mark.parametrize("mode", [3, 1, 0])
+@pytest.mark.parametrize("name, kernel, N, d", [("rbf8704x128", "rbf", 8704, 128), ("linear8704x256", "linear", 8704, 256)])
+def test_matvec_at_a_size_that_reaches_the_256_row_kernel_vs_the_references_own_kernels(name, kernel, N, d, mode):
+    """tile_matvec_f32_pair (256-row workgroups on block pairs, the headline kernel) runs from 64 row blocks = 8 192 points on; the goldens
+    generated from the reference's kernels stopped at 2 000 points, so that kernel was pinned only through the restated oracle.  tests/golden/pair_matvec.npz
+    holds q, QA_cost and 512 sampled rows of ONE implicit matvec of the reference's own OpenMP kernels (liblssvm_ref.so, one thread; svm_kernel.cpp:33-54,
+    q_kernel.cpp:18-55) on 8 704 x 128 rbf and 8 704 x 256 linear (two feature-panel passes of the pair kernel), fp32, plus the same rows of its float64 run.
+    The reference tests its kernels on a 5 000 x 2 000 file with 128 eps element-wise (tests/CMakeLists.txt:36-69, custom_test_macros.hpp:114-137)."""
+    global PAIR_MATVEC
+    if PAIR_MATVEC is None:
+        PAIR_MATVEC = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pair_matvec.npz"))
+    G = PAIR_MATVEC
+    import hashlib
+
+    X, _ = make_blobs_pm1(N, d, seed=11, dtype=np.float32)
+    assert np.array_equal(np.frombuffer(hashlib.sha256(X.tobytes()).digest(), dtype=np.uint8), G[f"{name}/X_sha256"])  # the inputs the fixture was made from
+    n = N - 1
+    rhs = np.random.default_rng(77).uniform(1.0, 2.0, size=n).astype(np.float32)
+    rows = G[f"{name}/rows"]
+    eps = np.finfo(np.float32).eps
+    _capi.set_option("gram_mode", mode)
+    p = Parameter(kernel_type=kernel, degree=3)
+    with backend.ResidentProblem(p, X) as prob:
+        info = prob.info()
+        assert info["symmetric"] == 1 and info["gram_mode"] == {3: 2, 1: 1, 0: 0}[mode]
+        q, QA = prob.q()
+        got = prob.matvec(rhs, np.zeros(n, np.float32), 1.0)
+    if kernel == "linear":
+        assert np.array_equal(q, G[f"{name}/q"])
+    assert ol.float_near(q, G[f"{name}/q"], 16) and abs(float(QA) - float(G[f"{name}/QA_cost"])) <= 4 * eps * abs(float(G[f"{name}/QA_cost"]))
+    ref32, ref64, scale = G[f"{name}/matvec_p1_rows"], G[f"{name}/matvec_p1_rows64"], float(G[f"{name}/matvec_p1_absmax"])
+    e_ref = float(np.max(np.abs(ref32 - ref64))) / scale
+    e_gpu = float(np.max(np.abs(got[rows] - ref64))) / scale
+    e_vs_ref = float(np.max(np.abs(got[rows].astype(np.float64) - ref32))) / scale
+    print(f"\n{name} gram mode {mode}: sampled rows vs the reference's float64 run {e_gpu / eps:.2f} eps [the reference's fp32 run: {e_ref / eps:.1f} eps]   vs the reference's fp32 run {e_vs_ref / eps:.1f} eps")
+    assert ol.float_near(got[rows], ref32, 128)          # the reference's own element-wise criterion against its fp32 result
+    assert e_vs_ref <= e_ref + 4 * eps                   # as close to the reference's fp32 rows as the reference's own rounding allows
+    assert e_gpu <= 4 * eps                              # and within 4 eps of what the reference's kernels compute in float64
