@@ -466,15 +466,47 @@ def main():
         sampler = PowerSampler(local_rank)
         if sampler.available:
             sampler.start()
+    # throttle residency of the timed region ("power-bound" as a counter, not an inference): the firmware's accumulators through amd-smi,
+    # read just outside the region, and the violation flags once from a side thread in its middle (host processes only; nothing touches the device's queues)
+    smi0 = smi_mid = None
+    mid_thread = None
+    if sampler is not None:
+        from plssvm_amd.hwmon import smi_snapshot, throttle_between
+
+        smi0 = smi_snapshot()
+        if smi0 is not None:
+            import threading
+
+            mid_box = {}
+
+            def mid():
+                time.sleep(max(0.5, 0.25 * args.steps * max(float(i0["avg_iteration_ms"]), 1.0) * 1e-3))
+                mid_box["snap"] = smi_snapshot()
+
+            mid_thread = threading.Thread(target=mid, daemon=True)
     barrier()
     t0 = time.perf_counter()
     w0 = time.time()
+    if mid_thread is not None:
+        mid_thread.start()
     prob.cg_step(args.steps)
     prob.synchronize()
     barrier()
     t1 = time.perf_counter()
     w1 = time.time()
     i1 = prob.info()
+    throttle = None
+    if smi0 is not None:
+        mid_thread.join(40.0)
+        smi1 = smi_snapshot()
+        throttle = throttle_between(smi0, smi1, w0, w1)
+        smi_mid = mid_box.get("snap")
+        if throttle is not None and smi_mid is not None and w0 <= smi_mid[0] <= w1:
+            throttle["flags_in_mid_region"] = smi_mid[1]["status"]
+            throttle["socket_power_w_in_mid_region"] = smi_mid[1]["socket_power_w"]
+            throttle["gfx_clocks_mhz_in_mid_region"] = smi_mid[1]["gfx_clocks_mhz"]
+        if throttle is not None:
+            throttle["source"] = "amd-smi metric --json: throttle.*_accumulated over accumulation_counter (firmware residency counters), read before and after the timed region; flags from one reading inside it"
     board_power = None
     if sampler is not None and sampler.available:
         from plssvm_amd.hwmon import median
@@ -483,7 +515,8 @@ def main():
         watts, ghz = sampler.window(w0, w1)
         if watts:
             board_power = {"median_w": median(watts), "max_w": max(watts), "cap_w": sampler.cap_watts(), "shader_clock_ghz_median": median(ghz), "samples": len(watts),
-                           "source": f"amdgpu hwmon of PCI {sampler.bus}, every 20 ms over the last 70 % of the timed region"}
+                           "source": f"amdgpu hwmon of PCI {sampler.bus}, every 20 ms over the last 70 % of the timed region",
+                           "energy_j_per_step": sum(watts) / len(watts) * (w1 - w0) / max(args.steps, 1), "throttle": throttle}
 
     elapsed = t1 - t0
     if dist is not None:

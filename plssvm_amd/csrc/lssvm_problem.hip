@@ -989,10 +989,10 @@ template <typename T>
 void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
     // this shard's part of the implicit K * v: tile kernel over its row blocks (band by band), slabs added in a fixed order
     hipStream_t st = stream_.s;
-    // sampled matvecs: every `stride`-th, starting with the LAST of each run of `stride` -- never launch 0, the cold first matvec of cg_begin, which
-    // would otherwise carry `stride` times its weight in the average
+    // sampled matvecs: every `stride`-th, starting with the LAST of each run of `stride`, plus launches 1 ... 16 (a run of a few iterations still reports a
+    // kernel time) -- never launch 0, the cold first matvec of cg_begin, which would otherwise carry `stride` times its weight in the average
     const uint64_t stride = static_cast<uint64_t>(event_stride());
-    const bool timed = matvec_launches_ % stride == stride - 1;
+    const bool timed = matvec_launches_ % stride == stride - 1 || (matvec_launches_ >= 1 && matvec_launches_ <= 16);  // (short runs: every one of the first sixteen after launch 0)
     ++matvec_launches_;
     auto free_event = [&]() -> EvPair * {
         if (!timed) return nullptr;

@@ -79,3 +79,68 @@ class PowerSampler(threading.Thread):
 def median(values):
     s = sorted(values)
     return None if not s else (s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2]))
+
+
+def smi_snapshot(gpu_index: int = 0, timeout_s: float = 30.0):
+    """What `amd-smi metric --json` reports for one GPU right now (an ordinary user may run it): the firmware's throttle-residency accumulators
+    (`ppt_accumulated` counts the ticks of `accumulation_counter` during which the power limit held the clock down), the violation status flags, socket power,
+    the energy counter and the shader clocks.  (wall time, dict) or None where the tool or the device is not there.  Takes about a second of HOST time: call it
+    outside a timed region, or from a side thread."""
+    import json
+    import shutil
+    import subprocess
+
+    exe = shutil.which("amd-smi") or "/opt/rocm/bin/amd-smi"
+    try:
+        t = time.time()
+        out = subprocess.run([exe, "metric", "--json"], capture_output=True, text=True, timeout=timeout_s).stdout
+        start = out.find("{")
+        data = json.loads(out[start:]) if start >= 0 else None
+    except (OSError, ValueError, subprocess.SubprocessError):
+        return None
+    gpus = data.get("gpu_data", data) if isinstance(data, dict) else data
+    if not isinstance(gpus, list) or not gpus:
+        return None
+    g = next((x for x in gpus if isinstance(x, dict) and x.get("gpu") == gpu_index), gpus[0])
+
+    def num(x):
+        if isinstance(x, dict):
+            x = x.get("value")
+        return float(x) if isinstance(x, (int, float)) else None
+
+    thr = g.get("throttle", {}) if isinstance(g.get("throttle"), dict) else {}
+    clocks = [num(v.get("clk")) for k, v in sorted((g.get("clock") or {}).items()) if k.startswith("gfx_") and isinstance(v, dict)]
+    snap = {"accumulation_counter": num(thr.get("accumulation_counter")),
+            "residency": {k[:-len("_accumulated")]: num(thr.get(k)) for k in ("prochot_accumulated", "ppt_accumulated", "socket_thermal_accumulated", "vr_thermal_accumulated", "hbm_thermal_accumulated")},
+            "status": {k[:-len("_violation_status")]: thr.get(k) for k in ("prochot_violation_status", "ppt_violation_status", "socket_thermal_violation_status", "vr_thermal_violation_status",
+                                                                            "hbm_thermal_violation_status") if isinstance(thr.get(k), str)},
+            "socket_power_w": num((g.get("power") or {}).get("socket_power")),
+            "energy_j": num((g.get("energy") or {}).get("total_energy_consumption")),
+            "gfx_clocks_mhz": [c for c in clocks if c is not None]}
+    return t, snap
+
+
+def throttle_between(s0, s1, t_begin: float, t_end: float):
+    """Throttle residencies of the window [t_begin, t_end] (the timed region) from two smi_snapshot()s taken just outside it: the accumulators tick at a fixed
+    rate (ticks per second = counter difference / wall difference of the snapshots), a throttler's residency is its tick difference in seconds -- reported as a
+    fraction of the timed region, at most 1 (the chip idles between the snapshots and the region, where nothing throttles)."""
+    if s0 is None or s1 is None:
+        return None
+    (w0, a), (w1, b) = s0, s1
+    if a["accumulation_counter"] is None or b["accumulation_counter"] is None or w1 <= w0 or t_end <= t_begin:
+        return None
+    ticks = b["accumulation_counter"] - a["accumulation_counter"]
+    if ticks <= 0:
+        return None
+    rate = ticks / (w1 - w0)
+    out = {"ticks_per_s": rate, "snapshot_window_s": w1 - w0, "timed_region_s": t_end - t_begin, "residency_frac_of_timed_region": {}, "residency_s": {}}
+    for name, v1 in b["residency"].items():
+        v0 = a["residency"].get(name)
+        if v0 is None or v1 is None:
+            continue
+        sec = (v1 - v0) / rate
+        out["residency_s"][name] = sec
+        out["residency_frac_of_timed_region"][name] = min(1.0, sec / (t_end - t_begin))
+    if a["energy_j"] is not None and b["energy_j"] is not None:
+        out["energy_j_between_snapshots"] = b["energy_j"] - a["energy_j"]
+    return out
