@@ -252,7 +252,7 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
 
 /* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT).  set_option changes the process-wide DEFAULTS;
  * every problem / solve takes a snapshot of them when it is created, so later changes never affect a live problem.  The defaults can
- * be preset from the environment: LSSVM_MI355_OPTIONS="name=value,name=value" (read once when the library is loaded).  Twelve options here, two
+ * be preset from the environment: LSSVM_MI355_OPTIONS="name=value,name=value" (read once when the library is loaded).  Thirteen options here, two
  * testing aids in plssvm_amd_testing.h -- who sets each besides the tests: DESIGN.md section 4.5 (round 4 retired xcd_map, lds_extra_kb, item_order,
  * linear_panel_features, check_shards, rbf_direct_above and mfma_shape = 1: measured, decided, constants now):
  *   "rbf_form"      fp32 rbf: 0 = automatic (default): the norm expansion c_i + c_j + x_i'.x_j' on the matrix cores, unless
@@ -266,6 +266,10 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *                   far inside the fp32 range); 0 = start values c_i + c_j
  *   "j_chunk_tiles" number of 128-column tiles per work item; 0 = automatic (default: about 4096 work items per device, 2 ... 16 tiles each,
  *                   up to 64 for the split kernels; 256-row workgroups: the length whose replayed dispatch over the CUs finishes first)
+ *   "j_chunk_head"  256-row workgroups (see "mfma_shape"): the FIRST `count` column chunks of every pair of row blocks have `tiles` tiles instead of j_chunk_tiles, value =
+ *                   1024 count + tiles; their short work items are dispatched last and fill the final dispatch round of a launch that is only a few rounds long.
+ *                   0 (default) = none (measured: the replay's cost model cannot rank splits that differ by the few per cent a head moves); 1 = let the replayed
+ *                   dispatch choose a head with the chunk length (j_chunk_tiles = 0)
  *   "symmetric"     1 = evaluate only the kernel-matrix tiles on/below the diagonal and mirror them (default; any num_features -- beyond 512 (fp32) /
  *                   256 (fp64) features over feature panels -- except fp32 with gram_mode = 0 beyond 512 features and a negative polynomial
  *                   degree, which run the full square),

@@ -328,6 +328,9 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
         } else if (n == "j_chunk_tiles") {
             LSSVM_REQUIRE(value >= 0 && value <= (1 << 20), "j_chunk_tiles out of range");
             lssvm::options().j_chunk_tiles = value;
+        } else if (n == "j_chunk_head") {
+            LSSVM_REQUIRE(value >= 0 && value < (1 << 20), "j_chunk_head out of range (1024 count + tiles)");
+            lssvm::options().j_chunk_head = value;
         } else if (n == "symmetric") {
             lssvm::options().symmetric = value != 0 ? 1 : 0;
         } else if (n == "tile_kernel") {
@@ -393,6 +396,8 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             *value_out = lssvm::options().rbf_fold;
         } else if (n == "j_chunk_tiles") {
             *value_out = lssvm::options().j_chunk_tiles;
+        } else if (n == "j_chunk_head") {
+            *value_out = lssvm::options().j_chunk_head;
         } else if (n == "symmetric") {
             *value_out = lssvm::options().symmetric;
         } else if (n == "tile_kernel") {

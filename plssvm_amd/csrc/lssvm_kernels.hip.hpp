@@ -207,13 +207,14 @@ __global__ __launch_bounds__(1024) void k_reduce_colslab(const T *__restrict__ c
     }
 }
 
-/* SYM: Kv[row_begin + i] = sum of the row slabs of the column chunks that exist for the row's block (chunks 0 .. ib / jc_tiles) */
+/* SYM: Kv[row_begin + i] = sum of the row slabs of the column chunks that exist for the row's block (the chunks that begin at or before tile ib) */
 template <typename T>
-__global__ void k_reduce_partials_sym(const T *__restrict__ partial, long part_stride, int jc_tiles, int ib_begin, int nrows, T *__restrict__ Kv, int accumulate) {
+__global__ void k_reduce_partials_sym(const T *__restrict__ partial, long part_stride, int jc_tiles, int jc_head_tiles, int jc_head_count, int ib_begin, int nrows, T *__restrict__ Kv,
+                                      int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nrows) {
         const int ib = ib_begin + i / TILE;
-        const int nchunks = ib / jc_tiles + 1;
+        const int nchunks = chunks_upto(ib, jc_tiles, jc_head_tiles, jc_head_count);
         T s = partial[i];
         for (int c = 1; c < nchunks; ++c) s += partial[static_cast<size_t>(c) * part_stride + i];
         const int row = ib_begin * TILE + i;

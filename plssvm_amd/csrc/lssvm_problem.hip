@@ -556,8 +556,10 @@ static std::vector<int> band_edges(int ib_begin, int ib_end_all, size_t real_siz
 /* The (row block, column chunk) work items of one band in DISPATCH order: column chunk major (concurrent workgroups share the chunk; the
    hardware dispatches workgroups in item order as CU slots free up).  order >= 1 (ITEM_ORDER): the items cut short by the diagonal go last in
    their band, longest first, so that the final dispatch round is made of the shortest items.  .x = absolute row block, .y = chunk. */
-static std::vector<int2> band_items(int band_begin, int band_end, int jc_tiles, int num_jc, int order, bool pairs) {
+static std::vector<int2> band_items(int band_begin, int band_end, int jc_tiles, int num_jc, int order, bool pairs, int head_tiles = 0, int head_count = 0) {
     std::vector<int2> full, cut;
+    auto cbegin = [&](int jc) { return chunk_begin(jc, jc_tiles, head_tiles, head_count); };
+    auto clen = [&](int jc) { return chunk_len(jc, jc_tiles, head_tiles, head_count); };
     const int rows = pairs ? 2 : 1;  // row blocks per work item: block pairs (2p, 2p + 1) for the 256-row workgroups (.x = the even block; the band edges are even)
     const int nrow_items = (band_end - band_begin + rows - 1) / rows;
     if (order >= 4) {
@@ -572,7 +574,7 @@ static std::vector<int2> band_items(int band_begin, int band_end, int jc_tiles, 
             for (int jc = 0; jc < num_jc; ++jc) {
                 for (int k = g0; k < std::min(g0 + GROUP, nrow_items); ++k) {
                     const int ib = band_begin + rows * k;
-                    if (jc * jc_tiles > ib + rows - 1) continue;
+                    if (cbegin(jc) > ib + rows - 1) continue;
                     seq.push_back(make_int2(ib, jc));
                 }
             }
@@ -593,12 +595,13 @@ static std::vector<int2> band_items(int band_begin, int band_end, int jc_tiles, 
         for (int k = 0; k < nrow_items; ++k) {
             const int ib = band_begin + rows * (order == 2 ? nrow_items - 1 - k : k);
             const int last = ib + rows - 1;  // the item's tiles end at the diagonal of its LAST block
-            if (jc * jc_tiles > last) continue;
-            const bool is_cut = (jc + 1) * jc_tiles > last + 1;  // fewer than jc_tiles tiles
+            if (cbegin(jc) > last) continue;
+            const bool is_cut = cbegin(jc) + clen(jc) > last + 1 || clen(jc) < jc_tiles;  // fewer than jc_tiles tiles: cut by the diagonal, or a chunk of the short head
             (order >= 1 && is_cut ? cut : full).push_back(make_int2(ib, jc));
         }
     }
-    std::stable_sort(cut.begin(), cut.end(), [&](const int2 &x, const int2 &y) { return (x.x + rows - x.y * jc_tiles) > (y.x + rows - y.y * jc_tiles); });
+    auto item_tiles = [&](const int2 &it) { return std::min(cbegin(it.y) + clen(it.y), it.x + rows) - cbegin(it.y); };
+    std::stable_sort(cut.begin(), cut.end(), [&](const int2 &x, const int2 &y) { return item_tiles(x) > item_tiles(y); });
     if (order == 3) {
         // XCD-aware: the hardware deals consecutive workgroups round-robin over the 8 XCDs (observed, a speed matter only), each with an L2 of its own.
         // In column-chunk major order the workgroups that stream one chunk are spread over all eight L2s, which each fetch it from the fabric; here list
@@ -639,34 +642,66 @@ static std::vector<int2> band_items(int band_begin, int band_end, int jc_tiles, 
  * profiles/r04_chunk_sweep_pair.log).  The host therefore replays the hardware's dispatch (items in list order onto the slot that frees up
  * first) for a handful of candidate lengths with the cost model  item = tiles + 2.6  (the work-item prologue and tail in tile units, fitted to
  * that sweep) and takes the shortest makespan.  Large launches (more than 64 items per slot at the longest chunk) keep the longest chunk. */
-static int choose_pair_chunk(int ib_begin, int ib_end, int num_tiles, size_t real_size, const Options &o, int slots) {
+struct PairChunks {
+    int tiles = 64, head_tiles = 0, head_count = 0;
+};
+static int num_chunks(int num_tiles, int tiles, int head_tiles, int head_count) {
+    const int head = head_count * head_tiles;
+    return head_count + (std::max(num_tiles - head, 0) + tiles - 1) / tiles;
+}
+/* Round 5: the replay also tries a HEAD of short chunks -- the first `head_count` column chunks of every row pair have `head_tiles` tiles -- whose items are
+ * dispatched last, longest first, together with the items cut short by the diagonal: long items for the bulk of a launch (fewer row-panel loads), short ones
+ * to fill its final dispatch round.  Only where a launch is a few rounds long (at most 8 items per slot at the longest chunk: that is where the last round
+ * decides; ADVICE r04: no long replays of large launches).
+ * MEASURED (profiles/r05_ab_chunk_head.log, same box, against every uniform length): the replay's pick with heads is 2.5 % faster than the best uniform length at
+ * 40 000 points and 1 % at 70 000, but 2.5 % SLOWER at 30 000 and 1 % at 50 000 -- the cost model (tiles + 2.6; refitted on that log: rms error 5 % whatever the
+ * constant) cannot rank candidates that lie within a few per cent, which is all a head moves.  So the automatic choice stays with uniform chunks; heads are
+ * searched only on request (option j_chunk_head = 1) and can be given explicitly (1024 count + tiles). */
+static PairChunks choose_pair_chunk(int ib_begin, int ib_end, int num_tiles, size_t real_size, const Options &o, int slots) {
     const int cap = 64;
+    PairChunks best_c;
     const long area = (static_cast<long>(ib_end) * (ib_end + 1) - static_cast<long>(ib_begin) * (ib_begin + 1)) / 4;  // pair-tiles, about
-    if (area / cap > 64L * slots) return cap;
+    if (area / cap > 64L * slots) return best_c;
     const std::vector<int> edge = band_edges(ib_begin, ib_end, real_size, o);
+    const bool few_rounds = area / cap <= 8L * slots && edge.size() == 2;
     double best = 0.0;
-    int best_jc = 0;
-    for (const int jc : { 2, 3, 4, 6, 8, 10, 12, 16, 20, 24, 32, 40, 48, 64 }) {
-        const int num_jc = (num_tiles + jc - 1) / jc;
+    bool have = false;
+    auto replay = [&](int jc, int head_tiles, int head_count) {
+        const int num_jc = num_chunks(num_tiles, jc, head_tiles, head_count);
         double total = 0.0;
         for (size_t k = 0; k + 1 < edge.size(); ++k) {
             if (edge[k + 1] <= edge[k]) continue;
             std::vector<double> slot(static_cast<size_t>(slots), 0.0);  // a min-heap of the slots' finish times
             auto later = [](double x, double y) { return x > y; };
-            for (const int2 &it : band_items(edge[k], edge[k + 1], jc, num_jc, ITEM_ORDER, true)) {
-                const int tiles = std::min(std::min((it.y + 1) * jc, it.x + 2), num_tiles) - it.y * jc;
+            for (const int2 &it : band_items(edge[k], edge[k + 1], jc, num_jc, ITEM_ORDER, true, head_tiles, head_count)) {
+                const int b = chunk_begin(it.y, jc, head_tiles, head_count);
+                const int tiles = std::min(std::min(b + chunk_len(it.y, jc, head_tiles, head_count), it.x + 2), num_tiles) - b;
                 std::pop_heap(slot.begin(), slot.end(), later);
                 slot.back() += static_cast<double>(std::max(tiles, 0)) + 2.6;
                 std::push_heap(slot.begin(), slot.end(), later);
             }
             total += *std::max_element(slot.begin(), slot.end());
         }
-        if (best_jc == 0 || total < best) {
+        if (!have || total < best) {
             best = total;
-            best_jc = jc;
+            have = true;
+            best_c.tiles = jc;
+            best_c.head_tiles = head_count > 0 ? head_tiles : 0;
+            best_c.head_count = head_count;
+        }
+    };
+    for (const int jc : { 2, 3, 4, 6, 8, 10, 12, 16, 20, 24, 32, 40, 48, 64 }) replay(jc, 0, 0);
+    if (few_rounds && o.j_chunk_head == 1) {  // (not the default: measured a wash, see the comment above)
+        for (const int jc : { 24, 32, 40, 48, 56, 64 }) {
+            for (const int hc : { 1, 2, 3, 4, 6, 8 }) {
+                for (const int ht : { 4, 8, 12, 16, 20, 24 }) {
+                    if (ht >= jc || hc * ht + jc > num_tiles) continue;
+                    replay(jc, ht, hc);
+                }
+            }
         }
     }
-    return best_jc;
+    return best_c;
 }
 
 /* ------------------------------------------------------------------ Problem: one device's shard ------------------------------------------------------------------ */
@@ -786,7 +821,10 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         if (pair_) {
             int cus = 256;  // one such workgroup per CU
             LSSVM_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_));
-            jc_tiles_ = choose_pair_chunk(ib_begin_, static_cast<int>(ib_end), num_tiles_, sizeof(T), opt_, std::max(cus, 1));
+            const PairChunks pc = choose_pair_chunk(ib_begin_, static_cast<int>(ib_end), num_tiles_, sizeof(T), opt_, std::max(cus, 1));
+            jc_tiles_ = pc.tiles;
+            jc_head_tiles_ = pc.head_tiles;
+            jc_head_count_ = pc.head_count;
         }
         // panels inside a tile, symmetric variant: SHORT items in row-group major order (wide_order_ below) -- the shorter the better at every shape
         // (12 > 8 > 4 > 2 tiles, profiles/r04_ab_wide_item_order_groups.log, r04_ab_wide_final.log); longer only where the partial slabs would grow
@@ -804,10 +842,16 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
                                        : 128.0 * static_cast<double>(ldx_probe) * 8.0;
         wide_order_ = panel_bytes <= 640e3 ? 4 : 5;
     }
-    num_jc_ = (num_tiles_ + jc_tiles_ - 1) / jc_tiles_;
+    if (pair_ && opt_.j_chunk_head >= 1024) {  // an explicit head (option j_chunk_head = 1024 count + tiles): tests, A/B runs
+        jc_head_count_ = static_cast<int>(opt_.j_chunk_head / 1024);
+        jc_head_tiles_ = static_cast<int>(opt_.j_chunk_head % 1024);
+        if (jc_head_count_ <= 0 || jc_head_tiles_ <= 0 || jc_head_count_ * jc_head_tiles_ >= num_tiles_) jc_head_count_ = jc_head_tiles_ = 0;
+    }
+    if (!pair_) jc_head_count_ = jc_head_tiles_ = 0;
+    num_jc_ = num_chunks(num_tiles_, jc_tiles_, jc_head_tiles_, jc_head_count_);
     if (const char *dbg = std::getenv("LSSVM_MI355_DEBUG"); dbg != nullptr && dbg[0] == '1') {
-        std::fprintf(stderr, "[plssvm_amd] shard %d/%d on device %d: row blocks [%d, %d) of %d, %d tiles per work item, symmetric %d\n", rank_, world_, device_, ib_begin_,
-                     ib_begin_ + num_ib_, num_tiles_, jc_tiles_, sym_ ? 1 : 0);
+        std::fprintf(stderr, "[plssvm_amd] shard %d/%d on device %d: row blocks [%d, %d) of %d, %d tiles per work item (head: %d chunks of %d), symmetric %d\n", rank_, world_, device_,
+                     ib_begin_, ib_begin_ + num_ib_, num_tiles_, jc_tiles_, jc_head_count_, jc_head_tiles_, sym_ ? 1 : 0);
     }
     inv_cost_ = static_cast<double>(T(1) / static_cast<T>(params_.cost));  // "1 / params.cost" in real_type, csvm.cpp:297
 
@@ -902,7 +946,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
             band.ib_end = edge[k + 1];
             band.item_begin = static_cast<int>(items.size());
             band.pair_origin = pairs_below(band.ib_begin);
-            for (const int2 &it : band_items(band.ib_begin, band.ib_end, jc_tiles_, num_jc_, opt_.item_order_dev != 0 ? static_cast<int>(opt_.item_order_dev) : (wide_order_ != 0 ? wide_order_ : ITEM_ORDER), pair_)) items.push_back(make_int2(it.x - ib_begin_, it.y));
+            for (const int2 &it : band_items(band.ib_begin, band.ib_end, jc_tiles_, num_jc_, opt_.item_order_dev != 0 ? static_cast<int>(opt_.item_order_dev) : (wide_order_ != 0 ? wide_order_ : ITEM_ORDER), pair_, jc_head_tiles_, jc_head_count_)) items.push_back(make_int2(it.x - ib_begin_, it.y));
             band.item_count = static_cast<int>(items.size()) - band.item_begin;
             // (block pairs: the records of the pair's SECOND block, which is padding behind an odd last block)
             max_records = std::max(max_records, pairs_below(pair_ ? round_up(band.ib_end, 2) : band.ib_end) - band.pair_origin);
@@ -957,6 +1001,8 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     a.num_ib = num_ib_;
     a.num_jt = num_tiles_;
     a.jc_tiles = jc_tiles_;
+    a.jc_head_tiles = jc_head_tiles_;
+    a.jc_head_count = jc_head_count_;
     a.ncols_valid = n_;
     set_kernel_scalars(a, tile_params_, rbf_direct_);
     if (poly_prescaled_) a.gamma = T(1);
@@ -1067,7 +1113,7 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
                 }
             }
             // rows of this device's blocks: the slabs of the column chunks that exist for each block, added on top
-            hipLaunchKernelGGL(k_reduce_partials_sym<T>, dim3((nrows + 255) / 256), dim3(256), 0, st, partial_.p, a.part_stride, jc_tiles_, ib_begin_, nrows, Kv_.p, 1);
+            hipLaunchKernelGGL(k_reduce_partials_sym<T>, dim3((nrows + 255) / 256), dim3(256), 0, st, partial_.p, a.part_stride, jc_tiles_, jc_head_tiles_, jc_head_count_, ib_begin_, nrows, Kv_.p, 1);
         }
     } else {
         EvPair *ev = free_event();

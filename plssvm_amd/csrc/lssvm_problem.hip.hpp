@@ -63,6 +63,7 @@ struct Options {
     int64_t rbf_fold = 1;        // fp32 rbf on the split kernels: 1 = folded column records (2^c_j d_j | 2^c_j), accumulators start from c_i as the C
                                  // operand of their first MFMA (default, while the exponent scale stays below 200); 0 = start values c_i + c_j by vector adds
     int64_t j_chunk_tiles = 0;   // 128-column tiles per work item; 0 = automatic (see Problem<T>'s constructor)
+    int64_t j_chunk_head = 0;    // 256-row workgroups: 0 = none; 1 = chosen by the replayed dispatch (with j_chunk_tiles = 0); 1024 count + tiles = the first `count` column chunks have `tiles` tiles
     int64_t symmetric = 1;         // 1: evaluate only the tiles on/below the diagonal and mirror them, 0: full square
     int64_t tile_kernel = 0;       // 0: automatic (resident-row-panel kernels where they exist), 1: always the generic v1 kernel (the cross-checks' yardstick)
     int64_t gram_mode = 3;         // fp32 Gram tiles: 0 = v_mfma_f32 chains; 1 = "bf16x6"; 2 = "f16x3" without the representability check; 3 (default) = f16x3
@@ -325,6 +326,7 @@ class Problem {
     int num_tiles_ = 0;  // ceil(n / TILE): row blocks == column tiles
     int ib_begin_ = 0, num_ib_ = 0, ib_per_rank_ = 0;
     int jc_tiles_ = 16, num_jc_ = 1;
+    int jc_head_tiles_ = 0, jc_head_count_ = 0;  // 256-row workgroups: a head of short column chunks (choose_pair_chunk)
     int nvec_ = 0;  // allocated vector length (multiple of TILE * world)
     bool rbf_direct_ = false;
     double rbf_r2_ = 0.0;  // fp32 rbf: 2 gamma log2(e) max|x - mean|^2

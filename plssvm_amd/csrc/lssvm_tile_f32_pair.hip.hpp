@@ -76,8 +76,8 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
     const int ib0 = a.ib_begin + ibl;
     const int my_ib = ib0 + HALF;
     const int row0 = ib0 * TILE;
-    const int jt_begin = jc * a.jc_tiles;
-    const int jt_end = min(min(jt_begin + a.jc_tiles, ib0 + 2), a.num_jt);
+    const int jt_begin = chunk_begin(jc, a.jc_tiles, a.jc_head_tiles, a.jc_head_count);
+    const int jt_end = min(min(jt_begin + chunk_len(jc, a.jc_tiles, a.jc_head_tiles, a.jc_head_count), ib0 + 2), a.num_jt);
     const int ntiles = jt_end - jt_begin;
     if (ntiles <= 0) return;
     const int nsteps = ntiles * NKC;
@@ -160,8 +160,13 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
     }
     // ---- the row panel (this wave's 32 rows, all features, all row planes) ----
     bf16x8 afrag[PLA][2 * NK64][2];
+    // rbf on f16 planes: row plane 0 (2^-6 hi) is row plane 2 (2^6 hi) times 2^-12 -- one exact f16 multiplication (the conversion that made plane 0 rounds the
+    // same product the same way) -- so two planes are loaded and the third is derived in registers: a third less of the row panel, whose load is most of a work
+    // item's start (192 -> 128 KiB per item at ~11 B / cycle / CU).  Bit-identical; 1 000 000 x 128: 267.8 -> 266.7 ms, 50 000 x 128: 0.759 -> 0.755 ms per
+    // iteration, same box, interleaved (profiles/r05_ab_mfma_order_and_derived_row_plane.log, "lib_v_derive")
+    constexpr int P_FIRST = (F16 && PLA == 3) ? 1 : 0;
 #pragma unroll
-    for (int p = 0; p < PLA; ++p) {
+    for (int p = P_FIRST; p < PLA; ++p) {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const uint16_t *xr = a.Xr16 + p * a.plane_stride_r + static_cast<size_t>(row0 + wave * 32 + 16 * rb + r) * a.ldx16 + 8 * g;
@@ -187,6 +192,13 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
     }
     // (retire the ordinary loads HERE: none may be outstanding once the counted waits of the hand-overs begin)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if constexpr (P_FIRST == 1) {
+        typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+#pragma unroll
+        for (int kk = 0; kk < 2 * NK64; ++kk)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) afrag[0][kk][rb] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(f16x8_t, afrag[PLA - 1][kk][rb]) * static_cast<_Float16>(0x1p-12f));
+    }
 #pragma unroll
     for (int p = 0; p < PLA; ++p)
 #pragma unroll

@@ -68,7 +68,9 @@ struct TileArgs {
     int num_ib;       // number of row blocks of this device
     int num_jt;       // number of column tiles in total
     int jc_tiles;     // column tiles per work item
-    int num_jc;       // number of column chunks = ceil(num_jt / jc_tiles)
+    int num_jc;       // number of column chunks = ceil(num_jt / jc_tiles); with a head (below): jc_head_count + ceil((num_jt - head tiles) / jc_tiles)
+    int jc_head_tiles;  // 256-row workgroups only (0 elsewhere): the FIRST jc_head_count column chunks have this many tiles instead of jc_tiles -- short items that
+    int jc_head_count;  // every row pair has, dispatched last: they fill the final dispatch round of a small launch (chunk_begin / chunk_len below)
     int row_pair;     // host side only: != 0 selects the 256-row-workgroup kernels (items = block pairs, lssvm_tile_f32_pair.hip.hpp)
     int pair_lag;     // host side only: steps the second half of such a workgroup runs behind the first
     int mfma_shape;   // host side only: option mfma_shape (2 = 128-row workgroups, 3 = 256-row workgroups where they apply)
@@ -78,6 +80,17 @@ struct TileArgs {
     T gamma;          // polynomial: gamma ; rbf fp64: 2 * gamma ; rbf fp32: unused (folded into the pre-scaled data) ; direct rbf: -gamma*log2(e)
     T coef0;          // polynomial
 };
+
+/* column chunk jc of a launch covers the tiles [chunk_begin, chunk_begin + chunk_len): a head of `head_count` short chunks, then chunks of `tiles` */
+__host__ __device__ inline int chunk_begin(int jc, int tiles, int head_tiles, int head_count) {
+    return jc < head_count ? jc * head_tiles : head_count * head_tiles + (jc - head_count) * tiles;
+}
+__host__ __device__ inline int chunk_len(int jc, int tiles, int head_tiles, int head_count) { return jc < head_count ? head_tiles : tiles; }
+/* number of chunks that begin at or before tile `last` */
+__host__ __device__ inline int chunks_upto(int last, int tiles, int head_tiles, int head_count) {
+    const int head = head_count * head_tiles;
+    return last < head ? last / head_tiles + 1 : head_count + (last - head) / tiles + 1;
+}
 
 constexpr int F32_KC = 32;  // fp32: features per k-chunk (one 128-byte line per row)
 constexpr int F32_LS = 36;  // fp32: padded LDS row stride in floats (144 B: 16-B aligned, conflict-free ds_read_b128)

@@ -457,6 +457,35 @@ def test_results_are_bitwise_reproducible_and_independent_of_the_work_split(kern
     assert ol.rel_inf(m3, m16) < 16 * np.finfo(np.float32).eps
 
 
+@pytest.mark.parametrize("kernel, d, shards", [("rbf", 128, 1), ("linear", 200, 1), ("polynomial", 64, 1), ("rbf", 96, 3)])
+def test_a_head_of_short_column_chunks_changes_only_the_association(oracle, kernel, d, shards):
+    """Round 5: the 256-row workgroups may cut the FIRST column chunks of every row pair short (option j_chunk_head = 1024 count + tiles; chosen by the replayed
+    dispatch for launches of a few rounds): their items fill the last dispatch round.  A chunk map is a work split -- same tiles, same fixed-order slabs -- so
+    every head gives the float64 oracle's rows within the kernel-level bar, agrees with the uniform split to the association, and repeats bit for bit; and
+    the automatic choice (j_chunk_tiles = 0, whatever it picks for this shape) does too."""
+    N = 9100  # 72 row blocks: the 256-row workgroups run from 64 on
+    X, _ = make_blobs_pm1(N, d, seed=13, dtype=np.float32)
+    n = N - 1
+    p = Parameter(kernel_type=kernel, degree=3)
+    eps = np.finfo(np.float32).eps
+    rows = np.array([0, 1, 127, 128, 255, 256, 257, 640, 4000, 8191, 8192, 9000, n - 1])
+    devices = [0] * shards if shards > 1 else None
+    results = {}
+    for name, tiles, head in (("uniform", 8, 0), ("head 3 x 2", 8, 3 * 1024 + 2), ("head 1 x 5", 16, 1 * 1024 + 5), ("head 6 x 3", 24, 6 * 1024 + 3), ("head as long as the triangle allows", 40, 2 * 1024 + 30),
+                              ("automatic", 0, 0), ("automatic with a head", 0, 1)):
+        _capi.set_option("j_chunk_tiles", tiles)
+        _capi.set_option("j_chunk_head", head)
+        with backend.ResidentProblem(p, X, devices=devices) as prob:
+            err, got, rhs = _sampled_rows_vs_oracle(oracle, prob, kernel, X, rows)
+            again = prob.matvec(rhs, np.zeros(n, np.float32), 1.0)
+        assert err < 16 * eps, (name, err / eps)
+        assert np.array_equal(got, again), name
+        results[name] = got
+    base = results["uniform"]
+    for name, got in results.items():
+        assert ol.rel_inf(got, base) < 64 * eps, name  # (on the scale of the RESULT, whose rank-1 terms cancel: the bar of the sharded runs; measured 18 eps)
+
+
 def test_resident_problem_stepping_equals_one_shot():
     X, y = make_blobs_pm1(900, 24, seed=4, dtype=np.float64)
     p = Parameter(kernel_type="rbf")
