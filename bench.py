@@ -524,6 +524,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     steps_done = int(i1["iterations"] - i0["iterations"])
+    # every rank runs the identical O(n) kernels on the identical exchanged vector: the CG scalars must be the SAME BITS on all ranks (the library checks that
+    # across the shards of one process at cg_finish; across processes only the application can): delta after the timed steps, compared over the side channel
+    ranks_agree = None
+    if dist is not None:
+        import struct
+
+        mine = struct.pack("<dQ", float(i1["residuum"]), int(i1["iterations"]))
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        ranks_agree = all(e == everyone[0] for e in everyone)
+        if not ranks_agree:
+            print(f"[bench rank {rank}] the ranks DISAGREE on the residuum after the timed steps: {[struct.unpack('<dQ', e) for e in everyone]}", file=sys.stderr, flush=True)
 
     n = N - 1
     flop_step = 2.0 * n * n * d
@@ -590,7 +602,7 @@ def main():
                               "accumulated in fp32 on the f16 matrix cores"}.get(gram_mode, "native " + wl["dtype"] + " matrix-core fma chains"),
             "config": {"workload": wl["desc"], "num_points": N, "num_features": d, "kernel": wl["kernel"], "gamma": 1.0 / d, "cost": 1.0,
                        "seed": args.seed, "library_options": args.option, "parallelism": parallelism, "shards": shards, "exchange": exchange_names.get(int(i1.get("exchange", 0)), "?"),
-                       "residuum_after_timed_steps": i1["residuum"],
+                       "residuum_after_timed_steps": i1["residuum"], "residuum_bit_equal_on_all_ranks": ranks_agree,
                        # what RCCL itself reports for the communicator the partial vectors travelled over (ncclCommCount / ncclCommCuDevice on rank 0), and the
                        # file its entry points were resolved from -- null / 0 when no RCCL exchange ran
                        "rccl_nranks": int(i1.get("rccl_nranks", 0)), "rccl_rank0_device": (int(i1["rccl_device"]) if int(i1.get("rccl_nranks", 0)) > 0 else None),

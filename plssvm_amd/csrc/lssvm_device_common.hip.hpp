@@ -75,26 +75,27 @@ __device__ __forceinline__ double fast_exp_f64(double x) {
     return __builtin_ldexp(p, static_cast<int>(k));
 }
 
-/* 2^t in double for the rbf epilogue of the fp64 v2 kernel (the data carries sqrt(2 gamma log2(e)), so the MFMA chain leaves
- * t = log2(K)): t = k + r, k = rint(t), |r| <= 1/2, 2^r by its degree-12 Taylor polynomial in r ln2 (truncation 1.7e-16), v_ldexp_f64
- * for the scale (underflow to 0 included).  16 vector instructions instead of the 20 of fast_exp_f64(acc * 2 gamma): every one of
- * them costs matrix-core time beside v_mfma_f64.  (A 64-entry table + degree-5 polynomial needs 13, but its per-lane LDS gathers
- * serialise in the register-bound epilogue: measured 16 % SLOWER.) */
+/* 2^t in double for the rbf epilogue of the fp64 kernels (the data carries sqrt(2 gamma log2(e)), so the MFMA chain leaves t = log2(K)): t = k + r, k = rint(t),
+ * |r| <= 1/2, 2^r by a degree-10 polynomial -- the interpolant of 2^r in the Chebyshev nodes of [-1/2, 1/2] (near-minimax: 1.4 eps of truncation with the
+ * coefficients rounded to double; the Taylor polynomial of rounds 1-4 needed degree 12 for 0.8 eps) --, v_ldexp_f64 for the scale (underflow to 0 included).
+ * 14 vector instructions per element; every one of them costs matrix-core time beside v_mfma_f64 -- on gfx950 NO vector instruction overlaps with an fp64 MFMA,
+ * integer and fp32 ones included (profiles/r01_microbench_mfma_beside_valu.log: 4 v_fma_f64 per MFMA 77 -> 55 TFLOP/s, 4 integer instructions 77 -> 59), which
+ * is why a v_exp_f32 seed corrected in fp64 cannot pay: a seed of 24 bits leaves the correction a full-length polynomial, and the
+ * instructions it would move to the fp32 pipe cost the same issue time.  What is left is the count: 16 -> 14 here (p(0) = 1 exactly: K_ii = 1).
+ * (A 64-entry table + degree-5 polynomial needs 13, but its per-lane LDS gathers serialise in the register-bound epilogue: measured 16 % SLOWER.) */
 __device__ __forceinline__ double exp2_f64(double t) {
     const double k = __builtin_rint(t);
     const double r = t - k;
-    double p = 2.5678435993488196e-11;
-    p = fma(p, r, 4.44553827187081e-10);
-    p = fma(p, r, 7.054911620801121e-09);
-    p = fma(p, r, 1.0178086009239696e-07);
-    p = fma(p, r, 1.3215486790144305e-06);
-    p = fma(p, r, 1.5252733804059838e-05);
-    p = fma(p, r, 0.00015403530393381606);
-    p = fma(p, r, 0.0013333558146428441);
-    p = fma(p, r, 0.009618129107628477);
-    p = fma(p, r, 0.055504108664821576);
-    p = fma(p, r, 0.2402265069591007);
-    p = fma(p, r, 0.6931471805599453);
+    double p = 7.072585949269224e-09;
+    p = fma(p, r, 1.0208690299958306e-07);
+    p = fma(p, r, 1.321544258792169e-06);
+    p = fma(p, r, 1.5252657260200837e-05);
+    p = fma(p, r, 0.0001540353044173605);
+    p = fma(p, r, 0.0013333558230164974);
+    p = fma(p, r, 0.009618129107606888);
+    p = fma(p, r, 0.05550410866444772);
+    p = fma(p, r, 0.24022650695910097);
+    p = fma(p, r, 0.69314718055995);
     p = fma(p, r, 1.0);
     return __builtin_ldexp(p, static_cast<int>(k));
 }

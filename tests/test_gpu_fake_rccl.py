@@ -128,4 +128,4 @@ def test_bench_line_of_four_ranks_reports_what_rccl_saw(tmp_path):
     cfg = line["config"]
     assert cfg["rccl_nranks"] == 4 and cfg["rccl_rank0_device"] == 0 and cfg["rccl_is_stand_in"] and os.path.samefile(cfg["rccl_library"], STAND_IN)
     assert cfg["shards"] == 4 and cfg["exchange"] == "RCCL all-reduce" and line["steps"] == 6 and line["n_gpus"] == 1
-    assert np.isfinite(cfg["residuum_after_timed_steps"]) and line["value"] > 0
+    assert np.isfinite(cfg["residuum_after_timed_steps"]) and line["value"] > 0 and cfg["residuum_bit_equal_on_all_ranks"] is True
