@@ -89,11 +89,25 @@ def smi_snapshot(gpu_index: int = 0, timeout_s: float = 30.0):
     import json
     import shutil
     import subprocess
+    import sys
 
+    # Under a profiler that pre-loads itself into every process (rocprofv3 --pmc: LD_PRELOAD / HSA_TOOLS_LIB) the tool's own start-up would initialise the GPU in
+    # the helper process too, and amd-smi's "#!/usr/bin/env python3" is then an exec out of a GPU-initialised process, which this pool's boxes refuse (seen in
+    # round 5's first PMC passes): no throttle reading in profiled runs.  Elsewhere the script is started by the interpreter directly -- no `env` hop.
+    if any(k in os.environ for k in ("HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     exe = shutil.which("amd-smi") or "/opt/rocm/bin/amd-smi"
+    script = os.path.realpath(exe)
+    try:
+        with open(script, "rb") as f:
+            first = f.readline()
+        is_python = first.startswith(b"#!") and b"python" in first
+    except OSError:
+        return None
+    cmd = [sys.executable, script] if is_python else [exe]
     try:
         t = time.time()
-        out = subprocess.run([exe, "metric", "--json"], capture_output=True, text=True, timeout=timeout_s).stdout
+        out = subprocess.run(cmd + ["metric", "--json"], capture_output=True, text=True, timeout=timeout_s).stdout
         start = out.find("{")
         data = json.loads(out[start:]) if start >= 0 else None
     except (OSError, ValueError, subprocess.SubprocessError):

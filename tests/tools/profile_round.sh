@@ -1,12 +1,15 @@
 #!/bin/bash
 # One GPU-box call that produces everything profiles/ holds for a round: bench lines for the four GPU workloads, the
 # rocprofv3 kernel-trace summaries of the same commands, and the PMC passes (separate runs, counters only).
-# usage: tests/tools/profile_round.sh <tag>      (outputs under gpurun_out/<tag>_*)
+# usage: tests/tools/profile_round.sh <tag> [workloads of the profiled passes, default "c2 c3 c4 c5"]     (outputs under gpurun_out/<tag>_*)
+#        PROFILE_ONLY=1: skip the plain bench lines and the microbenchmark (re-take of the rocprofv3 / PMC passes alone)
 TAG=${1:-rXX}
+PWLS=${2:-"c2 c3 c4 c5"}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
+if [ -z "$PROFILE_ONLY" ]; then
 for wl in c2 c3 c4 c5; do
   # (short launches need enough timed steps for the chip to settle: 10 steps of the 0.7 ms c2 iteration measure 0.79 ms per launch, 200 steps 0.705)
   st=20; [ $wl = c5 ] && st=5; [ $wl = c2 ] && st=200
@@ -21,16 +24,17 @@ for wl in c2 c3 c5; do
   python3 bench.py --workload $wl --steps $st --warmup 2 --gram-mode 0 --no-cpu-baseline > $O/${TAG}_bench_${wl}_n1_native_f32_mfma.json 2> $O/${TAG}_bench_${wl}_native.err
   python3 bench.py --workload $wl --steps $st --warmup 2 --gram-mode 1 --no-cpu-baseline --no-native-reference > $O/${TAG}_bench_${wl}_n1_bf16x6.json 2> $O/${TAG}_bench_${wl}_bf16x6.err
 done
-for wl in c2 c3 c4 c5; do
+fi
+for wl in $PWLS; do
   rm -rf $O/prof_$wl
   st=5; [ $wl = c2 ] && st=100
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -- python3 bench.py --workload $wl --steps $st --warmup 1 --no-cpu-baseline --no-native-reference --no-ceiling > $O/prof_$wl.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -- python3 bench.py --workload $wl --steps $st --warmup 1 --no-cpu-baseline --no-native-reference --no-ceiling --no-other-workloads > $O/prof_$wl.log 2>&1
   f=$(find $O/prof_$wl -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" $O/${TAG}_rocprofv3_kernel_stats_bench_${wl}.csv
   grep "^{" $O/prof_$wl.log | tail -1 > $O/${TAG}_rocprofv3_bench_line_${wl}.json
 done
-: > $O/${TAG}_pmc_tile_matvec.txt
-for wl in c2 c3 c4 c5; do
+[ -z "$PROFILE_ONLY" ] && : > $O/${TAG}_pmc_tile_matvec.txt
+for wl in $PWLS; do
   rm -rf $O/pmc_$wl
   bash tests/tools/pmc_passes.sh $wl 3 $O/pmc_$wl
   python3 tests/tools/pmc_summarize.py $wl $O/pmc_$wl --json $O/${TAG}_hbm_traffic.json --key ${wl}_n1 --profile profiles/${TAG}_pmc_tile_matvec.txt >> $O/${TAG}_pmc_tile_matvec.txt 2>&1
