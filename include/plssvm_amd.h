@@ -82,7 +82,7 @@ typedef struct lssvm_cg_info {
     int32_t rbf_direct;      /* fp32 rbf: 1 if the formula-exact (x_i - x_j)^2 kernel ran instead of the matrix-core norm expansion (option rbf_form) */
     double rbf_exponent_scale; /* fp32 rbf, rbf_form 0: 2 gamma log2(e) max|x - mean|^2, the quantity compared with rbf_direct_above */
     uint64_t matvec_timed;   /* of matvec_launches, the matvecs whose tile-kernel launches were bracketed by HIP events AND have been read back (short matvecs
-                              * are sampled: launches 1 ... 16 and then every 8th, never the first after cg_begin) */
+                              * are sampled: launches 1 ... 4 and then every 8th, never the first after cg_begin) */
     double matvec_kernel_ms_total; /* summed device time of the tile-kernel launches of those matvec_timed matvecs (slowest shard of this process): differences of
                                     * (matvec_kernel_ms_total, matvec_timed) between two lssvm_mi355_problem_info calls give the average over the steps between them */
     int32_t rccl_nranks;     /* exchange == 1: ncclCommCount of the communicator the partial vectors travel over (what RCCL itself says, not what was asked for); else 0 */

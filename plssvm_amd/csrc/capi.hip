@@ -321,7 +321,7 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
         LSSVM_REQUIRE(name != nullptr, "name must not be NULL");
         const std::string n(name);
         if (n == "rbf_form") {
-            LSSVM_REQUIRE(value >= 0 && value <= 2, "rbf_form must be 0 (automatic), 1 (direct) or 2 (matrix cores)");
+            LSSVM_REQUIRE(value >= 0 && value <= 3, "rbf_form must be 0 (automatic), 1 (direct), 2 (matrix cores, norm expansion) or 3 (matrix cores, grid planes)");
             lssvm::options().rbf_form = value;
         } else if (n == "rbf_fold") {
             lssvm::options().rbf_fold = value != 0 ? 1 : 0;

@@ -298,7 +298,7 @@ __device__ __forceinline__ double column_sums_of_4_blocks(const double (&c)[4]) 
 /* The v2 kernels take the polynomial degree class as part of their kernel-type template parameter, so every instantiation
  * carries ONE epilogue (the three-way runtime switch of with_degree_class made the register allocator budget for the generic
  * integer-power path and spill in the cube path). */
-__host__ __device__ constexpr int v2_base_kt(int kt) { return (kt == KT_POLY2 || kt == KT_POLY3) ? KT_POLY : (kt == KT_RBFF ? KT_RBF : kt); }
+__host__ __device__ constexpr int v2_base_kt(int kt) { return (kt == KT_POLY2 || kt == KT_POLY3) ? KT_POLY : ((kt == KT_RBFF || kt == KT_RBFG) ? KT_RBF : kt); }
 __host__ __device__ constexpr int v2_degree_class(int kt) { return kt == KT_POLY3 ? 3 : (kt == KT_POLY2 ? 2 : 0); }
 
 /* LDS geometry of the fp32 v2 kernels (tile_matvec_f32_v2, tile_matvec_f32_s6) */

@@ -24,13 +24,18 @@ namespace lssvm {
 /* folded != 0 (rbf on the 16x16x32 bf16x6 kernels): dc[jt][0..127] = 2^c_j * d_j, dc[jt][128..255] = 2^c_j -- the tile kernel then starts its
  * accumulators from c_i alone (as the C operand of the first MFMA) and evaluates K_ij d_j = 2^acc * (2^c_j d_j); used only while
  * |c| <= 100, so neither factor leaves the fp32 range */
-__global__ void k_pack_dc(const float *__restrict__ dvec, const float *__restrict__ cc, int ncols_padded, float *__restrict__ dc, int folded, float *__restrict__ zero, int nzero) {
+/* folded == 2 (rbf on grid planes, KT_RBFG): dc[jt][0..127] = E_j * d_j, dc[jt][128..255] = cc_j = sigma^2 ch_j (the exact start value); E_j = efac[j] */
+__global__ void k_pack_dc(const float *__restrict__ dvec, const float *__restrict__ cc, int ncols_padded, float *__restrict__ dc, int folded, float *__restrict__ zero, int nzero,
+                          const float *__restrict__ efac) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < nzero) zero[j] = 0.0f;  // (the symmetric variant ADDS into K*v: the vector is cleared here instead of by a memset of its own)
     if (j >= ncols_padded) return;
     const int jt = j >> 7, l = j & 127;
     const float c = (cc != nullptr) ? cc[j] : 0.0f;
-    if (folded) {
+    if (folded == 2) {
+        dc[static_cast<size_t>(jt) * 256 + l] = efac[j] * dvec[j];
+        dc[static_cast<size_t>(jt) * 256 + 128 + l] = c;
+    } else if (folded) {
         const float e = __builtin_amdgcn_exp2f(c);
         dc[static_cast<size_t>(jt) * 256 + l] = e * dvec[j];
         dc[static_cast<size_t>(jt) * 256 + 128 + l] = e;
@@ -177,7 +182,8 @@ __global__ void k_reduce_partials(const T *__restrict__ partial, long part_strid
  * walk the row blocks with stride 1024 / W (four independent partial sums each, for memory-level parallelism), then the groups'
  * sums are added in group order -- the order depends only on the shape, never on timing. */
 template <typename T, int W>
-__global__ __launch_bounds__(1024) void k_reduce_colslab(const T *__restrict__ colslab, long pair_origin, int ib_begin, int ib_end, int ib_step, T *__restrict__ Kv) {
+__global__ __launch_bounds__(1024) void k_reduce_colslab(const T *__restrict__ colslab, long pair_origin, int ib_begin, int ib_end, int ib_step, T *__restrict__ Kv,
+                                                         const T *__restrict__ col_factor = nullptr) {  // col_factor (rbf on grid planes): the column's folded factor E_j, applied to the summed records
     constexpr int SUB = TILE / W;
     constexpr int G = 1024 / W;
     __shared__ T red[G][W];
@@ -203,6 +209,7 @@ __global__ __launch_bounds__(1024) void k_reduce_colslab(const T *__restrict__ c
         T s = red[0][l];
 #pragma unroll
         for (int k = 1; k < G; ++k) s += red[k][l];
+        if (col_factor != nullptr) s *= col_factor[c * W + l];
         Kv[c * W + l] += s;
     }
 }

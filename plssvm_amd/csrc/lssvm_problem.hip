@@ -301,7 +301,7 @@ static bool rbf_wants_direct_form(const Options &o, const lssvm_params &p, const
     if (M2 != nullptr) sq = std::max(sq, max_centred_sqnorm<T>(*M2, mean, s));
     const double r2 = 2.0 * static_cast<double>(static_cast<T>(p.gamma)) * 1.4426950408889634 * sq;
     if (r2_out != nullptr) *r2_out = r2;
-    if (o.rbf_form == 2) return false;  // matrix cores whatever the scale (r2 is still reported: it decides the record form)
+    if (o.rbf_form == 2 || o.rbf_form == 3) return false;  // matrix cores whatever the scale (r2 is still reported: it decides the record form; 3: grid planes, decided by the caller)
     return r2 > RBF_DIRECT_ABOVE;
 }
 
@@ -730,6 +730,16 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     X_.upload(X, mem_kind, num_points, num_features, static_cast<size_t>(nvec_) + TILE, st);
     // fp32 rbf: matrix cores (norm expansion) or the formula-exact vector-ALU kernel?  (every shard sees the same data: same decision)
     rbf_direct_ = rbf_wants_direct_form<T>(opt_, params_, X_, nullptr, st, &rbf_r2_);
+    // Large exponent scales (round 5): between RBF_DIRECT_ABOVE and RBF_GRID_MAX_R2, on at most 128 features and with operand planes allowed, the matrix cores run the
+    // rbf kernel on GRID planes (KT_RBFG, lssvm_tile_f32_split.hip.hpp) -- the direct form's accuracy at about twice the f16x3 time instead of five times.  A rule on
+    // the data's scale, the shape and the options: every shard sees the same data and decides alike.  (predict_values keeps the direct kernel there.)
+    if constexpr (std::is_same_v<T, float>) {
+        const bool grid_shape = params_.kernel_type == LSSVM_KERNEL_RBF && opt_.gram_mode != 0 && opt_.tile_kernel != 1 && round_up(static_cast<long>(num_features), 64) <= 128;
+        if (grid_shape && (opt_.rbf_form == 3 || (opt_.rbf_form == 0 && rbf_r2_ > RBF_DIRECT_ABOVE && rbf_r2_ <= RBF_GRID_MAX_R2)) && std::isfinite(rbf_r2_) && rbf_r2_ <= RBF_GRID_MAX_R2) {
+            rbf_grid_ = true;
+            rbf_direct_ = false;
+        }
+    }
     // symmetric variant: v2 kernels only; a negative polynomial degree can give inf on zero-padded rows -> full square
     const int ldx_probe = padded_features<T>(num_features);
     bool v2_ok = std::is_same_v<T, float> ? v2_eligible(opt_, ldx_probe, rbf_direct_) : v2_eligible_f64(opt_, ldx_probe);
@@ -797,7 +807,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         // (rbf: that kernel folds BOTH exponent terms out of the chain -- only while |c| = R2 / 2 stays small and the folded records are on)
         const bool rbf_ok = tile_params_.kernel_type != LSSVM_KERNEL_RBF || (opt_.rbf_fold != 0 && rbf_r2_ <= 2.0 * PAIR_FOLD_MAX_C);
         // (below 64 row blocks -- 8 192 points -- the 128-row workgroups have more items to spread over the chip: 3 000 points 13.8 against 19.7 us)
-        pair_ = sym_ && opt_.gram_mode != 0 && opt_.mfma_shape >= 3 && !wide_nl_ && !poly_generic && narrow && rbf_ok && num_tiles_ >= PAIR_MIN_TILES;
+        pair_ = sym_ && opt_.gram_mode != 0 && opt_.mfma_shape >= 3 && !wide_nl_ && !poly_generic && narrow && rbf_ok && num_tiles_ >= PAIR_MIN_TILES && !rbf_grid_;
     }
     {
         int ib_end = 0;
@@ -901,7 +911,30 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     }
     if constexpr (std::is_same_v<T, float>) {
         // the (centred, scaled) data once more as operand planes of the split kernels (features in natural order): see make_planes
-        if (!wide_linear_) make_planes(opt_, tile_params_, rbf_direct_, X_, nullptr, planes_, nullptr, st, wide_nl_, false, f16_probe_failed_);
+        if (rbf_grid_) {
+            // grid planes: g from the exponent scale alone (max|x_k| <= sqrt(R2), so |h / g| <= 2048 holds with it; (R2 + 160) / (g^2 / 2) <= 2^24 keeps the h.h chain of
+            // every pair that matters -- |t| <= 150, beyond that 2^t is 0 in fp32 -- exact), sigma moves the largest |h| below f16's maximum
+            const double r2 = std::max(rbf_r2_, 1.0);
+            const double g = std::exp2(std::ceil(std::log2(std::max(std::sqrt((r2 + 160.0) * 0x1p-23), std::sqrt(r2) / 2048.0))));
+            grid_sigma_ = static_cast<float>(std::exp2(std::floor(std::log2(60000.0 / (std::sqrt(r2) + g)))));
+            planes_.ldx16 = static_cast<int>(round_up(static_cast<long>(X_.dfeat), 64));
+            planes_.nplanes = 3;
+            planes_.shift = 0;
+            planes_.buf.alloc_zero(static_cast<size_t>(3) * X_.rows_alloc * planes_.ldx16, st);
+            efac_.alloc_zero(X_.rows_alloc, st);
+            DevBuf<unsigned> stats;
+            stats.alloc_zero(4, st);
+            split_grid_planes(X_.data.p, X_.ldx, X_.dfeat, static_cast<size_t>(X_.rows_alloc), planes_.ldx16, static_cast<float>(g), grid_sigma_, planes_.buf.p,
+                              static_cast<size_t>(X_.rows_alloc) * planes_.ldx16, c_.p, efac_.p, stats.p, st);
+            unsigned bad = 0;
+            LSSVM_HIP_CHECK(hipMemcpyAsync(&bad, stats.p, sizeof(bad), hipMemcpyDeviceToHost, st));
+            LSSVM_HIP_CHECK(hipStreamSynchronize(st));
+            if (bad != 0) throw Error(LSSVM_ERR_INTERNAL, "the grid planes of the rbf kernel do not represent this data (option rbf_form = 1 selects the direct kernel)");
+            planes_.mode = 2;  // f16 planes (the launcher picks the grid kernel from TileArgs::rbf_grid)
+            if (const char *dbg = std::getenv("LSSVM_MI355_DEBUG"); dbg != nullptr && dbg[0] == '1') {
+                std::fprintf(stderr, "[plssvm_amd] rbf on grid planes: exponent scale %.1f, g = 2^%d, sigma = 2^%d\n", rbf_r2_, static_cast<int>(std::log2(g)), static_cast<int>(std::log2(grid_sigma_)));
+            }
+        } else if (!wide_linear_) make_planes(opt_, tile_params_, rbf_direct_, X_, nullptr, planes_, nullptr, st, wide_nl_, false, f16_probe_failed_);
         if ((wide_nl_ || pair_) && planes_.mode == 0) throw Error(LSSVM_ERR_INTERNAL, "no operand planes for a path that was chosen from the shape alone");
         if (wide_nl_ && sym_) {
             // the row side of the panels-inside-a-tile kernel: the planes once more, every 16 x 32 block stored as the A fragment a wave loads
@@ -914,7 +947,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
             LSSVM_HIP_CHECK(hipGetLastError());
         }
         // rbf: folded records while the exponent terms stay small (rbf_r2_ = 2 max|c| in the exponent's unit)
-        if (planes_.mode != 0) dc_folded_ = tile_params_.kernel_type == LSSVM_KERNEL_RBF && opt_.rbf_fold != 0 && rbf_r2_ <= FOLD_MAX_R2;
+        if (planes_.mode != 0) dc_folded_ = tile_params_.kernel_type == LSSVM_KERNEL_RBF && opt_.rbf_fold != 0 && rbf_r2_ <= FOLD_MAX_R2 && !rbf_grid_;
     }
     interleave_features<T>(X_, st);
     if constexpr (std::is_same_v<T, double>) {
@@ -1005,6 +1038,11 @@ TileArgs<T> Problem<T>::tile_args(const T *v_dev) const {
     a.jc_head_count = jc_head_count_;
     a.ncols_valid = n_;
     set_kernel_scalars(a, tile_params_, rbf_direct_);
+    if (rbf_grid_) {
+        a.gamma = static_cast<T>(1.0 / (static_cast<double>(grid_sigma_) * static_cast<double>(grid_sigma_)));  // the chain carries sigma^2 t
+        a.er = efac_.p;
+        a.rbf_grid = 1;
+    }
     if (poly_prescaled_) a.gamma = T(1);
     if constexpr (std::is_same_v<T, float>) {
         a.Xr16f = planes_frag_.p;
@@ -1035,10 +1073,10 @@ template <typename T>
 void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
     // this shard's part of the implicit K * v: tile kernel over its row blocks (band by band), slabs added in a fixed order
     hipStream_t st = stream_.s;
-    // sampled matvecs: every `stride`-th, starting with the LAST of each run of `stride`, plus launches 1 ... 16 (a run of a few iterations still reports a
-    // kernel time) -- never launch 0, the cold first matvec of cg_begin, which would otherwise carry `stride` times its weight in the average
+    // sampled matvecs: every `stride`-th, starting with the LAST of each run of `stride`, plus launches 1 ... 4 (a run of a few iterations still reports a
+    // kernel time; no more than four: the first launches of a solve run a few per cent slow and would weigh on the average of a run of a hundred) -- never launch 0, the cold first matvec of cg_begin, which would otherwise carry `stride` times its weight in the average
     const uint64_t stride = static_cast<uint64_t>(event_stride());
-    const bool timed = matvec_launches_ % stride == stride - 1 || (matvec_launches_ >= 1 && matvec_launches_ <= 16);  // (short runs: every one of the first sixteen after launch 0)
+    const bool timed = matvec_launches_ % stride == stride - 1 || (matvec_launches_ >= 1 && matvec_launches_ <= 4);  // (short runs: every one of the first four after launch 0)
     ++matvec_launches_;
     auto free_event = [&]() -> EvPair * {
         if (!timed) return nullptr;
@@ -1062,7 +1100,7 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
         const int nzero = clear ? static_cast<int>(nvec_) : 0;
         const int nthreads = std::max(ncols, nzero);
         if constexpr (std::is_same_v<T, float>) {
-            hipLaunchKernelGGL(k_pack_dc, dim3((nthreads + 255) / 256), dim3(256), 0, st, v_dev, c_.p, ncols, dc_.p, a.dc_folded, Kv_.p, nzero);
+            hipLaunchKernelGGL(k_pack_dc, dim3((nthreads + 255) / 256), dim3(256), 0, st, v_dev, c_.p, ncols, dc_.p, rbf_grid_ ? 2 : a.dc_folded, Kv_.p, nzero, rbf_grid_ ? efac_.p : static_cast<const float *>(nullptr));
         } else {
             hipLaunchKernelGGL(k_pack_dc_f64, dim3((nthreads + 255) / 256), dim3(256), 0, st, v_dev, c_.p, ncols, dc_.p, Kv_.p, nzero);
         }
@@ -1106,7 +1144,7 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
                 if (band.ib_end > 1) {
                     if constexpr (std::is_same_v<T, float>) {
                         // (block pairs: one record per pair and column tile, kept as the record of the pair's second -- odd -- block)
-                        hipLaunchKernelGGL((k_reduce_colslab<T, 128>), dim3(band.ib_end - 1), dim3(1024), 0, st, colslab_.p, band.pair_origin, band.ib_begin, pair_ ? round_up(band.ib_end, 2) : band.ib_end, pair_ ? 2 : 1, Kv_.p);
+                        hipLaunchKernelGGL((k_reduce_colslab<T, 128>), dim3(band.ib_end - 1), dim3(1024), 0, st, colslab_.p, band.pair_origin, band.ib_begin, pair_ ? round_up(band.ib_end, 2) : band.ib_end, pair_ ? 2 : 1, Kv_.p, rbf_grid_ ? efac_.p : static_cast<const T *>(nullptr));
                     } else {  // fp64: records per 64-column sub-tile
                         hipLaunchKernelGGL((k_reduce_colslab<T, 64>), dim3(2 * (band.ib_end - 1)), dim3(1024), 0, st, colslab_.p, band.pair_origin, band.ib_begin, band.ib_end, 1, Kv_.p);
                     }
@@ -1633,7 +1671,7 @@ void Solver<T>::fill_info(lssvm_cg_info *info) {
     info->devices_used = world_;
     info->converged = converged_ ? 1 : 0;
     info->symmetric = p0.sym_ ? 1 : 0;
-    info->gram_mode = (p0.planes_.mode != 0 && p0.dc_.p != nullptr) ? p0.planes_.mode : 0;  // (a split kernel is dispatched only where both exist)
+    info->gram_mode = (p0.planes_.mode != 0 && p0.dc_.p != nullptr) ? (p0.rbf_grid_ ? 3 : p0.planes_.mode) : 0;  // (a split kernel is dispatched only where both exist; 3: rbf on grid planes)
     info->local_devices = static_cast<int32_t>(shards_.size());
     info->rbf_direct = p0.rbf_direct_ ? 1 : 0;
     info->rbf_exponent_scale = p0.rbf_r2_;
@@ -1775,7 +1813,7 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
         dc.alloc_zero(static_cast<size_t>(num_jt) * 256, s);
         const int ncols = num_jt * TILE;
         if constexpr (std::is_same_v<T, float>) {
-            hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, s, a.p, cS.p, ncols, dc.p, dc_folded, static_cast<float *>(nullptr), 0);
+            hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, s, a.p, cS.p, ncols, dc.p, dc_folded, static_cast<float *>(nullptr), 0, static_cast<const float *>(nullptr));
         } else {
             hipLaunchKernelGGL(k_pack_dc_f64, dim3((ncols + 255) / 256), dim3(256), 0, s, a.p, cS.p, ncols, dc.p, static_cast<double *>(nullptr), 0);
         }

@@ -58,7 +58,7 @@ struct Error : std::runtime_error {
 struct Options {
     // the 14 options of the product (lssvm_mi355_set_option; include/plssvm_amd.h documents them; round 4 retired xcd_map, lds_extra_kb, item_order,
     // linear_panel_features, check_shards, rbf_direct_above and mfma_shape = 1 -- measured, decided, now constants below)
-    int64_t rbf_form = 0;        // fp32 rbf: 0 automatic (matrix cores unless the exponent scale of the data exceeds RBF_DIRECT_ABOVE), 1 always the direct
+    int64_t rbf_form = 0;        // fp32 rbf: 0 automatic (matrix cores: norm expansion up to the exponent scale RBF_DIRECT_ABOVE, grid planes up to RBF_GRID_MAX_R2 on <= 128 features; else direct), 3 = grid planes where they exist, 1 always the direct
                                  // (x_i - x_j)^2 kernel on the vector ALU, 2 always the norm expansion on the matrix cores
     int64_t rbf_fold = 1;        // fp32 rbf on the split kernels: 1 = folded column records (2^c_j d_j | 2^c_j), accumulators start from c_i as the C
                                  // operand of their first MFMA (default, while the exponent scale stays below 200); 0 = start values c_i + c_j by vector adds
@@ -84,6 +84,8 @@ struct Options {
     int64_t pair_lag = 0;          // make DEV=1: plane-chunk steps waves 4-7 of a 256-row workgroup run behind waves 0-3 (0 = lock step: the shipped form; 1, 3
                                    // measured slower)
 };
+constexpr double RBF_GRID_MAX_R2 = 16384.0;   // rbf_form 0: grid planes (KT_RBFG) between RBF_DIRECT_ABOVE and this exponent scale, on at most 128 features: their error grows with the cross
+                                              // terms |h||s| ~ R2 sqrt(d) 2^-12 (7 eps of a row's summands at R2 = 12 600, d = 128 in the model of tests/tools/grid_planes_model.py)
 constexpr double RBF_DIRECT_ABOVE = 32.0;     // rbf_form 0: the formula-exact kernel above this exponent scale 2 gamma log2(e) max|x - mean|^2 (absolute error of the
                                               // matrix-core exponent ~ 2^-24 x that; [-1, 1]-scaled data with gamma = 1 / num_features has <= 3)
 constexpr int LINEAR_IN_TILE_BELOW = 10000;   // fp32 linear kernel on more than 256 features and fewer points than this: ONE launch of the polynomial tile kernels with degree 1
@@ -244,6 +246,8 @@ bool v2_eligible(const Options &o, int ldx, bool rbf_direct);
 void split_bf16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, uint16_t *planes, size_t plane_stride, hipStream_t s);  // tile_launch_f32s.hip
 /* the f16 planes of `scale` * X (scale = a power of two; shift = 0: two planes, shift > 0: the three shifted planes of the rbf kernels) + the representation
  * statistics {max rel^2, max |rest|^2, max |y|^2} as float bits */
+void split_grid_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, float g, float sigma, uint16_t *planes, size_t plane_stride, float *chg, float *efac, unsigned *stats,
+                       hipStream_t s);  // tile_launch_f32h.hip
 void split_f16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, float scale, int shift, uint16_t *planes, size_t plane_stride, unsigned *stats, hipStream_t s);  // tile_launch_f32h.hip
 void absmax_f32(const float *X, int ldx, int dfeat, size_t rows, unsigned *out, hipStream_t s);  // tile_launch_f32h.hip
 bool v2_eligible_f64(const Options &o, int ldx);
@@ -330,6 +334,9 @@ class Problem {
     int nvec_ = 0;  // allocated vector length (multiple of TILE * world)
     bool rbf_direct_ = false;
     double rbf_r2_ = 0.0;  // fp32 rbf: 2 gamma log2(e) max|x - mean|^2
+    bool rbf_grid_ = false;      // fp32 rbf on GRID planes (KT_RBFG): large exponent scales on the matrix cores at the direct form's accuracy (Problem<T>'s constructor)
+    float grid_sigma_ = 1.0f;    // ... the planes carry sigma x (a power of two), the chain sigma^2 t
+    DevBuf<T> efac_;             // ... E_i = 2^(c_i - ch_i) per row (c_ then holds sigma^2 ch_i)
     bool dc_folded_ = false;  // the (d_j | c_j) records carry (2^c_j d_j | 2^c_j): rbf on the 16x16x32 bf16x6 kernels
     bool pair_ = false;            // fp32 symmetric variant on the split kernels, <= 128 features per pass: 256-row workgroups on block pairs (lssvm_tile_f32_pair.hip.hpp)
     int part_blocks() const { return pair_ ? round_up(std::max(num_ib_, 1), 2) : std::max(num_ib_, 1); }  // row blocks of a row slab (whole pairs)

@@ -52,14 +52,32 @@ template <int KT, int NK64, bool SYM, bool HAND, int PL>
 __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
     static_assert(PL == 3 || PL == 2, "three bf16 planes (bf16x6) or two f16 planes (f16x3)");
     constexpr bool F16 = PL == 2;
-    constexpr int NKC = PL * NK64;  // plane-chunks (steps) per tile: for every 64-feature chunk the planes hi, mid (, lo)
+    // KT_RBFG ("grid planes", round 5; f16, hand-scheduled groups only): THREE column planes (h | s1 | s2, all carrying the scale sigma) and FOUR phases per tile, each
+    // over all 64-feature chunks:   0: h x h      1: h x (s1, s2)      2: s1 x (h, s1)      3: s2 x h      (column plane x row planes)
+    // -- six plane products like bf16x6, the h plane streamed twice -- because ORDER matters here: the accumulators start from sigma^2 (ch_i + ch_j) (ch = -|h|^2 / 2,
+    // multiples of g^2 / 2) and take ALL h.h products first (multiples of g^2): every partial sum is exactly representable, so phase 0 leaves
+    // -sigma^2 |h_i - h_j|^2 / 2 EXACTLY -- small for near pairs -- and the remaining terms are added at the magnitude of the result, not of the norms.
+    constexpr bool GRID = KT == KT_RBFG;
+    static_assert(!GRID || (HAND && PL == 2), "the grid-plane kernel exists with f16 planes and hand-scheduled groups only");
+    constexpr int NKC = GRID ? 4 * NK64 : PL * NK64;  // steps per tile: for every 64-feature chunk the planes hi, mid (, lo) -- grid planes: four phases x chunks
+    constexpr auto col_plane_of = [](int kc) constexpr { return GRID ? (kc / NK64 == 0 ? 0 : kc / NK64 - 1) : kc % PL; };
+    constexpr auto chunk_of = [](int kc) constexpr { return GRID ? kc % NK64 : kc / PL; };
+    constexpr auto nq_of = [](int kc) constexpr { return GRID ? ((kc / NK64 == 1 || kc / NK64 == 2) ? 2 : 1) : PL - kc % PL; };
     // ROW planes held in registers.  bf16x6: the three planes.  f16x3: the two planes -- or, for rbf (which cannot pre-scale the data: the
     // chain must leave the exponent itself), the SHIFTED planes P0 = 2^-6 hi, P1 = 2^6 mid, P2 = 2^6 hi (k_split_f16x2): the columns stream
     // (P0, P1), the rows hold (P2, P1) against column plane P0 and P0 against column plane P1, so that every product carries the net scale 1
     // while mid stays a normal f16 for entries down to 2^-8 instead of 2^-2.
-    constexpr int PLA = F16 ? ((KT == KT_RBF || KT == KT_RBFF) ? 3 : 2) : 3;
+    constexpr int PLA = F16 ? ((KT == KT_RBF || KT == KT_RBFF || GRID) ? 3 : 2) : 3;
     // row plane of the q-th product of column plane p
     constexpr auto row_plane = [](int p, int q) constexpr { return (F16 && PLA == 3) ? (p == 0 ? (q == 0 ? 2 : 1) : 0) : q; };
+    // ... of step kc (grid planes: by phase)
+    constexpr auto row_plane_of = [row_plane](int kc, int q) constexpr {
+        if (GRID) {
+            const int ph = kc / NK64;
+            return ph == 0 ? 0 : (ph == 1 ? (q == 0 ? 1 : 2) : (ph == 2 ? (q == 0 ? 0 : 1) : 0));
+        }
+        return row_plane(kc % PL, q);
+    };
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char *ring = smem_raw;                                                          // [V2_RING][128 rows][128 B]
     char *dcs = smem_raw + V2_RING * V2_SLOT_BYTES;                                 // [V2_DC_SLOTS][256 floats]
@@ -102,11 +120,11 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
             for (int kk = 0; kk < 2 * NK64; ++kk) afrag[p][kk][rb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(xr + 32 * kk));
         }
     }
-    if constexpr (KT == KT_RBF || KT == KT_RBFF) {
-        if (tid < TILE) cis[tid] = a.cr[row0 + tid];
+    if constexpr (KT == KT_RBF || KT == KT_RBFF || GRID) {
+        if (tid < TILE) cis[tid] = a.cr[row0 + tid];  // (grid planes: sigma^2 ch_i)
     }
     if constexpr (SYM) {
-        if (tid < TILE) dis[tid] = a.dvec[row0 + tid];
+        if (tid < TILE) dis[tid] = GRID ? a.dvec[row0 + tid] * a.er[row0 + tid] : a.dvec[row0 + tid];  // (grid planes: the row's folded factor E_i rides on d_i)
     }
     // make the compiler retire these ordinary loads HERE, before any LDS-DMA is in flight
 #pragma unroll
@@ -131,7 +149,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
         if (LSSVM_DBG(a, 16) && step > 3) return;  // ablation: no DMA after the prologue
         const int t = LSSVM_DBG(a, 1) ? 0 : step / NKC;  // ablation bit 1: always the same (L2-resident) tile
         const int kc = LSSVM_DBG(a, 1) ? 0 : step - t * NKC;
-        const char *base = sgpr_ptr(a.Xc16 + (kc % PL) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (kc / PL) * 64);
+        const char *base = sgpr_ptr(a.Xc16 + col_plane_of(kc) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + chunk_of(kc) * 64);
         const unsigned slot = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(dma_lds + static_cast<unsigned>(step % V2_RING) * V2_SLOT_BYTES)));
         static_for<0, 4>([&](auto i_c) { lds_dma16<decltype(i_c)::value * 1024>(dma_off[decltype(i_c)::value], base, slot); });
     };
@@ -147,7 +165,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
         if (LSSVM_DBG(a, 16)) return;
         if (LSSVM_DBG(a, 64) && i != 0) return;   // bit 64: a quarter of the DMA instructions (timing only)
         if (LSSVM_DBG(a, 128) && wave != 0) return;  // bit 128: only wave 0 issues DMA
-        const char *base = xc_tile + (KC3 / NKC) * tile_bytes + (KC % PL) * plane_bytes + (KC / PL) * 128;  // (f16x3 at 64 features: NKC = 2, three steps ahead can be TWO tiles ahead)
+        const char *base = xc_tile + (KC3 / NKC) * tile_bytes + col_plane_of(KC) * plane_bytes + chunk_of(KC) * 128;  // (f16x3 at 64 features: NKC = 2, three steps ahead can be TWO tiles ahead)
         lds_dma16<i * 1024>(dma_off[i], sgpr_ptr(base), dma_lds + slot_idx * V2_SLOT_BYTES);
     };
     auto issue_dc = [&](int t) {
@@ -262,7 +280,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
             // (KT_RBFF, folded records: the accumulators start from c_i, which the FIRST MFMA of every accumulator takes as its C operand -- the
             // same four values for all eight column blocks of a row block, loaded once per work item into civ0: no start-value instruction and
             // no LDS read at the head of a tile.  c_j comes in as the factor 2^c_j of the record.)
-            if constexpr (KT == KT_RBF) {  // the accumulators start at c_i + c_j
+            if constexpr (KT == KT_RBF || GRID) {  // the accumulators start at c_i + c_j (grid planes: sigma^2 (ch_i + ch_j), an exact sum)
                 f32x4 civ[2];
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) civ[rb] = *reinterpret_cast<const f32x4 *>(cis + wave * 32 + 16 * rb + 4 * g);
@@ -279,7 +297,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
         const unsigned phase = static_cast<unsigned>(s0) & (V2_RING - 1);  // ring slot of the tile's first step (uniform)
         static_for<0, NKC>([&](auto kc_c) {
             constexpr int kc = decltype(kc_c)::value;
-            constexpr int chunk = kc / PL, plane = kc % PL;
+            constexpr int chunk = chunk_of(kc), plane = col_plane_of(kc);
             const int step = s0 + kc;
             const unsigned slot_off = ((phase + kc) & (V2_RING - 1)) * V2_SLOT_BYTES;
             const unsigned slot_next_off = ((phase + kc + 1) & (V2_RING - 1)) * V2_SLOT_BYTES;
@@ -291,8 +309,8 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
                 // is there a group after this one?  (steady state: always; last tiles of the work item: not after the very last group)
                 const bool more = !decltype(checked)::value || mm < 3 || step + 1 < nsteps;
                 if constexpr (HAND) {
-                    constexpr int NQ = PL - plane;
-                    constexpr int Z = ((KT != KT_RBF) && kc == 0 && kk == 0) ? (KT == KT_RBFF ? 2 : 1) : 0;  // first MFMA of every accumulator of this column half: C = 0 (or c_i: KT_RBFF)
+                    constexpr int NQ = nq_of(kc);
+                    constexpr int Z = ((KT != KT_RBF && !GRID) && kc == 0 && kk == 0) ? (KT == KT_RBFF ? 2 : 1) : 0;  // first MFMA of every accumulator of this column half: C = 0 (or c_i: KT_RBFF)
                     constexpr int CUR = mm & 1;
                     if constexpr (mm == 2) {
                         if constexpr (SYM) {
@@ -310,7 +328,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
                     f32x4 &c0 = acc[0][4 * cbh + 0], &c1 = acc[1][4 * cbh + 0], &c2 = acc[0][4 * cbh + 1], &c3 = acc[1][4 * cbh + 1];
                     f32x4 &c4 = acc[0][4 * cbh + 2], &c5 = acc[1][4 * cbh + 2], &c6 = acc[0][4 * cbh + 3], &c7 = acc[1][4 * cbh + 3];
                     // row planes 0 .. NQ - 1 of this k32 step (the dispatcher ignores the operands beyond 2 NQ)
-                    constexpr int P0 = row_plane(plane, 0), P1 = NQ >= 2 ? row_plane(plane, 1) : P0, P2 = NQ >= 3 ? row_plane(plane, 2) : P0;
+                    constexpr int P0 = row_plane_of(kc, 0), P1 = NQ >= 2 ? row_plane_of(kc, 1) : P0, P2 = NQ >= 3 ? row_plane_of(kc, 2) : P0;
                     const bf16x8 &a00 = afrag[P0][2 * chunk + kk][0], &a01 = afrag[P0][2 * chunk + kk][1];
                     const bf16x8 &a10 = afrag[P1][2 * chunk + kk][0], &a11 = afrag[P1][2 * chunk + kk][1];
                     const bf16x8 &a20 = afrag[P2][2 * chunk + kk][0], &a21 = afrag[P2][2 * chunk + kk][1];
@@ -413,7 +431,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
                     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float kv = LSSVM_DBG(a, 2) ? acc[rb][cb][e] : apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(acc[rb][cb][e], a);  // bit 2: no exp
+                            float kv = LSSVM_DBG(a, 2) ? acc[rb][cb][e] : apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(GRID ? acc[rb][cb][e] * a.gamma : acc[rb][cb][e], a);  // bit 2: no exp; grid planes: the chain carries sigma^2, gamma = sigma^-2
                             if constexpr (KT == KT_POLY) {
                                 if (padcol[cb]) kv = 0.0f;
                             }
@@ -484,6 +502,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
         v += __shfl_xor(v, 2);
         v += __shfl_xor(v, 1);
         if constexpr (KT == KT_LINEAR && F16) v *= a.out_scale;
+        if constexpr (GRID) v *= a.er[row0 + wave * 32 + 16 * (i >> 2) + 4 * g + (i & 3)];  // the row's folded factor E_i, once per work item
         rowpart[i] = v;
     }
     if (r == 0) {
@@ -525,6 +544,12 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
     s6w_body<KT, NK64, SYM, false, 2>(a);
 }
 constexpr int F16_HAND_MAX_NK64 = 2;
+/* rbf on grid planes (KT_RBFG, round 5): f16 planes (h | s1 | s2), six plane products in four phases, hand-scheduled groups, <= 128 features */
+template <int NK64, bool SYM>
+__global__ __launch_bounds__(TILE_THREADS, 2) LSSVM_HAND_VGPR_CAP void tile_matvec_f32_g6h(const TileArgs<float> a) {
+    static_assert(NK64 <= F16_HAND_MAX_NK64, "the hand-scheduled groups assume the 256-register budget of two waves per SIMD");
+    s6w_body<KT_RBFG, NK64, SYM, true, 2>(a);
+}
 template <int KT, int NK64, bool SYM>
 __global__ __launch_bounds__(TILE_THREADS, 2) LSSVM_HAND_VGPR_CAP void tile_matvec_f32_f3h(const TileArgs<float> a) {
     static_assert(NK64 <= F16_HAND_MAX_NK64, "the hand-scheduled groups assume the 256-register budget of two waves per SIMD");

@@ -18,6 +18,8 @@ constexpr int KT_POLY2 = 3;  // v2 tile kernels only: polynomial with degree 2 /
 constexpr int KT_POLY3 = 4;
 constexpr int KT_RBFF = 5;   // bf16x6 16x16x32 kernels only: rbf with the FOLDED records (w_j = 2^c_j d_j | e_j = 2^c_j): the accumulators start from c_i as
                              // the C operand of their first MFMA (no start-value adds), K_ij = 2^acc * e_j
+constexpr int KT_RBFG = 6;   // f16 kernels of s6w_body only (round 5): rbf on GRID planes -- x = h + s1 + s2 with h on a grid of spacing g, so that the accumulator, started from
+                             // sigma^2 (ch_i + ch_j) and fed the h.h products first, holds -|h_i - h_j|^2 / 2 EXACTLY before the small terms arrive
 
 constexpr int TILE = 128;          // rows / columns of one workgroup tile of the implicit matrix
 constexpr int TILE_THREADS = 256;  // 4 wave64 arranged 2 x 2, each owning a 64 x 64 sub-tile
@@ -41,6 +43,8 @@ struct TileArgs {
     const T *cr;      // rbf: -0.5 * |x_i|^2 per row-side point
     const T *cc;      // rbf: -0.5 * |x_j|^2 per column-side point
     const T *dvec;    // [num_jt*TILE] vector multiplied from the right, EXACT zeros beyond the valid columns
+    const T *er;      // KT_RBFG: E_i = 2^(c_i - ch_i) per row (the part of the exponent the grid norms leave out, folded as a factor); NULL otherwise
+    int rbf_grid;     // host side only: != 0 selects the grid-plane rbf kernel (KT_RBFG)
     const T *dc;      // v2 kernels: packed [num_jt][256] records (d_j | c_j) for LDS-DMA (k_pack_dc); KT_RBFF: (2^c_j d_j | 2^c_j)
     int dc_folded;    // host side only: 1 if the records carry the folded form (rbf on the 16x16x32 bf16x6 kernels while |c| stays small)
     const uint16_t *Xr16;  // fp32 split kernels: the row side as three bf16 planes [3][rows][ldx16] (hi, mid, lo: x = hi + mid + lo exactly; "bf16x6")

@@ -66,6 +66,48 @@ __global__ void k_split_f16x2(const float *__restrict__ X, int ldx, int dfeat, s
     }
 }
 
+/* GRID planes of the centred, scaled rbf data y (round 5, KT_RBFG; lssvm_tile_f32_split.hip.hpp): h = g rint(y / g), s = y - h (exact), planes [3][rows][ldx16] =
+ * (f16(sigma h) -- exact: |h / g| <= 2048 --, s1 = f16(sigma s), s2 = f16(sigma s - s1)); per row chg = sigma^2 ch with ch = -|h|^2 / 2 (a multiple of g^2 / 2: exact in
+ * fp32 while (R2 + 160) / (g^2 / 2) <= 2^24, the host's choice of g) and E = 2^(c - ch), c = -|y|^2 / 2 in double: the part of the exponent the grid norms leave out.
+ * stats[0] becomes a NaN pattern if a plane overflows f16 (the host then falls back).  One wave per row. */
+__global__ void k_split_grid_f16(const float *__restrict__ X, int ldx, int dfeat, size_t rows, int ldx16, float g, float sigma, uint16_t *__restrict__ planes, size_t plane_stride,
+                                 float *__restrict__ chg, float *__restrict__ efac, unsigned *__restrict__ stats) {
+    const size_t row = static_cast<size_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float inv_g = 1.0f / g;  // (a power of two)
+    double sh = 0.0, sy = 0.0;
+    bool overflow = false;
+    for (int f = lane; f < ldx16; f += 64) {
+        const float y = f < dfeat ? X[row * ldx + f] : 0.0f;
+        const float h = rintf(y * inv_g) * g;
+        const float sres = (y - h) * sigma;
+        const float hs = h * sigma;
+        const _Float16 p0 = static_cast<_Float16>(hs);
+        const _Float16 p1 = static_cast<_Float16>(sres);
+        const _Float16 p2 = static_cast<_Float16>(sres - static_cast<float>(p1));
+        overflow = overflow || !(fabsf(hs) <= 65504.0f) || static_cast<float>(p0) != hs;
+        planes[row * ldx16 + f] = __builtin_bit_cast(uint16_t, p0);
+        planes[plane_stride + row * ldx16 + f] = __builtin_bit_cast(uint16_t, p1);
+        planes[2 * plane_stride + row * ldx16 + f] = __builtin_bit_cast(uint16_t, p2);
+        sh = fma(static_cast<double>(h), static_cast<double>(h), sh);
+        sy = fma(static_cast<double>(y), static_cast<double>(y), sy);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sh += __shfl_xor(sh, off);
+        sy += __shfl_xor(sy, off);
+    }
+    if (lane == 0) {
+        const double ch = -0.5 * sh, c = -0.5 * sy;
+        const float chs = static_cast<float>(static_cast<double>(sigma) * static_cast<double>(sigma) * ch);
+        chg[row] = chs;
+        efac[row] = static_cast<float>(exp2(c - ch));
+        if (static_cast<double>(chs) != static_cast<double>(sigma) * static_cast<double>(sigma) * ch) overflow = true;  // (the start value must be exact)
+    }
+    if (__any(overflow) && lane == 0) atomicMax(stats + 0, 0x7FC00000u);
+}
+
 /* max |x| over the valid entries of X (as a float bit pattern, atomicMax) */
 __global__ void k_absmax(const float *__restrict__ X, int ldx, int dfeat, size_t rows, unsigned *__restrict__ out) {
     const size_t total = rows * static_cast<size_t>(ldx);
@@ -134,7 +176,22 @@ static void launch_f3(const TileArgs<float> &a, int kernel_type, dim3 grid, hipS
             }
             break;
         default:
-            if (a.dc_folded != 0) {
+            if (a.rbf_grid != 0) {  // grid planes (KT_RBFG): hand-scheduled groups, at most 128 features
+                const dim3 block(TILE_THREADS);
+                switch (a.nk64) {
+#ifndef LSSVM_DEV_SUBSET
+                    case 1:
+                        ensure_dynamic_lds(tile_matvec_f32_g6h<1, SYM>, V2_LDS_BYTES);
+                        hipLaunchKernelGGL((tile_matvec_f32_g6h<1, SYM>), grid, block, V2_LDS_BYTES, s, a);
+                        break;
+#endif
+                    case 2:
+                        ensure_dynamic_lds(tile_matvec_f32_g6h<2, SYM>, V2_LDS_BYTES);
+                        hipLaunchKernelGGL((tile_matvec_f32_g6h<2, SYM>), grid, block, V2_LDS_BYTES, s, a);
+                        break;
+                    default: throw Error(LSSVM_ERR_INTERNAL, "no grid-plane rbf tile kernel for this number of features");
+                }
+            } else if (a.dc_folded != 0) {
                 launch_f3_kt<KT_RBFF, SYM>(a, grid, s);
             } else {
                 launch_f3_kt<KT_RBF, SYM>(a, grid, s);
@@ -161,6 +218,12 @@ void launch_f16_tile_kernel(const TileArgs<float> &a, int kernel_type, dim3 grid
 
 void split_f16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, float scale, int shift, uint16_t *planes, size_t plane_stride, unsigned *stats, hipStream_t s) {
     hipLaunchKernelGGL(k_split_f16x2, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, X, ldx, dfeat, rows, ldx16, scale, shift, planes, plane_stride, stats);
+    LSSVM_HIP_CHECK(hipGetLastError());
+}
+
+void split_grid_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, float g, float sigma, uint16_t *planes, size_t plane_stride, float *chg, float *efac, unsigned *stats,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_split_grid_f16, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, X, ldx, dfeat, rows, ldx16, g, sigma, planes, plane_stride, chg, efac, stats);
     LSSVM_HIP_CHECK(hipGetLastError());
 }
 

@@ -340,20 +340,25 @@ def test_rbf_large_exponent_scale_switches_to_the_direct_kernel(oracle, case):
     scale = K @ absv + (2.0 + np.abs(q64)) * absv.sum() + np.abs(q64) @ absv + absv
     eps = np.finfo(np.float32).eps
     errs = {}
-    for form in (0, 2):
+    for form in (0, 2, 3, 1):
         _capi.set_option("rbf_form", form)
         with backend.ResidentProblem(p, X) as prob:
             info = prob.info()
             got = prob.matvec(v, np.zeros(n, np.float32), 1.0)
         if form == 0:
             r2 = info["rbf_exponent_scale"]
-            direct = info["rbf_direct"]
-            assert direct == (1 if r2 > 32 else 0) and (case == "gamma1" or direct == 1)  # gamma = 1 sits just below the threshold (R2 ~ 26)
+            grid = info["gram_mode"] == 3
+            # round 5: above the threshold the automatic choice is the matrix cores on GRID planes (KT_RBFG), no longer the direct kernel (128 features, R2 <= 16 384)
+            assert info["rbf_direct"] == 0 and grid == (r2 > 32) and (case == "gamma1" or grid)  # gamma = 1 sits just below the threshold (R2 ~ 26)
+        elif form == 1:
+            assert info["rbf_direct"] == 1
         else:
-            assert info["rbf_direct"] == 0
+            assert info["rbf_direct"] == 0 and info["gram_mode"] == (3 if form == 3 else 2)
         # the GPU's own q (fp32) enters the rank-1 terms: compare K*v + rank-1 with the float64 product of the SAME fp32 data
         errs[form] = float(np.max(np.abs(got - want) / scale))
-    assert errs[0] < (16 if direct else 32) * eps, (case, errs, r2)  # below the threshold the matrix-core form keeps 32 eps: the threshold's promise
+    print(f"\n{case}: exponent scale {r2:.1f}: automatic {errs[0] / eps:.2f} eps, grid planes {errs[3] / eps:.2f} eps, direct kernel {errs[1] / eps:.2f} eps, norm expansion {errs[2] / eps:.1f} eps")
+    assert errs[0] < (16 if grid else 32) * eps, (case, errs, r2)  # below the threshold the norm expansion keeps 32 eps: the threshold's promise
+    assert errs[3] < 16 * eps and errs[1] < 16 * eps, (case, errs, r2)  # the grid planes hold the direct form's bar at every scale
     assert errs[2] < 2.0 ** -22 * max(r2, 32.0), (case, errs, r2)
     # predict_values takes the same decision
     alpha = rng.uniform(-1, 1, size=N).astype(np.float32)
@@ -363,7 +368,70 @@ def test_rbf_large_exponent_scale_switches_to_the_direct_kernel(oracle, case):
     scale_p = Kp @ np.abs(alpha.astype(np.float64)) + 0.25
     _capi.set_option("rbf_form", 0)
     got_p, _ = backend.predict_values(p, X, alpha, 0.25, None, pts)
-    assert np.max(np.abs(got_p - want_p) / scale_p) < (16 if direct else 32) * eps
+    assert np.max(np.abs(got_p - want_p) / scale_p) < (16 if r2 > 32 else 32) * eps  # (predict_values keeps the direct kernel above the threshold)
+
+
+@pytest.mark.parametrize("d, gamma, spread, devices", [(128, 2.0, 1.0, None), (128, 30.0, 1.0, None), (64, 8.0, 1.0, None), (100, 1.0 / 100, 25.0, None), (40, 60.0, 1.0, None),
+                                                       (128, 4.0, 1.0, [0, 0, 0]), (96, 100.0, 1.0, None)])
+def test_rbf_on_grid_planes_keeps_the_direct_forms_accuracy_on_the_matrix_cores(oracle, d, gamma, spread, devices):
+    """Round 5.  Exponent scales R2 = 2 gamma log2(e) max|x - mean|^2 from 80 to 13 000 on 40 ... 128 features, data with
+    near-duplicate points (the pairs that lose digits in the norm expansion) and far ones.  The automatic choice is the matrix cores on GRID planes (tile_matvec_f32_g6h:
+    x = h + s1 + s2 with h on a grid, the accumulators started from sigma^2 (ch_i + ch_j) and fed the h.h products first, so that the large terms cancel EXACTLY);
+    asserted against the float64 oracle on the scale of each row's summands, symmetric and full square, one device and three shards: below 16 eps like the direct
+    kernel -- which the same data also runs (rbf_form = 1) -- where the norm expansion (rbf_form = 2) is off by tens to thousands of eps; and a CG solve on the grid
+    planes ends where the direct kernel's ends."""
+    rng = np.random.default_rng(5)
+    N = 1700
+    X, y = make_blobs_pm1(N, d, seed=6, dtype=np.float32)
+    X = (X * spread).astype(np.float32)
+    X[1::2] = (X[0::2] + rng.normal(0, 2e-3 * spread, size=X[0::2].shape)).astype(np.float32)  # near-duplicate pairs
+    p = Parameter(kernel_type="rbf", gamma=gamma)
+    n = N - 1
+    X64 = X.astype(np.float64)
+    q64 = oracle.q("rbf", X64, gamma=gamma)
+    # a right-hand side orthogonal to 1 and to q: the rank-1 terms of Abar v (QA S - q.v, S q_i; three orders of magnitude above K v on such data) vanish, and the
+    # comparison sees the kernel matrix itself
+    v64 = rng.uniform(-1, 1, size=n)
+    basis = np.linalg.qr(np.stack([np.ones(n), q64], axis=1))[0]
+    for _ in range(2):
+        v64 = v64 - basis @ (basis.T @ v64)
+    v = v64.astype(np.float32)
+    v64 = v.astype(np.float64)
+    want = oracle.matvec("rbf", X64, q64, v64, np.zeros(n), 2.0, 1.0, 1.0, gamma=gamma)
+    sq = np.einsum("ij,ij->i", X64, X64)
+    K = np.exp(-gamma * np.maximum(sq[:n, None] + sq[None, :n] - 2.0 * (X64[:n] @ X64[:n].T), 0.0))
+    absv = np.abs(v64)
+    scale = K @ absv + (2.0 + np.abs(q64)) * absv.sum() + np.abs(q64) @ absv + absv
+    scale_k = K @ absv + absv + (2.0 + np.abs(q64)) * abs(v64.sum()) + abs(q64 @ v64)  # (what is left of the rank-1 terms after the fp32 rounding of v)
+    eps = np.finfo(np.float32).eps
+    errs, errs_k = {}, {}
+    for name, form, sym in (("automatic", 0, 1), ("automatic, full square", 0, 0), ("direct", 1, 1), ("norm expansion", 2, 1)):
+        _capi.set_option("rbf_form", form)
+        _capi.set_option("symmetric", sym)
+        with backend.ResidentProblem(p, X, devices=devices) as prob:
+            info = prob.info()
+            got = prob.matvec(v, np.zeros(n, np.float32), 1.0)
+            again = prob.matvec(v, np.zeros(n, np.float32), 1.0)
+        assert np.array_equal(got, again)
+        r2 = info["rbf_exponent_scale"]
+        if form == 0:
+            assert 32 < r2 <= 16384 and info["gram_mode"] == 3 and info["rbf_direct"] == 0 and info["symmetric"] == sym, (r2, info)
+        errs[name] = float(np.max(np.abs(got - want) / scale))
+        errs_k[name] = float(np.max(np.abs(got - want) / scale_k))
+    print(f"\n{N} x {d}, gamma {gamma:g}, exponent scale {r2:.0f}: on the scale of all summands: " + ", ".join(f"{k} {e / eps:.2f} eps" for k, e in errs.items())
+          + "; of the K v summands alone: " + ", ".join(f"{k} {e / eps:.1f} eps" for k, e in errs_k.items()))
+    assert errs["automatic"] < 16 * eps and errs["automatic, full square"] < 16 * eps and errs["direct"] < 16 * eps, errs
+    # the sharper yardstick: sum_j K_ij |v_j| alone (the rank-1 terms, evaluated in double by the library, are 10 ... 1000 x larger and would hide the kernel's error)
+    assert errs_k["automatic"] < 32 * eps and errs_k["automatic, full square"] < 32 * eps and errs_k["automatic"] < 2 * errs_k["direct"] + 4 * eps, errs_k
+    assert errs_k["norm expansion"] > 4 * errs_k["automatic"], errs_k  # what the grid planes are for
+    if devices is None:
+        sol = {}
+        for form in (0, 1):
+            _capi.set_option("rbf_form", form)
+            _capi.set_option("symmetric", 1)
+            sol[form] = backend.solve_system_of_linear_equations(p, X, y, 1e-6, 300)
+        assert abs(int(sol[0][2]["iterations"]) - int(sol[1][2]["iterations"])) <= 2
+        assert ol.rel_inf(sol[0][0], sol[1][0]) < 1e-3 and abs(float(sol[0][1]) - float(sol[1][1])) < 1e-3 * max(1.0, abs(float(sol[1][1])))
 
 
 def test_rbf_folded_and_unfolded_column_records_agree(oracle):

@@ -35,11 +35,12 @@ def main():
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--variant", action="append", default=[])
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--gamma", type=float, default=None, help="rbf / polynomial gamma (default 1 / features)")
     args = ap.parse_args()
     variants = args.variant or [""]
     dt = np.dtype(args.dtype)
     X, y = make_blobs_pm1(args.points, args.features, seed=42, dtype=dt)
-    p = Parameter(kernel_type=args.kernel)
+    p = Parameter(kernel_type=args.kernel, gamma=args.gamma)
     defaults = {n: _capi.get_option(n) for n in _capi.OPTION_NAMES + _capi.DEV_OPTION_NAMES}
     ref = None
     v = np.random.default_rng(1).uniform(-1, 1, size=args.points - 1).astype(dt)

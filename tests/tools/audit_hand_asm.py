@@ -19,7 +19,7 @@ import re
 import subprocess
 import sys
 
-HAND = re.compile(r"tile_matvec_f32_(s6h|f3h|f3p|pair)")
+HAND = re.compile(r"tile_matvec_f32_(s6h|f3h|g6h|f3p|pair)")
 
 
 def first_private(name):
