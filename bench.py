@@ -187,7 +187,7 @@ def kernel_ms_between(i0, i1):
 
 
 def plane_products_of(gram_mode: int) -> float:
-    return {0: 1.0, 1: 6.0, 2: 3.0}[gram_mode]
+    return {0: 1.0, 1: 6.0, 2: 3.0, 3: 6.0}[gram_mode]  # (3: rbf on f16 grid planes, six plane products)
 
 
 def short_leg(name, steps, warmup, seed, device):
@@ -230,7 +230,7 @@ def short_leg(name, steps, warmup, seed, device):
             "avg_launch_ms": kern_ms, "launches": launches, "launches_timed": timed, "tile_launches_per_matvec": int(i1.get("tile_launches_per_matvec", 1)),
             "frac": (2.0 * use_mac * d * pp / kern_s / 1e12 / peak) if kern_ms > 0 else None,
             "executed_frac": (2.0 * exe_mac * d * pp / kern_s / 1e12 / peak) if kern_ms > 0 else None, "peak": peak,
-            "gram_mode": {0: "native", 1: "bf16x6", 2: "f16x3"}[gram_mode], "dtype": "f32" if wl["dtype"] == "float32" else "f64", "symmetric": symmetric}
+            "gram_mode": {0: "native", 1: "bf16x6", 2: "f16x3", 3: "f16 grid planes"}[gram_mode], "dtype": "f32" if wl["dtype"] == "float32" else "f64", "symmetric": symmetric}
 
 
 def free_port() -> int:
@@ -566,7 +566,7 @@ def main():
     # fp32-equivalent accuracy.  The roofline of those kernels is the dense 16-bit MFMA peak (16 x the f32 MFMA rate,
     # MI355X_MICROARCH.md "Matrix cores": f16 and bf16 take the same cycles), and the kernel's own flop count is 3 x / 6 x the fp32 count.
     gram_mode = int(i1.get("gram_mode", 0))
-    gram_name = {0: "native", 1: "bf16x6", 2: "f16x3"}[gram_mode]
+    gram_name = {0: "native", 1: "bf16x6", 2: "f16x3", 3: "f16 grid planes"}[gram_mode]
     bf16x6 = gram_mode != 0  # (a split mode on the 16-bit matrix cores)
     plane_products = plane_products_of(gram_mode)
     fp32_equivalent = achieved
@@ -599,7 +599,9 @@ def main():
             "dtype": "f32" if wl["dtype"] == "float32" else "f64", "data": "synthetic",
             "arithmetic": {1: "fp32 operands split exactly into 3 bf16 planes, 6 plane products per multiply-add accumulated in fp32 on the bf16 matrix cores",
                            2: "fp32 operands as 2 f16 planes (hi + mid, representation checked on the data at set-up), 3 plane products per multiply-add "
-                              "accumulated in fp32 on the f16 matrix cores"}.get(gram_mode, "native " + wl["dtype"] + " matrix-core fma chains"),
+                              "accumulated in fp32 on the f16 matrix cores",
+                           3: "rbf with a large exponent scale: fp32 operands as 3 f16 planes (a grid plane + 2 rest planes), 6 plane products per multiply-add accumulated in fp32 "
+                              "on the f16 matrix cores, the grid-plane products first so that the large terms cancel exactly"}.get(gram_mode, "native " + wl["dtype"] + " matrix-core fma chains"),
             "config": {"workload": wl["desc"], "num_points": N, "num_features": d, "kernel": wl["kernel"], "gamma": 1.0 / d, "cost": 1.0,
                        "seed": args.seed, "library_options": args.option, "parallelism": parallelism, "shards": shards, "exchange": exchange_names.get(int(i1.get("exchange", 0)), "?"),
                        "residuum_after_timed_steps": i1["residuum"], "residuum_bit_equal_on_all_ranks": ranks_agree,
@@ -656,7 +658,7 @@ def main():
                 prob = None
             import ctypes as C
 
-            f16_bit = 2 if gram_mode == 2 else 0  # the bare loop runs the instruction of the kernel it is compared with
+            f16_bit = 2 if gram_mode in (2, 3) else 0  # the bare loop runs the instruction of the kernel it is compared with
 
             def ceiling(b_from_lds):
                 tf, ghz, nominal = C.c_double(0), C.c_double(0), C.c_double(0)

@@ -75,7 +75,8 @@ typedef struct lssvm_cg_info {
     int32_t devices_used;    /* world size of the row-block sharding (1 = single GPU) */
     int32_t converged;       /* 1 if the stop test delta <= eps^2 * delta0 fired */
     int32_t symmetric;       /* 1 if the implicit matvec evaluated only the tiles on/below the diagonal (half the multiply-adds) */
-    int32_t gram_mode;       /* fp32: how the Gram tiles ran: 0 = native v_mfma_f32 chains, 1 = "bf16x6" (exact 3-way bf16 split), 2 = "f16x3" (two f16 planes per operand) */
+    int32_t gram_mode;       /* fp32: how the Gram tiles ran: 0 = native v_mfma_f32 chains, 1 = "bf16x6" (exact 3-way bf16 split), 2 = "f16x3" (two f16 planes per operand),
+                              * 3 = rbf on f16 GRID planes (three planes, six products: option rbf_form) */
     int32_t local_devices;   /* devices driven by THIS process (1 for a single GPU and for one process per GPU) */
     int32_t exchange;        /* how the partial K*v vectors were combined per matvec: 0 none, 1 RCCL (all-reduce / all-gather), 2 peer kernels over xGMI */
     int32_t tile_launches_per_matvec; /* tile-kernel launches per implicit matvec: row-block bands (option colslab_band_mb) x feature panels of a wide linear problem; matvec_kernel_ms is their SUM */
@@ -258,8 +259,11 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *   "rbf_form"      fp32 rbf: 0 = automatic (default): the norm expansion c_i + c_j + x_i'.x_j' on the matrix cores, unless
  *                   R2 = 2 gamma log2(e) max|x - mean|^2 exceeds 32 -- the expansion's exponent carries an absolute error of
  *                   ~2^-24 R2 whatever the distance of the pair, which nearby pairs (K ~ 1) see as a relative error of K
- *                   ([-1,1]-scaled data with gamma = 1 / num_features has R2 <= 3); then, and with
- *                   1 = always, the formula-exact (x_i - x_j)^2 kernel on the vector ALU runs (5x slower); 2 = always the matrix cores
+ *                   ([-1,1]-scaled data with gamma = 1 / num_features has R2 <= 3); then, up to R2 = 8192 and on at most 128 features, the matrix
+ *                   cores on GRID planes (since round 5: x = h + s1 + s2 with h on a grid, the accumulators started from the exact grid norms and
+ *                   fed the h.h products first, so that the large terms cancel exactly -- the direct form's accuracy at 1.6x the f16x3 time); beyond
+ *                   that, and with 1 = always, the formula-exact (x_i - x_j)^2 kernel on the vector ALU (10x slower than the grid planes at
+ *                   50 000 x 128); 2 = always the norm expansion; 3 = the grid planes wherever they exist (R2 <= 8192, <= 128 features)
  *   "rbf_fold"      fp32 rbf on the split kernels: 1 (default) = the column records carry (2^c_j d_j | 2^c_j) and the accumulators start
  *                   from c_i as the C operand of their first MFMA (256-row workgroups: from 0, the row's term folded too) -- no start-value
  *                   instructions, K_ij = 2^acc 2^c_j (one more rounding than 2^(acc + c_j); used while the exponent scale R2 <= 200 keeps both factors

@@ -137,7 +137,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
     // ---- LDS-DMA addressing: identical to tile_matvec_f32_s6 (the LDS image does not depend on the MFMA shape) ----
     unsigned dma_off[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < (GRID ? 2 : 4); ++i) {
         const int row = 8 * (4 * wave + i) + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         dma_off[i] = 2u * static_cast<unsigned>(row * a.ldx16 + 8 * c);
@@ -151,7 +151,16 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
         const int kc = LSSVM_DBG(a, 1) ? 0 : step - t * NKC;
         const char *base = sgpr_ptr(a.Xc16 + col_plane_of(kc) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + chunk_of(kc) * 64);
         const unsigned slot = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(dma_lds + static_cast<unsigned>(step % V2_RING) * V2_SLOT_BYTES)));
-        static_for<0, 4>([&](auto i_c) { lds_dma16<decltype(i_c)::value * 1024>(dma_off[decltype(i_c)::value], base, slot); });
+        // (grid planes: pieces i and i + 2 lie 16 rows apart with the same swizzle, so two lane offsets + a uniform 32 ldx16 bytes on the base do for four -- the
+        // 128-feature symmetric instantiation has no two registers to spare)
+        static_for<0, 4>([&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            if constexpr (GRID) {
+                lds_dma16<i * 1024>(dma_off[i & 1], sgpr_ptr(base + (i >> 1) * 32 * a.ldx16), slot);
+            } else {
+                lds_dma16<i * 1024>(dma_off[i], base, slot);
+            }
+        });
     };
     // steady state: the chunk (tile t or t + 1, plane-chunk KC known at compile time) costs two scalar adds per DMA instead of the divisions and
     // 64-bit multiplies of the generic form; `xc_tile` = first byte of column tile t in plane 0 (uniform), advanced once per tile
@@ -166,7 +175,11 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
         if (LSSVM_DBG(a, 64) && i != 0) return;   // bit 64: a quarter of the DMA instructions (timing only)
         if (LSSVM_DBG(a, 128) && wave != 0) return;  // bit 128: only wave 0 issues DMA
         const char *base = xc_tile + (KC3 / NKC) * tile_bytes + col_plane_of(KC) * plane_bytes + chunk_of(KC) * 128;  // (f16x3 at 64 features: NKC = 2, three steps ahead can be TWO tiles ahead)
-        lds_dma16<i * 1024>(dma_off[i], sgpr_ptr(base), dma_lds + slot_idx * V2_SLOT_BYTES);
+        if constexpr (GRID) {
+            lds_dma16<i * 1024>(dma_off[i & 1], sgpr_ptr(base + (i >> 1) * 32 * a.ldx16), dma_lds + slot_idx * V2_SLOT_BYTES);
+        } else {
+            lds_dma16<i * 1024>(dma_off[i], sgpr_ptr(base), dma_lds + slot_idx * V2_SLOT_BYTES);
+        }
     };
     auto issue_dc = [&](int t) {
         if (lane < 16) {

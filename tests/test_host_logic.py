@@ -144,3 +144,26 @@ def test_bench_parent_stops_when_its_ranks_fail():
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode != 0 and time.time() - t0 < 300
     assert "no HIP device is visible" in out.stderr or "needs an MI355X" in out.stderr, out.stderr[-500:]
+
+
+def test_the_grid_plane_rbf_scheme_in_the_numpy_model():
+    """Round 5: the arithmetic of the rbf kernel on GRID planes (tile_matvec_f32_g6h) restated in numpy (tests/tools/grid_planes_model.py) --
+    float16 planes, exact products, one fp32 rounding per 32-feature MFMA.  On clustered data with an exponent scale of ~1300 (gamma = 10) the accumulator chain over the
+    grid plane must be EXACT for every pair whose kernel value is not zero in fp32, the grid planes must stay within a small factor of the formula-exact direct form, and
+    the norm expansion they replace must be two orders of magnitude off -- the premise of the automatic choice between exponent scales of 32 and 8 192."""
+    import importlib.util
+    import math
+
+    from conftest import ROOT
+
+    spec = importlib.util.spec_from_file_location("grid_planes_model", os.path.join(ROOT, "tests", "tools", "grid_planes_model.py"))
+    gm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gm)
+    X = gm.clustered(np.random.default_rng(3), 256, 128, 0.02)
+    r = gm.model(X, 10.0)
+    assert 500 < r["r2"] < 8192 and r["hh_exact"]
+    assert r["grid planes"][1] < 4 * max(r["direct"][1], 1.0) and r["grid planes"][0] < 4 * max(r["direct"][0], 2.0)
+    assert r["norm expansion"][1] > 50 * r["grid planes"][1]
+    for r2 in (1.0, 33.0, 500.0, 8192.0):
+        g, sigma = gm.grid_parameters(r2)
+        assert (r2 + 160.0) / (g * g / 2.0) <= 2.0 ** 24 and math.sqrt(r2) / g <= 2048 and (math.sqrt(r2) + g) * sigma <= 65504
