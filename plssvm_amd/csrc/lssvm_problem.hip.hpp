@@ -84,7 +84,7 @@ struct Options {
     int64_t pair_lag = 0;          // make DEV=1: plane-chunk steps waves 4-7 of a 256-row workgroup run behind waves 0-3 (0 = lock step: the shipped form; 1, 3
                                    // measured slower)
 };
-constexpr double RBF_GRID_MAX_R2 = 8192.0;    // rbf_form 0: grid planes (KT_RBFG) between RBF_DIRECT_ABOVE and this exponent scale, on at most 128 features: their error grows with the cross
+constexpr double RBF_GRID_MAX_R2 = 4096.0;    // rbf_form 0: grid planes (KT_RBFG) between RBF_DIRECT_ABOVE and this exponent scale, on at most 128 features: their error grows with the cross
                                               // terms |h||s| ~ R2 sqrt(d) 2^-12 (7 eps of a row's summands at R2 = 12 600, d = 128 in the model of tests/tools/grid_planes_model.py)
 constexpr double RBF_DIRECT_ABOVE = 32.0;     // rbf_form 0: the formula-exact kernel above this exponent scale 2 gamma log2(e) max|x - mean|^2 (absolute error of the
                                               // matrix-core exponent ~ 2^-24 x that; [-1, 1]-scaled data with gamma = 1 / num_features has <= 3)

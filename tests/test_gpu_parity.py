@@ -348,7 +348,7 @@ def test_rbf_large_exponent_scale_switches_to_the_direct_kernel(oracle, case):
         if form == 0:
             r2 = info["rbf_exponent_scale"]
             grid = info["gram_mode"] == 3
-            # round 5: above the threshold the automatic choice is the matrix cores on GRID planes (KT_RBFG), no longer the direct kernel (128 features, R2 <= 8 192)
+            # round 5: above the threshold the automatic choice is the matrix cores on GRID planes (KT_RBFG), no longer the direct kernel (128 features, R2 <= 4 096)
             assert info["rbf_direct"] == 0 and grid == (r2 > 32) and (case == "gamma1" or grid)  # gamma = 1 sits just below the threshold (R2 ~ 26)
         elif form == 1:
             assert info["rbf_direct"] == 1
@@ -372,9 +372,9 @@ def test_rbf_large_exponent_scale_switches_to_the_direct_kernel(oracle, case):
 
 
 @pytest.mark.parametrize("d, gamma, spread, devices", [(128, 2.0, 1.0, None), (128, 30.0, 1.0, None), (64, 8.0, 1.0, None), (100, 1.0 / 100, 25.0, None), (40, 60.0, 1.0, None),
-                                                       (128, 4.0, 1.0, [0, 0, 0]), (96, 100.0, 1.0, None), (96, 500.0, 1.0, None)])
+                                                       (128, 4.0, 1.0, [0, 0, 0]), (96, 100.0, 1.0, None), (96, 250.0, 1.0, None)])
 def test_rbf_on_grid_planes_keeps_the_direct_forms_accuracy_on_the_matrix_cores(oracle, d, gamma, spread, devices):
-    """Round 5.  Exponent scales R2 = 2 gamma log2(e) max|x - mean|^2 from 40 to 8 000 on 40 ... 128 features, data with
+    """Round 5.  Exponent scales R2 = 2 gamma log2(e) max|x - mean|^2 from 40 to 4 000 on 40 ... 128 features, data with
     near-duplicate points (the pairs that lose digits in the norm expansion) and far ones.  The automatic choice is the matrix cores on GRID planes (tile_matvec_f32_g6h:
     x = h + s1 + s2 with h on a grid, the accumulators started from sigma^2 (ch_i + ch_j) and fed the h.h products first, so that the large terms cancel EXACTLY);
     asserted against the float64 oracle on the scale of each row's summands, symmetric and full square, one device and three shards: below 16 eps like the direct
@@ -415,14 +415,16 @@ def test_rbf_on_grid_planes_keeps_the_direct_forms_accuracy_on_the_matrix_cores(
         assert np.array_equal(got, again)
         r2 = info["rbf_exponent_scale"]
         if form == 0:
-            assert 32 < r2 <= 8192 and info["gram_mode"] == 3 and info["rbf_direct"] == 0 and info["symmetric"] == sym, (r2, info)
+            assert 32 < r2 <= 4096 and info["gram_mode"] == 3 and info["rbf_direct"] == 0 and info["symmetric"] == sym, (r2, info)
         errs[name] = float(np.max(np.abs(got - want) / scale))
         errs_k[name] = float(np.max(np.abs(got - want) / scale_k))
     print(f"\n{N} x {d}, gamma {gamma:g}, exponent scale {r2:.0f}: on the scale of all summands: " + ", ".join(f"{k} {e / eps:.2f} eps" for k, e in errs.items())
           + "; of the K v summands alone: " + ", ".join(f"{k} {e / eps:.1f} eps" for k, e in errs_k.items()))
     assert errs["automatic"] < 16 * eps and errs["automatic, full square"] < 16 * eps and errs["direct"] < 16 * eps, errs
     # the sharper yardstick: sum_j K_ij |v_j| alone (the rank-1 terms, evaluated in double by the library, are 10 ... 1000 x larger and would hide the kernel's error)
-    assert errs_k["automatic"] < 32 * eps and errs_k["automatic, full square"] < 32 * eps and errs_k["automatic"] < 2 * errs_k["direct"] + 4 * eps, errs_k
+    # (measured: 1.3 ... 5.8 eps up to an exponent scale of 1 600, 12.8 eps at 7 950 -- the error grows with the cross terms |h||s| ~ R2 sqrt(d) 2^-12 -- which is why the
+    # automatic choice ends at 4 096; the direct kernel: 0.8 ... 2.5 eps; the norm expansion: 33 ... 6 600 eps)
+    assert errs_k["automatic"] < 16 * eps and errs_k["automatic, full square"] < 16 * eps and errs_k["direct"] < 16 * eps, errs_k
     assert errs_k["norm expansion"] > 4 * errs_k["automatic"], errs_k  # what the grid planes are for
     if devices is None:
         sol = {}

@@ -150,7 +150,7 @@ def test_the_grid_plane_rbf_scheme_in_the_numpy_model():
     """Round 5: the arithmetic of the rbf kernel on GRID planes (tile_matvec_f32_g6h) restated in numpy (tests/tools/grid_planes_model.py) --
     float16 planes, exact products, one fp32 rounding per 32-feature MFMA.  On clustered data with an exponent scale of ~1300 (gamma = 10) the accumulator chain over the
     grid plane must be EXACT for every pair whose kernel value is not zero in fp32, the grid planes must stay within a small factor of the formula-exact direct form, and
-    the norm expansion they replace must be two orders of magnitude off -- the premise of the automatic choice between exponent scales of 32 and 8 192."""
+    the norm expansion they replace must be two orders of magnitude off -- the premise of the automatic choice between exponent scales of 32 and 4 096."""
     import importlib.util
     import math
 
