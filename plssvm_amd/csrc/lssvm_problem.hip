@@ -416,6 +416,36 @@ static void make_planes(const Options &o, const lssvm_params &p, bool rbf_direct
     }
 }
 
+/* rbf on GRID planes (KT_RBFG): the rule that chooses them, and the planes of one (centred, scaled) matrix */
+static bool rbf_wants_grid_planes(const Options &o, const lssvm_params &p, size_t num_features, double r2) {
+    const bool shape = p.kernel_type == LSSVM_KERNEL_RBF && o.gram_mode != 0 && o.tile_kernel != 1 && round_up(static_cast<long>(num_features), 64) <= 128;
+    return shape && std::isfinite(r2) && r2 <= RBF_GRID_MAX_R2 && (o.rbf_form == 3 || (o.rbf_form == 0 && r2 > RBF_DIRECT_ABOVE));
+}
+/* g from the exponent scale alone (max|x_k| <= sqrt(R2), so |h / g| <= 2048 holds with it; (R2 + 160) / (g^2 / 2) <= 2^24 keeps the h.h chain of every pair that matters -- |t| <= 150,
+ * beyond that 2^t is 0 in fp32 -- exact); sigma moves the largest |h| below f16's maximum.  `chg` (rows_alloc floats, allocated) receives sigma^2 ch_i, `efac` is allocated here. */
+static float make_grid_planes(const DeviceMatrix<float> &M, double r2_in, PlaneSet &out, float *chg, DevBuf<float> &efac, hipStream_t s) {
+    const double r2 = std::max(r2_in, 1.0);
+    const double g = std::exp2(std::ceil(std::log2(std::max(std::sqrt((r2 + 160.0) * 0x1p-23), std::sqrt(r2) / 2048.0))));
+    const float sigma = static_cast<float>(std::exp2(std::floor(std::log2(60000.0 / (std::sqrt(r2) + g)))));
+    out.ldx16 = static_cast<int>(round_up(static_cast<long>(M.dfeat), 64));
+    out.nplanes = 3;
+    out.shift = 0;
+    out.buf.alloc_zero(static_cast<size_t>(3) * M.rows_alloc * out.ldx16, s);
+    efac.alloc_zero(M.rows_alloc, s);
+    DevBuf<unsigned> stats;
+    stats.alloc_zero(4, s);
+    split_grid_planes(M.data.p, M.ldx, M.dfeat, static_cast<size_t>(M.rows_alloc), out.ldx16, static_cast<float>(g), sigma, out.buf.p, static_cast<size_t>(M.rows_alloc) * out.ldx16, chg, efac.p, stats.p, s);
+    unsigned bad = 0;
+    LSSVM_HIP_CHECK(hipMemcpyAsync(&bad, stats.p, sizeof(bad), hipMemcpyDeviceToHost, s));
+    LSSVM_HIP_CHECK(hipStreamSynchronize(s));
+    if (bad != 0) throw Error(LSSVM_ERR_INTERNAL, "the grid planes of the rbf kernel do not represent this data (option rbf_form = 1 selects the direct kernel)");
+    out.mode = 2;  // f16 planes (the launcher picks the grid kernel from TileArgs::rbf_grid)
+    if (const char *dbg = std::getenv("LSSVM_MI355_DEBUG"); dbg != nullptr && dbg[0] == '1') {
+        std::fprintf(stderr, "[plssvm_amd] rbf on grid planes: exponent scale %.1f, g = 2^%d, sigma = 2^%d\n", r2_in, static_cast<int>(std::log2(g)), static_cast<int>(std::log2(sigma)));
+    }
+    return sigma;
+}
+
 /* the plane fields of TileArgs; `gamma` must hold the kernel's own gamma already */
 static void set_plane_args(TileArgs<float> &a, const lssvm_params &p, const PlaneSet &cols, const PlaneSet &rows, size_t col_rows_alloc, size_t row_rows_alloc) {
     a.Xr16 = rows.buf.p;
@@ -732,10 +762,9 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     rbf_direct_ = rbf_wants_direct_form<T>(opt_, params_, X_, nullptr, st, &rbf_r2_);
     // Large exponent scales (round 5): between RBF_DIRECT_ABOVE and RBF_GRID_MAX_R2, on at most 128 features and with operand planes allowed, the matrix cores run the
     // rbf kernel on GRID planes (KT_RBFG, lssvm_tile_f32_split.hip.hpp) -- the direct form's accuracy at about twice the f16x3 time instead of five times.  A rule on
-    // the data's scale, the shape and the options: every shard sees the same data and decides alike.  (predict_values keeps the direct kernel there.)
+    // the data's scale, the shape and the options: every shard sees the same data and decides alike; predict_values takes the same decision.
     if constexpr (std::is_same_v<T, float>) {
-        const bool grid_shape = params_.kernel_type == LSSVM_KERNEL_RBF && opt_.gram_mode != 0 && opt_.tile_kernel != 1 && round_up(static_cast<long>(num_features), 64) <= 128;
-        if (grid_shape && (opt_.rbf_form == 3 || (opt_.rbf_form == 0 && rbf_r2_ > RBF_DIRECT_ABOVE && rbf_r2_ <= RBF_GRID_MAX_R2)) && std::isfinite(rbf_r2_) && rbf_r2_ <= RBF_GRID_MAX_R2) {
+        if (rbf_wants_grid_planes(opt_, params_, num_features, rbf_r2_)) {
             rbf_grid_ = true;
             rbf_direct_ = false;
         }
@@ -912,28 +941,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     if constexpr (std::is_same_v<T, float>) {
         // the (centred, scaled) data once more as operand planes of the split kernels (features in natural order): see make_planes
         if (rbf_grid_) {
-            // grid planes: g from the exponent scale alone (max|x_k| <= sqrt(R2), so |h / g| <= 2048 holds with it; (R2 + 160) / (g^2 / 2) <= 2^24 keeps the h.h chain of
-            // every pair that matters -- |t| <= 150, beyond that 2^t is 0 in fp32 -- exact), sigma moves the largest |h| below f16's maximum
-            const double r2 = std::max(rbf_r2_, 1.0);
-            const double g = std::exp2(std::ceil(std::log2(std::max(std::sqrt((r2 + 160.0) * 0x1p-23), std::sqrt(r2) / 2048.0))));
-            grid_sigma_ = static_cast<float>(std::exp2(std::floor(std::log2(60000.0 / (std::sqrt(r2) + g)))));
-            planes_.ldx16 = static_cast<int>(round_up(static_cast<long>(X_.dfeat), 64));
-            planes_.nplanes = 3;
-            planes_.shift = 0;
-            planes_.buf.alloc_zero(static_cast<size_t>(3) * X_.rows_alloc * planes_.ldx16, st);
-            efac_.alloc_zero(X_.rows_alloc, st);
-            DevBuf<unsigned> stats;
-            stats.alloc_zero(4, st);
-            split_grid_planes(X_.data.p, X_.ldx, X_.dfeat, static_cast<size_t>(X_.rows_alloc), planes_.ldx16, static_cast<float>(g), grid_sigma_, planes_.buf.p,
-                              static_cast<size_t>(X_.rows_alloc) * planes_.ldx16, c_.p, efac_.p, stats.p, st);
-            unsigned bad = 0;
-            LSSVM_HIP_CHECK(hipMemcpyAsync(&bad, stats.p, sizeof(bad), hipMemcpyDeviceToHost, st));
-            LSSVM_HIP_CHECK(hipStreamSynchronize(st));
-            if (bad != 0) throw Error(LSSVM_ERR_INTERNAL, "the grid planes of the rbf kernel do not represent this data (option rbf_form = 1 selects the direct kernel)");
-            planes_.mode = 2;  // f16 planes (the launcher picks the grid kernel from TileArgs::rbf_grid)
-            if (const char *dbg = std::getenv("LSSVM_MI355_DEBUG"); dbg != nullptr && dbg[0] == '1') {
-                std::fprintf(stderr, "[plssvm_amd] rbf on grid planes: exponent scale %.1f, g = 2^%d, sigma = 2^%d\n", rbf_r2_, static_cast<int>(std::log2(g)), static_cast<int>(std::log2(grid_sigma_)));
-            }
+            grid_sigma_ = make_grid_planes(X_, rbf_r2_, planes_, c_.p, efac_, st);
         } else if (!wide_linear_) make_planes(opt_, tile_params_, rbf_direct_, X_, nullptr, planes_, nullptr, st, wide_nl_, false, f16_probe_failed_);
         if ((wide_nl_ || pair_) && planes_.mode == 0) throw Error(LSSVM_ERR_INTERNAL, "no operand planes for a path that was chosen from the shape alone");
         if (wide_nl_ && sym_) {
@@ -1750,7 +1758,16 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     P.upload(points, LSSVM_MEM_HOST, npoints, nfeat, 0, s);
     DevBuf<T> cS, cP;
     double rbf_r2 = 0.0;
-    const bool rbf_direct = rbf_wants_direct_form<T>(opt, params, S, &P, s, &rbf_r2);  // same rule as the training matvec (Problem<T>)
+    bool rbf_direct = rbf_wants_direct_form<T>(opt, params, S, &P, s, &rbf_r2);  // same rule as the training matvec (Problem<T>)
+    bool rbf_grid = false;
+    if constexpr (std::is_same_v<T, float>) {
+        if (rbf_wants_grid_planes(opt, params, nfeat, rbf_r2)) {
+            rbf_grid = true;
+            rbf_direct = false;
+        }
+    }
+    DevBuf<T> eS, eP;  // grid planes: the folded factors E of the support vectors and of the points
+    float grid_sigma = 1.0f;
     int dc_folded = 0;
     if (params.kernel_type == LSSVM_KERNEL_RBF && !rbf_direct) {
         center_columns<T>(S, &P, rbf_prescale<T>(params, v2_eligible_f64(opt, S.ldx) || wide_nonlinear_f64(opt, params, nfeat)), s);
@@ -1778,10 +1795,13 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     // fp32: both sides once more as operand planes (the split kernels, full-square instance: rows = points, columns = support vectors)
     PlaneSet planesS, planesP;
     if constexpr (std::is_same_v<T, float>) {
-        if (v2) {
+        if (v2 && rbf_grid) {
+            grid_sigma = make_grid_planes(S, rbf_r2, planesS, cS.p, eS, s);
+            (void) make_grid_planes(P, rbf_r2, planesP, cP.p, eP, s);  // (the same exponent scale: the same grid and the same sigma)
+        } else if (v2) {
             make_planes(opt, params, rbf_direct, S, &P, planesS, &planesP, s, wide);
             if (wide && planesS.mode == 0) throw Error(LSSVM_ERR_INTERNAL, "no operand planes for the wide rbf / polynomial path");
-            if (planesS.mode != 0) dc_folded = (params.kernel_type == LSSVM_KERNEL_RBF && opt.rbf_fold != 0 && rbf_r2 <= FOLD_MAX_R2) ? 1 : 0;
+            if (planesS.mode != 0) dc_folded = (params.kernel_type == LSSVM_KERNEL_RBF && opt.rbf_fold != 0 && rbf_r2 <= FOLD_MAX_R2 && !rbf_grid) ? 1 : 0;
         }
     }
     interleave_features<T>(S, s);
@@ -1813,7 +1833,7 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
         dc.alloc_zero(static_cast<size_t>(num_jt) * 256, s);
         const int ncols = num_jt * TILE;
         if constexpr (std::is_same_v<T, float>) {
-            hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, s, a.p, cS.p, ncols, dc.p, dc_folded, static_cast<float *>(nullptr), 0, static_cast<const float *>(nullptr));
+            hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, s, a.p, cS.p, ncols, dc.p, rbf_grid ? 2 : dc_folded, static_cast<float *>(nullptr), 0, rbf_grid ? eS.p : static_cast<const float *>(nullptr));
         } else {
             hipLaunchKernelGGL(k_pack_dc_f64, dim3((ncols + 255) / 256), dim3(256), 0, s, a.p, cS.p, ncols, dc.p, static_cast<double *>(nullptr), 0);
         }
@@ -1834,6 +1854,11 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     if (poly_prescaled) ta.gamma = T(1);
     if constexpr (std::is_same_v<T, float>) {
         if (planesS.mode != 0) set_plane_args(ta, params, planesS, planesP, static_cast<size_t>(S.rows_alloc), static_cast<size_t>(P.rows_alloc));
+        if (rbf_grid) {
+            ta.gamma = static_cast<T>(1.0 / (static_cast<double>(grid_sigma) * static_cast<double>(grid_sigma)));
+            ta.er = eP.p;
+            ta.rbf_grid = 1;
+        }
     }
     ta.wide_panels = wide ? 1 : 0;
     set_launch_options(ta, opt);

@@ -427,6 +427,20 @@ def test_rbf_on_grid_planes_keeps_the_direct_forms_accuracy_on_the_matrix_cores(
     assert errs_k["automatic"] < 16 * eps and errs_k["automatic, full square"] < 16 * eps and errs_k["direct"] < 16 * eps, errs_k
     assert errs_k["norm expansion"] > 4 * errs_k["automatic"], errs_k  # what the grid planes are for
     if devices is None:
+        # predict_values takes the same decision (grid planes of the support vectors and of the points, one grid and one scale for both)
+        alpha = rng.uniform(-1, 1, size=N).astype(np.float32)
+        pts = (X[:200] + rng.normal(0, 3e-3 * spread, size=(200, d))).astype(np.float32)
+        want_p, _ = oracle.predict_values("rbf", X64, alpha.astype(np.float64), 0.25, pts.astype(np.float64), gamma=gamma)
+        p64 = pts.astype(np.float64)
+        Kp = np.exp(-gamma * np.maximum(np.einsum("ij,ij->i", p64, p64)[:, None] + sq[None, :] - 2.0 * (p64 @ X64.T), 0.0))
+        scale_p = Kp @ np.abs(alpha.astype(np.float64)) + 0.25
+        perr = {}
+        for form in (0, 1, 2):
+            _capi.set_option("rbf_form", form)
+            got_p, _ = backend.predict_values(p, X, alpha, 0.25, None, pts)
+            perr[form] = float(np.max(np.abs(got_p - want_p) / scale_p))
+        print(f"predict_values: automatic {perr[0] / eps:.2f} eps, direct {perr[1] / eps:.2f} eps, norm expansion {perr[2] / eps:.1f} eps")
+        assert perr[0] < 16 * eps and perr[1] < 16 * eps and perr[2] > 4 * perr[0], perr
         sol = {}
         for form in (0, 1):
             _capi.set_option("rbf_form", form)
