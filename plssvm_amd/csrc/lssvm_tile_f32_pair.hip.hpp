@@ -245,9 +245,10 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
                 constexpr int Z = (kc == 0 && kk == 0) ? 1 : 0;  // first MFMA of every accumulator of this column half: C = 0
                 constexpr int CUR = mm & 1;
                 if constexpr (mm == 2) {
-                    if constexpr (HALF == 1) {
-                        if (kc == 0 && t > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    }
+                    // BOTH halves retire their LDS traffic before the hand-over barrier that precedes flush_cols(t - 1): the colred stores of tile t - 1 (all eight waves)
+                    // must have landed when waves 4 and 5 read them.  (For waves 0-3 the wait is already implied by the lgkmcnt(0) at the head of the two groups in
+                    // front of it; spelled out so that a re-schedule of the groups cannot turn it into a race -- ADVICE r04.)
+                    if (kc == 0 && t > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if constexpr (!decltype(checked)::value) {
                         if (!LSSVM_DBG(a, 16)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                         if (!LSSVM_DBG(a, 8)) __builtin_amdgcn_s_barrier();  // ablation bit 8: no hand-over barrier in the steady state

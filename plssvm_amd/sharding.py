@@ -41,8 +41,12 @@ def sym_block_partition(n: int, world: int):
     Returns ``[(block_begin, block_end), ...]``."""
     import math
 
+    def llround(x: float) -> int:  # C's llround for x >= 0 (half away from zero; x - floor(x) is exact, x + 0.5 need not be: ADVICE r04)
+        f = math.floor(x)
+        return int(f) + (1 if x - f >= 0.5 else 0)
+
     tiles = (n + TILE - 1) // TILE
-    bounds = [0] + [min(max(2 * int(math.floor(0.5 * tiles * math.sqrt(r / world) + 0.5)), 0), tiles) for r in range(1, world)] + [tiles]
+    bounds = [0] + [min(max(2 * llround(0.5 * tiles * math.sqrt(r / world)), 0), tiles) for r in range(1, world)] + [tiles]
     return [(bounds[r], bounds[r + 1]) for r in range(world)]
 
 

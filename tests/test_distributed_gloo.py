@@ -168,6 +168,19 @@ def test_the_librarys_own_partition_equals_the_python_restatement(n, world):
     assert covered == tiles and sym[0][0] == 0 and sym[-1][1] == tiles
 
 
+def test_python_and_library_partitions_agree_over_a_sweep_of_shapes():
+    """the even shard boundaries are computed twice -- `sym_block_boundary` (llround) in the library, `sym_block_partition` in plssvm_amd/sharding.py --
+    and must match exactly (peer connection, flop accounting).  Every number of row blocks from 1 to 2 500 and every world from 1 to 16, through the host-only C entry
+    point (no device needed)."""
+    from plssvm_amd import _capi
+
+    for tiles in list(range(1, 2501)) + [7813, 15626, 23438]:
+        n = tiles * sharding.TILE
+        for world in range(1, 17):
+            sym = sharding.sym_block_partition(n, world)
+            assert [_capi.shard_blocks(n + 1, world, r, True) for r in range(world)] == sym, (tiles, world)
+
+
 def test_bench_spawns_its_own_ranks_without_a_launcher():
     """`python bench.py --gpus 2` typed as is must start two child ranks itself (no torchrun).  Without a GPU every child stops at the
     loud "needs an MI355X" check -- which proves the parent spawned ranks with RANK / WORLD_SIZE set and returned their exit code
