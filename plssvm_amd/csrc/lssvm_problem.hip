@@ -418,7 +418,7 @@ static void make_planes(const Options &o, const lssvm_params &p, bool rbf_direct
 
 /* rbf on GRID planes (KT_RBFG): the rule that chooses them, and the planes of one (centred, scaled) matrix */
 static bool rbf_wants_grid_planes(const Options &o, const lssvm_params &p, size_t num_features, double r2) {
-    const bool shape = p.kernel_type == LSSVM_KERNEL_RBF && o.gram_mode != 0 && o.tile_kernel != 1 && round_up(static_cast<long>(num_features), 64) <= 128;
+    const bool shape = p.kernel_type == LSSVM_KERNEL_RBF && o.gram_mode != 0 && o.tile_kernel != 1 && round_up(static_cast<long>(num_features), 64) <= F16_RBF_MAX_FEATURES;  // (one-pass rbf kernels: 384)
     return shape && std::isfinite(r2) && r2 <= RBF_GRID_MAX_R2 && (o.rbf_form == 3 || (o.rbf_form == 0 && r2 > RBF_DIRECT_ABOVE));
 }
 /* g from the exponent scale alone (max|x_k| <= sqrt(R2), so |h / g| <= 2048 holds with it; (R2 + 160) / (g^2 / 2) <= 2^24 keeps the h.h chain of every pair that matters -- |t| <= 150,
@@ -760,7 +760,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     X_.upload(X, mem_kind, num_points, num_features, static_cast<size_t>(nvec_) + TILE, st);
     // fp32 rbf: matrix cores (norm expansion) or the formula-exact vector-ALU kernel?  (every shard sees the same data: same decision)
     rbf_direct_ = rbf_wants_direct_form<T>(opt_, params_, X_, nullptr, st, &rbf_r2_);
-    // Large exponent scales (round 5): between RBF_DIRECT_ABOVE and RBF_GRID_MAX_R2, on at most 128 features and with operand planes allowed, the matrix cores run the
+    // Large exponent scales (round 5): between RBF_DIRECT_ABOVE and RBF_GRID_MAX_R2, on at most 384 features and with operand planes allowed, the matrix cores run the
     // rbf kernel on GRID planes (KT_RBFG, lssvm_tile_f32_split.hip.hpp) -- the direct form's accuracy at about twice the f16x3 time instead of five times.  A rule on
     // the data's scale, the shape and the options: every shard sees the same data and decides alike; predict_values takes the same decision.
     if constexpr (std::is_same_v<T, float>) {
@@ -853,8 +853,9 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         const long area = sym_ ? (ib_end * (ib_end + 1) - static_cast<long>(ib_begin_) * (ib_begin_ + 1)) / 2 : static_cast<long>(num_ib_) * num_tiles_;
         // the bf16x6 kernel has the costlier work-item prologue (three planes of the row panel) and the faster tiles: longer chunks
         // (measured 16 -> 64 tiles: +1.5 % at 100 000 points, +2 % at 300 000; the native kernels are flat or lose beyond 16)
-        const bool split = wide_linear_ || wide_nl_ || std::is_same_v<T, float> && opt_.gram_mode != 0 && v2_eligible(opt_, ldx_probe, rbf_direct_)
-                           && round_up(static_cast<long>(num_features), 64) <= ((opt_.gram_mode == 1 || tile_params_.kernel_type == LSSVM_KERNEL_RBF) ? SPLIT_MAX_FEATURES : F16_MAX_FEATURES);
+        const bool split = wide_linear_ || wide_nl_
+                           || (std::is_same_v<T, float> && opt_.gram_mode != 0 && v2_eligible(opt_, ldx_probe, rbf_direct_)
+                               && round_up(static_cast<long>(num_features), 64) <= ((opt_.gram_mode == 1 || tile_params_.kernel_type == LSSVM_KERNEL_RBF) ? SPLIT_MAX_FEATURES : F16_MAX_FEATURES));
         const long cap = split ? 64 : 16;
         jc_tiles_ = static_cast<int>(std::min<long>(cap, std::max<long>(2, (area + 2048) / 4096)));
         if (pair_) {

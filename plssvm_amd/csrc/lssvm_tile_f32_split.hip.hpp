@@ -58,7 +58,7 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
     // multiples of g^2 / 2) and take ALL h.h products first (multiples of g^2): every partial sum is exactly representable, so phase 0 leaves
     // -sigma^2 |h_i - h_j|^2 / 2 EXACTLY -- small for near pairs -- and the remaining terms are added at the magnitude of the result, not of the norms.
     constexpr bool GRID = KT == KT_RBFG;
-    static_assert(!GRID || (HAND && PL == 2), "the grid-plane kernel exists with f16 planes and hand-scheduled groups only");
+    static_assert(!GRID || PL == 2, "the grid-plane kernel exists with f16 planes only");
     constexpr int NKC = GRID ? 4 * NK64 : PL * NK64;  // steps per tile: for every 64-feature chunk the planes hi, mid (, lo) -- grid planes: four phases x chunks
     constexpr auto col_plane_of = [](int kc) constexpr { return GRID ? (kc / NK64 == 0 ? 0 : kc / NK64 - 1) : kc % PL; };
     constexpr auto chunk_of = [](int kc) constexpr { return GRID ? kc % NK64 : kc / PL; };
@@ -396,18 +396,18 @@ __device__ __forceinline__ void s6w_body(const TileArgs<float> &a) {
                     LSSVM_SCHED_BARRIER();
                 }
 #pragma unroll
-                for (int q = 0; q < PL; ++q) {
-                    if (q + plane > PL - 1) continue;
+                for (int q = 0; q < (GRID ? 2 : PL); ++q) {
+                    if (GRID ? q >= nq_of(kc) : q + plane > PL - 1) continue;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const int cb = 4 * cbh + c;
                         const bf16x8 bv = __builtin_bit_cast(bf16x8, bcur[c]);
 #pragma unroll
                         for (int rb = 0; rb < 2; ++rb) {
-                            const bf16x8 av = afrag[row_plane(plane, q)][2 * chunk + kk][rb];
+                            const bf16x8 av = afrag[row_plane_of(kc, q)][2 * chunk + kk][rb];
                             if (KT == KT_RBFF && kc == 0 && kk == 0 && q == 0) {
                                 acc[rb][cb] = plane_mfma<F16>(av, bv, civ0[rb]);
-                            } else if (KT != KT_RBF && kc == 0 && kk == 0 && q == 0) {
+                            } else if (KT != KT_RBF && !GRID && kc == 0 && kk == 0 && q == 0) {
                                 const f32x4 zero = { 0.f, 0.f, 0.f, 0.f };
                                 acc[rb][cb] = plane_mfma<F16>(av, bv, zero);
                             } else {
@@ -557,7 +557,13 @@ __global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec
     s6w_body<KT, NK64, SYM, false, 2>(a);
 }
 constexpr int F16_HAND_MAX_NK64 = 2;
-/* rbf on grid planes (KT_RBFG, round 5): f16 planes (h | s1 | s2), six plane products in four phases, hand-scheduled groups, <= 128 features */
+/* rbf on grid planes (KT_RBFG, round 5): f16 planes (h | s1 | s2), six plane products in four phases; hand-scheduled groups up to 128 features (g6h), the
+ * compiler-scheduled ones up to 384 (g6w: one workgroup per CU beyond 128, like the f16x3 rbf kernels -- three row planes in registers) */
+template <int NK64, bool SYM>
+__global__ __launch_bounds__(TILE_THREADS, (NK64 <= 2 ? 2 : 1)) void tile_matvec_f32_g6w(const TileArgs<float> a) {
+    static_assert(NK64 <= 6, "row panel does not fit the register file");
+    s6w_body<KT_RBFG, NK64, SYM, false, 2>(a);
+}
 template <int NK64, bool SYM>
 __global__ __launch_bounds__(TILE_THREADS, 2) LSSVM_HAND_VGPR_CAP void tile_matvec_f32_g6h(const TileArgs<float> a) {
     static_assert(NK64 <= F16_HAND_MAX_NK64, "the hand-scheduled groups assume the 256-register budget of two waves per SIMD");

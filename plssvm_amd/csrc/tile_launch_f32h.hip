@@ -189,6 +189,15 @@ static void launch_f3(const TileArgs<float> &a, int kernel_type, dim3 grid, hipS
                         ensure_dynamic_lds(tile_matvec_f32_g6h<2, SYM>, V2_LDS_BYTES);
                         hipLaunchKernelGGL((tile_matvec_f32_g6h<2, SYM>), grid, block, V2_LDS_BYTES, s, a);
                         break;
+#ifndef LSSVM_DEV_SUBSET
+#define LSSVM_G6W_CASE(N)                                                                         \
+    case N:                                                                                       \
+        ensure_dynamic_lds(tile_matvec_f32_g6w<N, SYM>, V2_LDS_BYTES);                            \
+        hipLaunchKernelGGL((tile_matvec_f32_g6w<N, SYM>), grid, block, V2_LDS_BYTES, s, a);       \
+        break;
+                    LSSVM_G6W_CASE(3) LSSVM_G6W_CASE(4) LSSVM_G6W_CASE(5) LSSVM_G6W_CASE(6)
+#undef LSSVM_G6W_CASE
+#endif
                     default: throw Error(LSSVM_ERR_INTERNAL, "no grid-plane rbf tile kernel for this number of features");
                 }
             } else if (a.dc_folded != 0) {
