@@ -419,7 +419,10 @@ static void make_planes(const Options &o, const lssvm_params &p, bool rbf_direct
 /* rbf on GRID planes (KT_RBFG): the rule that chooses them, and the planes of one (centred, scaled) matrix */
 static bool rbf_wants_grid_planes(const Options &o, const lssvm_params &p, size_t num_features, double r2) {
     const bool shape = p.kernel_type == LSSVM_KERNEL_RBF && o.gram_mode != 0 && o.tile_kernel != 1 && round_up(static_cast<long>(num_features), 64) <= F16_RBF_MAX_FEATURES;  // (one-pass rbf kernels: 384)
-    return shape && std::isfinite(r2) && r2 <= RBF_GRID_MAX_R2 && (o.rbf_form == 3 || (o.rbf_form == 0 && r2 > RBF_DIRECT_ABOVE));
+    // (the cross terms |h||s| grow like R2 sqrt(d): the limit is RBF_GRID_MAX_R2 at 128 features and sqrt(128 / d) of it beyond -- 2 365 at 384; a 300-case random run at the
+    // flat limit had its worst case, 15.7 eps, on wide data at the top of the range: profiles/r05_grid_stress_seed31.log)
+    const double limit = RBF_GRID_MAX_R2 * std::sqrt(128.0 / static_cast<double>(std::max<size_t>(num_features, 128)));
+    return shape && std::isfinite(r2) && r2 <= limit && (o.rbf_form == 3 || (o.rbf_form == 0 && r2 > RBF_DIRECT_ABOVE));
 }
 /* g from the exponent scale alone (max|x_k| <= sqrt(R2), so |h / g| <= 2048 holds with it; (R2 + 160) / (g^2 / 2) <= 2^24 keeps the h.h chain of every pair that matters -- |t| <= 150,
  * beyond that 2^t is 0 in fp32 -- exact); sigma moves the largest |h| below f16's maximum.  `chg` (rows_alloc floats, allocated) receives sigma^2 ch_i, `efac` is allocated here. */

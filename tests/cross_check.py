@@ -63,6 +63,19 @@ def wide_case(seed: int, index: int, f64: bool) -> dict:
                 degree=int(rng.choice([1, 2, 3, 4])), gamma=float(rng.choice([1.0, 0.3])) / d, coef0=float(rng.choice([0.0, 1.0])), data_seed=100 + index, v_seed=int(rng.integers(1 << 30)))
 
 
+def grid_case(seed: int, index: int) -> dict:
+    """rbf with a LARGE exponent scale (round 5): gamma d between 60 and 3 500, i.e. exponent scales of ~60 ... 4 000 on [-1, 1]-scaled data -- the automatic choice is the matrix
+    cores on grid planes (tile_matvec_f32_g6h up to 128 features, _g6w up to 384) and the direct kernel beyond the limits; ragged shapes and feature counts, both variants,
+    chunk lengths, bands, shards.  The right-hand side is made orthogonal to 1 and q (`orthogonal_v`), so that the comparison sees the kernel matrix and not the rank-1 terms."""
+    rng = np.random.default_rng([seed, index, 5])
+    N = int(rng.choice([2, 3, 100, 129, 257, 640, 1000, 1537, 2500, 4100, 8322, 9001]))
+    d = int(rng.choice([1, 3, 16, 31, 64, 65, 100, 128, 129, 192, 200, 256, 257, 300, 320, 384, 385, 500]))
+    opts = dict(gram_mode=int(rng.choice([3, 3, 2, 1])), j_chunk_tiles=int(rng.choice([0, 0, 1, 2, 3, 7])), symmetric=int(rng.choice([1, 1, 0])), colslab_band_mb=int(rng.choice([2048, 1])),
+                rbf_fold=int(rng.choice([1, 0])), mfma_shape=int(rng.choice([3, 2])))
+    return dict(family="grid", dtype="float32", kernel="rbf", N=N, d=d, opts=opts, shards=int(rng.choice([1, 1, 2, 3, 8])), degree=3,
+                gamma=float(rng.choice([60.0, 300.0, 1500.0, 3500.0])) / d, coef0=0.0, data_seed=700 + index, v_seed=int(rng.integers(1 << 30)), orthogonal_v=True)
+
+
 def describe(case: dict) -> str:
     return (f"{case['family']} {case['dtype']} {case['kernel']} N {case['N']} d {case['d']} degree {case['degree']} coef0 {case['coef0']} gamma*d {case['gamma'] * case['d']:.1f} "
             f"shards {case['shards']} {case['opts']}")
@@ -74,6 +87,18 @@ def run_case(case: dict) -> dict:
     X, _ = make_blobs_pm1(N, d, seed=case["data_seed"], dtype=dtype.type)
     p = Parameter(kernel_type=kernel, gamma=case["gamma"], degree=degree, coef0=case["coef0"], cost=1.0)
     v = np.random.default_rng(case["v_seed"]).uniform(-1, 1, N - 1).astype(dtype)
+    if case.get("orthogonal_v") and N > 3:
+        # orthogonal to 1 and to q = k(x_i, x_last) (float64 from the same data), then rounded: the rank-1 terms of Abar v all but vanish
+        Xq = X.astype(np.float64)
+        if kernel == "rbf":
+            qq = np.exp(-p.gamma * np.sum((Xq[:N - 1] - Xq[N - 1]) ** 2, axis=1))
+        else:
+            qq = Xq[:N - 1] @ Xq[N - 1]
+        basis = np.linalg.qr(np.stack([np.ones(N - 1), qq], axis=1))[0]
+        v64o = v.astype(np.float64)
+        for _ in range(2):
+            v64o = v64o - basis @ (basis.T @ v64o)
+        v = v64o.astype(dtype)
     zero = np.zeros(N - 1, dtype)
     defaults = {k: _capi.get_option(k) for k in OPTION_KEYS}
     out, info = {}, {}
