@@ -301,8 +301,8 @@ static bool rbf_wants_direct_form(const Options &o, const lssvm_params &p, const
     if (M2 != nullptr) sq = std::max(sq, max_centred_sqnorm<T>(*M2, mean, s));
     const double r2 = 2.0 * static_cast<double>(static_cast<T>(p.gamma)) * 1.4426950408889634 * sq;
     if (r2_out != nullptr) *r2_out = r2;
-    if (o.rbf_form == 2 || o.rbf_form == 3) return false;  // matrix cores whatever the scale (r2 is still reported: it decides the record form; 3: grid planes, decided by the caller)
-    return r2 > RBF_DIRECT_ABOVE;
+    if (o.rbf_form == 2) return false;  // the norm expansion whatever the scale (r2 is still reported: it decides the record form)
+    return r2 > RBF_DIRECT_ABOVE;       // (0 and 3: the caller then moves to the grid planes where they exist -- rbf_wants_grid_planes -- and stays here where they do not)
 }
 
 /* fp32: reorder the features of every group of 8 to 0,2,4,6,1,3,5,7 (the operand order of the MFMA kernels); fp64: nothing */

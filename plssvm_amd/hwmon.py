@@ -105,12 +105,19 @@ def smi_snapshot(gpu_index: int = 0, timeout_s: float = 30.0):
     except OSError:
         return None
     cmd = [sys.executable, script] if is_python else [exe]
-    try:
-        t = time.time()
-        out = subprocess.run(cmd + ["metric", "--json"], capture_output=True, text=True, timeout=timeout_s).stdout
-        start = out.find("{")
-        data = json.loads(out[start:]) if start >= 0 else None
-    except (OSError, ValueError, subprocess.SubprocessError):
+    data, t = None, time.time()
+    # (first for this GPU alone -- on an 8-GPU node the full report takes seconds --, then, should the tool not know the flag, for all)
+    for extra in (["-g", str(gpu_index)], []):
+        try:
+            t = time.time()
+            out = subprocess.run(cmd + ["metric"] + extra + ["--json"], capture_output=True, text=True, timeout=timeout_s).stdout
+            start = min((i for i in (out.find("{"), out.find("[")) if i >= 0), default=-1)
+            data = json.loads(out[start:]) if start >= 0 else None
+        except (OSError, ValueError, subprocess.SubprocessError):
+            data = None
+        if data:
+            break
+    if not data:
         return None
     gpus = data.get("gpu_data", data) if isinstance(data, dict) else data
     if not isinstance(gpus, list) or not gpus:
