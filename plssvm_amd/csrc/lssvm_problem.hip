@@ -674,7 +674,7 @@ static std::vector<int2> band_items(int band_begin, int band_end, int jc_tiles, 
  * 20 000 x 128: 0.186 ms with 3-tile items, 0.144 with 16, 0.136 with 32; 10 000 points: 0.070 / 0.049 with 2 / 8 tiles;
  * profiles/r04_chunk_sweep_pair.log).  The host therefore replays the hardware's dispatch (items in list order onto the slot that frees up
  * first) for a handful of candidate lengths with the cost model  item = tiles + 2.6  (the work-item prologue and tail in tile units, fitted to
- * that sweep) and takes the shortest makespan.  Large launches (more than 64 items per slot at the longest chunk) keep the longest chunk. */
+ * that sweep) and takes the shortest makespan.  Large launches (more than 16 items per slot at the longest chunk) keep the longest chunk. */
 struct PairChunks {
     int tiles = 64, head_tiles = 0, head_count = 0;
 };
@@ -694,7 +694,7 @@ static PairChunks choose_pair_chunk(int ib_begin, int ib_end, int num_tiles, siz
     const int cap = 64;
     PairChunks best_c;
     const long area = (static_cast<long>(ib_end) * (ib_end + 1) - static_cast<long>(ib_begin) * (ib_begin + 1)) / 4;  // pair-tiles, about
-    if (area / cap > 64L * slots) return best_c;
+    if (area / cap > 16L * slots) return best_c;  // (beyond ~16 dispatch rounds the last round no longer decides, and the replay itself costs: 16 of 27 ms of set-up at 250 000 points)
     const std::vector<int> edge = band_edges(ib_begin, ib_end, real_size, o);
     const bool few_rounds = area / cap <= 8L * slots && edge.size() == 2;
     double best = 0.0;
