@@ -259,11 +259,11 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *   "rbf_form"      fp32 rbf: 0 = automatic (default): the norm expansion c_i + c_j + x_i'.x_j' on the matrix cores, unless
  *                   R2 = 2 gamma log2(e) max|x - mean|^2 exceeds 32 -- the expansion's exponent carries an absolute error of
  *                   ~2^-24 R2 whatever the distance of the pair, which nearby pairs (K ~ 1) see as a relative error of K
- *                   ([-1,1]-scaled data with gamma = 1 / num_features has R2 <= 3); then, up to R2 = 4096 and on at most 384 features, the matrix
+ *                   ([-1,1]-scaled data with gamma = 1 / num_features has R2 <= 3); then, up to R2 = 4096 (times sqrt(128 / num_features) beyond 128 features), the matrix
  *                   cores on GRID planes (since round 5: x = h + s1 + s2 with h on a grid, the accumulators started from the exact grid norms and
  *                   fed the h.h products first, so that the large terms cancel exactly -- the direct form's accuracy at 1.6x the f16x3 time); beyond
  *                   that, and with 1 = always, the formula-exact (x_i - x_j)^2 kernel on the vector ALU (10x slower than the grid planes at
- *                   50 000 x 128); 2 = always the norm expansion; 3 = the grid planes wherever they exist (R2 <= 4096, <= 384 features)
+ *                   50 000 x 128); 2 = always the norm expansion; 3 = the grid planes wherever they exist (R2 within that limit)
  *   "rbf_fold"      fp32 rbf on the split kernels: 1 (default) = the column records carry (2^c_j d_j | 2^c_j) and the accumulators start
  *                   from c_i as the C operand of their first MFMA (256-row workgroups: from 0, the row's term folded too) -- no start-value
  *                   instructions, K_ij = 2^acc 2^c_j (one more rounding than 2^(acc + c_j); used while the exponent scale R2 <= 200 keeps both factors

@@ -418,7 +418,7 @@ static void make_planes(const Options &o, const lssvm_params &p, bool rbf_direct
 
 /* rbf on GRID planes (KT_RBFG): the rule that chooses them, and the planes of one (centred, scaled) matrix */
 static bool rbf_wants_grid_planes(const Options &o, const lssvm_params &p, size_t num_features, double r2) {
-    const bool shape = p.kernel_type == LSSVM_KERNEL_RBF && o.gram_mode != 0 && o.tile_kernel != 1 && round_up(static_cast<long>(num_features), 64) <= F16_RBF_MAX_FEATURES;  // (one-pass rbf kernels: 384)
+    const bool shape = p.kernel_type == LSSVM_KERNEL_RBF && o.gram_mode != 0 && o.tile_kernel != 1;  // (<= 128 features: _g6h, <= 384: _g6w, beyond: the panels-inside-a-tile kernel)
     // (the cross terms |h||s| grow like R2 sqrt(d): the limit is RBF_GRID_MAX_R2 at 128 features and sqrt(128 / d) of it beyond -- 2 365 at 384; a 300-case random run at the
     // flat limit had its worst case, 15.7 eps, on wide data at the top of the range: profiles/r05_grid_stress_seed31.log)
     const double limit = RBF_GRID_MAX_R2 * std::sqrt(128.0 / static_cast<double>(std::max<size_t>(num_features, 128)));
@@ -426,11 +426,11 @@ static bool rbf_wants_grid_planes(const Options &o, const lssvm_params &p, size_
 }
 /* g from the exponent scale alone (max|x_k| <= sqrt(R2), so |h / g| <= 2048 holds with it; (R2 + 160) / (g^2 / 2) <= 2^24 keeps the h.h chain of every pair that matters -- |t| <= 150,
  * beyond that 2^t is 0 in fp32 -- exact); sigma moves the largest |h| below f16's maximum.  `chg` (rows_alloc floats, allocated) receives sigma^2 ch_i, `efac` is allocated here. */
-static float make_grid_planes(const DeviceMatrix<float> &M, double r2_in, PlaneSet &out, float *chg, DevBuf<float> &efac, hipStream_t s) {
+static float make_grid_planes(const DeviceMatrix<float> &M, double r2_in, PlaneSet &out, float *chg, DevBuf<float> &efac, hipStream_t s, bool wide_nl) {
     const double r2 = std::max(r2_in, 1.0);
     const double g = std::exp2(std::ceil(std::log2(std::max(std::sqrt((r2 + 160.0) * 0x1p-23), std::sqrt(r2) / 2048.0))));
     const float sigma = static_cast<float>(std::exp2(std::floor(std::log2(60000.0 / (std::sqrt(r2) + g)))));
-    out.ldx16 = static_cast<int>(round_up(static_cast<long>(M.dfeat), 64));
+    out.ldx16 = static_cast<int>(round_up(static_cast<long>(M.dfeat), wide_nl ? 128 : 64));  // (the panels-inside-a-tile kernel walks panels of 128 features)
     out.nplanes = 3;
     out.shift = 0;
     out.buf.alloc_zero(static_cast<size_t>(3) * M.rows_alloc * out.ldx16, s);
@@ -763,7 +763,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     X_.upload(X, mem_kind, num_points, num_features, static_cast<size_t>(nvec_) + TILE, st);
     // fp32 rbf: matrix cores (norm expansion) or the formula-exact vector-ALU kernel?  (every shard sees the same data: same decision)
     rbf_direct_ = rbf_wants_direct_form<T>(opt_, params_, X_, nullptr, st, &rbf_r2_);
-    // Large exponent scales (round 5): between RBF_DIRECT_ABOVE and RBF_GRID_MAX_R2, on at most 384 features and with operand planes allowed, the matrix cores run the
+    // Large exponent scales (round 5): between RBF_DIRECT_ABOVE and RBF_GRID_MAX_R2, at any width, with operand planes allowed, the matrix cores run the
     // rbf kernel on GRID planes (KT_RBFG, lssvm_tile_f32_split.hip.hpp) -- the direct form's accuracy at about twice the f16x3 time instead of five times.  A rule on
     // the data's scale, the shape and the options: every shard sees the same data and decides alike; predict_values takes the same decision.
     if constexpr (std::is_same_v<T, float>) {
@@ -945,7 +945,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     if constexpr (std::is_same_v<T, float>) {
         // the (centred, scaled) data once more as operand planes of the split kernels (features in natural order): see make_planes
         if (rbf_grid_) {
-            grid_sigma_ = make_grid_planes(X_, rbf_r2_, planes_, c_.p, efac_, st);
+            grid_sigma_ = make_grid_planes(X_, rbf_r2_, planes_, c_.p, efac_, st, wide_nl_);
         } else if (!wide_linear_) make_planes(opt_, tile_params_, rbf_direct_, X_, nullptr, planes_, nullptr, st, wide_nl_, false, f16_probe_failed_);
         if ((wide_nl_ || pair_) && planes_.mode == 0) throw Error(LSSVM_ERR_INTERNAL, "no operand planes for a path that was chosen from the shape alone");
         if (wide_nl_ && sym_) {
@@ -1800,8 +1800,8 @@ void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t 
     PlaneSet planesS, planesP;
     if constexpr (std::is_same_v<T, float>) {
         if (v2 && rbf_grid) {
-            grid_sigma = make_grid_planes(S, rbf_r2, planesS, cS.p, eS, s);
-            (void) make_grid_planes(P, rbf_r2, planesP, cP.p, eP, s);  // (the same exponent scale: the same grid and the same sigma)
+            grid_sigma = make_grid_planes(S, rbf_r2, planesS, cS.p, eS, s, wide);
+            (void) make_grid_planes(P, rbf_r2, planesP, cP.p, eP, s, wide);  // (the same exponent scale: the same grid and the same sigma)
         } else if (v2) {
             make_planes(opt, params, rbf_direct, S, &P, planesS, &planesP, s, wide);
             if (wide && planesS.mode == 0) throw Error(LSSVM_ERR_INTERNAL, "no operand planes for the wide rbf / polynomial path");

@@ -58,7 +58,7 @@ struct Error : std::runtime_error {
 struct Options {
     // the 14 options of the product (lssvm_mi355_set_option; include/plssvm_amd.h documents them; round 4 retired xcd_map, lds_extra_kb, item_order,
     // linear_panel_features, check_shards, rbf_direct_above and mfma_shape = 1 -- measured, decided, now constants below)
-    int64_t rbf_form = 0;        // fp32 rbf: 0 automatic (matrix cores: norm expansion up to the exponent scale RBF_DIRECT_ABOVE, grid planes up to RBF_GRID_MAX_R2 on <= 384 features; else direct), 3 = grid planes where they exist, 1 always the direct
+    int64_t rbf_form = 0;        // fp32 rbf: 0 automatic (matrix cores: norm expansion up to the exponent scale RBF_DIRECT_ABOVE, grid planes up to RBF_GRID_MAX_R2 (times sqrt(128 / features) beyond 128 features); else direct), 3 = grid planes where they exist, 1 always the direct
                                  // (x_i - x_j)^2 kernel on the vector ALU, 2 always the norm expansion on the matrix cores
     int64_t rbf_fold = 1;        // fp32 rbf on the split kernels: 1 = folded column records (2^c_j d_j | 2^c_j), accumulators start from c_i as the C
                                  // operand of their first MFMA (default, while the exponent scale stays below 200); 0 = start values c_i + c_j by vector adds
@@ -84,7 +84,7 @@ struct Options {
     int64_t pair_lag = 0;          // make DEV=1: plane-chunk steps waves 4-7 of a 256-row workgroup run behind waves 0-3 (0 = lock step: the shipped form; 1, 3
                                    // measured slower)
 };
-constexpr double RBF_GRID_MAX_R2 = 4096.0;    // rbf_form 0: grid planes (KT_RBFG) between RBF_DIRECT_ABOVE and this exponent scale, on at most 384 features: their error grows with the cross
+constexpr double RBF_GRID_MAX_R2 = 4096.0;    // rbf_form 0: grid planes (KT_RBFG) between RBF_DIRECT_ABOVE and this exponent scale (at any width): their error grows with the cross
                                               // terms |h||s| ~ R2 sqrt(d) 2^-12 (7 eps of a row's summands at R2 = 12 600, d = 128 in the model of tests/tools/grid_planes_model.py)
 constexpr double RBF_DIRECT_ABOVE = 32.0;     // rbf_form 0: the formula-exact kernel above this exponent scale 2 gamma log2(e) max|x - mean|^2 (absolute error of the
                                               // matrix-core exponent ~ 2^-24 x that; [-1, 1]-scaled data with gamma = 1 / num_features has <= 3)

@@ -28,9 +28,14 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
     static_assert(PL == 3 || PL == 2, "three bf16 planes (bf16x6) or two f16 planes (f16x3)");
     static_assert(KT != KT_LINEAR, "the linear kernel takes feature-panel passes of the 128-feature kernels");
     constexpr bool F16 = PL == 2;
+    // KT_RBFG (rbf on GRID planes, round 5; s6w_body / DESIGN.md section 4.1.2): three f16 planes (h | s1 | s2) and TWO sweeps over the feature panels of a tile -- sweep A: the
+    // h x h products of ALL panels (they must come first: with the exact start values they leave -sigma^2 |h_i - h_j|^2 / 2 exactly), sweep B: per panel and 64-feature chunk
+    // the column planes h, s1, s2 against the row planes (s1, s2), (h, s1), (h).  Sweep A keeps row plane h of the panel in registers, sweep B all three.
+    constexpr bool GRID = KT == KT_RBFG;
+    static_assert(!GRID || PL == 2, "the grid-plane kernel exists with f16 planes only");
     constexpr int NK64 = 2;          // 64-feature chunks per panel
     constexpr int NKC = PL * NK64;   // plane-chunks (steps) per tile-panel
-    constexpr int PLA = F16 ? ((KT == KT_RBF || KT == KT_RBFF) ? 3 : 2) : 3;  // row planes in registers (s6w_body: the shifted rbf planes)
+    constexpr int PLA = F16 ? ((KT == KT_RBF || KT == KT_RBFF || GRID) ? 3 : 2) : 3;  // row planes in registers (s6w_body: the shifted rbf planes)
     constexpr auto row_plane = [](int p, int q) constexpr { return (F16 && PLA == 3) ? (p == 0 ? (q == 0 ? 2 : 1) : 0) : q; };
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char *ring = smem_raw;                                                          // [V2_RING][128 rows][128 B]
@@ -60,7 +65,7 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
     const int ntiles = jt_end - jt_begin;
     if (ntiles <= 0) return;
     const int panels = a.nk64 / NK64;          // (uniform; the planes are padded to a multiple of 128 features)
-    const int steps_per_tile = panels * NKC;
+    const int steps_per_tile = GRID ? panels * (4 * NK64) : panels * NKC;  // (grid planes: sweep A NK64 steps per panel, sweep B 3 NK64)
     const int nsteps = ntiles * steps_per_tile;
     const long rec0 = SYM ? (static_cast<long>(ib) * (ib - 1) / 2 - a.pair_origin) : 0;
 
@@ -74,10 +79,10 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
     // profiles/r04_ablation_wide.log), and the vector memory path they share with the column stream counts line requests, not bytes.
     const unsigned row_lane_off = SYM ? 16u * static_cast<unsigned>(lane) : 2u * static_cast<unsigned>(r * a.ldx16 + 8 * g);
     const size_t frag_rows16 = SYM ? a.plane_stride_r / static_cast<size_t>(a.ldx16) / 16 : 0;  // 16-row blocks of a plane (uniform; once per work item)
-    auto load_row_chunk = [&](int p, auto chunk_c) {  // the 64-feature chunk `chunk` of panel p: k32 steps 2 chunk, 2 chunk + 1
+    auto load_row_chunk_planes = [&](int p, auto chunk_c, auto pl0_c, auto pl1_c) {  // planes [pl0, pl1) of the 64-feature chunk `chunk` of panel p: k32 steps 2 chunk, 2 chunk + 1
         constexpr int chunk = decltype(chunk_c)::value;
 #pragma unroll
-        for (int pl = 0; pl < PLA; ++pl) {
+        for (int pl = decltype(pl0_c)::value; pl < decltype(pl1_c)::value; ++pl) {
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 if constexpr (SYM) {
@@ -94,13 +99,24 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
             }
         }
     };
-    auto load_row_panel = [&](int p) { static_for<0, NK64>([&](auto c) { load_row_chunk(p, c); }); };
-    load_row_panel(0);
-    if constexpr (KT == KT_RBF || KT == KT_RBFF) {
-        if (tid < TILE) cis[tid] = a.cr[row0 + tid];
+    auto load_row_chunk = [&](int p, auto chunk_c) { load_row_chunk_planes(p, chunk_c, std::integral_constant<int, 0>{}, std::integral_constant<int, PLA>{}); };
+    auto load_row_chunk_h = [&](int p, auto chunk_c) { load_row_chunk_planes(p, chunk_c, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); };  // (grid planes, sweep A)
+    if constexpr (GRID) {
+#pragma unroll
+        for (int pl = 1; pl < PLA; ++pl)
+#pragma unroll
+            for (int kk = 0; kk < 2 * NK64; ++kk)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) afrag[pl][kk][rb] = bf16x8{};  // (loaded at the end of the first sweep A)
+        static_for<0, NK64>([&](auto c) { load_row_chunk_h(0, c); });
+    } else {
+        static_for<0, NK64>([&](auto c) { load_row_chunk(0, c); });
+    }
+    if constexpr (KT == KT_RBF || KT == KT_RBFF || GRID) {
+        if (tid < TILE) cis[tid] = a.cr[row0 + tid];  // (grid planes: sigma^2 ch_i)
     }
     if constexpr (SYM) {
-        if (tid < TILE) dis[tid] = a.dvec[row0 + tid];
+        if (tid < TILE) dis[tid] = GRID ? a.dvec[row0 + tid] * a.er[row0 + tid] : a.dvec[row0 + tid];  // (grid planes: the row's folded factor E_i rides on d_i)
     }
     // make the compiler retire these ordinary loads HERE, before any LDS-DMA is in flight
 #pragma unroll
@@ -124,9 +140,27 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
     auto issue_chunk = [&](int step) {  // step = (tile t, panel p, plane-chunk kc): plane kc % PL of the 64-feature chunk kc / PL of panel p
         const int t = step / steps_per_tile;
         const int in_tile = step - t * steps_per_tile;
-        const int p = in_tile / NKC;
-        const int kc = in_tile - p * NKC;
-        const char *base = sgpr_ptr(a.Xc16 + (kc % PL) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (p * NK64 + kc / PL) * 64);
+        int p, chunk, plane;
+        if constexpr (GRID) {
+            const int a_steps = panels * NK64;
+            if (in_tile < a_steps) {  // sweep A: column plane h
+                p = in_tile / NK64;
+                chunk = in_tile - p * NK64;
+                plane = 0;
+            } else {                  // sweep B: per chunk the column planes h, s1, s2
+                const int rem = in_tile - a_steps;
+                p = rem / (3 * NK64);
+                const int kc = rem - p * (3 * NK64);
+                chunk = kc / 3;
+                plane = kc - 3 * chunk;
+            }
+        } else {
+            p = in_tile / NKC;
+            const int kc = in_tile - p * NKC;
+            chunk = kc / PL;
+            plane = kc % PL;
+        }
+        const char *base = sgpr_ptr(a.Xc16 + plane * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (p * NK64 + chunk) * 64);
         const unsigned slot = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(dma_lds + static_cast<unsigned>(step % V2_RING) * V2_SLOT_BYTES)));
         static_for<0, 4>([&](auto i_c) { lds_dma16<decltype(i_c)::value * 1024>(dma_off[decltype(i_c)::value], base, slot); });
     };
@@ -156,7 +190,7 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
     asm volatile("" ::: "memory");
 
     f32x4 civ0[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
-    if constexpr (KT == KT_RBF || KT == KT_RBFF) {
+    if constexpr (KT == KT_RBF || KT == KT_RBFF || GRID) {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) civ0[rb] = *reinterpret_cast<const f32x4 *>(cis + wave * 32 + 16 * rb + 4 * g);
     }
@@ -200,7 +234,7 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
         const bool tile_sym = SYM && (jt_begin + t < ib);  // strictly below the diagonal
         const float *dcr = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);
         // start values of the chain: rbf c_i + c_j, rbf with folded records c_i (c_j is the factor 2^c_j of the record), polynomial 0
-        if constexpr (KT == KT_RBF) {
+        if constexpr (KT == KT_RBF || GRID) {  // (grid planes: sigma^2 (ch_i + ch_j), an exact sum)
 #pragma unroll
             for (int cb = 0; cb < 8; ++cb) {
                 const float cjv = dcr[128 + cb * 16 + r];
@@ -215,15 +249,20 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) acc[rb][cb] = civ0[rb];  // (zero for the polynomial kernels)
         }
-        for (int p = 0; p < panels; ++p) {
+        // SWEEP 0: the bf16x6 / f16x3 kernels (one sweep: per panel and chunk the column planes against the row planes of equal or lower order);
+        // grid planes: SWEEP 1 = A (h x h of every panel), SWEEP 2 = B (the remaining five products of every panel)
+        auto panel_steps = [&](int p, auto sweep_c) {
+            constexpr int SWEEP = decltype(sweep_c)::value;
+            constexpr int NKS = SWEEP == 0 ? NKC : (SWEEP == 1 ? NK64 : 3 * NK64);  // steps of this panel in this sweep
             // (the row panel of this tile-panel was requested chunk by chunk while the previous one was being multiplied: see below)
             const bool more_panels = t + 1 < ntiles || p + 1 < panels;
             const int p_next = p + 1 < panels ? p + 1 : 0;  // (the row panel depends on the feature panel only, not on the tile)
-            const int s0 = t * steps_per_tile + p * NKC;
+            const int s0 = t * steps_per_tile + (SWEEP == 2 ? panels * NK64 : 0) + p * NKS;
             const unsigned phase = static_cast<unsigned>(s0) & (V2_RING - 1);
-            static_for<0, NKC>([&](auto kc_c) {
+            static_for<0, NKS>([&](auto kc_c) {
                 constexpr int kc = decltype(kc_c)::value;
-                constexpr int chunk = kc / PL, plane = kc % PL;
+                constexpr int chunk = SWEEP == 0 ? kc / PL : (SWEEP == 1 ? kc : kc / 3);
+                constexpr int plane = SWEEP == 0 ? kc % PL : (SWEEP == 1 ? 0 : kc % 3);
                 const int step = s0 + kc;
                 const unsigned slot_off = ((phase + kc) & (V2_RING - 1)) * V2_SLOT_BYTES;
                 const unsigned slot_next_off = ((phase + kc + 1) & (V2_RING - 1)) * V2_SLOT_BYTES;
@@ -241,11 +280,11 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
                     }
                     if constexpr (mm == 2) {
                         // (the colred writes of the previous tile's epilogue must have completed before the barrier publishes them)
-                        if constexpr (SYM) {
+                        if constexpr (SYM && SWEEP != 2) {  // (the first step of a tile lies in sweep 0 / A)
                             if (kc == 0 && p == 0 && t > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         }
                         handover(step);
-                        if constexpr (SYM) {
+                        if constexpr (SYM && SWEEP != 2) {
                             if (kc == 0 && p == 0 && t > 0) flush_cols(t - 1);  // (tile t - 1 < t <= the diagonal tile: always off-diagonal)
                         }
                         LSSVM_SCHED_BARRIER();
@@ -257,24 +296,49 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
                         }
                         LSSVM_SCHED_BARRIER();
                     }
+                    // the row planes this column plane meets: sweep 0: those of equal or lower order; A: h; B: h -> (s1, s2), s1 -> (h, s1), s2 -> (h)
+                    constexpr int NQ = SWEEP == 0 ? PL - plane : (SWEEP == 1 ? 1 : (plane == 2 ? 1 : 2));
 #pragma unroll
-                    for (int q = 0; q < PL; ++q) {
-                        if (q + plane > PL - 1) continue;
+                    for (int q = 0; q < NQ; ++q) {
+                        constexpr auto rp = [](int pl, int qq) constexpr { return SWEEP == 0 ? -1 : (SWEEP == 1 ? 0 : (pl == 0 ? 1 + qq : (pl == 1 ? qq : 0))); };
+                        const int rpl = SWEEP == 0 ? row_plane(plane, q) : rp(plane, q);
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const int cb = 4 * cbh + c;
                             const bf16x8 bv = __builtin_bit_cast(bf16x8, bcur[c]);
 #pragma unroll
-                            for (int rb = 0; rb < 2; ++rb) acc[rb][cb] = plane_mfma<F16>(afrag[row_plane(plane, q)][2 * chunk + kk][rb], bv, acc[rb][cb]);
+                            for (int rb = 0; rb < 2; ++rb) acc[rb][cb] = plane_mfma<F16>(afrag[rpl][2 * chunk + kk][rb], bv, acc[rb][cb]);
                         }
                     }
                 });
                 // the last plane of a 64-feature chunk is through: its row fragments are dead, the registers take the same chunk of the NEXT
                 // tile-panel -- requested half a tile-panel or more before its first use instead of in front of it
-                if constexpr (plane == PL - 1) {
-                    if (more_panels && !LSSVM_DBG(a, 1)) load_row_chunk(p_next, std::integral_constant<int, chunk>{});  // ablation bit 1: no row-panel re-loads
+                if constexpr (SWEEP == 0) {
+                    if constexpr (plane == PL - 1) {
+                        if (more_panels && !LSSVM_DBG(a, 1)) load_row_chunk(p_next, std::integral_constant<int, chunk>{});  // ablation bit 1: no row-panel re-loads
+                    }
+                } else if constexpr (SWEEP == 1) {  // sweep A: plane h of the next panel -- or, behind the last panel, ALL planes of panel 0 for sweep B
+                    if (p + 1 < panels) {
+                        load_row_chunk_h(p + 1, std::integral_constant<int, chunk>{});
+                    } else {
+                        load_row_chunk(0, std::integral_constant<int, chunk>{});
+                    }
+                } else {  // sweep B: all planes of the next panel -- or, behind the last panel, plane h of panel 0 for the next tile's sweep A
+                    if constexpr (plane == 2) {
+                        if (p + 1 < panels) {
+                            load_row_chunk(p + 1, std::integral_constant<int, chunk>{});
+                        } else if (t + 1 < ntiles) {
+                            load_row_chunk_h(0, std::integral_constant<int, chunk>{});
+                        }
+                    }
                 }
             });
+        };
+        if constexpr (GRID) {
+            for (int p = 0; p < panels; ++p) panel_steps(p, std::integral_constant<int, 1>{});
+            for (int p = 0; p < panels; ++p) panel_steps(p, std::integral_constant<int, 2>{});
+        } else {
+            for (int p = 0; p < panels; ++p) panel_steps(p, std::integral_constant<int, 0>{});
         }
         // ---- epilogue of the tile (s6w_body's, with the mirrored column sums where the tile is off the diagonal) ----
         auto epilogue = [&](auto with_cols) {
@@ -295,7 +359,7 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float kv = apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(acc[rb][cb][e], a);
+                        const float kv = apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(GRID ? acc[rb][cb][e] * a.gamma : acc[rb][cb][e], a);  // (grid planes: the chain carries sigma^2)
                         rowpart[4 * rb + e] = fmaf(kv, djv, rowpart[4 * rb + e]);
                         if constexpr (COLS) {
                             kvp[e & 1] = kv;
@@ -344,6 +408,7 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
         v += __shfl_xor(v, 4);
         v += __shfl_xor(v, 2);
         v += __shfl_xor(v, 1);
+        if constexpr (GRID) v *= a.er[row0 + wave * 32 + 16 * (i >> 2) + 4 * g + (i & 3)];  // the row's folded factor E_i, once per work item
         rowpart[i] = v;
     }
     if (r == 0) {

@@ -34,7 +34,12 @@ static void launch_wide(const TileArgs<float> &a, int kernel_type, dim3 grid, hi
             }
             break;
         case KT_RBF:
-            if (a.dc_folded != 0) {
+            if (a.rbf_grid != 0) {  // rbf on grid planes (KT_RBFG): f16 planes only
+                const dim3 block(TILE_THREADS);
+                if (a.planes_f16 == 0) throw Error(LSSVM_ERR_INTERNAL, "the grid-plane rbf kernel runs on f16 planes");
+                ensure_dynamic_lds(tile_matvec_f32_wide<KT_RBFG, 2, SYM>, lssvm::V2_LDS_BYTES);
+                hipLaunchKernelGGL((tile_matvec_f32_wide<KT_RBFG, 2, SYM>), grid, block, lssvm::V2_LDS_BYTES, s, a);
+            } else if (a.dc_folded != 0) {
                 launch_wide_kt<KT_RBFF, SYM>(a, grid, s);
             } else {
                 launch_wide_kt<KT_RBF, SYM>(a, grid, s);

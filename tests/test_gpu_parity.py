@@ -372,9 +372,9 @@ def test_rbf_large_exponent_scale_switches_to_the_direct_kernel(oracle, case):
 
 
 @pytest.mark.parametrize("d, gamma, spread, devices", [(128, 2.0, 1.0, None), (128, 30.0, 1.0, None), (64, 8.0, 1.0, None), (100, 1.0 / 100, 25.0, None), (40, 60.0, 1.0, None),
-                                                       (128, 4.0, 1.0, [0, 0, 0]), (96, 100.0, 1.0, None), (96, 250.0, 1.0, None), (256, 2.0, 1.0, None), (200, 6.0, 1.0, [0, 0]), (384, 1.5, 1.0, None), (330, 20.0, 1.0, None)])
+                                                       (128, 4.0, 1.0, [0, 0, 0]), (96, 100.0, 1.0, None), (96, 250.0, 1.0, None), (256, 2.0, 1.0, None), (200, 6.0, 1.0, [0, 0]), (384, 1.5, 1.0, None), (330, 20.0, 1.0, None), (640, 1.0, 1.0, None), (1000, 0.5, 1.0, [0, 0]), (513, 3.0, 1.0, None)])
 def test_rbf_on_grid_planes_keeps_the_direct_forms_accuracy_on_the_matrix_cores(oracle, d, gamma, spread, devices):
-    """Round 5.  Exponent scales R2 = 2 gamma log2(e) max|x - mean|^2 from 40 to 4 000 on 40 ... 384 features, data with
+    """Round 5.  Exponent scales R2 = 2 gamma log2(e) max|x - mean|^2 from 40 to 4 000 on 40 ... 1 000 features, data with
     near-duplicate points (the pairs that lose digits in the norm expansion) and far ones.  The automatic choice is the matrix cores on GRID planes (tile_matvec_f32_g6h:
     x = h + s1 + s2 with h on a grid, the accumulators started from sigma^2 (ch_i + ch_j) and fed the h.h products first, so that the large terms cancel EXACTLY);
     asserted against the float64 oracle on the scale of each row's summands, symmetric and full square, one device and three shards: below 16 eps like the direct
