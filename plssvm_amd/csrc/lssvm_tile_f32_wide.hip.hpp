@@ -419,8 +419,13 @@ __device__ __forceinline__ void s6x_body(const TileArgs<float> &a) {
 }
 
 /* PL = 2: f16x3 (two f16 column planes), PL = 3: bf16x6 (three bf16 planes).  Two waves per SIMD. */
+/* (the grid-plane instantiation spills 15 ... 41 registers at two waves per SIMD; one wave per SIMD -- no spills -- measured 39 % SLOWER: 40 000 x 1 024 8.4 -> 11.7 ms, 60 000 x 640
+ * 11.6 -> 16.2 ms, same box, tests/tools/build_unit_variant.sh widegrid1 tile_launch_f32x -DLSSVM_WIDE_GRID_WAVES=1) */
+#ifndef LSSVM_WIDE_GRID_WAVES
+#define LSSVM_WIDE_GRID_WAVES 2
+#endif
 template <int KT, int PL, bool SYM>
-__global__ __launch_bounds__(TILE_THREADS, 2) void tile_matvec_f32_wide(const TileArgs<float> a) {
+__global__ __launch_bounds__(TILE_THREADS, (KT == KT_RBFG ? LSSVM_WIDE_GRID_WAVES : 2)) void tile_matvec_f32_wide(const TileArgs<float> a) {
     s6x_body<KT, PL, SYM>(a);
 }
 
