@@ -272,8 +272,8 @@ int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
  *                   up to 64 for the split kernels; 256-row workgroups: the length whose replayed dispatch over the CUs finishes first)
  *   "j_chunk_head"  256-row workgroups (see "mfma_shape"): the FIRST `count` column chunks of every pair of row blocks have `tiles` tiles instead of j_chunk_tiles, value =
  *                   1024 count + tiles; their short work items are dispatched last and fill the final dispatch round of a launch that is only a few rounds long.
- *                   0 (default) = none (measured: the replay's cost model cannot rank splits that differ by the few per cent a head moves); 1 = let the replayed
- *                   dispatch choose a head with the chunk length (j_chunk_tiles = 0)
+ *                   1 (default) = the replayed dispatch chooses a head together with the chunk length (j_chunk_tiles = 0; 3-5 % at 20 000-50 000 points since the
+ *                   launches are persistent and draw their items from per-XCD counters); 0 = none
  *   "symmetric"     1 = evaluate only the kernel-matrix tiles on/below the diagonal and mirror them (default; any num_features -- beyond 512 (fp32) /
  *                   256 (fp64) features over feature panels -- except fp32 with gram_mode = 0 beyond 512 features and a negative polynomial
  *                   degree, which run the full square),

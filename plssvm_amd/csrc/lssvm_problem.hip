@@ -684,21 +684,32 @@ static int num_chunks(int num_tiles, int tiles, int head_tiles, int head_count) 
 }
 /* Round 5: the replay also tries a HEAD of short chunks -- the first `head_count` column chunks of every row pair have `head_tiles` tiles -- whose items are
  * dispatched last, longest first, together with the items cut short by the diagonal: long items for the bulk of a launch (fewer row-panel loads), short ones
- * to fill its final dispatch round.  Only where a launch is a few rounds long (at most 8 items per slot at the longest chunk: that is where the last round
- * decides; ADVICE r04: no long replays of large launches).
- * MEASURED (profiles/r05_ab_chunk_head.log, same box, against every uniform length): the replay's pick with heads is 2.5 % faster than the best uniform length at
- * 40 000 points and 1 % at 70 000, but 2.5 % SLOWER at 30 000 and 1 % at 50 000 -- the cost model (tiles + 2.6; refitted on that log: rms error 5 % whatever the
- * constant) cannot rank candidates that lie within a few per cent, which is all a head moves.  So the automatic choice stays with uniform chunks; heads are
- * searched only on request (option j_chunk_head = 1) and can be given explicitly (1024 count + tiles). */
+ * to fill its end.  Searched where a launch is a few rounds long (at most 8 items per slot at the longest chunk: that is where the last round
+ * decides; ADVICE r04: no long replays of large launches); a fixed head of two 16-tile chunks up to 32 items per slot, none beyond.
+ * MEASURED, same box, against the replay's best uniform length (option j_chunk_head = 0):
+ *   - with one workgroup per item, dealt by the hardware (profiles/r05_ab_chunk_head.log): -2.5 % at 40 000 points, -1 % at 70 000, but +2.5 % at 30 000 and +1 % at
+ *     50 000 -- a wash: that deal is in order and static per XCD (tests/tools/item_trace.py: CUs wait 8 ... 40 us in front of the short items, and the launch ends
+ *     with its slowest XCD whatever the items);
+ *   - with the PERSISTENT launches that draw their items from per-XCD counters (pair_queue_fetch; profiles/r05_queue_chunk_sweep.log, r05_queue_head_large.log):
+ *     -5.4 % at 20 000 points, -4.5 % at 30 000, -3.5 % at 40 000, -2.6 % at 50 000, -0.9 % at 70 000, -1.6 % at 100 000, -1.0 % at 150 000, nothing at 250 000.
+ * So heads are the default since the launches are persistent. */
 static PairChunks choose_pair_chunk(int ib_begin, int ib_end, int num_tiles, size_t real_size, const Options &o, int slots) {
     const int cap = 64;
     PairChunks best_c;
     const long area = (static_cast<long>(ib_end) * (ib_end + 1) - static_cast<long>(ib_begin) * (ib_begin + 1)) / 4;  // pair-tiles, about
-    if (area / cap > 16L * slots) return best_c;  // (beyond ~16 dispatch rounds the last round no longer decides, and the replay itself costs: 16 of 27 ms of set-up at 250 000 points)
+    if (area / cap > 16L * slots) {  // (beyond ~16 dispatch rounds the last round no longer decides, and the replay itself costs: 16 of 27 ms of set-up at 250 000 points)
+        if (o.j_chunk_head == 1 && area / cap <= 32L * slots && num_tiles > 2 * 16 + cap) {
+            best_c.head_tiles = 16;
+            best_c.head_count = 2;
+        }
+        return best_c;
+    }
     const std::vector<int> edge = band_edges(ib_begin, ib_end, real_size, o);
     const bool few_rounds = area / cap <= 8L * slots && edge.size() == 2;
     double best = 0.0;
     bool have = false;
+    const double item_cost = 2.6;  // (with the persistent launches a traced item costs 1.2 tiles beside its tiles -- tests/tools/item_trace.py --; replays with 1.2 and 0.6 choose within
+                                   // 1 % of this one, 2.6 a little better from 70 000 points on: profiles/r05_queue_chunk_sweep.log)
     auto replay = [&](int jc, int head_tiles, int head_count) {
         const int num_jc = num_chunks(num_tiles, jc, head_tiles, head_count);
         double total = 0.0;
@@ -710,7 +721,7 @@ static PairChunks choose_pair_chunk(int ib_begin, int ib_end, int num_tiles, siz
                 const int b = chunk_begin(it.y, jc, head_tiles, head_count);
                 const int tiles = std::min(std::min(b + chunk_len(it.y, jc, head_tiles, head_count), it.x + 2), num_tiles) - b;
                 std::pop_heap(slot.begin(), slot.end(), later);
-                slot.back() += static_cast<double>(std::max(tiles, 0)) + 2.6;
+                slot.back() += static_cast<double>(std::max(tiles, 0)) + item_cost;
                 std::push_heap(slot.begin(), slot.end(), later);
             }
             total += *std::max_element(slot.begin(), slot.end());
@@ -724,7 +735,12 @@ static PairChunks choose_pair_chunk(int ib_begin, int ib_end, int num_tiles, siz
         }
     };
     for (const int jc : { 2, 3, 4, 6, 8, 10, 12, 16, 20, 24, 32, 40, 48, 64 }) replay(jc, 0, 0);
-    if (few_rounds && o.j_chunk_head == 1) {  // (not the default: measured a wash, see the comment above)
+    if (!few_rounds && o.j_chunk_head == 1 && edge.size() == 2) {
+        for (const int jc : { 48, 64 }) {
+            if (2 * 16 + jc <= num_tiles) replay(jc, 16, 2);
+        }
+    }
+    if (few_rounds && o.j_chunk_head == 1) {
         for (const int jc : { 24, 32, 40, 48, 56, 64 }) {
             for (const int hc : { 1, 2, 3, 4, 6, 8 }) {
                 for (const int ht : { 4, 8, 12, 16, 20, 24 }) {
@@ -891,6 +907,14 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         if (jc_head_count_ <= 0 || jc_head_tiles_ <= 0 || jc_head_count_ * jc_head_tiles_ >= num_tiles_) jc_head_count_ = jc_head_tiles_ = 0;
     }
     if (!pair_) jc_head_count_ = jc_head_tiles_ = 0;
+    // 256-row workgroups: PERSISTENT launches, the work items drawn from per-XCD counters (pair_queue_fetch, lssvm_tile_f32_pair.hip.hpp) instead of one workgroup per
+    // item dealt by the hardware -- whose deal is static per XCD (every eighth workgroup, whatever the XCD's pace: the eight clocks of one chip differ by 3-5 %) and in
+    // order.  Same box, interleaved, bit-identical: 1 000 000 x 128 rbf 264.9 -> 256.8 ms per iteration (-3.0 %), 200 000 x 256 linear 20.05 -> 19.49 (-3.0 %),
+    // 50 000 x 128 unchanged (profiles/r05_ab_pair_queue.log).  LSSVM_MI355_PAIR_QUEUE=0 in the environment: the former launches (A/B runs).
+    if (const char *pq = std::getenv("LSSVM_MI355_PAIR_QUEUE"); pair_ && !(pq != nullptr && pq[0] == '0')) {
+        queue_.alloc_zero(512, st);
+        LSSVM_HIP_CHECK(hipDeviceGetAttribute(&queue_min_items_, hipDeviceAttributeMultiprocessorCount, device_));
+    }
     num_jc_ = num_chunks(num_tiles_, jc_tiles_, jc_head_tiles_, jc_head_count_);
     if (const char *dbg = std::getenv("LSSVM_MI355_DEBUG"); dbg != nullptr && dbg[0] == '1') {
         std::fprintf(stderr, "[plssvm_amd] shard %d/%d on device %d: row blocks [%d, %d) of %d, %d tiles per work item (head: %d chunks of %d), symmetric %d\n", rank_, world_, device_,
@@ -948,9 +972,10 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
             grid_sigma_ = make_grid_planes(X_, rbf_r2_, planes_, c_.p, efac_, st, wide_nl_);
         } else if (!wide_linear_) make_planes(opt_, tile_params_, rbf_direct_, X_, nullptr, planes_, nullptr, st, wide_nl_, false, f16_probe_failed_);
         if ((wide_nl_ || pair_) && planes_.mode == 0) throw Error(LSSVM_ERR_INTERNAL, "no operand planes for a path that was chosen from the shape alone");
-        if (wide_nl_ && sym_) {
+        if ((wide_nl_ && sym_) || pair_) {
             // the row side of the panels-inside-a-tile kernel: the planes once more, every 16 x 32 block stored as the A fragment a wave loads
-            // (lssvm_tile_f32_wide.hip.hpp: the row fragments are re-loaded at every tile-panel -- whole cache lines instead of half lines)
+            // (lssvm_tile_f32_wide.hip.hpp: the row fragments are re-loaded at every tile-panel -- whole cache lines instead of half lines);
+            // the 256-row workgroups load a work item's row panel from it (1 KiB contiguous per load instruction instead of 64 bytes of each of 16 rows)
             const size_t plane_elems = static_cast<size_t>(X_.rows_alloc) * planes_.ldx16;
             planes_frag_.alloc_zero(static_cast<size_t>(planes_.nplanes) * plane_elems, st);
             const size_t pieces = static_cast<size_t>(planes_.nplanes) * X_.rows_alloc * (planes_.ldx16 / 8);
@@ -1127,6 +1152,7 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
             TileArgs<T> ap = a;
             if constexpr (std::is_same_v<T, float>) {
                 if (wide_linear_) {
+                    if (ap.Xr16f != nullptr) ap.Xr16f += static_cast<size_t>(panel) * (panel_features / 64) * (X_.rows_alloc / 16) * 1024;  // (the 64-feature chunk is the outermost index of a plane)
                     ap.Xr16 += static_cast<size_t>(panel) * panel_features;
                     ap.Xc16 += static_cast<size_t>(panel) * panel_features;
                     ap.nk64 = std::min(panel_features, planes_.ldx16 - panel * panel_features) / 64;
@@ -1143,6 +1169,13 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
                 ab.items = items_.p + band.item_begin;
                 ab.num_items = band.item_count;
                 ab.pair_origin = band.pair_origin;
+                if constexpr (std::is_same_v<T, float>) {
+                    if (queue_.p != nullptr && band.item_count > queue_min_items_) {  // (a launch of no more items than CUs: one workgroup per item, no counters -- 2 % faster there)
+                        ab.queue = queue_.p + 256 * queue_set_;
+                        ab.queue_next = queue_.p + 256 * (1 - queue_set_);
+                        queue_set_ ^= 1;
+                    }
+                }
                 EvPair *ev = free_event();
                 if (ev != nullptr) LSSVM_HIP_CHECK(hipEventRecord(ev->a.e, st));
                 launch_tile_kernel<T>(ab, tile_params_.kernel_type, rbf_direct_, num_jc_, st);

@@ -63,7 +63,7 @@ struct Options {
     int64_t rbf_fold = 1;        // fp32 rbf on the split kernels: 1 = folded column records (2^c_j d_j | 2^c_j), accumulators start from c_i as the C
                                  // operand of their first MFMA (default, while the exponent scale stays below 200); 0 = start values c_i + c_j by vector adds
     int64_t j_chunk_tiles = 0;   // 128-column tiles per work item; 0 = automatic (see Problem<T>'s constructor)
-    int64_t j_chunk_head = 0;    // 256-row workgroups: 0 = none; 1 = chosen by the replayed dispatch (with j_chunk_tiles = 0); 1024 count + tiles = the first `count` column chunks have `tiles` tiles
+    int64_t j_chunk_head = 1;    // 256-row workgroups: 0 = none; 1 = chosen by the replayed dispatch (with j_chunk_tiles = 0; default); 1024 count + tiles = the first `count` column chunks have `tiles` tiles
     int64_t symmetric = 1;         // 1: evaluate only the tiles on/below the diagonal and mirror them, 0: full square
     int64_t tile_kernel = 0;       // 0: automatic (resident-row-panel kernels where they exist), 1: always the generic v1 kernel (the cross-checks' yardstick)
     int64_t gram_mode = 3;         // fp32 Gram tiles: 0 = v_mfma_f32 chains; 1 = "bf16x6"; 2 = "f16x3" without the representability check; 3 (default) = f16x3
@@ -356,6 +356,9 @@ class Problem {
     bool sym_ = false;
     DevBuf<int2> items_;
     int num_items_ = 0;
+    DevBuf<unsigned> queue_;  // 256-row workgroups, persistent launches: two sets of eight item counters (a launch draws from one and zeroes the other)
+    int queue_set_ = 0;
+    int queue_min_items_ = 256;  // launches of more items than this (the CU count) are persistent
     DevBuf<T> colslab_;  // the records of the band in flight
     struct Band {
         int ib_begin, ib_end;       // row blocks [begin, end) of the band (global block indices)

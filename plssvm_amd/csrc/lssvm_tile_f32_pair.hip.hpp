@@ -36,10 +36,17 @@ constexpr int PR_ROWS = 2 * TILE;
 constexpr int PR_RING = 8;  // 16 KiB slots (power of two)
 constexpr size_t PR_LDS_BYTES = static_cast<size_t>(PR_RING) * V2_SLOT_BYTES + V2_DC_SLOTS * 1024 + (2 * PR_ROWS + 2 * PR_WAVES * TILE) * sizeof(float);  // ring + records + cis, dis, colred
 
+#ifdef LSSVM_ITEM_TRACE  // measurement builds only (tests/tools/item_trace.py): wave 0 of every work item stamps its phases with the constant 100 MHz clock
+__device__ unsigned long long *lssvm_item_trace = nullptr;  // [num_items][8]: entry, row panel loaded, tile loop entered, tile loop left, end, HW_ID, tiles, (spare)
+#define LSSVM_TRACE(slot) do { if (HALF == 0 && lssvm_item_trace != nullptr && threadIdx.x == 0) lssvm_item_trace[static_cast<size_t>(item_pos) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LSSVM_TRACE(slot) do { } while (0)
+#endif
+
 /* HALF: 0 = waves 0-3 (row block 2p), 1 = waves 4-7 (row block 2p + 1; LAGT = 0, the shipped form: in lock step with the first half).  Both halves
  * execute the same number of barriers. */
 template <int KT, int NK64, int PL, int HALF, int LAGT>
-__device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
+__device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int item_pos) {
     static_assert(PL == 3 || PL == 2, "three bf16 planes (bf16x6) or two f16 planes (f16x3)");
     static_assert(NK64 <= 2, "the hand-scheduled groups assume the 256-register budget of two waves per SIMD");
     static_assert(KT != KT_RBF, "rbf runs here with BOTH exponent terms folded (KT_RBFF, see below); the unfolded form stays on the 128-row kernels");
@@ -70,7 +77,8 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
 
     if constexpr (PRIO == 1) asm volatile("s_setprio 1");
     if constexpr (PRIO == 3) asm volatile("s_setprio 3");
-    const int2 it = a.items[blockIdx.x];
+    LSSVM_TRACE(0);
+    const int2 it = a.items[item_pos];
     const int ibl = __builtin_amdgcn_readfirstlane(it.x);  // local index of the pair's FIRST block (even)
     const int jc = __builtin_amdgcn_readfirstlane(it.y);
     const int ib0 = a.ib_begin + ibl;
@@ -165,13 +173,23 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
     // item's start (192 -> 128 KiB per item at ~11 B / cycle / CU).  Bit-identical; 1 000 000 x 128: 267.8 -> 266.7 ms, 50 000 x 128: 0.759 -> 0.755 ms per
     // iteration, same box, interleaved (profiles/r05_ab_mfma_order_and_derived_row_plane.log, "lib_v_derive")
     constexpr int P_FIRST = (F16 && PLA == 3) ? 1 : 0;
+    const size_t frag_chunk = a.plane_stride_r / static_cast<size_t>(a.ldx16) / 16 * 1024;  // elements between the 64-feature chunks of a fragment-major plane
 #pragma unroll
     for (int p = P_FIRST; p < PLA; ++p) {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
+            // from the FRAGMENT-MAJOR copy of the planes (TileArgs::Xr16f, k_planes_fragment_major: [plane][64-feature chunk][16-row block][2 k-steps][64 lanes][8]):
+            // every load instruction of a wave reads 1 KiB in one piece -- row-major it read 64 bytes of each of 16 rows, and the row panel, which nothing
+            // overlaps with (one workgroup per CU), took 4.5 us of a work item (tests/tools/item_trace.py)
+#ifndef LSSVM_PAIR_ROW_MAJOR_PANEL
+            const uint16_t *xr = a.Xr16f + p * a.plane_stride_r + static_cast<size_t>((row0 >> 4) + wave * 2 + rb) * 1024 + lane * 8;
+#pragma unroll
+            for (int kk = 0; kk < 2 * NK64; ++kk) afrag[p][kk][rb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(xr + (kk >> 1) * frag_chunk + (kk & 1) * 512));
+#else  // (A/B builds: the former loads from the row-major planes)
             const uint16_t *xr = a.Xr16 + p * a.plane_stride_r + static_cast<size_t>(row0 + wave * 32 + 16 * rb + r) * a.ldx16 + 8 * g;
 #pragma unroll
             for (int kk = 0; kk < 2 * NK64; ++kk) afrag[p][kk][rb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(xr + 32 * kk));
+#endif
         }
     }
     // rbf: K_ij = 2^c_i 2^(x_i . x_j) 2^c_j with BOTH exponent terms folded out of the chain -- the column's as the record's factor e_j (k_pack_dc:
@@ -192,6 +210,7 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
     }
     // (retire the ordinary loads HERE: none may be outstanding once the counted waits of the hand-overs begin)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    LSSVM_TRACE(1);
     if constexpr (P_FIRST == 1) {
         typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 #pragma unroll
@@ -342,8 +361,10 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
     // scratch reload in the loop drains the LDS-DMA queue)
     const int nmain = max(0, min(ntiles - TAIL_TILES, ib0 - jt_begin));
     int t = 0;
+    LSSVM_TRACE(2);
     for (; t < nmain; ++t) tile_body(t, std::false_type{});
     for (; t < ntiles; ++t) tile_body(t, std::true_type{});
+    LSSVM_TRACE(3);
     // the leading half accompanies the lagging half's last LAGT steps (hand-overs only)
     if constexpr (HALF == 0) {
 #pragma unroll
@@ -380,6 +401,45 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) dst[16 * (i >> 2) + (i & 3)] = rowpart[i];
     }
+#ifdef LSSVM_ITEM_TRACE
+    LSSVM_TRACE(4);
+    if (HALF == 0 && lssvm_item_trace != nullptr && threadIdx.x == 0) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        lssvm_item_trace[static_cast<size_t>(item_pos) * 8 + 5] = (static_cast<unsigned long long>(xcc) << 32) | hw;
+        lssvm_item_trace[static_cast<size_t>(item_pos) * 8 + 6] = static_cast<unsigned long long>(ntiles);
+    }
+#endif
+}
+
+/* The next work item of a PERSISTENT launch (TileArgs::queue), or -1.  The item list is laid out for the hardware's round-robin deal of workgroups to the
+ * eight XCDs (position 8 k + x = lane x: a lane streams one column chunk at a time through ITS L2); a workgroup draws from the lane of the XCD it runs on and,
+ * once that lane is empty, from the lane with the most items left.  Which CU evaluates an item changes no result (every item owns its slab rows and records).
+ * Why: the hardware's own deal is STATIC -- every XCD gets every eighth workgroup whatever its pace, and the XCDs of one chip differ by 3-5 % (per-XCD clocks;
+ * tests/tools/item_trace.py, profiles/r05_item_trace.log): the launch ends when the slowest lane does.  It also dispatches in order, so a CU waits for its
+ * successor while a workgroup further up the list waits for a slot elsewhere (gaps of 8 ... 40 us in front of the short items at the end of a list). */
+__device__ __forceinline__ int pair_queue_fetch(unsigned *ctr, int xcc, int num_items) {
+    auto lane_items = [&](int x) { return (num_items - x + 7) >> 3; };
+    auto taken = [&](int x) { return static_cast<int>(min(__hip_atomic_load(ctr + 32 * x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), static_cast<unsigned>(lane_items(x)))); };
+    int x = xcc;  // (the own lane without a look first: one round trip to the counters per item, not two; a counter may overshoot its lane's length)
+    for (;;) {
+        if (x < 0) {
+            int most = 0;
+            for (int o = 0; o < 8; ++o) {
+                const int left = lane_items(o) - taken(o);
+                if (left > most) {
+                    most = left;
+                    x = o;
+                }
+            }
+            if (x < 0) return -1;
+        }
+        const unsigned k = atomicAdd(ctr + 32 * x, 1u);
+        if (k < static_cast<unsigned>(lane_items(x))) return x + 8 * static_cast<int>(k);
+        x = -1;  // (another workgroup took the lane's last item in between)
+    }
 }
 
 /* PL = 2: f16x3 ("f3d"), PL = 3: bf16x6 ("s6d").  LAGT: steps the second half runs behind (0 = lock step). */
@@ -389,10 +449,31 @@ __global__ __launch_bounds__(PR_THREADS, 2) LSSVM_HAND_VGPR_CAP void tile_matvec
 #pragma unroll
     for (int i = 0; i < LSSVM_CODE_SHIFT; ++i) asm volatile("s_nop 0");
 #endif
-    if (__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6) < 4) {  // (a scalar branch: the halves are whole waves)
-        pair_body<KT, NK64, PL, 0, LAGT>(a);
-    } else {
-        pair_body<KT, NK64, PL, 1, LAGT>(a);
+    __shared__ int next_pos;
+    const bool first_half = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6) < 4;  // (a scalar branch: the halves are whole waves)
+    unsigned *const queue = a.queue;
+    int xcc = 0;
+    if (queue != nullptr) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        xcc = static_cast<int>(id & 7u);
+        if (blockIdx.x == 0 && threadIdx.x < 8) a.queue_next[32 * threadIdx.x] = 0u;
+    }
+    int pos = static_cast<int>(blockIdx.x);
+    for (;;) {
+        if (queue != nullptr) {
+            if (threadIdx.x == 0) next_pos = pair_queue_fetch(queue, xcc, a.num_items);
+            __syncthreads();
+            pos = __builtin_amdgcn_readfirstlane(next_pos);
+            if (pos < 0) break;
+        }
+        if (first_half) {
+            pair_body<KT, NK64, PL, 0, LAGT>(a, pos);
+        } else {
+            pair_body<KT, NK64, PL, 1, LAGT>(a, pos);
+        }
+        if (queue == nullptr) break;
+        __syncthreads();  // every wave has left the item's LDS (ring, records, column sums, next_pos) before the next prologue writes it
     }
 }
 

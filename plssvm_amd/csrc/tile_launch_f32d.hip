@@ -11,7 +11,13 @@ namespace lssvm {
 
 template <int KT, int NK64, int PL>
 static void launch_pair_lag(const TileArgs<float> &a, hipStream_t s) {
-    const dim3 grid(static_cast<unsigned>(a.num_items)), block(PR_THREADS);
+    int cus = 256;
+    if (a.queue != nullptr) {  // persistent launch: one workgroup per CU (140 KiB of LDS each), the items drawn from the problem's counters
+        int dev = 0;
+        LSSVM_HIP_CHECK(hipGetDevice(&dev));
+        LSSVM_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const dim3 grid(static_cast<unsigned>(a.queue != nullptr ? std::min(a.num_items, std::max(cus, 8)) : a.num_items)), block(PR_THREADS);
 #define LSSVM_PAIR_LAG(L)                                                                           \
     case L:                                                                                         \
         ensure_dynamic_lds(tile_matvec_f32_pair<KT, NK64, PL, L>, PR_LDS_BYTES);                    \
@@ -60,6 +66,7 @@ static void launch_pair(const TileArgs<float> &a, int kernel_type, hipStream_t s
 
 void launch_pair_tile_kernel(const TileArgs<float> &a, int kernel_type, hipStream_t s) {
     if (a.items == nullptr || a.num_items <= 0) return;
+    if (a.Xr16f == nullptr) throw Error(LSSVM_ERR_INTERNAL, "the 256-row tile kernel needs the fragment-major row planes");
     if (a.planes_f16 != 0) {
         launch_pair<2>(a, kernel_type, s);
     } else {
@@ -73,3 +80,9 @@ void launch_pair_tile_kernel(const TileArgs<float> &a, int kernel_type, hipStrea
 }
 
 }  // namespace lssvm
+
+#ifdef LSSVM_ITEM_TRACE
+extern "C" int lssvm_debug_set_item_trace(void *device_buffer) {  // measurement builds only: where the work items of the NEXT launches stamp their phases (NULL = off)
+    return static_cast<int>(hipMemcpyToSymbol(HIP_SYMBOL(lssvm::lssvm_item_trace), &device_buffer, sizeof(void *)));
+}
+#endif

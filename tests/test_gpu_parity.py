@@ -555,16 +555,20 @@ def test_a_head_of_short_column_chunks_changes_only_the_association(oracle, kern
     rows = np.array([0, 1, 127, 128, 255, 256, 257, 640, 4000, 8191, 8192, 9000, n - 1])
     devices = [0] * shards if shards > 1 else None
     results = {}
-    for name, tiles, head in (("uniform", 8, 0), ("head 3 x 2", 8, 3 * 1024 + 2), ("head 1 x 5", 16, 1 * 1024 + 5), ("head 6 x 3", 24, 6 * 1024 + 3), ("head as long as the triangle allows", 40, 2 * 1024 + 30),
-                              ("automatic", 0, 0), ("automatic with a head", 0, 1)):
-        _capi.set_option("j_chunk_tiles", tiles)
-        _capi.set_option("j_chunk_head", head)
-        with backend.ResidentProblem(p, X, devices=devices) as prob:
-            err, got, rhs = _sampled_rows_vs_oracle(oracle, prob, kernel, X, rows)
-            again = prob.matvec(rhs, np.zeros(n, np.float32), 1.0)
-        assert err < 16 * eps, (name, err / eps)
-        assert np.array_equal(got, again), name
-        results[name] = got
+    try:
+        for name, tiles, head in (("uniform", 8, 0), ("head 3 x 2", 8, 3 * 1024 + 2), ("head 1 x 5", 16, 1 * 1024 + 5), ("head 6 x 3", 24, 6 * 1024 + 3), ("head as long as the triangle allows", 40, 2 * 1024 + 30),
+                                  ("automatic without a head", 0, 0), ("automatic", 0, 1)):
+            _capi.set_option("j_chunk_tiles", tiles)
+            _capi.set_option("j_chunk_head", head)
+            with backend.ResidentProblem(p, X, devices=devices) as prob:
+                err, got, rhs = _sampled_rows_vs_oracle(oracle, prob, kernel, X, rows)
+                again = prob.matvec(rhs, np.zeros(n, np.float32), 1.0)
+            assert err < 16 * eps, (name, err / eps)
+            assert np.array_equal(got, again), name
+            results[name] = got
+    finally:
+        _capi.set_option("j_chunk_tiles", 0)
+        _capi.set_option("j_chunk_head", 1)
     base = results["uniform"]
     for name, got in results.items():
         assert ol.rel_inf(got, base) < 64 * eps, name  # (on the scale of the RESULT, whose rank-1 terms cancel: the bar of the sharded runs; measured 18 eps)

@@ -49,9 +49,14 @@ def main():
         for var in variants:
             for n, val in defaults.items():
                 _capi.set_option(n, val)
+            env_set = []
             for kv in filter(None, var.split(",")):
                 k, val = kv.split("=")
-                _capi.set_option(k.strip(), int(val))
+                if k.startswith("ENV:"):  # an environment switch of the library for this variant only (read when the problem is created)
+                    os.environ[k[4:]] = val
+                    env_set.append(k[4:])
+                else:
+                    _capi.set_option(k.strip(), int(val))
             with backend.ResidentProblem(p, X) as prob:
                 extra = ""
                 if args.check and rep == 0:
@@ -70,6 +75,8 @@ def main():
                 i1 = prob.info()
                 nt = i1["matvec_timed"] - i0["matvec_timed"]  # (short matvecs are event-bracketed by sampling: average over the timed ones)
                 k_ms = (i1["matvec_kernel_ms_total"] - i0["matvec_kernel_ms_total"]) / max(nt, 1)
+                for k in env_set:
+                    del os.environ[k]
                 print(f"rep {rep}  {var or '(defaults)':40s} tile kernel {k_ms:9.4f} ms   iteration {wall:9.4f} ms   sym {i1['symmetric']} gram {i1['gram_mode']}{extra}", flush=True)
     for n, val in defaults.items():
         _capi.set_option(n, val)
