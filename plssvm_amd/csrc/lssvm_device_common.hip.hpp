@@ -51,6 +51,78 @@ __device__ __forceinline__ bool decode_work_item(const TileArgs<T> &a, int &ibl,
     return true;
 }
 
+/* ------------------------------------------------------------------ work items of a symmetric launch ------------------------------------------------------------------
+ * (Used by the 256-row workgroups, lssvm_tile_f32_pair.hip.hpp.  Round 5 also put EVERY kernel of the symmetric variant on it: nothing gained -- the fp64 kernels hold
+ * 2.36 GHz on all XCDs, the 128-row fp32 kernels run two workgroups per CU -- and the item loop cost registers: fp64 linear 100 000 x 128 +4.8 %, native fp32 polynomial
+ * +2.2 %, 7 000 x 128 +12 %; profiles/r05_ab_generic_queue.log.  Those kernels keep one workgroup per item.)
+ * One workgroup per item (TileArgs::queue == NULL: item = list position blockIdx.x, dealt by the hardware), or a PERSISTENT launch: as many workgroups as the device
+ * runs at once, each drawing list positions from eight counters until the list is empty.  The item list is laid out for the hardware's round-robin deal of
+ * workgroups to the eight XCDs (position 8 k + x = lane x: a lane streams one column chunk at a time through ITS L2); a workgroup draws from the lane of the XCD it
+ * runs on and, once that lane is empty, from the lane with the most items left.  Which CU evaluates an item changes no result (every item owns its slab rows and
+ * records).  Why: the hardware's own deal is STATIC -- every XCD gets every eighth workgroup whatever its pace, and the XCDs of one chip differ by up to 8 % per tile
+ * (per-XCD clocks; tests/tools/item_trace.py, profiles/r05_item_trace.log: at 1 000 000 x 128 the XCDs of one band launch end between 31.9 and 34.3 ms, 3.4 % of
+ * CUs x time idle at its end; with the counters they end within 0.1 ms, the fast XCD having taken 9 % more tiles than the slow one).  It also dispatches in
+ * order, so a CU waits for its successor while a workgroup further up the list waits for a slot elsewhere (8 ... 40 us in front of the short items at the end of a
+ * list). */
+__device__ __forceinline__ int work_queue_fetch(unsigned *ctr, int xcc, int num_items) {
+    auto lane_items = [&](int x) { return (num_items - x + 7) >> 3; };
+    auto taken = [&](int x) { return static_cast<int>(min(__hip_atomic_load(ctr + 32 * x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), static_cast<unsigned>(lane_items(x)))); };
+    int x = xcc;  // (the own lane without a look first: one round trip to the counters per item, not two; a counter may overshoot its lane's length)
+    for (;;) {
+        if (x < 0) {
+            int most = 0;
+            for (int o = 0; o < 8; ++o) {
+                const int left = lane_items(o) - taken(o);
+                if (left > most) {
+                    most = left;
+                    x = o;
+                }
+            }
+            if (x < 0) return -1;
+        }
+        const unsigned k = atomicAdd(ctr + 32 * x, 1u);
+        if (k < static_cast<unsigned>(lane_items(x))) return x + 8 * static_cast<int>(k);
+        x = -1;  // (another workgroup took the lane's last item in between)
+    }
+}
+
+/* body(list position) for this workgroup's item(s).  The counters of the problem's NEXT launch (TileArgs::queue_next) are zeroed by workgroup 0. */
+template <typename T, typename Body>
+__device__ __forceinline__ void for_each_work_item(const TileArgs<T> &a, Body &&body) {
+    __shared__ int next_pos;
+    unsigned *const queue = a.queue;
+    int xcc = 0;
+    if (queue != nullptr) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        xcc = static_cast<int>(id & 7u);
+        if (blockIdx.x == 0 && threadIdx.x < 8) a.queue_next[32 * threadIdx.x] = 0u;
+    }
+    int pos = static_cast<int>(blockIdx.x);
+    for (;;) {
+        if (queue != nullptr) {
+            if (threadIdx.x == 0) next_pos = work_queue_fetch(queue, xcc, a.num_items);
+            __syncthreads();
+            pos = __builtin_amdgcn_readfirstlane(next_pos);
+            if (pos < 0) break;
+        }
+        // the kernel arguments through a pointer the compiler cannot see across iterations: else every field an item reads (and every 64-bit product of two of
+        // them) is hoisted as loop invariant and stays in SGPRs for the whole item -- 20 to 30 of them spill into VGPR lanes, and the two-waves-per-SIMD kernels,
+        // which have no VGPR to give, start spilling those.  (The argument struct is the kernel's only parameter: offset 0 of the kernarg segment.)
+        // The floating-point scalars stay with the hoisted copy: two of them as SGPR operands of one v_fma_f32 inside the loop is a form this compiler's operand
+        // folding produces and its own verifier then rejects ("violates constant bus restriction").
+        auto kp = (const __attribute__((address_space(4))) TileArgs<T> *) __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        TileArgs<T> ai = *(const TileArgs<T> *) kp;
+        ai.gamma = a.gamma;
+        ai.coef0 = a.coef0;
+        ai.out_scale = a.out_scale;
+        body(ai, pos);
+        if (queue == nullptr) break;
+        __syncthreads();  // every wave has left the item's LDS (ring, records, column sums, next_pos) before the next prologue writes it
+    }
+}
+
 /* exp(x) in double for the rbf epilogue: 2^k * p(r), k = rint(x log2 e), r = x - k ln2 (two-part ln2), p = degree-13 Taylor
  * polynomial on |r| <= 0.347 (truncation 4e-18), 19 double-precision VALU operations instead of libm's ~40 with its
  * special-case branches; v_ldexp_f64 handles underflow to 0 for very negative x.  Relative error < 2 ulp. */

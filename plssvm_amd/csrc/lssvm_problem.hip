@@ -907,7 +907,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         if (jc_head_count_ <= 0 || jc_head_tiles_ <= 0 || jc_head_count_ * jc_head_tiles_ >= num_tiles_) jc_head_count_ = jc_head_tiles_ = 0;
     }
     if (!pair_) jc_head_count_ = jc_head_tiles_ = 0;
-    // 256-row workgroups: PERSISTENT launches, the work items drawn from per-XCD counters (pair_queue_fetch, lssvm_tile_f32_pair.hip.hpp) instead of one workgroup per
+    // 256-row workgroups: PERSISTENT launches, the work items drawn from per-XCD counters (for_each_work_item, lssvm_device_common.hip.hpp) instead of one workgroup per
     // item dealt by the hardware -- whose deal is static per XCD (every eighth workgroup, whatever the XCD's pace: the eight clocks of one chip differ by 3-5 %) and in
     // order.  Same box, interleaved, bit-identical: 1 000 000 x 128 rbf 264.9 -> 256.8 ms per iteration (-3.0 %), 200 000 x 256 linear 20.05 -> 19.49 (-3.0 %),
     // 50 000 x 128 unchanged (profiles/r05_ab_pair_queue.log).  LSSVM_MI355_PAIR_QUEUE=0 in the environment: the former launches (A/B runs).
@@ -1169,12 +1169,11 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
                 ab.items = items_.p + band.item_begin;
                 ab.num_items = band.item_count;
                 ab.pair_origin = band.pair_origin;
-                if constexpr (std::is_same_v<T, float>) {
-                    if (queue_.p != nullptr && band.item_count > queue_min_items_) {  // (a launch of no more items than CUs: one workgroup per item, no counters -- 2 % faster there)
-                        ab.queue = queue_.p + 256 * queue_set_;
-                        ab.queue_next = queue_.p + 256 * (1 - queue_set_);
-                        queue_set_ ^= 1;
-                    }
+                if (queue_.p != nullptr && band.item_count > queue_min_items_) {  // (a launch of no more items than CUs: one workgroup per item, no counters -- 2 % faster there)
+                    ab.queue = queue_.p + 256 * queue_set_;
+                    ab.queue_next = queue_.p + 256 * (1 - queue_set_);
+                    ab.queue_grid = queue_min_items_;
+                    queue_set_ ^= 1;
                 }
                 EvPair *ev = free_event();
                 if (ev != nullptr) LSSVM_HIP_CHECK(hipEventRecord(ev->a.e, st));

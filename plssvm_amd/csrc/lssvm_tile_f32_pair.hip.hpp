@@ -414,34 +414,6 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int it
 #endif
 }
 
-/* The next work item of a PERSISTENT launch (TileArgs::queue), or -1.  The item list is laid out for the hardware's round-robin deal of workgroups to the
- * eight XCDs (position 8 k + x = lane x: a lane streams one column chunk at a time through ITS L2); a workgroup draws from the lane of the XCD it runs on and,
- * once that lane is empty, from the lane with the most items left.  Which CU evaluates an item changes no result (every item owns its slab rows and records).
- * Why: the hardware's own deal is STATIC -- every XCD gets every eighth workgroup whatever its pace, and the XCDs of one chip differ by 3-5 % (per-XCD clocks;
- * tests/tools/item_trace.py, profiles/r05_item_trace.log): the launch ends when the slowest lane does.  It also dispatches in order, so a CU waits for its
- * successor while a workgroup further up the list waits for a slot elsewhere (gaps of 8 ... 40 us in front of the short items at the end of a list). */
-__device__ __forceinline__ int pair_queue_fetch(unsigned *ctr, int xcc, int num_items) {
-    auto lane_items = [&](int x) { return (num_items - x + 7) >> 3; };
-    auto taken = [&](int x) { return static_cast<int>(min(__hip_atomic_load(ctr + 32 * x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), static_cast<unsigned>(lane_items(x)))); };
-    int x = xcc;  // (the own lane without a look first: one round trip to the counters per item, not two; a counter may overshoot its lane's length)
-    for (;;) {
-        if (x < 0) {
-            int most = 0;
-            for (int o = 0; o < 8; ++o) {
-                const int left = lane_items(o) - taken(o);
-                if (left > most) {
-                    most = left;
-                    x = o;
-                }
-            }
-            if (x < 0) return -1;
-        }
-        const unsigned k = atomicAdd(ctr + 32 * x, 1u);
-        if (k < static_cast<unsigned>(lane_items(x))) return x + 8 * static_cast<int>(k);
-        x = -1;  // (another workgroup took the lane's last item in between)
-    }
-}
-
 /* PL = 2: f16x3 ("f3d"), PL = 3: bf16x6 ("s6d").  LAGT: steps the second half runs behind (0 = lock step). */
 template <int KT, int NK64, int PL, int LAGT>
 __global__ __launch_bounds__(PR_THREADS, 2) LSSVM_HAND_VGPR_CAP void tile_matvec_f32_pair(const TileArgs<float> a) {
@@ -449,32 +421,14 @@ __global__ __launch_bounds__(PR_THREADS, 2) LSSVM_HAND_VGPR_CAP void tile_matvec
 #pragma unroll
     for (int i = 0; i < LSSVM_CODE_SHIFT; ++i) asm volatile("s_nop 0");
 #endif
-    __shared__ int next_pos;
     const bool first_half = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6) < 4;  // (a scalar branch: the halves are whole waves)
-    unsigned *const queue = a.queue;
-    int xcc = 0;
-    if (queue != nullptr) {
-        unsigned id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-        xcc = static_cast<int>(id & 7u);
-        if (blockIdx.x == 0 && threadIdx.x < 8) a.queue_next[32 * threadIdx.x] = 0u;
-    }
-    int pos = static_cast<int>(blockIdx.x);
-    for (;;) {
-        if (queue != nullptr) {
-            if (threadIdx.x == 0) next_pos = pair_queue_fetch(queue, xcc, a.num_items);
-            __syncthreads();
-            pos = __builtin_amdgcn_readfirstlane(next_pos);
-            if (pos < 0) break;
-        }
+    for_each_work_item(a, [&](const auto &ai, int pos) {  // (one workgroup per item, or a persistent launch: lssvm_device_common.hip.hpp)
         if (first_half) {
-            pair_body<KT, NK64, PL, 0, LAGT>(a, pos);
+            pair_body<KT, NK64, PL, 0, LAGT>(ai, pos);
         } else {
-            pair_body<KT, NK64, PL, 1, LAGT>(a, pos);
+            pair_body<KT, NK64, PL, 1, LAGT>(ai, pos);
         }
-        if (queue == nullptr) break;
-        __syncthreads();  // every wave has left the item's LDS (ring, records, column sums, next_pos) before the next prologue writes it
-    }
+    });
 }
 
 }  // namespace lssvm

@@ -65,6 +65,7 @@ struct TileArgs {
     unsigned *queue;       // 256-row workgroups: NULL = one workgroup per item (grid = num_items); else the launch is PERSISTENT (one workgroup per CU) and the workgroups draw
                            // their items from eight counters, one per XCD lane of the item list (positions 8 k + x), [8][32] words apart -- lssvm_tile_f32_pair.hip.hpp
     unsigned *queue_next;  // the counters of this problem's NEXT launch: zeroed by this one
+    int queue_grid;        // host side only: workgroups of a persistent launch (the CUs of the device: one 256-row workgroup fits a CU)
     T *colslab;       // symmetric variant: [packed (ib, jt) pairs with jt < ib][TILE] column sums of the off-diagonal tiles
     long pair_origin; // symmetric variant: ib_begin * (ib_begin - 1) / 2, the record index of this device's first pair
     T *partial;       // [num_jc][part_stride] partial row sums, one slab per column chunk, indexed by the LOCAL row

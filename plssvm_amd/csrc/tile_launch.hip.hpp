@@ -6,6 +6,7 @@
 
 #include "lssvm_problem.hip.hpp"
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -35,6 +36,13 @@ template <typename T>
 static unsigned finish_mapping(TileArgs<T> &a, int num_jc) {
     a.num_jc = num_jc;  // (dbg and mfma_shape were filled in by the caller from ITS options: set_launch_options)
     return static_cast<unsigned>(a.num_ib) * static_cast<unsigned>(num_jc);
+}
+
+/* grid of a launch over the work-item list of the symmetric variant: one workgroup per item, or -- TileArgs::queue, for_each_work_item -- persistent workgroups that draw the
+ * items from the problem's counters: as many as the device runs at once (`per_cu` resident workgroups per CU; a kernel that fits only one lets the surplus find the list empty) */
+template <typename T>
+static dim3 sym_grid(const TileArgs<T> &a, int per_cu = 2) {
+    return dim3(static_cast<unsigned>(a.queue != nullptr ? std::min(a.num_items, std::max(per_cu * a.queue_grid, 8)) : a.num_items));
 }
 
 /* fp32 "bf16x6" split kernel (tile_launch_f32s.hip); `grid` is used by the full-square variant only */

@@ -11,13 +11,8 @@ namespace lssvm {
 
 template <int KT, int NK64, int PL>
 static void launch_pair_lag(const TileArgs<float> &a, hipStream_t s) {
-    int cus = 256;
-    if (a.queue != nullptr) {  // persistent launch: one workgroup per CU (140 KiB of LDS each), the items drawn from the problem's counters
-        int dev = 0;
-        LSSVM_HIP_CHECK(hipGetDevice(&dev));
-        LSSVM_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    }
-    const dim3 grid(static_cast<unsigned>(a.queue != nullptr ? std::min(a.num_items, std::max(cus, 8)) : a.num_items)), block(PR_THREADS);
+    // persistent launch (TileArgs::queue): one workgroup per CU (140 KiB of LDS each), the items drawn from the problem's counters; else one workgroup per item
+    const dim3 grid = sym_grid(a, 1), block(PR_THREADS);
 #define LSSVM_PAIR_LAG(L)                                                                           \
     case L:                                                                                         \
         ensure_dynamic_lds(tile_matvec_f32_pair<KT, NK64, PL, L>, PR_LDS_BYTES);                    \
