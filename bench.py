@@ -607,7 +607,7 @@ def main():
                        "residuum_after_timed_steps": i1["residuum"], "residuum_bit_equal_on_all_ranks": ranks_agree,
                        # what RCCL itself reports for the communicator the partial vectors travelled over (ncclCommCount / ncclCommCuDevice on rank 0), and the
                        # file its entry points were resolved from -- null / 0 when no RCCL exchange ran
-                       "rccl_nranks": int(i1.get("rccl_nranks", 0)), "rccl_rank0_device": (int(i1["rccl_device"]) if int(i1.get("rccl_nranks", 0)) > 0 else None),
+                       "persistent_launches": int(i1.get("persistent_launches", 0)), "rccl_nranks": int(i1.get("rccl_nranks", 0)), "rccl_rank0_device": (int(i1["rccl_device"]) if int(i1.get("rccl_nranks", 0)) > 0 else None),
                        "rccl_library": (backend.comm_library_path() if int(i1.get("rccl_nranks", 0)) > 0 else None),
                        "rccl_is_stand_in": stand_in is not None},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,

@@ -89,7 +89,8 @@ typedef struct lssvm_cg_info {
     int32_t rccl_nranks;     /* exchange == 1: ncclCommCount of the communicator the partial vectors travel over (what RCCL itself says, not what was asked for); else 0 */
     int32_t rccl_rank;       /* exchange == 1: ncclCommUserRank of this process's (first) communicator; else -1 */
     int32_t rccl_device;     /* exchange == 1: ncclCommCuDevice of that communicator; else -1 */
-    int32_t reserved_;
+    int32_t persistent_launches; /* of tile_launches_per_matvec, the launches that are PERSISTENT: one workgroup per CU, the work items drawn from per-XCD counters instead of one
+                                  * workgroup per item dealt by the hardware (256-row workgroups, launches of more items than CUs) */
 } lssvm_cg_info;
 
 /* ------------------------------------------------------------------------------------------------------------------ */

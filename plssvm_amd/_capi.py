@@ -49,7 +49,7 @@ class LssvmCgInfo(C.Structure):
                 ("target_residuum", C.c_double), ("epsilon", C.c_double), ("avg_iteration_ms", C.c_double), ("total_ms", C.c_double),
                 ("setup_ms", C.c_double), ("matvec_kernel_ms", C.c_double), ("matvec_launches", C.c_uint64), ("devices_used", C.c_int32),
                 ("converged", C.c_int32), ("symmetric", C.c_int32), ("gram_mode", C.c_int32), ("local_devices", C.c_int32), ("exchange", C.c_int32), ("tile_launches_per_matvec", C.c_int32), ("rbf_direct", C.c_int32), ("rbf_exponent_scale", C.c_double),
-                ("matvec_timed", C.c_uint64), ("matvec_kernel_ms_total", C.c_double), ("rccl_nranks", C.c_int32), ("rccl_rank", C.c_int32), ("rccl_device", C.c_int32), ("reserved_", C.c_int32)]
+                ("matvec_timed", C.c_uint64), ("matvec_kernel_ms_total", C.c_double), ("rccl_nranks", C.c_int32), ("rccl_rank", C.c_int32), ("rccl_device", C.c_int32), ("persistent_launches", C.c_int32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

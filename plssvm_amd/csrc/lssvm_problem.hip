@@ -1720,6 +1720,10 @@ void Solver<T>::fill_info(lssvm_cg_info *info) {
     info->rbf_direct = p0.rbf_direct_ ? 1 : 0;
     info->rbf_exponent_scale = p0.rbf_r2_;
     info->tile_launches_per_matvec = static_cast<int32_t>(std::max<size_t>(p0.bands_.size(), 1)) * p0.passes_per_matvec();  // bands x feature panels
+    info->persistent_launches = 0;
+    if (p0.queue_.p != nullptr) {
+        for (const auto &band : p0.bands_) info->persistent_launches += band.item_count > p0.queue_min_items_ ? p0.passes_per_matvec() : 0;
+    }
     info->exchange = exchange_ == Exchange::none ? 0 : ((exchange_ == Exchange::peer || exchange_ == Exchange::process_peer) ? 2 : 1);
     // what RCCL itself says about the communicator the partial vectors travel over (a bench line can then prove that N ranks met)
     info->rccl_nranks = 0;

@@ -574,6 +574,36 @@ def test_a_head_of_short_column_chunks_changes_only_the_association(oracle, kern
         assert ol.rel_inf(got, base) < 64 * eps, name  # (on the scale of the RESULT, whose rank-1 terms cancel: the bar of the sharded runs; measured 18 eps)
 
 
+@pytest.mark.parametrize("kernel, d, shards, band_mb", [("rbf", 128, 1, 0), ("linear", 200, 1, 0), ("polynomial", 64, 1, 1), ("rbf", 96, 3, 0), ("rbf", 128, 1, 1)])
+def test_persistent_launches_give_the_bits_of_one_workgroup_per_item(monkeypatch, kernel, d, shards, band_mb):
+    """Round 5: launches of the 256-row kernel with more work items than CUs are PERSISTENT -- one workgroup per CU, the items drawn from per-XCD counters (own lane
+    first, then the fullest; two counter sets per problem, a launch draws from one and zeroes the other) instead of one workgroup per item dealt by the hardware.  Which
+    CU evaluates an item must not change a bit: every item owns its slab rows and records.  Compared with the former launches (LSSVM_MI355_PAIR_QUEUE=0, read when a
+    problem is created) over a fixed-length solve that crosses several matvecs -- every launch the counters must have been re-armed by its predecessor --, with several
+    band launches per matvec (1 MiB bands), feature-panel passes (200 features) and three shards on one device (three problems, three streams, three counter pairs)."""
+    N = 16_500  # 129 row blocks -> 65 block pairs; with 2-tile items some 2 100 items per launch (256 CUs)
+    X, y = make_blobs_pm1(N, d, seed=21, dtype=np.float32)
+    p = Parameter(kernel_type=kernel, degree=3)
+    devices = [0] * shards if shards > 1 else None
+    _capi.set_option("j_chunk_tiles", 2)
+    if band_mb:
+        _capi.set_option("colslab_band_mb", band_mb)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LSSVM_MI355_PAIR_QUEUE", mode)
+        with backend.ResidentProblem(p, X, devices=devices) as prob:
+            info = prob.info()
+            prob.cg_begin(y, 1e-30)
+            prob.cg_step(7)
+            alpha, rho, fin = prob.cg_finish()
+        assert info["symmetric"] == 1
+        assert (info["persistent_launches"] > 0) == (mode == "1"), info
+        if mode == "1":
+            assert info["persistent_launches"] <= info["tile_launches_per_matvec"] and (band_mb == 0 or info["tile_launches_per_matvec"] > 1)
+        out[mode] = (alpha, rho, fin["residuum"])
+    assert np.array_equal(out["0"][0], out["1"][0]) and out["0"][1] == out["1"][1] and out["0"][2] == out["1"][2]
+
+
 def test_resident_problem_stepping_equals_one_shot():
     X, y = make_blobs_pm1(900, 24, seed=4, dtype=np.float64)
     p = Parameter(kernel_type="rbf")
