@@ -12,9 +12,10 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <mutex>
 #include <thread>
-#include <cstdlib>
 
 namespace lssvm {
 
@@ -706,38 +707,35 @@ static PairChunks choose_pair_chunk(int ib_begin, int ib_end, int num_tiles, siz
     }
     const std::vector<int> edge = band_edges(ib_begin, ib_end, real_size, o);
     const bool few_rounds = area / cap <= 8L * slots && edge.size() == 2;
-    double best = 0.0;
-    bool have = false;
     const double item_cost = 2.6;  // (with the persistent launches a traced item costs 1.2 tiles beside its tiles -- tests/tools/item_trace.py --; replays with 1.2 and 0.6 choose within
                                    // 1 % of this one, 2.6 a little better from 70 000 points on: profiles/r05_queue_chunk_sweep.log)
-    auto replay = [&](int jc, int head_tiles, int head_count) {
-        const int num_jc = num_chunks(num_tiles, jc, head_tiles, head_count);
+    struct Candidate {
+        int jc, head_tiles, head_count;
+        double makespan;
+    };
+    auto replay = [&](Candidate &c) {  // (a pure function of the candidate: the replays run side by side below)
+        const int num_jc = num_chunks(num_tiles, c.jc, c.head_tiles, c.head_count);
         double total = 0.0;
         for (size_t k = 0; k + 1 < edge.size(); ++k) {
             if (edge[k + 1] <= edge[k]) continue;
             std::vector<double> slot(static_cast<size_t>(slots), 0.0);  // a min-heap of the slots' finish times
             auto later = [](double x, double y) { return x > y; };
-            for (const int2 &it : band_items(edge[k], edge[k + 1], jc, num_jc, ITEM_ORDER, true, head_tiles, head_count)) {
-                const int b = chunk_begin(it.y, jc, head_tiles, head_count);
-                const int tiles = std::min(std::min(b + chunk_len(it.y, jc, head_tiles, head_count), it.x + 2), num_tiles) - b;
+            for (const int2 &it : band_items(edge[k], edge[k + 1], c.jc, num_jc, ITEM_ORDER, true, c.head_tiles, c.head_count)) {
+                const int b = chunk_begin(it.y, c.jc, c.head_tiles, c.head_count);
+                const int tiles = std::min(std::min(b + chunk_len(it.y, c.jc, c.head_tiles, c.head_count), it.x + 2), num_tiles) - b;
                 std::pop_heap(slot.begin(), slot.end(), later);
                 slot.back() += static_cast<double>(std::max(tiles, 0)) + item_cost;
                 std::push_heap(slot.begin(), slot.end(), later);
             }
             total += *std::max_element(slot.begin(), slot.end());
         }
-        if (!have || total < best) {
-            best = total;
-            have = true;
-            best_c.tiles = jc;
-            best_c.head_tiles = head_count > 0 ? head_tiles : 0;
-            best_c.head_count = head_count;
-        }
+        c.makespan = total;
     };
-    for (const int jc : { 2, 3, 4, 6, 8, 10, 12, 16, 20, 24, 32, 40, 48, 64 }) replay(jc, 0, 0);
+    std::vector<Candidate> cands;
+    for (const int jc : { 2, 3, 4, 6, 8, 10, 12, 16, 20, 24, 32, 40, 48, 64 }) cands.push_back({ jc, 0, 0, 0.0 });
     if (!few_rounds && o.j_chunk_head == 1 && edge.size() == 2) {
         for (const int jc : { 48, 64 }) {
-            if (2 * 16 + jc <= num_tiles) replay(jc, 16, 2);
+            if (2 * 16 + jc <= num_tiles) cands.push_back({ jc, 16, 2, 0.0 });
         }
     }
     if (few_rounds && o.j_chunk_head == 1) {
@@ -745,11 +743,29 @@ static PairChunks choose_pair_chunk(int ib_begin, int ib_end, int num_tiles, siz
             for (const int hc : { 1, 2, 3, 4, 6, 8 }) {
                 for (const int ht : { 4, 8, 12, 16, 20, 24 }) {
                     if (ht >= jc || hc * ht + jc > num_tiles) continue;
-                    replay(jc, ht, hc);
+                    cands.push_back({ jc, ht, hc, 0.0 });
                 }
             }
         }
     }
+    // some 230 replays of a thousand items each: 8 ms of the set-up of a 50 000-point problem on one thread (a problem that iterates in 0.7 ms), 1 ms on eight; the
+    // choice -- the first candidate of the list with the shortest makespan -- does not depend on how the replays are spread
+    const unsigned nthreads = cands.size() >= 32 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    std::atomic<size_t> next{ 0 };
+    auto worker = [&] {
+        for (size_t k = next.fetch_add(1); k < cands.size(); k = next.fetch_add(1)) replay(cands[k]);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+    worker();
+    for (std::thread &t : pool) t.join();
+    const Candidate *best = &cands[0];
+    for (const Candidate &c : cands) {
+        if (c.makespan < best->makespan) best = &c;
+    }
+    best_c.tiles = best->jc;
+    best_c.head_tiles = best->head_count > 0 ? best->head_tiles : 0;
+    best_c.head_count = best->head_count;
     return best_c;
 }
 
