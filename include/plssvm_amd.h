@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define PLSSVM_AMD_ABI_VERSION 3 /* 2: multi-device entry points (_multi), lssvm_cg_info grew local_devices / exchange; 3: lssvm_cg_info grew matvec_timed /
-                                  * matvec_kernel_ms_total / rccl_nranks / rccl_rank / rccl_device */
+                                  * matvec_kernel_ms_total / rccl_nranks / rccl_rank / rccl_device / persistent_launches */
 
 typedef enum lssvm_status {
     LSSVM_SUCCESS = 0,
