@@ -303,6 +303,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_update_x_r(T *__restrict__ x, T
     }
 }
 
+/* (Round 5 also let the block of k_update_x_r that finishes last do k_finish_delta's work -- a ticket, two device-scope fences, a second tree: 2 us SLOWER per
+ * iteration than the single-block launch it saves, at every size (profiles/r05_ab_fused_chain.log): a device-scope release writes an XCD's L2 back.  Withdrawn.) */
 /* r_i = b_i - (Abar x)_i ; part = sum r^2       (csvm.cpp:101-107 and the refresh :140-145).  Uses SC_SUMX / SC_QX. */
 template <typename T>
 __global__ __launch_bounds__(RED_THREADS) void k_residual(const T *__restrict__ Kv, const T *__restrict__ x, const T *__restrict__ q, const T *__restrict__ b,
@@ -342,18 +344,47 @@ __global__ __launch_bounds__(RED_THREADS) void k_finish_delta(const double *__re
     }
 }
 
-/* d = beta d + r ; part = (sum d, sum q d) for the next matvec     (csvm.cpp:163) */
+__device__ __forceinline__ void pack_dc_entry(const PackDc<float> &pk, int j, float dj) {  // (the statements of k_pack_dc: the same bits)
+    const int jt = j >> 7, l = j & 127;
+    const float c = (pk.cc != nullptr) ? pk.cc[j] : 0.0f;
+    if (pk.folded == 2) {
+        pk.dc[static_cast<size_t>(jt) * 256 + l] = pk.efac[j] * dj;
+        pk.dc[static_cast<size_t>(jt) * 256 + 128 + l] = c;
+    } else if (pk.folded) {
+        const float e = __builtin_amdgcn_exp2f(c);
+        pk.dc[static_cast<size_t>(jt) * 256 + l] = e * dj;
+        pk.dc[static_cast<size_t>(jt) * 256 + 128 + l] = e;
+    } else {
+        pk.dc[static_cast<size_t>(jt) * 256 + l] = dj;
+        pk.dc[static_cast<size_t>(jt) * 256 + 128 + l] = c;
+    }
+}
+__device__ __forceinline__ void pack_dc_entry(const PackDc<double> &pk, int j, double dj) {  // (k_pack_dc_f64)
+    const int st = j >> 6, l = j & 63;
+    pk.dc[static_cast<size_t>(st) * 128 + l] = dj;
+    pk.dc[static_cast<size_t>(st) * 128 + 64 + l] = (pk.cc != nullptr) ? pk.cc[j] : 0.0;
+}
+
+/* d = beta d + r ; part = (sum d, sum q d) for the next matvec     (csvm.cpp:163); with pk.dc: the records of that matvec too (d is exactly zero beyond n) */
 template <typename T>
 __global__ __launch_bounds__(RED_THREADS) void k_update_d(T *__restrict__ d, const T *__restrict__ r, const T *__restrict__ q, const double *__restrict__ sc,
-                                                          int n, int copy_only, double *__restrict__ part) {
+                                                          int n, int copy_only, double *__restrict__ part, const PackDc<T> pk) {
     __shared__ double lds[8];
     const T beta = static_cast<T>(sc[SC_BETA]);
     double acc[2] = { 0.0, 0.0 };
-    for (int i = blockIdx.x * RED_THREADS + threadIdx.x; i < n; i += RED_BLOCKS * RED_THREADS) {
-        const T di = copy_only ? r[i] : beta * d[i] + r[i];
-        d[i] = di;
-        acc[0] += static_cast<double>(di);
-        acc[1] += static_cast<double>(di) * static_cast<double>(q[i]);
+    const int end = pk.dc != nullptr ? max(n, max(pk.ncols, pk.nzero)) : n;
+    for (int i = blockIdx.x * RED_THREADS + threadIdx.x; i < end; i += RED_BLOCKS * RED_THREADS) {
+        T di = T(0);
+        if (i < n) {
+            di = copy_only ? r[i] : beta * d[i] + r[i];
+            d[i] = di;
+            acc[0] += static_cast<double>(di);
+            acc[1] += static_cast<double>(di) * static_cast<double>(q[i]);
+        }
+        if (pk.dc != nullptr) {
+            if (i < pk.nzero) pk.zero[i] = T(0);
+            if (i < pk.ncols) pack_dc_entry(pk, i, di);
+        }
     }
     block_reduce<2>(acc, lds);
     if (threadIdx.x == 0) {

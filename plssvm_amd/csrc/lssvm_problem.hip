@@ -1144,8 +1144,10 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
     // symmetric variant: row sums of the device's blocks and the mirrored column sums of every band are ADDED into K*v (and, sharded, every rank
     // adds into all earlier rows): start from zero -- by the kernel that packs the records where there is one, by a memset otherwise
     const bool clear = zero_first || sym_;
-    const bool pack = dc_.p != nullptr && num_ib_ > 0;
-    if (clear && !pack) LSSVM_HIP_CHECK(hipMemsetAsync(Kv_.p, 0, static_cast<size_t>(nvec_) * sizeof(T), st));
+    const bool prepacked = d_packed_ && v_dev == d_.p;  // k_update_d has left the records of d_ and cleared K*v (pack_for_d)
+    d_packed_ = false;                                  // (either they are consumed now, or dc_ is about to hold another vector's)
+    const bool pack = dc_.p != nullptr && num_ib_ > 0 && !prepacked;
+    if (clear && !pack && !prepacked) LSSVM_HIP_CHECK(hipMemsetAsync(Kv_.p, 0, static_cast<size_t>(nvec_) * sizeof(T), st));
     if (num_ib_ <= 0) return;
     TileArgs<T> a = tile_args(v_dev);
     if (pack) {  // v2 kernels: pack (d_j | c_j) records for the LDS-DMA
@@ -1225,6 +1227,25 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
         hipLaunchKernelGGL(k_reduce_partials<T>, dim3((nrows + 255) / 256), dim3(256), 0, st, partial_.p, a.part_stride, num_jc_, ib_begin_ * TILE, nrows, Kv_.p);
     }
     LSSVM_HIP_CHECK(hipGetLastError());
+}
+
+/* The records of the NEXT implicit matvec -- always K * d in the CG loop -- are packed by the kernel that updates d (k_update_d) instead of a k_pack_dc launch
+ * in front of the tile kernel: what that kernel needs, and the note that it has been done.  `zero_first` as enqueue_apply_K_local's. */
+template <typename T>
+PackDc<T> Problem<T>::pack_for_d(bool zero_first) {
+    PackDc<T> pk;
+    if (dc_.p == nullptr || num_ib_ <= 0) return pk;
+    pk.dc = dc_.p;
+    pk.cc = c_.p;
+    pk.ncols = num_tiles_ * TILE;
+    pk.zero = Kv_.p;
+    pk.nzero = (zero_first || sym_) ? static_cast<int>(nvec_) : 0;
+    if constexpr (std::is_same_v<T, float>) {
+        pk.folded = rbf_grid_ ? 2 : (dc_folded_ ? 1 : 0);
+        pk.efac = rbf_grid_ ? efac_.p : nullptr;
+    }
+    d_packed_ = true;
+    return pk;
 }
 
 template <typename T>
@@ -1536,6 +1557,15 @@ void Solver<T>::matvec(const void *d, void *ret_inout, double add) {
     sync_all();
 }
 
+/* k_update_d packs the next matvec's records (Problem::pack_for_d) -- except over the IPC exchange: there a rank may clear its partial vector only once every peer
+ * has read the previous one, which the host establishes in apply_K, after the direction update. */
+template <typename T>
+PackDc<T> Solver<T>::pack_with_direction(Problem<T> &p) {
+    if (exchange_ == Exchange::process_peer) return PackDc<T>{};
+    const bool skip = world_ > 1 && opt_.skip_collective != 0;
+    return p.pack_for_d((p.sym_ && exchange_ != Exchange::none) || skip);
+}
+
 template <typename T>
 void Solver<T>::cg_begin(const void *y, double eps) {
     LSSVM_REQUIRE(y != nullptr, "The right hand side vector must not be empty!");
@@ -1567,7 +1597,7 @@ void Solver<T>::cg_begin(const void *y, double eps) {
         hipLaunchKernelGGL(k_residual<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->Kres_, p->x_.p, p->q_.p, p->b_.p, p->sc_.p, p->n_, p->inv_cost_, p->QA_cost_, p->r_.p, p->part(PART_RR));
         hipLaunchKernelGGL(k_finish_delta, dim3(1), dim3(RED_THREADS), 0, st, p->part(PART_RR), p->sc_.p, p->sc_.p + SC_COUNT - 1, 1);  // csvm.cpp:107-108
         // d = r   (csvm.cpp:111), and -- as partial sums that k_Ad_and_dAd finishes for itself -- the sums the next matvec's rank-1 terms need
-        hipLaunchKernelGGL(k_update_d<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->d_.p, p->r_.p, p->q_.p, p->sc_.p, p->n_, 1, p->part(PART_D));
+        hipLaunchKernelGGL(k_update_d<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->d_.p, p->r_.p, p->q_.p, p->sc_.p, p->n_, 1, p->part(PART_D), pack_with_direction(*p));
         LSSVM_HIP_CHECK(hipGetLastError());
     }
     Problem<T> &p0 = *shards_[0];
@@ -1591,7 +1621,7 @@ void Solver<T>::cg_step(uint64_t iterations, int *done_out) {
         for (auto &p : shards_) {
             p->activate();
             hipStream_t st = p->stream();
-            hipLaunchKernelGGL(k_update_d<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->d_.p, p->r_.p, p->q_.p, p->sc_.p, p->n_, 0, p->part(PART_D));
+            hipLaunchKernelGGL(k_update_d<T>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, p->d_.p, p->r_.p, p->q_.p, p->sc_.p, p->n_, 0, p->part(PART_D), pack_with_direction(*p));
             LSSVM_HIP_CHECK(hipGetLastError());
         }
     };

@@ -281,6 +281,7 @@ class Problem {
     void activate() const { LSSVM_HIP_CHECK(hipSetDevice(device_)); }
     /* Kv_ <- this shard's part of K * v (complete for a world of one): tile kernel + fixed-order reductions */
     void enqueue_apply_K_local(const T *v_dev, bool zero_first);
+    PackDc<T> pack_for_d(bool zero_first);  // what k_update_d needs to pack the records of d_ (dc == NULL: this problem packs per matvec); marks them as present
     void enqueue_sum_and_qdot(const T *v_dev, int slot_sum, int slot_q);
     void drain_events();
     hipStream_t stream() const { return stream_.s; }
@@ -352,6 +353,7 @@ class Problem {
     T *Kres_ = nullptr;  // the exchanged K * v the O(n) kernels read: Kv_ itself, or Ksum_ when peer kernels do the exchange
     DevBuf<T> partial_;
     DevBuf<T> dc_;  // v2 kernels: packed (d_j | c_j) records
+    bool d_packed_ = false;  // dc_ holds the records of d_ and K*v is cleared: k_update_d left them (pack_for_d), the next implicit matvec of d_ launches no k_pack_dc
     // symmetric variant
     bool sym_ = false;
     DevBuf<int2> items_;
@@ -484,6 +486,7 @@ class Solver final : public ProblemBase {
     void apply_K(Vec which);  // every shard: Kres_ <- K * v (all rows)
     void exchange();
     void sync_all();
+    PackDc<T> pack_with_direction(Problem<T> &p);
     T *vec_of(Problem<T> &p, Vec which) const { return which == Vec::d ? p.d_.p : (which == Vec::x ? p.x_.p : p.tmp_.p); }
 
     Options opt_{};

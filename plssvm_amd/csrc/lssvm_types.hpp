@@ -89,6 +89,16 @@ struct TileArgs {
     T coef0;          // polynomial
 };
 
+/* What k_update_d needs to leave the NEXT implicit matvec's column records behind (k_pack_dc / k_pack_dc_f64 folded into it, round 5: one launch less per CG
+ * iteration -- VERDICT r04 item 6): dc == NULL = no packing.  `folded` as k_pack_dc's; `zero` / `nzero` the vector the symmetric variant adds into. */
+template <typename T>
+struct PackDc {
+    T *dc = nullptr;
+    const T *cc = nullptr;
+    const T *efac = nullptr;
+    T *zero = nullptr;
+    int ncols = 0, nzero = 0, folded = 0;
+};
 /* column chunk jc of a launch covers the tiles [chunk_begin, chunk_begin + chunk_len): a head of `head_count` short chunks, then chunks of `tiles` */
 __host__ __device__ inline int chunk_begin(int jc, int tiles, int head_tiles, int head_count) {
     return jc < head_count ? jc * head_tiles : head_count * head_tiles + (jc - head_count) * tiles;
