@@ -252,6 +252,18 @@ int lssvm_mi355_libsvm_fill_f32(lssvm_mi355_libsvm_file *file, float *X, uint64_
 int lssvm_mi355_libsvm_fill_f64(lssvm_mi355_libsvm_file *file, double *X, uint64_t ldx, double *labels);
 int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
 
+/* ---- ARFF data files (the second format of plssvm::data_set, include/plssvm/detail/io/arff_parsing.hpp:57-372) ----
+ * The same contract as the LIBSVM reader above: a multi-threaded fast path for WELL-FORMED files -- "@RELATION name", "@ATTRIBUTE name NUMERIC" per feature, at
+ * most one "@ATTRIBUTE class {l1,l2,...}" with numeric labels, "@DATA", then dense rows (one value per attribute) or sparse rows ("{index value,...}", zero-based
+ * attribute indices) whose labels are among the header's.  int_labels != 0: the caller's label type is an integer, the labels must be written as plain integers.
+ * `fill` writes the dense row-major matrix and the labels (always double; may be NULL).  Any irregularity -> LSSVM_ERR_INVALID_ARGUMENT without a diagnosis:
+ * callers re-parse with their reference-exact parser for the error message (plssvm_amd/io_arff.py does).  Host code only, no device needed. */
+typedef struct lssvm_mi355_arff_file lssvm_mi355_arff_file;
+int lssvm_mi355_arff_open(const char *path, int int_labels, lssvm_mi355_arff_file **file_out, uint64_t *num_points, uint64_t *num_features, int *has_label);
+int lssvm_mi355_arff_fill_f32(lssvm_mi355_arff_file *file, float *X, uint64_t ldx, double *labels);
+int lssvm_mi355_arff_fill_f64(lssvm_mi355_arff_file *file, double *X, uint64_t ldx, double *labels);
+int lssvm_mi355_arff_close(lssvm_mi355_arff_file *file);
+
 /* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT).  set_option changes the process-wide DEFAULTS;
  * every problem / solve takes a snapshot of them when it is created, so later changes never affect a live problem.  The defaults can
  * be preset from the environment: LSSVM_MI355_OPTIONS="name=value,name=value" (read once when the library is loaded).  Thirteen options here, two

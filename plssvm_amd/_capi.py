@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "lssvm_mi355_cg_begin", "lssvm_mi355_cg_step", "lssvm_mi355_cg_finish", "lssvm_mi355_problem_synchronize", "lssvm_mi355_problem_info",
     "lssvm_mi355_measure_bf16_mfma_ceiling", "lssvm_mi355_comm_library_path", "lssvm_mi355_set_option", "lssvm_mi355_get_option",
     "lssvm_mi355_libsvm_open", "lssvm_mi355_libsvm_fill_f32", "lssvm_mi355_libsvm_fill_f64", "lssvm_mi355_libsvm_close",
+    "lssvm_mi355_arff_open", "lssvm_mi355_arff_fill_f32", "lssvm_mi355_arff_fill_f64", "lssvm_mi355_arff_close",
 ]
 
 

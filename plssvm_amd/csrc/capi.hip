@@ -5,6 +5,7 @@
  */
 #include "lssvm_problem.hip.hpp"
 
+#include "arff_reader.hpp"
 #include "libsvm_reader.hpp"
 
 #include <dlfcn.h>
@@ -492,6 +493,41 @@ int lssvm_mi355_libsvm_fill_f64(lssvm_mi355_libsvm_file *file, double *X, uint64
     });
 }
 int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file) {
+    return guarded([&] { delete file; });
+}
+
+/* ---- ARFF data files: fast reader for well-formed files (arff_reader.hpp) ---- */
+struct lssvm_mi355_arff_file {
+    lssvm::ArffFile impl;
+};
+
+int lssvm_mi355_arff_open(const char *path, int int_labels, lssvm_mi355_arff_file **file_out, uint64_t *num_points, uint64_t *num_features, int *has_label) {
+    return guarded([&] {
+        LSSVM_REQUIRE(path != nullptr && file_out != nullptr && num_points != nullptr && num_features != nullptr && has_label != nullptr,
+                      "path / output pointers must not be NULL");
+        *file_out = nullptr;
+        auto f = std::make_unique<lssvm_mi355_arff_file>();
+        if (!f->impl.open(path)) throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, std::string("Couldn't find file: '") + path + "'!");
+        if (!f->impl.scan(int_labels != 0)) throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "not a well-formed ARFF data file for the fast reader");
+        *num_points = f->impl.num_points();
+        *num_features = f->impl.num_features();
+        *has_label = f->impl.has_label() ? 1 : 0;
+        *file_out = f.release();
+    });
+}
+int lssvm_mi355_arff_fill_f32(lssvm_mi355_arff_file *file, float *X, uint64_t ldx, double *labels) {
+    return guarded([&] {
+        LSSVM_REQUIRE(file != nullptr && X != nullptr, "file / X must not be NULL");
+        if (!file->impl.fill<float>(X, ldx, labels)) throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "not a well-formed ARFF data file for the fast reader");
+    });
+}
+int lssvm_mi355_arff_fill_f64(lssvm_mi355_arff_file *file, double *X, uint64_t ldx, double *labels) {
+    return guarded([&] {
+        LSSVM_REQUIRE(file != nullptr && X != nullptr, "file / X must not be NULL");
+        if (!file->impl.fill<double>(X, ldx, labels)) throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "not a well-formed ARFF data file for the fast reader");
+    });
+}
+int lssvm_mi355_arff_close(lssvm_mi355_arff_file *file) {
     return guarded([&] { delete file; });
 }
 

@@ -121,8 +121,41 @@ def parse_arff_header(lines, label_type=float):
     return num_features, header_line + 1, labels, (label_idx if has_label else 0)
 
 
-def parse_arff_data(filename, dtype=np.float64, label_type=float):
+def _parse_native(filename, dtype, label_type):
+    """Fast path: libplssvm_amd's multi-threaded reader for well-formed files (csrc/arff_reader.hpp).  Returns None when the library is not built or the
+    file is anything but plainly well formed -- the Python parser below then decides (and words the error exactly like the reference)."""
+    dtype = np.dtype(dtype)
+    if label_type not in (float, int) or dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+        return None
+    try:
+        import ctypes as C
+        import os
+
+        from . import _capi
+    except (ImportError, OSError):
+        return None
+    lib = _capi.lib
+    handle = C.c_void_p()
+    npts, nfeat, has_label = C.c_uint64(), C.c_uint64(), C.c_int()
+    if lib.lssvm_mi355_arff_open(os.fsencode(filename), C.c_int(1 if label_type is int else 0), C.byref(handle), C.byref(npts), C.byref(nfeat), C.byref(has_label)) != 0:
+        return None
+    try:
+        X = np.empty((npts.value, nfeat.value), dtype=dtype)
+        y = np.empty(npts.value, dtype=np.float64) if has_label.value else None
+        fill = lib.lssvm_mi355_arff_fill_f32 if dtype == np.float32 else lib.lssvm_mi355_arff_fill_f64
+        if fill(handle, _capi.ptr(X), C.c_uint64(nfeat.value), _capi.ptr(y) if y is not None else None) != 0:
+            return None
+    finally:
+        lib.lssvm_mi355_arff_close(handle)
+    return X, ([label_type(v) for v in y.tolist()] if y is not None else None)
+
+
+def parse_arff_data(filename, dtype=np.float64, label_type=float, use_native: bool = True):
     """Returns ``(X[num_points, num_features], labels or None)`` -- arff_parsing.hpp:196-372."""
+    if use_native:
+        fast = _parse_native(filename, dtype, label_type)
+        if fast is not None:
+            return fast
     lines = read_lines(filename, "%")
     num_features, first, unique, label_idx = parse_arff_header(lines, label_type)
     has_label = bool(unique)

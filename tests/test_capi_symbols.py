@@ -152,13 +152,13 @@ def test_generated_code_of_the_shipped_library_passes_the_audit():
     assert int(last.split()[0]) >= 40, last  # the hand-scheduled instantiations were found at all
 
 
-@pytest.mark.parametrize("exe_name, args", [("test_reader_sanitized", []), ("test_csvm_sanitized", ["--no-gpu"])])
+@pytest.mark.parametrize("exe_name, args", [("test_reader_sanitized", []), ("test_arff_reader_sanitized", []), ("test_csvm_sanitized", ["--no-gpu"])])
 def test_host_side_under_address_and_undefined_behaviour_sanitizers(exe_name, args):
     """CPU build only (GPU sanitizers are not available on this pool): the native LIBSVM reader on the shapes of the reference's
     invalid fixtures, every truncation and single-byte corruption of a valid file, overflowing indices, CR / CRLF, NUL bytes ... and the host side of
     the C++ adaptor (factory, named parameters, exceptions), both compiled with -fsanitize=address,undefined -fno-sanitize-recover.  The reader must
     refuse what is not well formed without ever touching memory it does not own (/root/reference/include/plssvm/detail/io/libsvm_parsing.hpp:118-229
-    is the rule book; the reference-exact diagnosis stays with plssvm_amd/io_libsvm.py)."""
+    is the rule book; the reference-exact diagnosis stays with plssvm_amd/io_libsvm.py).  Round 5: the native ARFF reader likewise (arff_parsing.hpp:57-372)."""
     exe = os.path.join(ROOT, "tests", "cpp", exe_name)
     if not os.path.isfile(exe):
         subprocess.run(["make", "-C", os.path.dirname(exe), exe_name], check=True, capture_output=True)
