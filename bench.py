@@ -295,6 +295,10 @@ def main():
     ap.add_argument("--rccl-timeout-s", type=float, default=120.0,
                     help="one process per GPU: how long the library's ncclCommInitRank may take before the ranks give up on RCCL (bootstrap hangs of minutes were "
                          "seen on single-GPU boxes of this pool)")
+    ap.add_argument("--balance-shares", action="store_true",
+                    help="one process per GPU, symmetric variant: after the warm-up the ranks compare the tile-kernel time of their (equal) shares, set shard weights "
+                         "proportional to their pace (lssvm_mi355_set_shard_weights; the data is replicated, so only the problem is rebuilt) and warm up again -- "
+                         "the devices of one node do not run at one pace (the boxes of this pool: 252 ... 277 ms for the same kernel)")
     ap.add_argument("--rank-devices", default=None,
                     help="one process per GPU: comma separated HIP ordinal per local rank (default: the local rank).  Repeats put several ranks on one device "
                          "-- a functional check of the rank path on a one-GPU box (needs --exchange 2, or --rccl-stand-in: the real RCCL refuses two ranks on one device)")
@@ -452,11 +456,40 @@ def main():
             from plssvm_amd.sharding import connect_peers
 
             connect_peers(dist, prob)  # HIP IPC: every rank maps every rank's partial vector
+    def create_problem():
+        pr = backend.ResidentProblem(params, X, device=local_rank, rank=rank, world=world)
+        if world > 1 and args.exchange == 2:
+            from plssvm_amd.sharding import connect_peers
+
+            connect_peers(dist, pr)  # HIP IPC: every rank maps every rank's partial vector
+        return pr
+
     prob.cg_begin(y, 1e-30)  # eps^2 underflows: the loop only stops early on delta == 0 (fixed iteration count)
     if args.warmup > 0:
         prob.cg_step(args.warmup)
     prob.synchronize()
     i0 = prob.info()
+    shard_weights = shares_before = None
+    if args.balance_shares and dist is not None and world > 1 and devices is None and int(i0.get("symmetric", 0)) == 1:
+        # shares by measured pace: every rank's tile-kernel time per matvec over the warm-up (its share of the triangle was 1 / world), gathered over the side channel
+        from plssvm_amd.sharding import triangle_share
+
+        mine = (float(i0["matvec_kernel_ms"]), triangle_share(N - 1, world, rank))
+        both = [None] * world
+        dist.all_gather_object(both, mine)
+        shares_before = [round(ms, 4) for ms, _ in both]
+        if all(ms > 0 for ms, _ in both) and max(shares_before) > 1.01 * min(shares_before):
+            pace = [area / ms for ms, area in both]
+            shard_weights = [v * world / sum(pace) for v in pace]
+            barrier()  # (HIP IPC: a rank's partial vector stays mapped by its peers until every rank is done with it)
+            prob.close()
+            _capi.set_shard_weights(shard_weights)  # (the same list on every rank: all_gather_object hands every rank the same values)
+            prob = create_problem()
+            prob.cg_begin(y, 1e-30)
+            if args.warmup > 0:
+                prob.cg_step(args.warmup)
+            prob.synchronize()
+            i0 = prob.info()
     # board power and shader clock of this rank's device while the timed steps run (a host thread reading two sysfs files every 20 ms: the
     # 16-bit tile kernels sit at the board's power cap, DESIGN.md 4.1.0 -- the line should say so for the box it was taken on)
     sampler = None
@@ -553,8 +586,8 @@ def main():
     #              (the reference's count, svm_kernel.cpp:36-39).  `roofline.achieved` = useful / kernel time, so frac <= 1.
     # The shares are dealt by equal area, so every shard's counts agree within a row block; priced here for shard `rank` (0 for one process).
     symmetric = bool(i1.get("symmetric", 0))
-    sq_mac, exe_mac = work_share(n, shards, rank, symmetric)
-    use_mac = triangle_share(n, shards, rank) if symmetric else sq_mac
+    sq_mac, exe_mac = work_share(n, shards, rank, symmetric, shard_weights)
+    use_mac = triangle_share(n, shards, rank, shard_weights) if symmetric else sq_mac
     kern_s = kern_ms * 1e-3
     square_launch, exec_launch, useful_launch = 2.0 * sq_mac * d, 2.0 * exe_mac * d, 2.0 * use_mac * d
     achieved = useful_launch / kern_s / 1e12 if kern_ms > 0 else 0.0
@@ -607,7 +640,7 @@ def main():
                        "residuum_after_timed_steps": i1["residuum"], "residuum_bit_equal_on_all_ranks": ranks_agree,
                        # what RCCL itself reports for the communicator the partial vectors travelled over (ncclCommCount / ncclCommCuDevice on rank 0), and the
                        # file its entry points were resolved from -- null / 0 when no RCCL exchange ran
-                       "persistent_launches": int(i1.get("persistent_launches", 0)), "rccl_nranks": int(i1.get("rccl_nranks", 0)), "rccl_rank0_device": (int(i1["rccl_device"]) if int(i1.get("rccl_nranks", 0)) > 0 else None),
+                       "persistent_launches": int(i1.get("persistent_launches", 0)), "shard_weights": ([round(w, 5) for w in shard_weights] if shard_weights else None), "share_kernel_ms_at_equal_shares": shares_before, "rccl_nranks": int(i1.get("rccl_nranks", 0)), "rccl_rank0_device": (int(i1["rccl_device"]) if int(i1.get("rccl_nranks", 0)) > 0 else None),
                        "rccl_library": (backend.comm_library_path() if int(i1.get("rccl_nranks", 0)) > 0 else None),
                        "rccl_is_stand_in": stand_in is not None},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,

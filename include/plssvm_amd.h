@@ -189,6 +189,12 @@ typedef struct lssvm_shard {
  * dealt by equal AREA (boundary r = round(blocks * sqrt(r / world))); else equal contiguous runs.  The partition every
  * Problem uses (plssvm_amd/sharding.py restates it for the flop accounting of bench.py). */
 int lssvm_mi355_shard_blocks(size_t num_points, int world, int rank, int symmetric, int64_t *block_begin, int64_t *block_end);
+/* Devices of unequal pace (the MI355X boxes of one pool run the same kernel in 252 ... 277 ms): rank r of a sharded SYMMETRIC problem gets weights[r] / sum of the triangle's area
+ * instead of 1 / world -- a process-wide default like the options below, snapshotted when a problem is created, applied when `count` equals the problem's world (any other
+ * length, or count = 0: equal shares).  EVERY rank of a sharded solve must set the same weights (the partition is computed locally by every rank); the data is replicated on
+ * every device, so a new partition costs a new problem, no data exchange.  bench.py --balance-shares measures the ranks' pace and sets them.  No counterpart in the reference
+ * (its multi-device split is by features, gpu_csvm.hpp:283-299). */
+int lssvm_mi355_set_shard_weights(const double *weights, int count);
 
 /* RCCL bootstrap: rank 0 obtains a 128-byte unique id and hands it to the other ranks out of band
  * (bench.py / the Python launcher broadcast it with torch.distributed); every rank then calls comm_init.

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "lssvm_mi355_solve_f32", "lssvm_mi355_solve_f64", "lssvm_mi355_solve_multi_f32", "lssvm_mi355_solve_multi_f64", "lssvm_mi355_predict_values_f32", "lssvm_mi355_predict_values_f64",
     "lssvm_mi355_generate_q_f32", "lssvm_mi355_generate_q_f64", "lssvm_mi355_run_device_kernel_f32", "lssvm_mi355_run_device_kernel_f64",
     "lssvm_mi355_calculate_w_f32", "lssvm_mi355_calculate_w_f64",
-    "lssvm_mi355_shard_blocks", "lssvm_mi355_comm_get_unique_id", "lssvm_mi355_comm_init", "lssvm_mi355_comm_destroy",
+    "lssvm_mi355_shard_blocks", "lssvm_mi355_set_shard_weights", "lssvm_mi355_comm_get_unique_id", "lssvm_mi355_comm_init", "lssvm_mi355_comm_destroy",
     "lssvm_mi355_problem_create", "lssvm_mi355_problem_create_multi", "lssvm_mi355_problem_ipc_export", "lssvm_mi355_problem_ipc_connect", "lssvm_mi355_problem_destroy", "lssvm_mi355_problem_get_q", "lssvm_mi355_problem_matvec",
     "lssvm_mi355_cg_begin", "lssvm_mi355_cg_step", "lssvm_mi355_cg_finish", "lssvm_mi355_problem_synchronize", "lssvm_mi355_problem_info",
     "lssvm_mi355_measure_bf16_mfma_ceiling", "lssvm_mi355_comm_library_path", "lssvm_mi355_set_option", "lssvm_mi355_get_option",
@@ -142,6 +142,14 @@ def shard_blocks(num_points: int, world: int, rank: int, symmetric: bool):
     b, e = C.c_int64(0), C.c_int64(0)
     check(lib.lssvm_mi355_shard_blocks(C.c_size_t(num_points), C.c_int(world), C.c_int(rank), C.c_int(1 if symmetric else 0), C.byref(b), C.byref(e)))
     return int(b.value), int(e.value)
+
+
+def set_shard_weights(weights=None) -> None:
+    """Shares of the triangle's area per rank of a sharded symmetric problem (``None`` / empty: equal shares) -- a process-wide default, snapshotted when a
+    problem is created; every rank must set the same list (``lssvm_mi355_set_shard_weights``)."""
+    w = [float(v) for v in (weights or [])]
+    arr = (C.c_double * len(w))(*w) if w else None
+    check(lib.lssvm_mi355_set_shard_weights(arr, C.c_int(len(w))))
 
 
 def set_option(name: str, value: int) -> None:

@@ -181,9 +181,21 @@ int lssvm_mi355_shard_blocks(size_t num_points, int world, int rank, int symmetr
         LSSVM_REQUIRE(num_points >= 2 && num_points < (size_t(1) << 31) - 4 * lssvm::TILE, "invalid number of data points");
         LSSVM_REQUIRE(world >= 1 && rank >= 0 && rank < world, "invalid shard descriptor");
         int b = 0, e = 0;
-        lssvm::shard_blocks(static_cast<int>((num_points - 1 + lssvm::TILE - 1) / lssvm::TILE), world, rank, symmetric != 0, b, e);
+        lssvm::shard_blocks(static_cast<int>((num_points - 1 + lssvm::TILE - 1) / lssvm::TILE), world, rank, symmetric != 0, b, e, &lssvm::options().shard_weights);
         *block_begin = b;
         *block_end = e;
+    });
+}
+
+int lssvm_mi355_set_shard_weights(const double *weights, int count) {
+    return guarded([&] {
+        LSSVM_REQUIRE(count >= 0 && count <= 4096 && (count == 0 || weights != nullptr), "invalid shard weights");
+        std::vector<double> w;
+        for (int k = 0; k < count; ++k) {
+            LSSVM_REQUIRE(std::isfinite(weights[k]) && weights[k] > 0.0, "shard weights must be positive and finite");
+            w.push_back(weights[k]);
+        }
+        lssvm::options().shard_weights = w;
     });
 }
 

@@ -184,19 +184,29 @@ static bool wide_nonlinear(const Options &o, const lssvm_params &p, bool rbf_dir
 /* first row block of rank r when the lower triangle is dealt by equal area: tiles * sqrt(r / world), rounded to an EVEN block index -- the
  * 256-row workgroups of lssvm_tile_f32_pair.hip.hpp work on the block pairs (2p, 2p + 1), which must not straddle two devices (every symmetric
  * partition follows the rule, whichever kernel runs: one partition per problem shape) */
-int sym_block_boundary(int num_tiles, int r, int world) {
+int sym_block_boundary(int num_tiles, int r, int world, const std::vector<double> *weights) {
     if (r <= 0) return 0;
     if (r >= world) return num_tiles;
-    const int b = 2 * static_cast<int>(std::llround(0.5 * static_cast<double>(num_tiles) * std::sqrt(static_cast<double>(r) / static_cast<double>(world))));
+    // the share of the triangle's AREA in front of rank r: r / world, or -- shard weights (lssvm_mi355_set_shard_weights: devices of unequal pace) -- the ranks' weights in front of it
+    double share = static_cast<double>(r) / static_cast<double>(world);
+    if (weights != nullptr && static_cast<int>(weights->size()) == world) {
+        double before = 0.0, all = 0.0;
+        for (int k = 0; k < world; ++k) {
+            all += (*weights)[static_cast<size_t>(k)];
+            if (k < r) before += (*weights)[static_cast<size_t>(k)];
+        }
+        share = before / all;
+    }
+    const int b = 2 * static_cast<int>(std::llround(0.5 * static_cast<double>(num_tiles) * std::sqrt(share)));
     return std::min(std::max(b, 0), num_tiles);
 }
 
-/* the row blocks [begin, end) of rank `rank`: equal AREAS of the lower triangle (symmetric variant: block ib costs ib + 1 tiles),
- * equal contiguous runs otherwise (every row costs the same) */
-void shard_blocks(int num_tiles, int world, int rank, bool symmetric, int &begin, int &end) {
+/* the row blocks [begin, end) of rank `rank`: equal (or weighted) AREAS of the lower triangle (symmetric variant: block ib costs ib + 1 tiles),
+ * equal contiguous runs otherwise (every row costs the same, and the all-gather of the full-square variant needs equal slices: no weights there) */
+void shard_blocks(int num_tiles, int world, int rank, bool symmetric, int &begin, int &end, const std::vector<double> *weights) {
     if (symmetric) {
-        begin = sym_block_boundary(num_tiles, rank, world);
-        end = sym_block_boundary(num_tiles, rank + 1, world);
+        begin = sym_block_boundary(num_tiles, rank, world, weights);
+        end = std::max(begin, sym_block_boundary(num_tiles, rank + 1, world, weights));
     } else {
         const int per_rank = (num_tiles + world - 1) / world;
         begin = std::min(rank * per_rank, num_tiles);
@@ -875,7 +885,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     }
     {
         int ib_end = 0;
-        shard_blocks(num_tiles_, world_, rank_, sym_, ib_begin_, ib_end);
+        shard_blocks(num_tiles_, world_, rank_, sym_, ib_begin_, ib_end, &opt_.shard_weights);
         num_ib_ = ib_end - ib_begin_;
     }
     if (opt_.j_chunk_tiles > 0) {

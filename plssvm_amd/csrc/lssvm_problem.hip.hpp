@@ -63,6 +63,7 @@ struct Options {
     int64_t rbf_fold = 1;        // fp32 rbf on the split kernels: 1 = folded column records (2^c_j d_j | 2^c_j), accumulators start from c_i as the C
                                  // operand of their first MFMA (default, while the exponent scale stays below 200); 0 = start values c_i + c_j by vector adds
     int64_t j_chunk_tiles = 0;   // 128-column tiles per work item; 0 = automatic (see Problem<T>'s constructor)
+    std::vector<double> shard_weights;  // symmetric variant, several ranks: rank r's share of the triangle's area is weight[r] / sum (empty or of another length: equal shares); lssvm_mi355_set_shard_weights
     int64_t j_chunk_head = 1;    // 256-row workgroups: 0 = none; 1 = chosen by the replayed dispatch (with j_chunk_tiles = 0; default); 1024 count + tiles = the first `count` column chunks have `tiles` tiles
     int64_t symmetric = 1;         // 1: evaluate only the tiles on/below the diagonal and mirror them, 0: full square
     int64_t tile_kernel = 0;       // 0: automatic (resident-row-panel kernels where they exist), 1: always the generic v1 kernel (the cross-checks' yardstick)
@@ -251,8 +252,8 @@ void split_grid_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx1
 void split_f16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, float scale, int shift, uint16_t *planes, size_t plane_stride, unsigned *stats, hipStream_t s);  // tile_launch_f32h.hip
 void absmax_f32(const float *X, int ldx, int dfeat, size_t rows, unsigned *out, hipStream_t s);  // tile_launch_f32h.hip
 bool v2_eligible_f64(const Options &o, int ldx);
-int sym_block_boundary(int num_tiles, int r, int world);
-void shard_blocks(int num_tiles, int world, int rank, bool symmetric, int &begin, int &end);
+int sym_block_boundary(int num_tiles, int r, int world, const std::vector<double> *weights = nullptr);
+void shard_blocks(int num_tiles, int world, int rank, bool symmetric, int &begin, int &end, const std::vector<double> *weights = nullptr);
 
 /* fp32: a data matrix once more as operand planes of the split tile kernels (make_planes in lssvm_problem.hip) */
 struct PlaneSet {

@@ -34,11 +34,12 @@ def row_block_partition(n: int, world: int):
     return out
 
 
-def sym_block_partition(n: int, world: int):
+def sym_block_partition(n: int, world: int, weights=None):
     """Symmetric variant (only the tiles on/below the diagonal are evaluated): row block ``ib`` costs ``ib + 1`` tiles, so the
     blocks are dealt by equal AREA -- boundary of rank r = tiles * sqrt(r / world) rounded to an EVEN block index (the 256-row
-    workgroups of the tile kernel work on block pairs; ``sym_block_boundary`` in plssvm_amd/csrc/lssvm_problem.hip).
-    Returns ``[(block_begin, block_end), ...]``."""
+    workgroups of the tile kernel work on block pairs; ``sym_block_boundary`` in plssvm_amd/csrc/lssvm_problem.hip).  ``weights``
+    (one positive number per rank; ``lssvm_mi355_set_shard_weights``): rank r gets ``weights[r] / sum`` of the area instead of ``1 / world``
+    -- devices of unequal pace.  Returns ``[(block_begin, block_end), ...]``."""
     import math
 
     def llround(x: float) -> int:  # C's llround for x >= 0 (half away from zero; x - floor(x) is exact, x + 0.5 need not be: ADVICE r04)
@@ -46,11 +47,21 @@ def sym_block_partition(n: int, world: int):
         return int(f) + (1 if x - f >= 0.5 else 0)
 
     tiles = (n + TILE - 1) // TILE
-    bounds = [0] + [min(max(2 * llround(0.5 * tiles * math.sqrt(r / world)), 0), tiles) for r in range(1, world)] + [tiles]
-    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+    if weights is not None and len(weights) == world:
+        total = 0.0
+        for w in weights:  # (running sums in the library's order: the two partitions must agree to the bit)
+            total += float(w)
+        shares, before = [], 0.0
+        for r in range(1, world):
+            before += float(weights[r - 1])
+            shares.append(before / total)
+    else:
+        shares = [r / world for r in range(1, world)]
+    bounds = [0] + [min(max(2 * llround(0.5 * tiles * math.sqrt(sh)), 0), tiles) for sh in shares] + [tiles]
+    return [(bounds[r], max(bounds[r], bounds[r + 1])) for r in range(world)]
 
 
-def work_share(n: int, world: int, rank: int, symmetric: bool):
+def work_share(n: int, world: int, rank: int, symmetric: bool, weights=None):
     """(algorithmic, executed) multiply-add counts per feature of one implicit matvec launch on ``rank``.
 
     Algorithmic = this rank's share of the full n x n square (SURVEY.md 8d: no symmetry credit in the metric);
@@ -59,7 +70,7 @@ def work_share(n: int, world: int, rank: int, symmetric: bool):
         r0, r1 = row_block_partition(n, world)[rank]
         return float(r1 - r0) * n, float(r1 - r0) * n
     tiles = (n + TILE - 1) // TILE
-    b0, b1 = sym_block_partition(n, world)[rank]
+    b0, b1 = sym_block_partition(n, world, weights)[rank]
     evaluated_tiles = (b1 * (b1 + 1) - b0 * (b0 + 1)) // 2          # sum of (ib + 1)
     mirrored_tiles = (b1 * (b1 - 1) - b0 * (b0 - 1)) // 2           # strictly lower tiles count twice in the square
     full_tiles = float(tiles) * tiles
@@ -68,10 +79,10 @@ def work_share(n: int, world: int, rank: int, symmetric: bool):
     return algorithmic, executed
 
 
-def triangle_share(n: int, world: int, rank: int) -> float:
+def triangle_share(n: int, world: int, rank: int, weights=None) -> float:
     """Multiply-adds per feature of the reference's own algorithm (kernel entries with j <= i only,
     src/plssvm/backends/OpenMP/svm_kernel.cpp:36-39) that fall into ``rank``'s row blocks of the symmetric partition."""
-    b0, b1 = sym_block_partition(n, world)[rank]
+    b0, b1 = sym_block_partition(n, world, weights)[rank]
     r0, r1 = min(b0 * TILE, n), min(b1 * TILE, n)
     return (r1 * (r1 + 1) - r0 * (r0 + 1)) / 2.0
 

@@ -199,3 +199,36 @@ def test_bench_spawns_its_own_ranks_without_a_launcher():
     assert out.returncode != 0
     # (the parent stops the siblings of a rank that failed: the second rank may be terminated before it reaches its own check)
     assert 1 <= out.stderr.count("bench.py needs an MI355X") <= 2, out.stderr
+
+
+def test_weighted_partitions_of_python_and_library_agree():
+    """Round 5: shares by weight (devices of unequal pace; lssvm_mi355_set_shard_weights).  The library's partition (host-only entry point, no device needed) and its
+    mirror in plssvm_amd/sharding.py must agree to the block for any weights -- both ranks' flop accounting and the peer connection rest on it --, the boundaries stay
+    even and monotone, the shares cover the triangle, their areas follow the weights within one pair of row blocks, and weights of another length than the world mean
+    equal shares."""
+    from plssvm_amd import _capi
+
+    rng = np.random.default_rng(17)
+    try:
+        for trial in range(1500):
+            world = int(rng.integers(1, 17))
+            tiles = int(rng.integers(1, 9000))
+            n = tiles * sharding.TILE
+            w = (rng.uniform(0.8, 1.2, size=world) if trial % 3 else rng.uniform(0.01, 100.0, size=world)).tolist()
+            _capi.set_shard_weights(w)
+            parts = sharding.sym_block_partition(n, world, w)
+            assert [_capi.shard_blocks(n + 1, world, r, True) for r in range(world)] == parts, (tiles, w)
+            assert parts[0][0] == 0 and parts[-1][1] == tiles and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            assert all(b % 2 == 0 or b == tiles for _, b in parts)
+            if tiles > 64 * world:
+                total = tiles * (tiles + 1) / 2
+                for r, (b0, b1) in enumerate(parts):
+                    area = (b1 * (b1 + 1) - b0 * (b0 + 1)) / 2
+                    assert abs(area - w[r] / sum(w) * total) <= 2.5 * (tiles + 2), (tiles, w, parts)
+        _capi.set_shard_weights([1.0, 2.0, 3.0])  # three weights, a world of four: equal shares
+        assert [_capi.shard_blocks(1000 * 128 + 1, 4, r, True) for r in range(4)] == sharding.sym_block_partition(1000 * 128, 4)
+        with pytest.raises(Exception):
+            _capi.set_shard_weights([1.0, -1.0])
+    finally:
+        _capi.set_shard_weights(None)
+    assert [_capi.shard_blocks(1000 * 128 + 1, 4, r, True) for r in range(4)] == sharding.sym_block_partition(1000 * 128, 4)

@@ -129,3 +129,20 @@ def test_bench_line_of_four_ranks_reports_what_rccl_saw(tmp_path):
     assert cfg["rccl_nranks"] == 4 and cfg["rccl_rank0_device"] == 0 and cfg["rccl_is_stand_in"] and os.path.samefile(cfg["rccl_library"], STAND_IN)
     assert cfg["shards"] == 4 and cfg["exchange"] == "RCCL all-reduce" and line["steps"] == 6 and line["n_gpus"] == 1
     assert np.isfinite(cfg["residuum_after_timed_steps"]) and line["value"] > 0 and cfg["residuum_bit_equal_on_all_ranks"] is True
+
+
+def test_bench_rebalances_the_shares_by_measured_pace(tmp_path):
+    """bench.py --balance-shares (round 5): the ranks compare the tile-kernel time of their equal shares after the warm-up, set shard weights proportional to their pace
+    (lssvm_mi355_set_shard_weights, the same list on every rank), rebuild their problems and run the timed steps on the new partition.  Three ranks on one device
+    through the stand-in: their times differ by whatever the time sharing of the device gives, so the path may or may not trigger -- either way the line must say what
+    it did, every rank must still hold the same residuum bits over the RCCL exchange, and the weights -- if set -- must be three positive numbers around one."""
+    _need_stand_in()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FAKE_RCCL_TIMEOUT_S="60")
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--rank-devices", "0,0,0", "--rccl-stand-in", STAND_IN, "--workload", "c2", "--steps", "6",
+                         "--warmup", "4", "--no-cpu-baseline", "--balance-shares"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    cfg = json.loads(pr.stdout.strip().splitlines()[-1])["config"]
+    assert cfg["rccl_nranks"] == 3 and cfg["residuum_bit_equal_on_all_ranks"] is True and np.isfinite(cfg["residuum_after_timed_steps"])
+    assert isinstance(cfg["share_kernel_ms_at_equal_shares"], list) and len(cfg["share_kernel_ms_at_equal_shares"]) == 3 and min(cfg["share_kernel_ms_at_equal_shares"]) > 0
+    w = cfg["shard_weights"]
+    assert w is None or (len(w) == 3 and all(0.3 < x < 3.0 for x in w) and abs(sum(w) - 3.0) < 1e-3)

@@ -894,6 +894,58 @@ def test_every_ranks_share_on_one_gpu(kernel, dtype, N, d, sym, world):
     assert all(s > 0 for s in shares[: min(world, (n + 127) // 128)])
 
 
+@pytest.mark.parametrize("kernel, dtype, N, d, weights", [("rbf", np.float32, 9100, 128, [3.0, 1.0, 2.0]), ("polynomial", np.float64, 2500, 64, [1.0, 1.0, 0.25, 4.0]),
+                                                          ("linear", np.float32, 3000, 200, [0.97, 1.0, 1.03, 1.0, 0.9, 1.1, 1.0, 1.0])])
+def test_weighted_shares_add_up_to_the_unsharded_product(kernel, dtype, N, d, weights):
+    """Round 5: devices of unequal pace get unequal shares of the triangle (lssvm_mi355_set_shard_weights: rank r evaluates weights[r] / sum of its area; the boundaries stay
+    even block indices).  Every rank's share evaluated in turn on ONE GPU with the exchange switched off: the partial products add up to the unsharded product
+    (every rank adds the rank-1 terms itself), the shares' sizes follow the weights, and the solve over all shards of one process -- peer exchange on one device --
+    gives the unsharded product (and in fp64 the unsharded solve's alpha)."""
+    from plssvm_amd import sharding
+
+    X, y = make_blobs_pm1(N, d, seed=33, dtype=dtype)
+    p = Parameter(kernel_type=kernel, cost=2.0)
+    n, world = N - 1, len(weights)
+    v = np.random.default_rng(9).uniform(-1, 1, size=n).astype(dtype)
+    zero = np.zeros(n, dtype)
+    with backend.ResidentProblem(p, X) as prob:
+        q, QA = prob.q()
+        single = prob.matvec(v, zero, 1.0)
+    a1, rho1, _ = backend.solve_system_of_linear_equations(p, X, y, 1e-30, 6)
+    _capi.set_shard_weights(weights)
+    try:
+        parts = sharding.sym_block_partition(n, world, weights)
+        assert [_capi.shard_blocks(N, world, r, True) for r in range(world)] == parts and parts[-1][1] == (n + 127) // 128
+        _capi.set_option("skip_collective", 1)
+        total = np.zeros(n, np.float64)
+        for rank in range(world):
+            with backend.ResidentProblem(p, X, rank=rank, world=world) as prob:
+                total += prob.matvec(v, zero, 1.0)
+        _capi.set_option("skip_collective", 0)
+        with backend.ResidentProblem(p, X, devices=[0] * world) as prob:
+            exchanged = prob.matvec(v, zero, 1.0)
+            prob.cg_begin(y, 1e-30)
+            prob.cg_step(6)
+            a2, rho2, _ = prob.cg_finish()
+    finally:
+        _capi.set_option("skip_collective", 0)
+        _capi.set_shard_weights(None)
+    q64, v64 = q.astype(np.float64), v.astype(np.float64)
+    S = v64.sum()
+    rank1 = v64 / 2.0 + (float(QA) * S - q64 @ v64) - S * q64
+    got = total - (world - 1) * rank1
+    eps = np.finfo(dtype).eps
+    assert np.max(np.abs(got - single)) < 256 * eps * (np.max(np.abs(single)) + np.max(np.abs(rank1)))
+    areas = [sharding.triangle_share(n, world, r, weights) for r in range(world)]
+    want = [w / sum(weights) * n * (n + 1) / 2 for w in weights]
+    assert all(abs(a - w) <= 2.5 * 256 * (n + 256) for a, w in zip(areas, want)), (areas, want)  # (within a pair of row blocks of the ideal boundary)
+    assert np.max(np.abs(exchanged - single)) < 256 * eps * (np.max(np.abs(single)) + np.max(np.abs(rank1)))  # all shards behind one call, partial vectors exchanged
+    if dtype == np.float64:  # (six fp32 CG iterations amplify the re-association beyond any useful bar: DESIGN.md section 5)
+        assert ol.rel_inf(a2, a1) < 1e-9 and abs(float(rho2) - float(rho1)) <= 1e-9 * max(1.0, abs(float(rho1)))
+    else:
+        assert np.all(np.isfinite(a2)) and np.isfinite(float(rho2))
+
+
 @pytest.mark.parametrize("kernel, dtype", [("rbf", np.float32), ("polynomial", np.float64), ("linear", np.float32)])
 def test_row_block_bands_of_the_column_slab(oracle, kernel, dtype):
     """The column-sum records of the symmetric variant are produced band by band into one slab (option colslab_band_mb; 1M points in fp32
