@@ -297,7 +297,7 @@ def main():
                          "seen on single-GPU boxes of this pool)")
     ap.add_argument("--balance-shares", action="store_true",
                     help="one process per GPU, symmetric variant: after the warm-up the ranks compare the tile-kernel time of their (equal) shares, set shard weights "
-                         "proportional to their pace (lssvm_mi355_set_shard_weights; the data is replicated, so only the problem is rebuilt) and warm up again -- "
+                         "proportional to their pace on the live problems (lssvm_mi355_problem_rebalance; the data is replicated, nothing moves) and warm up again -- "
                          "the devices of one node do not run at one pace (the boxes of this pool: 252 ... 277 ms for the same kernel)")
     ap.add_argument("--rank-devices", default=None,
                     help="one process per GPU: comma separated HIP ordinal per local rank (default: the local rank).  Repeats put several ranks on one device "
@@ -456,14 +456,6 @@ def main():
             from plssvm_amd.sharding import connect_peers
 
             connect_peers(dist, prob)  # HIP IPC: every rank maps every rank's partial vector
-    def create_problem():
-        pr = backend.ResidentProblem(params, X, device=local_rank, rank=rank, world=world)
-        if world > 1 and args.exchange == 2:
-            from plssvm_amd.sharding import connect_peers
-
-            connect_peers(dist, pr)  # HIP IPC: every rank maps every rank's partial vector
-        return pr
-
     prob.cg_begin(y, 1e-30)  # eps^2 underflows: the loop only stops early on delta == 0 (fixed iteration count)
     if args.warmup > 0:
         prob.cg_step(args.warmup)
@@ -481,11 +473,7 @@ def main():
         if all(ms > 0 for ms, _ in both) and max(shares_before) > 1.01 * min(shares_before):
             pace = [area / ms for ms, area in both]
             shard_weights = [v * world / sum(pace) for v in pace]
-            barrier()  # (HIP IPC: a rank's partial vector stays mapped by its peers until every rank is done with it)
-            prob.close()
-            _capi.set_shard_weights(shard_weights)  # (the same list on every rank: all_gather_object hands every rank the same values)
-            prob = create_problem()
-            prob.cg_begin(y, 1e-30)
+            prob.rebalance(shard_weights)  # (the same list on every rank: all_gather_object hands every rank the same values; the live problem is resharded, nothing is uploaded again)
             if args.warmup > 0:
                 prob.cg_step(args.warmup)
             prob.synchronize()

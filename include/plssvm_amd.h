@@ -195,6 +195,12 @@ int lssvm_mi355_shard_blocks(size_t num_points, int world, int rank, int symmetr
  * every device, so a new partition costs a new problem, no data exchange.  bench.py --balance-shares measures the ranks' pace and sets them.  No counterpart in the reference
  * (its multi-device split is by features, gpu_csvm.hpp:283-299). */
 int lssvm_mi355_set_shard_weights(const double *weights, int count);
+/* The same for a LIVE problem, between two lssvm_mi355_cg_step calls: the shards' row blocks, work items and slabs are rebuilt for new shares; the data, the vectors and the
+ * CG state stay (the implicit matrix does not change, only who evaluates which tiles).  weights == NULL, count == 0: shares by MEASURED pace -- every shard's tile-kernel time
+ * per matvec so far against the area of its share; one process driving all devices knows them, one process per GPU gathers them over the library's RCCL communicator (every rank
+ * must make the call; not over HIP IPC: explicit weights there, the same on every rank).  *changed_out = 0 where the times lie within 2 % of each other or the problem is not
+ * sharded / not symmetric.  A solve that wants it: cg_begin, a few cg_step, problem_rebalance, the remaining cg_step. */
+int lssvm_mi355_problem_rebalance(lssvm_mi355_problem *p, const double *weights, int count, int *changed_out);
 
 /* RCCL bootstrap: rank 0 obtains a 128-byte unique id and hands it to the other ranks out of band
  * (bench.py / the Python launcher broadcast it with torch.distributed); every rank then calls comm_init.

@@ -257,6 +257,15 @@ class ResidentProblem:
     def synchronize(self):
         check(lib.lssvm_mi355_problem_synchronize(self._h))
 
+    def rebalance(self, weights=None) -> bool:
+        """New shares for the ranks of a sharded symmetric problem, between two ``cg_step`` calls (``lssvm_mi355_problem_rebalance``): explicit ``weights`` (one per rank,
+        the same on every rank) or, ``None``, by the shards' measured pace.  Returns whether the shares changed."""
+        w = [float(v) for v in (weights or [])]
+        arr = (C.c_double * len(w))(*w) if w else None
+        changed = C.c_int(0)
+        check(lib.lssvm_mi355_problem_rebalance(self._h, arr, C.c_int(len(w)), C.byref(changed)))
+        return bool(changed.value)
+
     def ipc_export(self) -> bytes:
         """One process per GPU over HIP IPC: this rank's ``LSSVM_IPC_BLOB_BYTES`` blob (``lssvm_mi355_problem_ipc_export``)."""
         buf = (C.c_ubyte * _capi.LSSVM_IPC_BLOB_BYTES)()

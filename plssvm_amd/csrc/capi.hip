@@ -315,6 +315,13 @@ int lssvm_mi355_cg_finish(lssvm_mi355_problem *p, void *alpha_out, double *rho_o
 int lssvm_mi355_problem_synchronize(lssvm_mi355_problem *p) {
     return guarded([&] { impl_of(p)->synchronize(); });
 }
+int lssvm_mi355_problem_rebalance(lssvm_mi355_problem *p, const double *weights, int count, int *changed_out) {
+    return guarded([&] {
+        LSSVM_REQUIRE(count >= 0 && (weights == nullptr) == (count == 0), "weights and count go together (NULL, 0: measured shares)");
+        const int changed = impl_of(p)->rebalance(weights, count);
+        if (changed_out != nullptr) *changed_out = changed;
+    });
+}
 int lssvm_mi355_problem_info(lssvm_mi355_problem *p, lssvm_cg_info *info) {
     return guarded([&] {
         LSSVM_REQUIRE(info != nullptr, "info must not be NULL");

@@ -780,6 +780,124 @@ static PairChunks choose_pair_chunk(int ib_begin, int ib_end, int num_tiles, siz
 }
 
 /* ------------------------------------------------------------------ Problem: one device's shard ------------------------------------------------------------------ */
+/* The part of a problem that depends on WHICH row blocks this shard evaluates (constructor; reshard): the shard's blocks, the column chunks of its work items. */
+template <typename T>
+void Problem<T>::choose_shard_geometry() {
+    const size_t num_features = num_features_;
+    const int ldx_probe = ldx_probe_;
+    {
+        int ib_end = 0;
+        shard_blocks(num_tiles_, world_, rank_, sym_, ib_begin_, ib_end, &opt_.shard_weights);
+        num_ib_ = ib_end - ib_begin_;
+    }
+    if (opt_.j_chunk_tiles > 0) {
+        jc_tiles_ = static_cast<int>(opt_.j_chunk_tiles);
+    } else {
+        // automatic: long chunks amortise a work item's prologue (row panel load) and keep its row sums in registers, but the grid
+        // must fill 256 CUs x 2 workgroups several times over.  Measured optimum (tests/tools/gpu_probe.py --small, 3 000 ... 50 000
+        // points): about 4096 work items, between 2 and 16 tiles each.
+        const long ib_end = ib_begin_ + num_ib_;
+        const long area = sym_ ? (ib_end * (ib_end + 1) - static_cast<long>(ib_begin_) * (ib_begin_ + 1)) / 2 : static_cast<long>(num_ib_) * num_tiles_;
+        // the bf16x6 kernel has the costlier work-item prologue (three planes of the row panel) and the faster tiles: longer chunks
+        // (measured 16 -> 64 tiles: +1.5 % at 100 000 points, +2 % at 300 000; the native kernels are flat or lose beyond 16)
+        const bool split = wide_linear_ || wide_nl_
+                           || (std::is_same_v<T, float> && opt_.gram_mode != 0 && v2_eligible(opt_, ldx_probe, rbf_direct_)
+                               && round_up(static_cast<long>(num_features), 64) <= ((opt_.gram_mode == 1 || tile_params_.kernel_type == LSSVM_KERNEL_RBF) ? SPLIT_MAX_FEATURES : F16_MAX_FEATURES));
+        const long cap = split ? 64 : 16;
+        jc_tiles_ = static_cast<int>(std::min<long>(cap, std::max<long>(2, (area + 2048) / 4096)));
+        if (pair_) {
+            int cus = 256;  // one such workgroup per CU
+            LSSVM_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_));
+            const PairChunks pc = choose_pair_chunk(ib_begin_, static_cast<int>(ib_end), num_tiles_, sizeof(T), opt_, std::max(cus, 1));
+            jc_tiles_ = pc.tiles;
+            jc_head_tiles_ = pc.head_tiles;
+            jc_head_count_ = pc.head_count;
+        }
+        // panels inside a tile, symmetric variant: SHORT items in row-group major order (wide_order_ below) -- the shorter the better at every shape
+        // (12 > 8 > 4 > 2 tiles, profiles/r04_ab_wide_item_order_groups.log, r04_ab_wide_final.log); longer only where the partial slabs would grow
+        // beyond 256 per row
+        if (wide_nl_ && sym_) jc_tiles_ = static_cast<int>(std::min<long>(64, std::max<long>(2, (num_tiles_ + 255) / 256)));
+    }
+    if (wide_nl_ && sym_) {
+        // These kernels re-load a work item's row panel at EVERY column tile.  In the column-chunk major orders each of the 64 workgroups an XCD runs
+        // at a time has a row panel of its own -- 64 x 0.4 ... 1.6 MB against 4 MB of L2: the re-loads came from beyond L2 at HBM rate (60 000 x 640
+        // rbf: 54 GB of row planes per matvec, 6 TB/s).  Row-group major (band_items, order 4 / 5): an XCD works on FOUR (two, where a panel is
+        // beyond 640 KB) row blocks x their column chunks at a time, so their panels stay in its L2 and every column tile is streamed for the
+        // whole group: 60 000 x 640 rbf 8.5 -> 6.2 ms, 100 000 x 385 rbf 19.4 -> 12.4 ms.  Results do not depend on the order.
+        const double panel_bytes = std::is_same_v<T, float>
+                                       ? 128.0 * static_cast<double>(round_up(static_cast<long>(num_features), 128)) * ((tile_params_.kernel_type == LSSVM_KERNEL_RBF || opt_.gram_mode == 1) ? 3.0 : 2.0) * 2.0
+                                       : 128.0 * static_cast<double>(ldx_probe) * 8.0;
+        wide_order_ = panel_bytes <= 640e3 ? 4 : 5;
+    }
+    if (pair_ && opt_.j_chunk_head >= 1024) {  // an explicit head (option j_chunk_head = 1024 count + tiles): tests, A/B runs
+        jc_head_count_ = static_cast<int>(opt_.j_chunk_head / 1024);
+        jc_head_tiles_ = static_cast<int>(opt_.j_chunk_head % 1024);
+        if (jc_head_count_ <= 0 || jc_head_tiles_ <= 0 || jc_head_count_ * jc_head_tiles_ >= num_tiles_) jc_head_count_ = jc_head_tiles_ = 0;
+    }
+    if (!pair_) jc_head_count_ = jc_head_tiles_ = 0;
+    num_jc_ = num_chunks(num_tiles_, jc_tiles_, jc_head_tiles_, jc_head_count_);
+    if (const char *dbg = std::getenv("LSSVM_MI355_DEBUG"); dbg != nullptr && dbg[0] == '1') {
+        std::fprintf(stderr, "[plssvm_amd] shard %d/%d on device %d: row blocks [%d, %d) of %d, %d tiles per work item (head: %d chunks of %d), symmetric %d\n", rank_, world_, device_,
+                     ib_begin_, ib_begin_ + num_ib_, num_tiles_, jc_tiles_, jc_head_count_, jc_head_tiles_, sym_ ? 1 : 0);
+    }
+}
+
+/* ... and the device-side lists for it: the row slabs, the work items band by band, the column slab, the events around the band launches. */
+template <typename T>
+void Problem<T>::build_shard_lists(hipStream_t st) {
+    partial_.alloc_zero(static_cast<size_t>(std::max(num_jc_, 1)) * part_blocks() * TILE, st);
+    bands_.clear();
+    if (sym_) {
+        // Row-block BANDS.  Every evaluated off-diagonal tile leaves a 128-entry record of column sums (no atomics: one writer per record,
+        // k_reduce_colslab adds the records of a column in a fixed order).  All records of the triangle would be n_tiles^2 / 2 * 512 bytes
+        // (15.6 GB at 1M points in fp32); instead the device's row blocks are cut into bands of equal AREA whose records fit
+        // colslab_band_mb, the tile kernel runs band by band into the SAME slab and the band's records are folded into K*v before the
+        // next band overwrites them.  One band for up to ~360 000 points per device at the default 2 GiB.
+        const int ib_end_all = ib_begin_ + num_ib_;
+        const std::vector<int> edge = band_edges(ib_begin_, ib_end_all, sizeof(T), opt_);
+        std::vector<int2> items;
+        long max_records = 1;
+        for (size_t k = 0; k + 1 < edge.size(); ++k) {
+            Band band{};
+            band.ib_begin = edge[k];
+            band.ib_end = edge[k + 1];
+            band.item_begin = static_cast<int>(items.size());
+            band.pair_origin = pairs_below(band.ib_begin);
+            for (const int2 &it : band_items(band.ib_begin, band.ib_end, jc_tiles_, num_jc_, opt_.item_order_dev != 0 ? static_cast<int>(opt_.item_order_dev) : (wide_order_ != 0 ? wide_order_ : ITEM_ORDER), pair_, jc_head_tiles_, jc_head_count_)) items.push_back(make_int2(it.x - ib_begin_, it.y));
+            band.item_count = static_cast<int>(items.size()) - band.item_begin;
+            // (block pairs: the records of the pair's SECOND block, which is padding behind an odd last block)
+            max_records = std::max(max_records, pairs_below(pair_ ? round_up(band.ib_end, 2) : band.ib_end) - band.pair_origin);
+            if (band.ib_end > band.ib_begin) bands_.push_back(band);
+        }
+        num_items_ = static_cast<int>(items.size());
+        items_.alloc_zero(std::max<size_t>(items.size(), 1), st);
+        if (!items.empty()) LSSVM_HIP_CHECK(hipMemcpyAsync(items_.p, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+        colslab_.alloc_zero(static_cast<size_t>(max_records) * TILE, st);
+        LSSVM_HIP_CHECK(hipStreamSynchronize(st));  // `items` goes out of scope
+    }
+    // (two matvecs can be in flight -- enqueue-ahead -- and each issues bands x feature-panel passes tile launches: ADVICE r03, the later panels of a wide
+    // linear problem went untimed and the reported kernel time came out too low)
+    events_.resize(4 * std::max<size_t>(bands_.size(), 1) * static_cast<size_t>(std::max(passes_per_matvec(), 1)));
+}
+
+/* New shares for the ranks of a sharded symmetric problem (lssvm_mi355_problem_rebalance): the row blocks of this shard, its work items, slabs and bands are
+ * rebuilt for `weights`; the data, the operand planes, the vectors and the CG state are what they were -- the implicit matrix does not change, only who evaluates
+ * which of its tiles.  The caller has drained the stream. */
+template <typename T>
+void Problem<T>::reshard(const std::vector<double> &weights) {
+    LSSVM_REQUIRE(sym_ && world_ > 1 && static_cast<int>(weights.size()) == world_, "shares by weight exist for the symmetric variant of a sharded problem, one weight per rank");
+    select_device_checked(device_);
+    LSSVM_HIP_CHECK(hipStreamSynchronize(stream_.s));
+    drain_events();
+    opt_.shard_weights = weights;
+    choose_shard_geometry();
+    build_shard_lists(stream_.s);
+    d_packed_ = false;  // (the records of d_ are shard independent, but K*v is cleared again by the next matvec: the plain path)
+    matvec_ms_ = 0.0;
+    matvec_timed_ = 0;
+    LSSVM_HIP_CHECK(hipStreamSynchronize(stream_.s));
+}
+
 template <typename T>
 Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *X, int mem_kind, size_t num_points, size_t num_features, int device, int rank, int world) :
     opt_(opt), params_(params), device_(device), rank_(rank), world_(world) {
@@ -816,6 +934,8 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     }
     // symmetric variant: v2 kernels only; a negative polynomial degree can give inf on zero-padded rows -> full square
     const int ldx_probe = padded_features<T>(num_features);
+    ldx_probe_ = ldx_probe;
+    num_features_ = num_features;
     bool v2_ok = std::is_same_v<T, float> ? v2_eligible(opt_, ldx_probe, rbf_direct_) : v2_eligible_f64(opt_, ldx_probe);
     // FEW points, many features, linear kernel (fp32): the feature-panel passes below are launch-bound there -- 3 000 x 16 384: 128 passes 4.75 ms, the
     // polynomial kernel's ONE launch over the same panels 2.89 (profiles/r04_very_wide_probe.log).  Below LINEAR_IN_TILE_BELOW points and beyond 256
@@ -883,56 +1003,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         // (below 64 row blocks -- 8 192 points -- the 128-row workgroups have more items to spread over the chip: 3 000 points 13.8 against 19.7 us)
         pair_ = sym_ && opt_.gram_mode != 0 && opt_.mfma_shape >= 3 && !wide_nl_ && !poly_generic && narrow && rbf_ok && num_tiles_ >= PAIR_MIN_TILES && !rbf_grid_;
     }
-    {
-        int ib_end = 0;
-        shard_blocks(num_tiles_, world_, rank_, sym_, ib_begin_, ib_end, &opt_.shard_weights);
-        num_ib_ = ib_end - ib_begin_;
-    }
-    if (opt_.j_chunk_tiles > 0) {
-        jc_tiles_ = static_cast<int>(opt_.j_chunk_tiles);
-    } else {
-        // automatic: long chunks amortise a work item's prologue (row panel load) and keep its row sums in registers, but the grid
-        // must fill 256 CUs x 2 workgroups several times over.  Measured optimum (tests/tools/gpu_probe.py --small, 3 000 ... 50 000
-        // points): about 4096 work items, between 2 and 16 tiles each.
-        const long ib_end = ib_begin_ + num_ib_;
-        const long area = sym_ ? (ib_end * (ib_end + 1) - static_cast<long>(ib_begin_) * (ib_begin_ + 1)) / 2 : static_cast<long>(num_ib_) * num_tiles_;
-        // the bf16x6 kernel has the costlier work-item prologue (three planes of the row panel) and the faster tiles: longer chunks
-        // (measured 16 -> 64 tiles: +1.5 % at 100 000 points, +2 % at 300 000; the native kernels are flat or lose beyond 16)
-        const bool split = wide_linear_ || wide_nl_
-                           || (std::is_same_v<T, float> && opt_.gram_mode != 0 && v2_eligible(opt_, ldx_probe, rbf_direct_)
-                               && round_up(static_cast<long>(num_features), 64) <= ((opt_.gram_mode == 1 || tile_params_.kernel_type == LSSVM_KERNEL_RBF) ? SPLIT_MAX_FEATURES : F16_MAX_FEATURES));
-        const long cap = split ? 64 : 16;
-        jc_tiles_ = static_cast<int>(std::min<long>(cap, std::max<long>(2, (area + 2048) / 4096)));
-        if (pair_) {
-            int cus = 256;  // one such workgroup per CU
-            LSSVM_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_));
-            const PairChunks pc = choose_pair_chunk(ib_begin_, static_cast<int>(ib_end), num_tiles_, sizeof(T), opt_, std::max(cus, 1));
-            jc_tiles_ = pc.tiles;
-            jc_head_tiles_ = pc.head_tiles;
-            jc_head_count_ = pc.head_count;
-        }
-        // panels inside a tile, symmetric variant: SHORT items in row-group major order (wide_order_ below) -- the shorter the better at every shape
-        // (12 > 8 > 4 > 2 tiles, profiles/r04_ab_wide_item_order_groups.log, r04_ab_wide_final.log); longer only where the partial slabs would grow
-        // beyond 256 per row
-        if (wide_nl_ && sym_) jc_tiles_ = static_cast<int>(std::min<long>(64, std::max<long>(2, (num_tiles_ + 255) / 256)));
-    }
-    if (wide_nl_ && sym_) {
-        // These kernels re-load a work item's row panel at EVERY column tile.  In the column-chunk major orders each of the 64 workgroups an XCD runs
-        // at a time has a row panel of its own -- 64 x 0.4 ... 1.6 MB against 4 MB of L2: the re-loads came from beyond L2 at HBM rate (60 000 x 640
-        // rbf: 54 GB of row planes per matvec, 6 TB/s).  Row-group major (band_items, order 4 / 5): an XCD works on FOUR (two, where a panel is
-        // beyond 640 KB) row blocks x their column chunks at a time, so their panels stay in its L2 and every column tile is streamed for the
-        // whole group: 60 000 x 640 rbf 8.5 -> 6.2 ms, 100 000 x 385 rbf 19.4 -> 12.4 ms.  Results do not depend on the order.
-        const double panel_bytes = std::is_same_v<T, float>
-                                       ? 128.0 * static_cast<double>(round_up(static_cast<long>(num_features), 128)) * ((tile_params_.kernel_type == LSSVM_KERNEL_RBF || opt_.gram_mode == 1) ? 3.0 : 2.0) * 2.0
-                                       : 128.0 * static_cast<double>(ldx_probe) * 8.0;
-        wide_order_ = panel_bytes <= 640e3 ? 4 : 5;
-    }
-    if (pair_ && opt_.j_chunk_head >= 1024) {  // an explicit head (option j_chunk_head = 1024 count + tiles): tests, A/B runs
-        jc_head_count_ = static_cast<int>(opt_.j_chunk_head / 1024);
-        jc_head_tiles_ = static_cast<int>(opt_.j_chunk_head % 1024);
-        if (jc_head_count_ <= 0 || jc_head_tiles_ <= 0 || jc_head_count_ * jc_head_tiles_ >= num_tiles_) jc_head_count_ = jc_head_tiles_ = 0;
-    }
-    if (!pair_) jc_head_count_ = jc_head_tiles_ = 0;
+    choose_shard_geometry();
     // 256-row workgroups: PERSISTENT launches, the work items drawn from per-XCD counters (for_each_work_item, lssvm_device_common.hip.hpp) instead of one workgroup per
     // item dealt by the hardware -- whose deal is static per XCD (every eighth workgroup, whatever the XCD's pace: the eight clocks of one chip differ by 3-5 %) and in
     // order.  Same box, interleaved, bit-identical: 1 000 000 x 128 rbf 264.9 -> 256.8 ms per iteration (-3.0 %), 200 000 x 256 linear 20.05 -> 19.49 (-3.0 %),
@@ -940,11 +1011,6 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     if (const char *pq = std::getenv("LSSVM_MI355_PAIR_QUEUE"); pair_ && !(pq != nullptr && pq[0] == '0')) {
         queue_.alloc_zero(512, st);
         LSSVM_HIP_CHECK(hipDeviceGetAttribute(&queue_min_items_, hipDeviceAttributeMultiprocessorCount, device_));
-    }
-    num_jc_ = num_chunks(num_tiles_, jc_tiles_, jc_head_tiles_, jc_head_count_);
-    if (const char *dbg = std::getenv("LSSVM_MI355_DEBUG"); dbg != nullptr && dbg[0] == '1') {
-        std::fprintf(stderr, "[plssvm_amd] shard %d/%d on device %d: row blocks [%d, %d) of %d, %d tiles per work item (head: %d chunks of %d), symmetric %d\n", rank_, world_, device_,
-                     ib_begin_, ib_begin_ + num_ib_, num_tiles_, jc_tiles_, jc_head_count_, jc_head_tiles_, sym_ ? 1 : 0);
     }
     inv_cost_ = static_cast<double>(T(1) / static_cast<T>(params_.cost));  // "1 / params.cost" in real_type, csvm.cpp:297
 
@@ -960,7 +1026,6 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     ylast_.alloc_zero(num_points, st);
     part_.alloc_zero(static_cast<size_t>(PART_REGIONS) * RED_BLOCKS * 2, st);  // (four sets of partial sums: a kernel reduces its predecessor's while it writes its own)
     sc_.alloc_zero(SC_COUNT, st);
-    partial_.alloc_zero(static_cast<size_t>(std::max(num_jc_, 1)) * part_blocks() * TILE, st);
     host_sc_.alloc(SC_COUNT);
     host_delta_.alloc_mapped(1);
 
@@ -1026,37 +1091,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     if ((std::is_same_v<T, float> && (v2_eligible(opt_, X_.ldx, rbf_direct_) || wide_linear_ || wide_nl_)) || (std::is_same_v<T, double> && (v2_eligible_f64(opt_, X_.ldx) || wide_linear_ || wide_nl_))) {
         dc_.alloc_zero(static_cast<size_t>(std::max(num_tiles_, 1)) * 256, st);  // (d_j | c_j) records: 256 reals per 128 columns
     }
-    if (sym_) {
-        // Row-block BANDS.  Every evaluated off-diagonal tile leaves a 128-entry record of column sums (no atomics: one writer per record,
-        // k_reduce_colslab adds the records of a column in a fixed order).  All records of the triangle would be n_tiles^2 / 2 * 512 bytes
-        // (15.6 GB at 1M points in fp32); instead the device's row blocks are cut into bands of equal AREA whose records fit
-        // colslab_band_mb, the tile kernel runs band by band into the SAME slab and the band's records are folded into K*v before the
-        // next band overwrites them.  One band for up to ~360 000 points per device at the default 2 GiB.
-        const int ib_end_all = ib_begin_ + num_ib_;
-        const std::vector<int> edge = band_edges(ib_begin_, ib_end_all, sizeof(T), opt_);
-        std::vector<int2> items;
-        long max_records = 1;
-        for (size_t k = 0; k + 1 < edge.size(); ++k) {
-            Band band{};
-            band.ib_begin = edge[k];
-            band.ib_end = edge[k + 1];
-            band.item_begin = static_cast<int>(items.size());
-            band.pair_origin = pairs_below(band.ib_begin);
-            for (const int2 &it : band_items(band.ib_begin, band.ib_end, jc_tiles_, num_jc_, opt_.item_order_dev != 0 ? static_cast<int>(opt_.item_order_dev) : (wide_order_ != 0 ? wide_order_ : ITEM_ORDER), pair_, jc_head_tiles_, jc_head_count_)) items.push_back(make_int2(it.x - ib_begin_, it.y));
-            band.item_count = static_cast<int>(items.size()) - band.item_begin;
-            // (block pairs: the records of the pair's SECOND block, which is padding behind an odd last block)
-            max_records = std::max(max_records, pairs_below(pair_ ? round_up(band.ib_end, 2) : band.ib_end) - band.pair_origin);
-            if (band.ib_end > band.ib_begin) bands_.push_back(band);
-        }
-        num_items_ = static_cast<int>(items.size());
-        items_.alloc_zero(std::max<size_t>(items.size(), 1), st);
-        if (!items.empty()) LSSVM_HIP_CHECK(hipMemcpyAsync(items_.p, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice, st));
-        colslab_.alloc_zero(static_cast<size_t>(max_records) * TILE, st);
-        LSSVM_HIP_CHECK(hipStreamSynchronize(st));  // `items` goes out of scope
-    }
-    // (two matvecs can be in flight -- enqueue-ahead -- and each issues bands x feature-panel passes tile launches: ADVICE r03, the later panels of a wide
-    // linear problem went untimed and the reported kernel time came out too low)
-    events_.resize(4 * std::max<size_t>(bands_.size(), 1) * static_cast<size_t>(std::max(passes_per_matvec(), 1)));
+    build_shard_lists(st);
     for (EvPair &e : events_) {
         e.a.create(true);
         e.b.create(true);
@@ -1574,6 +1609,62 @@ PackDc<T> Solver<T>::pack_with_direction(Problem<T> &p) {
     if (exchange_ == Exchange::process_peer) return PackDc<T>{};
     const bool skip = world_ > 1 && opt_.skip_collective != 0;
     return p.pack_for_d((p.sym_ && exchange_ != Exchange::none) || skip);
+}
+
+/* Shares by measured pace (lssvm_mi355_problem_rebalance).  weights == NULL: every shard's tile-kernel time per implicit matvec so far (HIP events) against the area
+ * of its share -- one process driving all shards knows them all; one process per GPU gathers them over the library's RCCL communicator, so that every rank
+ * computes the same weights (no such channel over HIP IPC: explicit weights only).  Nothing changes where the times lie within 2 % of each other.  Call between
+ * cg_step calls. */
+template <typename T>
+int Solver<T>::rebalance(const double *weights, int count) {
+    if (world_ <= 1 || !shards_[0]->sym_) return 0;
+    sync_all();
+    std::vector<double> w;
+    if (weights != nullptr) {
+        LSSVM_REQUIRE(count == world_, "one weight per rank");
+        for (int k = 0; k < count; ++k) {
+            LSSVM_REQUIRE(std::isfinite(weights[k]) && weights[k] > 0.0, "shard weights must be positive and finite");
+            w.push_back(weights[k]);
+        }
+    } else {
+        // pace of rank r = area of its share / kernel time per matvec
+        std::vector<double> ms(static_cast<size_t>(world_), 0.0);
+        for (auto &p : shards_) {
+            p->activate();
+            p->drain_events();
+            ms[static_cast<size_t>(p->rank_)] = p->matvec_timed_ > 0 ? p->matvec_ms_ / static_cast<double>(p->matvec_timed_) : 0.0;
+        }
+        if (static_cast<int>(shards_.size()) != world_) {  // one process per GPU: every rank contributes its own time
+            LSSVM_REQUIRE(exchange_ == Exchange::process_rccl, "measured shares need the RCCL communicator between the processes (give explicit weights over HIP IPC)");
+            Problem<T> &p = *shards_[0];
+            p.activate();
+            DevBuf<double> all;
+            all.alloc_zero(static_cast<size_t>(world_), p.stream());
+            LSSVM_HIP_CHECK(hipMemcpyAsync(all.p + p.rank_, &ms[static_cast<size_t>(p.rank_)], sizeof(double), hipMemcpyHostToDevice, p.stream()));
+            Comm &c = comm();
+            nccl_check(c.pAllGather(all.p + p.rank_, all.p, 1, ncclDouble, c.comm, p.stream()), "ncclAllGather");
+            LSSVM_HIP_CHECK(hipMemcpyAsync(ms.data(), all.p, sizeof(double) * static_cast<size_t>(world_), hipMemcpyDeviceToHost, p.stream()));
+            LSSVM_HIP_CHECK(hipStreamSynchronize(p.stream()));
+        }
+        double lo = ms[0], hi = ms[0];
+        for (const double v : ms) {
+            lo = std::min(lo, v);
+            hi = std::max(hi, v);
+        }
+        if (!(lo > 0.0) || hi <= 1.02 * lo) return 0;  // (a rank without a timed matvec, or nothing to gain)
+        const int tiles = shards_[0]->num_tiles_;
+        double sum = 0.0;
+        for (int r = 0; r < world_; ++r) {
+            const double b0 = sym_block_boundary(tiles, r, world_, &shards_[0]->opt_.shard_weights), b1 = sym_block_boundary(tiles, r + 1, world_, &shards_[0]->opt_.shard_weights);
+            const double area = 0.5 * (b1 * (b1 + 1.0) - b0 * (b0 + 1.0));
+            w.push_back(std::max(area, 1.0) / ms[static_cast<size_t>(r)]);
+            sum += w.back();
+        }
+        for (double &v : w) v *= static_cast<double>(world_) / sum;
+    }
+    for (auto &p : shards_) p->reshard(w);
+    opt_.shard_weights = w;
+    return 1;
 }
 
 template <typename T>

@@ -282,6 +282,9 @@ class Problem {
     void activate() const { LSSVM_HIP_CHECK(hipSetDevice(device_)); }
     /* Kv_ <- this shard's part of K * v (complete for a world of one): tile kernel + fixed-order reductions */
     void enqueue_apply_K_local(const T *v_dev, bool zero_first);
+    void reshard(const std::vector<double> &weights);  // new shares of the triangle (lssvm_mi355_problem_rebalance): the data, the vectors and the CG state stay
+    void choose_shard_geometry();
+    void build_shard_lists(hipStream_t st);
     PackDc<T> pack_for_d(bool zero_first);  // what k_update_d needs to pack the records of d_ (dc == NULL: this problem packs per matvec); marks them as present
     void enqueue_sum_and_qdot(const T *v_dev, int slot_sum, int slot_q);
     void drain_events();
@@ -359,6 +362,8 @@ class Problem {
     bool sym_ = false;
     DevBuf<int2> items_;
     int num_items_ = 0;
+    int ldx_probe_ = 0;        // the padded feature count the kernel paths were chosen with (constructor), kept for reshard
+    size_t num_features_ = 0;
     DevBuf<unsigned> queue_;  // 256-row workgroups, persistent launches: two sets of eight item counters (a launch draws from one and zeroes the other)
     int queue_set_ = 0;
     int queue_min_items_ = 256;  // launches of more items than this (the CU count) are persistent
@@ -406,6 +411,7 @@ struct ProblemBase {
     virtual void cg_step(uint64_t iterations, int *done_out) = 0;
     virtual void cg_finish(void *alpha_out, double *rho_out, lssvm_cg_info *info) = 0;
     virtual void synchronize() = 0;
+    virtual int rebalance(const double *weights, int count) = 0;  // lssvm_mi355_problem_rebalance: 1 if the shares changed
     virtual void fill_info(lssvm_cg_info *info) = 0;
     virtual void ipc_export(void *blob_out, size_t blob_bytes) = 0;
     virtual void ipc_connect(const void *blobs, size_t total_bytes) = 0;
@@ -488,6 +494,7 @@ class Solver final : public ProblemBase {
     void exchange();
     void sync_all();
     PackDc<T> pack_with_direction(Problem<T> &p);
+    int rebalance(const double *weights, int count) override;
     T *vec_of(Problem<T> &p, Vec which) const { return which == Vec::d ? p.d_.p : (which == Vec::x ? p.x_.p : p.tmp_.p); }
 
     Options opt_{};

@@ -146,3 +146,18 @@ def test_bench_rebalances_the_shares_by_measured_pace(tmp_path):
     assert isinstance(cfg["share_kernel_ms_at_equal_shares"], list) and len(cfg["share_kernel_ms_at_equal_shares"]) == 3 and min(cfg["share_kernel_ms_at_equal_shares"]) > 0
     w = cfg["shard_weights"]
     assert w is None or (len(w) == 3 and all(0.3 < x < 3.0 for x in w) and abs(sum(w) - 3.0) < 1e-3)
+
+
+@pytest.mark.parametrize("world, dtype", [(3, "float64"), (4, "float32")])
+def test_ranks_rebalance_their_shares_over_the_rccl_communicator(tmp_path, world, dtype):
+    """lssvm_mi355_problem_rebalance with one process per rank (round 5): after four CG steps every rank gathers every rank's tile-kernel time with ONE ncclAllGather of a
+    double over the library's communicator, computes the same weights and rebuilds its shard (the data, the vectors and the CG state stay); then explicit weights
+    (1, 1.5, 2, ...) -- every rank must end up with the same bits again, the product after the rebalance must be the product before it up to the association, and the
+    solve must go on to the float64 run's answer like the single-device solve does."""
+    res = _run_ranks(tmp_path, world, ["--exchange", "1", "--kernel", "polynomial", "--dtype", dtype, "--points", "9100", "--features", "64", "--steps", "10", "--rebalance-after", "4"])
+    assert len({r["alpha_sha"] for r in res}) == 1 and len({r["rho"] for r in res}) == 1 and len({r["matvec_after_rebalance_sha"] for r in res}) == 1
+    assert all(r["rebalanced_by_weights"] for r in res) and len({r["rebalanced_by_measurement"] for r in res}) == 1
+    eps = 2.3e-16 if dtype == "float64" else 1.2e-7
+    assert all(r["matvec_after_rebalance_err"] < 256 * eps for r in res)
+    r0 = [r for r in res if r["rank"] == 0][0]
+    assert r0["rccl_nranks"] == world and r0["alpha_err64"] <= 2 * r0["single_err64"] + 1e-4  # (unconverged iterates of two associations: what ten CG steps amplify, 2e-6 in fp64)

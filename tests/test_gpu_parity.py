@@ -946,6 +946,45 @@ def test_weighted_shares_add_up_to_the_unsharded_product(kernel, dtype, N, d, we
         assert np.all(np.isfinite(a2)) and np.isfinite(float(rho2))
 
 
+@pytest.mark.parametrize("kernel, dtype, N, d, shards", [("polynomial", np.float64, 2500, 64, 3), ("rbf", np.float32, 16_500, 128, 4), ("linear", np.float64, 3000, 40, 8)])
+def test_a_live_problem_takes_new_shares_between_two_cg_steps(kernel, dtype, N, d, shards):
+    """lssvm_mi355_problem_rebalance (round 5): the shards of a sharded symmetric problem are rebuilt for new shares of the triangle while the solve is under way -- the
+    data, the operand planes, the vectors and the CG state stay, only who evaluates which tiles changes.  All shards behind one call on one device: explicit weights
+    (changed = True; the product of a scratch vector before and after agrees to the association; in fp64 the solve ends where the unsharded solve does), shares by
+    measured pace (whatever the time sharing of one device makes of it: the solve must go on either way), and a single-device problem (nothing to do)."""
+    X, y = make_blobs_pm1(N, d, seed=12, dtype=dtype)
+    p = Parameter(kernel_type=kernel, cost=2.0)
+    n = N - 1
+    eps = np.finfo(dtype).eps
+    v = np.random.default_rng(4).uniform(-1, 1, size=n).astype(dtype)
+    zero = np.zeros(n, dtype)
+    a1, rho1, i1 = backend.solve_system_of_linear_equations(p, X, y, 1e-10, 4000)  # to convergence: unconverged iterates of two associations differ by what CG amplifies
+    with backend.ResidentProblem(p, X) as single:
+        want = single.matvec(v, zero, 1.0)
+        assert single.rebalance() is False and single.rebalance([1.0]) is False
+    with backend.ResidentProblem(p, X, devices=[0] * shards) as prob:
+        before = prob.matvec(v, zero, 1.0)
+        prob.cg_begin(y, 1e-10)
+        prob.cg_step(3)
+        assert prob.rebalance([1.0 + (r % 3) for r in range(shards)]) is True
+        mid = prob.matvec(v, zero, 1.0)
+        prob.cg_step(3)
+        measured = prob.rebalance()  # shares by measured pace
+        after = prob.matvec(v, zero, 1.0)
+        prob.cg_step(4000)
+        a2, rho2, info = prob.cg_finish()
+        with pytest.raises(InvalidParameterError):
+            prob.rebalance([1.0] * (shards + 1))
+    assert info["converged"] == 1 and i1["converged"] == 1 and isinstance(measured, bool)
+    scale = 256 * eps * np.max(np.abs(want))
+    assert np.max(np.abs(before - want)) < scale and np.max(np.abs(mid - want)) < scale and np.max(np.abs(after - want)) < scale
+    if dtype == np.float64:
+        # both solves converged (eps 1e-10); alpha_N and rho lie in the direction of the all-ones vector, which a converged solve determines worst (4e-7 / 2e-6 measured)
+        assert ol.rel_inf(a2, a1) < 1e-5 and abs(float(rho2) - float(rho1)) <= 1e-4 * max(1.0, abs(float(rho1)))
+    else:
+        assert np.all(np.isfinite(a2))  # (two fp32 CG runs of different association do not reproduce each other: DESIGN.md section 5; the products above are the check)
+
+
 @pytest.mark.parametrize("kernel, dtype", [("rbf", np.float32), ("polynomial", np.float64), ("linear", np.float32)])
 def test_row_block_bands_of_the_column_slab(oracle, kernel, dtype):
     """The column-sum records of the symmetric variant are produced band by band into one slab (option colslab_band_mb; 1M points in fp32

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--features", type=int, default=128)
     ap.add_argument("--out", required=True)
     ap.add_argument("--rccl-stand-in", default=None)
+    ap.add_argument("--rebalance-after", type=int, default=0, help="exchange 1: after this many CG steps the ranks call problem_rebalance (measured shares, gathered over the RCCL communicator) and report what it did")
     args = ap.parse_args()
     stand_in = None
     if args.rccl_stand_in:  # BEFORE torch and the product library
@@ -72,16 +73,29 @@ def main():
                 connect_peers(dist, prob)
             got = prob.matvec(v, zero, 1.0)
             prob.cg_begin(y, 1e-30)
-            prob.cg_step(args.steps)
+            rebalanced = after = None
+            if args.rebalance_after > 0 and args.exchange == 1:
+                prob.cg_step(args.rebalance_after)
+                rebalanced = prob.rebalance()                      # by measured pace: every rank gathers every rank's time and computes the same weights
+                forced = prob.rebalance([1.0 + 0.5 * r for r in range(world)])  # and explicit ones, the same list on every rank
+                after = prob.matvec(v, zero, 1.0)                  # (the scratch vector's product: the CG state is untouched)
+                prob.cg_step(args.steps - args.rebalance_after)
+            else:
+                prob.cg_step(args.steps)
             alpha, rho, info = prob.cg_finish()
             dist.barrier()  # (IPC: a rank's vector stays mapped by its peers until they are done)
         out = {"rank": rank, "alpha_sha": hashlib.sha256(alpha.tobytes()).hexdigest(), "rho": float(rho), "devices_used": int(info["devices_used"]),
                "exchange": int(info["exchange"]), "symmetric": int(info["symmetric"]), "rccl_nranks": int(info["rccl_nranks"]), "rccl_rank": int(info["rccl_rank"]),
                "rccl_device": int(info["rccl_device"]), "iterations": int(info["iterations"])}
+        if after is not None:
+            out["rebalanced_by_measurement"] = bool(rebalanced)
+            out["rebalanced_by_weights"] = bool(forced)
+            out["matvec_after_rebalance_sha"] = hashlib.sha256(after.tobytes()).hexdigest()
+            out["matvec_after_rebalance_err"] = float(np.max(np.abs(after.astype(np.float64) - got.astype(np.float64))) / np.max(np.abs(got)))
         if args.exchange == 1:
             out["rccl_library"] = backend.comm_library_path()
             out["stand_in_loaded"] = bool(stand_in is not None and hasattr(ctypes.CDLL(out["rccl_library"]), "fake_rccl_marker"))
-        if args.exchange == 1 and stand_in is not None:
+        if args.exchange == 1 and stand_in is not None and after is None:
             # the same problem over HIP IPC + the peer kernel: the stand-in sums in rank order like k_peer_sum, so the two exchanges must agree bit for bit
             _capi.set_option("exchange", 2)
             with backend.ResidentProblem(p, X, device=local, rank=rank, world=world) as prob2:
