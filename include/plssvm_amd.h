@@ -278,7 +278,7 @@ int lssvm_mi355_arff_close(lssvm_mi355_arff_file *file);
 
 /* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT).  set_option changes the process-wide DEFAULTS;
  * every problem / solve takes a snapshot of them when it is created, so later changes never affect a live problem.  The defaults can
- * be preset from the environment: LSSVM_MI355_OPTIONS="name=value,name=value" (read once when the library is loaded).  Thirteen options here, two
+ * be preset from the environment: LSSVM_MI355_OPTIONS="name=value,name=value" (read once when the library is loaded).  Fourteen options here, two
  * testing aids in plssvm_amd_testing.h -- who sets each besides the tests: DESIGN.md section 4.5 (round 4 retired xcd_map, lds_extra_kb, item_order,
  * linear_panel_features, check_shards, rbf_direct_above and mfma_shape = 1: measured, decided, constants now):
  *   "rbf_form"      fp32 rbf: 0 = automatic (default): the norm expansion c_i + c_j + x_i'.x_j' on the matrix cores, unless
@@ -331,6 +331,8 @@ int lssvm_mi355_arff_close(lssvm_mi355_arff_file *file);
  *                   the NEXT matvec are enqueued before the host reads the stop test of the current iteration, so the device never waits for
  *                   the host; they touch d and K*d only, so a converged solve ends exactly where the reference's does, one matvec is discarded.
  *                   0 = the host reads every stop test before it enqueues anything further
+ *   "rebalance_after" lssvm_mi355_solve_multi_*: after this many CG iterations the shards get new shares of the triangle by their measured pace
+ *                   (lssvm_mi355_problem_rebalance with weights = NULL); 0 (default) = never -- devices are taken to run at one pace
  */
 int lssvm_mi355_set_option(const char *name, int64_t value);
 int lssvm_mi355_get_option(const char *name, int64_t *value_out);

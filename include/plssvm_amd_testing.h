@@ -25,7 +25,7 @@ int lssvm_mi355_measure_bf16_mfma_ceiling(int device, int b_from_lds, double set
  * harness loaded into the process first (tests/tools/; the library itself never looks for one). */
 int lssvm_mi355_comm_library_path(char *buf, size_t buf_len);
 
-/* option names understood by lssvm_mi355_set_option / _get_option besides the thirteen documented in plssvm_amd.h:
+/* option names understood by lssvm_mi355_set_option / _get_option besides the fourteen documented in plssvm_amd.h:
  *   "force_collective" 1 = run the per-matvec RCCL collective even with a world of 1 (testing aid; default 0)
  *   "skip_collective"  1 = problems created with world > 1 need no communicator and do NOT exchange their partial K*v (testing aid:
  *                      lets one GPU evaluate every rank's share in turn; default 0)

@@ -124,7 +124,7 @@ ABI_VERSION = 3
 LSSVM_IPC_BLOB_BYTES = 256
 # every tuning knob of lssvm_mi355_set_option (include/plssvm_amd.h)
 OPTION_NAMES = ["rbf_form", "rbf_fold", "j_chunk_tiles", "j_chunk_head", "symmetric", "tile_kernel", "gram_mode", "mfma_shape", "colslab_band_mb", "colslab_limit_mb", "force_collective", "skip_collective",
-                "exchange", "ipc_timeout_s", "enqueue_ahead_below_us"]
+                "exchange", "ipc_timeout_s", "enqueue_ahead_below_us", "rebalance_after"]
 # accepted with the value 0 everywhere, with other values in development builds only (make DEV=1 / -DLSSVM_ENABLE_ABLATION)
 DEV_OPTION_NAMES = ["pair_lag", "debug_ablate", "item_order_dev"]
 

@@ -58,7 +58,15 @@ void solve_one_shot(const lssvm_params *params, const T *X, size_t N, size_t d, 
     LSSVM_REQUIRE(alpha_out != nullptr && rho_out != nullptr, "alpha_out / rho_out must not be NULL");
     lssvm::Solver<T> prob(*params, X, LSSVM_MEM_HOST, N, d, lssvm::resolve_devices(devices, num_devices, N), nullptr);
     prob.cg_begin(y, static_cast<double>(eps));
-    prob.cg_step(max_iter, nullptr);
+    // option rebalance_after (several devices, symmetric variant): the first iterations measure every shard's pace, then the shares follow it (lssvm_mi355_problem_rebalance)
+    const uint64_t first = static_cast<uint64_t>(lssvm::options().rebalance_after);
+    if (first > 0 && first < max_iter) {
+        prob.cg_step(first, nullptr);
+        (void) prob.rebalance(nullptr, 0);
+        prob.cg_step(max_iter - first, nullptr);
+    } else {
+        prob.cg_step(max_iter, nullptr);
+    }
     double rho = 0.0;
     lssvm_cg_info local{};
     prob.cg_finish(alpha_out, &rho, &local);
@@ -401,6 +409,9 @@ int lssvm_mi355_set_option(const char *name, int64_t value) {
         } else if (n == "enqueue_ahead_below_us") {
             LSSVM_REQUIRE(value >= 0, "enqueue_ahead_below_us must not be negative");
             lssvm::options().enqueue_ahead_below_us = value;
+        } else if (n == "rebalance_after") {
+            LSSVM_REQUIRE(value >= 0, "rebalance_after must not be negative");
+            lssvm::options().rebalance_after = value;
         } else {
             throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "unknown option '" + n + "'");
         }
@@ -446,6 +457,8 @@ int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
             *value_out = lssvm::options().ipc_timeout_s;
         } else if (n == "enqueue_ahead_below_us") {
             *value_out = lssvm::options().enqueue_ahead_below_us;
+        } else if (n == "rebalance_after") {
+            *value_out = lssvm::options().rebalance_after;
         } else {
             throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "unknown option '" + n + "'");
         }

@@ -77,6 +77,7 @@ struct Options {
     int64_t skip_collective = 0;   // testing aid: sharded problems (world > 1) need no communicator and leave their PARTIAL K*v un-exchanged
     int64_t exchange = 0;          // several devices in ONE process: 0 = automatic (RCCL when the devices are distinct, else peer kernels), 1 = RCCL all-reduce / all-gather
                                    // (ncclCommInitAll), 2 = peer kernels: every device sums the partial vectors of all devices over xGMI in rank order
+    int64_t rebalance_after = 0;           // one-shot solves on several devices: after this many iterations the shards are given new shares by their measured pace (lssvm_mi355_problem_rebalance); 0 = never
     int64_t enqueue_ahead_below_us = 5000;  // CG: implicit matvecs shorter than this are enqueued ahead of the previous iteration's stop test (0 = never)
     int64_t ipc_timeout_s = 600;   // one process per GPU over HIP IPC: how long a rank waits for its peers at an exchange before it gives up
     // development builds only (the setter refuses them elsewhere)
@@ -481,6 +482,7 @@ class Solver final : public ProblemBase {
     void matvec(const void *d, void *ret_inout, double add) override;
     void cg_begin(const void *y, double eps) override;
     void cg_step(uint64_t iterations, int *done_out) override;
+    int rebalance(const double *weights, int count) override;
     void cg_finish(void *alpha_out, double *rho_out, lssvm_cg_info *info) override;
     void synchronize() override;
     void fill_info(lssvm_cg_info *info) override;
@@ -494,7 +496,6 @@ class Solver final : public ProblemBase {
     void exchange();
     void sync_all();
     PackDc<T> pack_with_direction(Problem<T> &p);
-    int rebalance(const double *weights, int count) override;
     T *vec_of(Problem<T> &p, Vec which) const { return which == Vec::d ? p.d_.p : (which == Vec::x ? p.x_.p : p.tmp_.p); }
 
     Options opt_{};

@@ -35,9 +35,9 @@ def test_header_and_binding_agree():
     public = open(HEADER).read()
     for knob in ("debug_ablate", "pair_lag", "skip_collective", "force_collective"):
         assert knob not in public, knob
-    # thirteen documented options + two testing aids = the fifteen the library accepts (+ those that exist in development builds only)
+    # fourteen documented options + two testing aids = the sixteen the library accepts (+ those that exist in development builds only)
     documented = re.findall(r'^ \*   "(\w+)"', public, flags=re.M)
-    assert sorted(documented + ["force_collective", "skip_collective"]) == sorted(_capi.OPTION_NAMES) and len(_capi.OPTION_NAMES) == 15
+    assert sorted(documented + ["force_collective", "skip_collective"]) == sorted(_capi.OPTION_NAMES) and len(_capi.OPTION_NAMES) == 16
     for name in _capi.OPTION_NAMES + _capi.DEV_OPTION_NAMES:
         _capi.get_option(name)
     for retired in ("xcd_map", "lds_extra_kb", "item_order", "linear_panel_features", "check_shards", "rbf_direct_above"):

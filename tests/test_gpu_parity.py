@@ -985,6 +985,23 @@ def test_a_live_problem_takes_new_shares_between_two_cg_steps(kernel, dtype, N, 
         assert np.all(np.isfinite(a2))  # (two fp32 CG runs of different association do not reproduce each other: DESIGN.md section 5; the products above are the check)
 
 
+def test_one_shot_solve_on_several_shards_rebalances_when_asked():
+    """Option rebalance_after (round 5; default 0 = never): lssvm_mi355_solve_multi_* runs that many iterations, gives the shards new shares by their measured pace
+    (lssvm_mi355_problem_rebalance) and finishes the solve -- the call a plssvm::csvm adaptor makes.  Four shards on one device: whatever the time sharing measures, the
+    converged solve is the single-device solve's within the CG-level fp64 bar; with more iterations asked for than the solve has, nothing happens."""
+    X, y = make_blobs_pm1(2600, 48, seed=19, dtype=np.float64)
+    p = Parameter(kernel_type="polynomial", degree=2, cost=2.0)
+    a1, rho1, i1 = backend.solve_system_of_linear_equations(p, X, y, 1e-10, 4000)
+    for after in (3, 10**6):
+        _capi.set_option("rebalance_after", after)
+        try:
+            a2, rho2, i2 = backend.solve_system_of_linear_equations(p, X, y, 1e-10, 4000, devices=[0] * 4)
+        finally:
+            _capi.set_option("rebalance_after", 0)
+        assert i1["converged"] == 1 and i2["converged"] == 1 and i2["devices_used"] == 4
+        assert ol.rel_inf(a2, a1) < 1e-5 and abs(float(rho2) - float(rho1)) <= 1e-4 * max(1.0, abs(float(rho1)))
+
+
 @pytest.mark.parametrize("kernel, dtype", [("rbf", np.float32), ("polynomial", np.float64), ("linear", np.float32)])
 def test_row_block_bands_of_the_column_slab(oracle, kernel, dtype):
     """The column-sum records of the symmetric variant are produced band by band into one slab (option colslab_band_mb; 1M points in fp32
