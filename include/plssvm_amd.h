@@ -264,6 +264,56 @@ int lssvm_mi355_libsvm_fill_f32(lssvm_mi355_libsvm_file *file, float *X, uint64_
 int lssvm_mi355_libsvm_fill_f64(lssvm_mi355_libsvm_file *file, double *X, uint64_t ldx, double *labels);
 int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file);
 
+/* ---- LIBSVM data files: writer (include/plssvm/detail/io/libsvm_parsing.hpp:244-296) ----
+ * `header` (may be NULL) is written verbatim first -- the reference's two comment lines "# This data set has been created at ..." and "# NxD" are the caller's
+ * to word.  Then one line per point: "label idx:val idx:val ... " -- every number as {:.10e}, zero features left out, one-based indices, a blank after every
+ * token, like the reference.  The label column: int_labels (whole numbers, written as integers), OR label_text + label_offsets (point i's label is the
+ * bytes [label_offsets[i], label_offsets[i + 1]) of label_text: string labels, or numbers the caller has already formatted), or neither: no labels.  The
+ * points are written in their order by all host threads (chunks of rows formatted concurrently, flushed in order): the file does not depend on the thread
+ * count (the reference's order is unspecified, :251).  Host code only, no device needed. */
+int lssvm_mi355_libsvm_write_f32(const char *path, const char *header, const float *X, uint64_t num_points, uint64_t num_features, uint64_t ldx,
+                                 const int64_t *int_labels, const char *label_text, const uint64_t *label_offsets);
+int lssvm_mi355_libsvm_write_f64(const char *path, const char *header, const double *X, uint64_t num_points, uint64_t num_features, uint64_t ldx,
+                                 const int64_t *int_labels, const char *label_text, const uint64_t *label_offsets);
+
+/* ---- LIBSVM model files: what plssvm-train writes and plssvm-predict reads (include/plssvm/detail/io/libsvm_model_parsing.hpp) ----
+ * Writer (:371-499): `header` -- the lines from the "#" time stamp to "SV" (:296-342; a dozen short lines, worded by the caller: plssvm_amd/model.py) -- is
+ * written verbatim, then `count` lines "alpha idx:val idx:val ... " ({:.10e}, zeros left out, a blank after every token) for the support vectors
+ * order[0 .. count) -- the caller lists them grouped by class in the order of the header's "label" line (:416-499); order == NULL: all of them as they lie
+ * (count must equal num_support_vectors).  Multi-threaded like the data writer, the same bytes for any thread count. */
+int lssvm_mi355_model_write_f32(const char *path, const char *header, const float *support_vectors, uint64_t num_support_vectors, uint64_t num_features,
+                                uint64_t ldx, const float *alpha, const uint64_t *order, uint64_t count);
+int lssvm_mi355_model_write_f64(const char *path, const char *header, const double *support_vectors, uint64_t num_support_vectors, uint64_t num_features,
+                                uint64_t ldx, const double *alpha, const uint64_t *order, uint64_t count);
+/* Reader (:64-262), the same contract as the data readers: a multi-threaded fast path for WELL-FORMED files -- every header key at most once and spelled
+ * out ("svm_type c_svc", "kernel_type linear|polynomial|rbf", "degree", "gamma", "coef0", "nr_class", "total_sv", "rho", "label", "nr_sv", then "SV"; any
+ * order and case), only the parameters its kernel uses, counts that add up, then exactly total_sv lines "alpha idx:val ..." that follow the data-file
+ * rules.  `open` maps and validates the file and reports the header; `labels` hands out the "label" line's entries (separated by single blanks, NUL
+ * terminated, lssvm_model_info.label_text_bytes bytes; the caller converts them to its label type and checks them for duplicates AFTER that conversion,
+ * as the reference does) and the nr_sv counts (nr_class entries); `fill` writes the support vectors (dense row-major, missing features = 0) and their
+ * weights.  Any irregularity -> LSSVM_ERR_INVALID_ARGUMENT without a diagnosis: callers re-parse with their reference-exact parser for the error message
+ * (plssvm_amd/model.py does). */
+typedef struct lssvm_model_info {
+    int32_t kernel_type; /* lssvm_kernel_type */
+    int32_t has_degree;  /* which of the kernel parameters the header states (an rbf / polynomial header may leave gamma to the 1 / num_features default) */
+    int32_t has_gamma;
+    int32_t has_coef0;
+    int64_t degree;
+    double gamma;
+    double coef0;
+    double rho;
+    uint64_t nr_class;
+    uint64_t total_sv;         /* = number of support-vector lines */
+    uint64_t num_features;     /* largest feature index of the body */
+    uint64_t label_text_bytes; /* bytes lssvm_mi355_model_labels writes into label_text_out, the terminating NUL included */
+} lssvm_model_info;
+typedef struct lssvm_mi355_model_file lssvm_mi355_model_file;
+int lssvm_mi355_model_open(const char *path, lssvm_mi355_model_file **file_out, lssvm_model_info *info);
+int lssvm_mi355_model_labels(lssvm_mi355_model_file *file, char *label_text_out, uint64_t label_text_bytes, uint64_t *nr_sv_out);
+int lssvm_mi355_model_fill_f32(lssvm_mi355_model_file *file, float *support_vectors, uint64_t ldx, float *alpha);
+int lssvm_mi355_model_fill_f64(lssvm_mi355_model_file *file, double *support_vectors, uint64_t ldx, double *alpha);
+int lssvm_mi355_model_close(lssvm_mi355_model_file *file);
+
 /* ---- ARFF data files (the second format of plssvm::data_set, include/plssvm/detail/io/arff_parsing.hpp:57-372) ----
  * The same contract as the LIBSVM reader above: a multi-threaded fast path for WELL-FORMED files -- "@RELATION name", "@ATTRIBUTE name NUMERIC" per feature, at
  * most one "@ATTRIBUTE class {l1,l2,...}" with numeric labels, "@DATA", then dense rows (one value per attribute) or sparse rows ("{index value,...}", zero-based

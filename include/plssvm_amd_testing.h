@@ -25,6 +25,10 @@ int lssvm_mi355_measure_bf16_mfma_ceiling(int device, int b_from_lds, double set
  * harness loaded into the process first (tests/tools/; the library itself never looks for one). */
 int lssvm_mi355_comm_library_path(char *buf, size_t buf_len);
 
+/* The file readers and writers (lssvm_mi355_libsvm_*, _arff_*, _model_*) use at most this many host threads; 0 (default) = as many as the hardware has,
+ * at most 32.  For the tests that a written file does not depend on the thread count. */
+int lssvm_mi355_set_io_threads(int threads);
+
 /* option names understood by lssvm_mi355_set_option / _get_option besides the fourteen documented in plssvm_amd.h:
  *   "force_collective" 1 = run the per-matvec RCCL collective even with a world of 1 (testing aid; default 0)
  *   "skip_collective"  1 = problems created with world > 1 need no communicator and do NOT exchange their partial K*v (testing aid:

@@ -34,8 +34,10 @@ EXPORTED_SYMBOLS = [
     "lssvm_mi355_shard_blocks", "lssvm_mi355_set_shard_weights", "lssvm_mi355_problem_rebalance", "lssvm_mi355_comm_get_unique_id", "lssvm_mi355_comm_init", "lssvm_mi355_comm_destroy",
     "lssvm_mi355_problem_create", "lssvm_mi355_problem_create_multi", "lssvm_mi355_problem_ipc_export", "lssvm_mi355_problem_ipc_connect", "lssvm_mi355_problem_destroy", "lssvm_mi355_problem_get_q", "lssvm_mi355_problem_matvec",
     "lssvm_mi355_cg_begin", "lssvm_mi355_cg_step", "lssvm_mi355_cg_finish", "lssvm_mi355_problem_synchronize", "lssvm_mi355_problem_info",
-    "lssvm_mi355_measure_bf16_mfma_ceiling", "lssvm_mi355_comm_library_path", "lssvm_mi355_set_option", "lssvm_mi355_get_option",
+    "lssvm_mi355_measure_bf16_mfma_ceiling", "lssvm_mi355_comm_library_path", "lssvm_mi355_set_io_threads", "lssvm_mi355_set_option", "lssvm_mi355_get_option",
     "lssvm_mi355_libsvm_open", "lssvm_mi355_libsvm_fill_f32", "lssvm_mi355_libsvm_fill_f64", "lssvm_mi355_libsvm_close",
+    "lssvm_mi355_libsvm_write_f32", "lssvm_mi355_libsvm_write_f64", "lssvm_mi355_model_write_f32", "lssvm_mi355_model_write_f64",
+    "lssvm_mi355_model_open", "lssvm_mi355_model_labels", "lssvm_mi355_model_fill_f32", "lssvm_mi355_model_fill_f64", "lssvm_mi355_model_close",
     "lssvm_mi355_arff_open", "lssvm_mi355_arff_fill_f32", "lssvm_mi355_arff_fill_f64", "lssvm_mi355_arff_close",
 ]
 
@@ -54,6 +56,13 @@ class LssvmCgInfo(C.Structure):
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class LssvmModelInfo(C.Structure):
+    """``lssvm_model_info``: the header of a model file as the native reader reports it."""
+    _fields_ = [("kernel_type", C.c_int32), ("has_degree", C.c_int32), ("has_gamma", C.c_int32), ("has_coef0", C.c_int32), ("degree", C.c_int64),
+                ("gamma", C.c_double), ("coef0", C.c_double), ("rho", C.c_double), ("nr_class", C.c_uint64), ("total_sv", C.c_uint64),
+                ("num_features", C.c_uint64), ("label_text_bytes", C.c_uint64)]
 
 
 class LssvmShard(C.Structure):

@@ -5,9 +5,6 @@
  */
 #include "lssvm_problem.hip.hpp"
 
-#include "arff_reader.hpp"
-#include "libsvm_reader.hpp"
-
 #include <dlfcn.h>
 #include <cstdlib>
 #include <memory>
@@ -15,27 +12,7 @@
 
 namespace {
 
-thread_local std::string g_last_error;
-
-template <typename F>
-int guarded(F &&f) {
-    try {
-        f();
-        return LSSVM_SUCCESS;
-    } catch (const lssvm::Error &e) {
-        g_last_error = e.what();
-        return e.status;
-    } catch (const std::bad_alloc &) {
-        g_last_error = "host allocation failed";
-        return LSSVM_ERR_OUT_OF_MEMORY;
-    } catch (const std::exception &e) {
-        g_last_error = e.what();
-        return LSSVM_ERR_INTERNAL;
-    } catch (...) {
-        g_last_error = "unknown error";
-        return LSSVM_ERR_INTERNAL;
-    }
-}
+using lssvm::guarded;
 
 struct Handle {
     std::unique_ptr<lssvm::ProblemBase> impl;
@@ -90,7 +67,7 @@ extern "C" {
 static_assert(sizeof(lssvm_cg_info) == 160, "lssvm_cg_info changed: bump PLSSVM_AMD_ABI_VERSION and plssvm_amd/_capi.py (LssvmCgInfo) with it");
 int lssvm_mi355_abi_version(void) { return PLSSVM_AMD_ABI_VERSION; }
 
-const char *lssvm_mi355_last_error(void) { return g_last_error.c_str(); }
+const char *lssvm_mi355_last_error(void) { return lssvm::last_error_message().c_str(); }
 
 int lssvm_mi355_device_count(void) {
     int count = 0;
@@ -98,7 +75,7 @@ int lssvm_mi355_device_count(void) {
     if (err != hipSuccess) {
         (void) hipGetLastError();
         if (err == hipErrorNoDevice) return 0;
-        g_last_error = std::string("hipGetDeviceCount failed: ") + hipGetErrorString(err);
+        lssvm::last_error_message() = std::string("hipGetDeviceCount failed: ") + hipGetErrorString(err);
         return 0;
     }
     return count;
@@ -491,76 +468,5 @@ struct EnvOptions {
 };
 const EnvOptions g_env_options;
 }  // namespace
-
-/* ---- LIBSVM data files: fast reader for well-formed files (libsvm_reader.hpp) ---- */
-struct lssvm_mi355_libsvm_file {
-    lssvm::LibsvmFile impl;
-};
-
-int lssvm_mi355_libsvm_open(const char *path, uint64_t skipped_lines, lssvm_mi355_libsvm_file **file_out, uint64_t *num_points, uint64_t *num_features,
-                            int *has_label) {
-    return guarded([&] {
-        LSSVM_REQUIRE(path != nullptr && file_out != nullptr && num_points != nullptr && num_features != nullptr && has_label != nullptr,
-                      "path / output pointers must not be NULL");
-        *file_out = nullptr;
-        auto f = std::make_unique<lssvm_mi355_libsvm_file>();
-        if (!f->impl.open(path, skipped_lines)) throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, std::string("Couldn't find file: '") + path + "'!");
-        if (!f->impl.scan()) throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "not a well-formed LIBSVM data file for the fast reader");
-        *num_points = f->impl.num_points();
-        *num_features = f->impl.num_features();
-        *has_label = f->impl.has_label() ? 1 : 0;
-        *file_out = f.release();
-    });
-}
-int lssvm_mi355_libsvm_fill_f32(lssvm_mi355_libsvm_file *file, float *X, uint64_t ldx, double *labels) {
-    return guarded([&] {
-        LSSVM_REQUIRE(file != nullptr && X != nullptr, "file / X must not be NULL");
-        if (!file->impl.fill<float>(X, ldx, labels)) throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "not a well-formed LIBSVM data file for the fast reader");
-    });
-}
-int lssvm_mi355_libsvm_fill_f64(lssvm_mi355_libsvm_file *file, double *X, uint64_t ldx, double *labels) {
-    return guarded([&] {
-        LSSVM_REQUIRE(file != nullptr && X != nullptr, "file / X must not be NULL");
-        if (!file->impl.fill<double>(X, ldx, labels)) throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "not a well-formed LIBSVM data file for the fast reader");
-    });
-}
-int lssvm_mi355_libsvm_close(lssvm_mi355_libsvm_file *file) {
-    return guarded([&] { delete file; });
-}
-
-/* ---- ARFF data files: fast reader for well-formed files (arff_reader.hpp) ---- */
-struct lssvm_mi355_arff_file {
-    lssvm::ArffFile impl;
-};
-
-int lssvm_mi355_arff_open(const char *path, int int_labels, lssvm_mi355_arff_file **file_out, uint64_t *num_points, uint64_t *num_features, int *has_label) {
-    return guarded([&] {
-        LSSVM_REQUIRE(path != nullptr && file_out != nullptr && num_points != nullptr && num_features != nullptr && has_label != nullptr,
-                      "path / output pointers must not be NULL");
-        *file_out = nullptr;
-        auto f = std::make_unique<lssvm_mi355_arff_file>();
-        if (!f->impl.open(path)) throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, std::string("Couldn't find file: '") + path + "'!");
-        if (!f->impl.scan(int_labels != 0)) throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "not a well-formed ARFF data file for the fast reader");
-        *num_points = f->impl.num_points();
-        *num_features = f->impl.num_features();
-        *has_label = f->impl.has_label() ? 1 : 0;
-        *file_out = f.release();
-    });
-}
-int lssvm_mi355_arff_fill_f32(lssvm_mi355_arff_file *file, float *X, uint64_t ldx, double *labels) {
-    return guarded([&] {
-        LSSVM_REQUIRE(file != nullptr && X != nullptr, "file / X must not be NULL");
-        if (!file->impl.fill<float>(X, ldx, labels)) throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "not a well-formed ARFF data file for the fast reader");
-    });
-}
-int lssvm_mi355_arff_fill_f64(lssvm_mi355_arff_file *file, double *X, uint64_t ldx, double *labels) {
-    return guarded([&] {
-        LSSVM_REQUIRE(file != nullptr && X != nullptr, "file / X must not be NULL");
-        if (!file->impl.fill<double>(X, ldx, labels)) throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "not a well-formed ARFF data file for the fast reader");
-    });
-}
-int lssvm_mi355_arff_close(lssvm_mi355_arff_file *file) {
-    return guarded([&] { delete file; });
-}
 
 }  // extern "C"

@@ -21,48 +21,24 @@
 #include <charconv>
 #include <cstddef>
 #include <cstdint>
-#include <cstdio>
 #include <string>
-#include <thread>
 #include <vector>
+
+#include "text_file.hpp"
 
 namespace lssvm {
 
 class LibsvmFile {
   public:
-    /* reads the file and indexes its data lines; returns false if the file cannot be read */
+    /* maps the file and indexes its data lines; returns false if the file cannot be read */
     bool open(const char *path, std::uint64_t skipped_lines) {
-        std::FILE *f = std::fopen(path, "rb");
-        if (f == nullptr) return false;
-        std::fseek(f, 0, SEEK_END);
-        const long size = std::ftell(f);
-        std::fseek(f, 0, SEEK_SET);
-        if (size < 0) {
-            std::fclose(f);
-            return false;
-        }
-        text_.resize(static_cast<std::size_t>(size));
-        const std::size_t got = size > 0 ? std::fread(&text_[0], 1, text_.size(), f) : 0;
-        std::fclose(f);
-        if (got != text_.size()) return false;
-        // line index
-        const char *b = text_.data();
-        const char *e = b + text_.size();
-        const char *p = b;
-        std::uint64_t seen = 0;
-        while (p < e) {
-            const char *q = p;
-            while (q < e && *q != '\n' && *q != '\r') ++q;
-            const char *s = p;
-            while (s < q && (*s == ' ' || *s == '\t' || *s == '\v' || *s == '\f')) ++s;
-            if (s < q && *s != '#') {
-                if (seen >= skipped_lines) lines_.push_back({ static_cast<std::size_t>(s - b), static_cast<std::size_t>(q - b) });
-                ++seen;
-            }
-            p = q + 1;
-        }
+        if (!text_.open(path)) return false;
+        index(0, skipped_lines);
         return true;
     }
+    /* the data lines of an opened text from offset `from` on (model files: the lines after "SV", model_io.hpp) */
+    void index(std::size_t from, std::uint64_t skipped_lines) { lines_ = text_.index_lines(from, '#', skipped_lines); }
+    TextFile &text() { return text_; }
 
     /* pass 1: validates the structure, finds the number of features and whether the lines are labelled */
     bool scan() {
@@ -128,9 +104,7 @@ class LibsvmFile {
     bool has_label() const { return has_label_; }
 
   private:
-    struct Line {
-        std::size_t begin, end;
-    };
+    using Line = TextFile::Line;
 
     static bool is_blank(char c) { return c == ' '; }  // tokens are separated by spaces; a tab makes the line "not well formed" here
 
@@ -176,29 +150,14 @@ class LibsvmFile {
         return true;
     }
 
-    unsigned num_threads() const {
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const std::size_t by_size = std::max<std::size_t>(1, lines_.size() / 2048);
-        return static_cast<unsigned>(std::min({ static_cast<std::size_t>(hw), std::size_t(32), by_size }));
-    }
+    unsigned num_threads() const { return io_threads(lines_.size(), 2048); }
 
     template <typename F>
     void run_parallel(unsigned nt, F &&body) const {
-        const std::size_t n = lines_.size();
-        if (nt <= 1) {
-            body(0u, std::size_t(0), n);
-            return;
-        }
-        std::vector<std::thread> pool;
-        pool.reserve(nt);
-        for (unsigned t = 0; t < nt; ++t) {
-            const std::size_t lo = n * t / nt, hi = n * (t + 1) / nt;
-            pool.emplace_back([&body, t, lo, hi] { body(t, lo, hi); });
-        }
-        for (std::thread &th : pool) th.join();
+        io_parallel(nt, lines_.size(), body);
     }
 
-    std::string text_;
+    TextFile text_;
     std::vector<Line> lines_;
     std::size_t num_features_ = 0;
     bool has_label_ = false;

@@ -13,6 +13,7 @@
  */
 #pragma once
 
+#include "lssvm_error.hpp"
 #include "lssvm_types.hpp"
 
 #include "../../include/plssvm_amd.h"
@@ -33,12 +34,7 @@
 
 namespace lssvm {
 
-/* ------------------------------------------------------------------ errors ------------------------------------------------------------------ */
-struct Error : std::runtime_error {
-    int status;
-    Error(int st, const std::string &msg) : std::runtime_error(msg), status(st) {}
-};
-
+/* ------------------------------------------------------------------ errors (lssvm::Error, LSSVM_REQUIRE: lssvm_error.hpp) ------------------------------------------------------------------ */
 #define LSSVM_HIP_CHECK(expr)                                                                                                         \
     do {                                                                                                                              \
         const hipError_t lssvm_err_ = (expr);                                                                                         \
@@ -47,11 +43,6 @@ struct Error : std::runtime_error {
                                  std::string("HIP assert '") + hipGetErrorName(lssvm_err_) + "' (" + std::to_string((int) lssvm_err_) + \
                                      "): " + hipGetErrorString(lssvm_err_) + " at " #expr);                                           \
         }                                                                                                                             \
-    } while (0)
-
-#define LSSVM_REQUIRE(cond, msg)                                              \
-    do {                                                                      \
-        if (!(cond)) throw ::lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, (msg)); \
     } while (0)
 
 /* ------------------------------------------------------------------ options ------------------------------------------------------------------ */

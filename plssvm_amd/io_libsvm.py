@@ -156,19 +156,52 @@ def parse_libsvm_data(filename, dtype=np.float64, skipped_lines: int = 0, label_
     return X, labels
 
 
-def write_libsvm_data(filename, X, labels=None, comment: str | None = None) -> None:
-    """Write a (sparse: zeros omitted) LIBSVM file, one-based indices (libsvm_parsing.hpp:254-296; format ``{:.10e}``)."""
-    X = np.asarray(X)
+def _label_text(lab) -> str:
+    """fmt's ``{}`` of a label: strings as they are, whole numbers without a fraction."""
+    if isinstance(lab, str):
+        return lab
+    if isinstance(lab, (int, np.integer)) or float(lab).is_integer():
+        return str(int(lab))
+    return repr(float(lab))
+
+
+def _write_native(filename, header, X, labels) -> bool:
+    if X.dtype not in (np.dtype(np.float32), np.dtype(np.float64)) or not X.flags.c_contiguous:
+        return False
+    try:
+        import ctypes as C
+
+        from . import _capi
+    except (ImportError, OSError):
+        return False
+    ints = text = offsets = None
+    if labels is not None:
+        arr = np.asarray(labels)
+        if arr.dtype.kind in "iu" or (arr.dtype.kind == "f" and np.all(np.isfinite(arr)) and np.all(arr == np.rint(arr)) and np.all(np.abs(arr) < 2.0**62)):
+            ints = np.ascontiguousarray(arr, dtype=np.int64)
+        else:
+            parts = [_label_text(lab).encode() for lab in labels]
+            text = b"".join(parts)
+            offsets = np.zeros(len(parts) + 1, dtype=np.uint64)
+            np.cumsum([len(t) for t in parts], out=offsets[1:])
+    write = _capi.lib.lssvm_mi355_libsvm_write_f32 if X.dtype == np.float32 else _capi.lib.lssvm_mi355_libsvm_write_f64
+    _capi.check(write(os.fsencode(filename), header.encode() if header else None, _capi.ptr(X), C.c_uint64(X.shape[0]), C.c_uint64(X.shape[1]), C.c_uint64(X.shape[1]),
+                      _capi.ptr(ints) if ints is not None else None, text, _capi.ptr(offsets) if offsets is not None else None))
+    return True
+
+
+def write_libsvm_data(filename, X, labels=None, comment: str | None = None, use_native: bool = True) -> None:
+    """Write a (sparse: zeros omitted) LIBSVM file, one-based indices, ``label idx:val idx:val `` with ``{:.10e}`` values and a blank after every token
+    (libsvm_parsing.hpp:254-296).  ``comment`` becomes a leading ``#`` line (the reference writes a time stamp and the shape there).  The rows are
+    formatted by the library's multi-threaded writer (csrc/model_io.hpp); the loop below writes the same bytes and is what is left without the library."""
+    X = np.ascontiguousarray(X)
+    if labels is not None and len(labels) != X.shape[0]:
+        raise InvalidFileFormatError(f"Number of data points ({X.shape[0]}) and number of labels ({len(labels)}) mismatch!")
+    header = f"# {comment}\n" if comment is not None else ""
+    if use_native and _write_native(filename, header, X, labels):
+        return
     with open(filename, "w") as f:
-        if comment is not None:
-            f.write(f"# {comment}\n")
+        f.write(header)
         for i in range(X.shape[0]):
-            parts = []
-            if labels is not None:
-                lab = labels[i]
-                parts.append(str(int(lab)) if isinstance(lab, (int, np.integer)) or float(lab).is_integer() else repr(float(lab)))
-            for j in range(X.shape[1]):
-                v = X[i, j]
-                if v != 0:
-                    parts.append(f"{j + 1}:{float(v):.10e}")
-            f.write(" ".join(parts) + "\n")
+            label = _label_text(labels[i]) + " " if labels is not None else ""
+            f.write(label + "".join(f"{j + 1}:{float(v):.10e} " for j, v in enumerate(X[i]) if v != 0) + "\n")

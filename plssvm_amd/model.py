@@ -26,6 +26,67 @@ def _fmt_label(lab):
     return str(int(f)) if f.is_integer() else repr(f)
 
 
+def _capi_or_none():
+    try:
+        from . import _capi
+    except (ImportError, OSError):
+        return None
+    return _capi
+
+
+def _save_native(filename, header, X, alpha, order) -> bool:
+    capi = _capi_or_none()
+    if capi is None or X.dtype not in (np.dtype(np.float32), np.dtype(np.float64)) or not X.flags.c_contiguous:
+        return False
+    import ctypes as C
+    import os
+
+    write = capi.lib.lssvm_mi355_model_write_f32 if X.dtype == np.float32 else capi.lib.lssvm_mi355_model_write_f64
+    capi.check(write(os.fsencode(filename), header.encode(), capi.ptr(X), C.c_uint64(X.shape[0]), C.c_uint64(X.shape[1]), C.c_uint64(X.shape[1]),
+                     capi.ptr(alpha), capi.ptr(order), C.c_uint64(order.size)))
+    return True
+
+
+def _load_native(filename, dtype, label_type):
+    """``(params, X, per_sv_labels, alpha, rho)`` from the library's reader, or None where it declines (the Python parser then decides)."""
+    capi = _capi_or_none()
+    if capi is None or dtype not in (np.dtype(np.float32), np.dtype(np.float64)) or label_type not in (float, int, str):
+        return None
+    import ctypes as C
+    import os
+
+    lib = capi.lib
+    handle, info = C.c_void_p(), capi.LssvmModelInfo()
+    if lib.lssvm_mi355_model_open(os.fsencode(filename), C.byref(handle), C.byref(info)) != 0:
+        return None
+    try:
+        text = C.create_string_buffer(int(info.label_text_bytes))
+        nr_sv = (C.c_uint64 * int(info.nr_class))()
+        if lib.lssvm_mi355_model_labels(handle, text, C.c_uint64(info.label_text_bytes), nr_sv) != 0:
+            return None
+        toks = text.value.decode("ascii").split(" ")
+        try:
+            labels = toks if label_type is str else [label_type(float(t)) for t in toks]
+        except (ValueError, OverflowError):
+            return None
+        if len(set(labels)) != len(labels):  # duplicates AFTER the conversion ("1" and "1.0"): the parser below words the error
+            return None
+        X = np.empty((int(info.total_sv), int(info.num_features)), dtype=dtype)
+        alpha = np.empty(int(info.total_sv), dtype=dtype)
+        fill = lib.lssvm_mi355_model_fill_f32 if dtype == np.float32 else lib.lssvm_mi355_model_fill_f64
+        if fill(handle, capi.ptr(X), C.c_uint64(X.shape[1]), capi.ptr(alpha)) != 0:
+            return None
+    finally:
+        lib.lssvm_mi355_model_close(handle)
+    try:
+        params = Parameter(kernel_type=KernelFunctionType(int(info.kernel_type)), degree=int(info.degree) if info.has_degree else 3,
+                           gamma=float(info.gamma) if info.has_gamma else None, coef0=float(info.coef0) if info.has_coef0 else 0.0)
+    except Exception:
+        return None
+    per_sv_labels = [lab for lab, cnt in zip(labels, list(nr_sv)) for _ in range(int(cnt))]
+    return params, X, per_sv_labels, alpha, float(info.rho)
+
+
 class Model:
     def __init__(self, params: Parameter, data: DataSet, alpha=None, rho=0.0):
         self.params = params
@@ -57,30 +118,51 @@ class Model:
         return self.alpha
 
     # ------------------------------------------------------------------ save
-    def save(self, filename) -> None:
+    def header_text(self) -> str:
+        """The lines from the time stamp to ``SV`` (libsvm_model_parsing.hpp:296-342, :381)."""
         p = self.params
-        X = self.data.data()
         labels = self.data.labels()
         order = self.data.different_labels()
-        counts = [sum(1 for lab in labels if lab == o) for o in order]
+        lab = np.asarray(labels)
+        counts = [int(np.count_nonzero(lab == o)) for o in order]
+        text = f"# This model file has been created at {datetime.datetime.now():%Y-%m-%d %H:%M:%S}\nsvm_type c_svc\nkernel_type {p.kernel_type}\n"
+        if p.kernel_type == KernelFunctionType.POLYNOMIAL:
+            text += f"degree {p.degree}\ngamma {p.gamma!r}\ncoef0 {p.coef0!r}\n"
+        elif p.kernel_type == KernelFunctionType.RBF:
+            text += f"gamma {p.gamma!r}\n"
+        text += (f"nr_class 2\nlabel {' '.join(_fmt_label(o) for o in order)}\ntotal_sv {self.data.num_data_points()}\n"
+                 f"nr_sv {' '.join(str(c) for c in counts)}\nrho {float(self.rho)!r}\nSV\n")
+        return text
+
+    def class_order(self) -> np.ndarray:
+        """Row indices grouped by class in the order of the ``label`` line, ascending inside a class (libsvm_model_parsing.hpp:416-499)."""
+        lab = np.asarray(self.data.labels())
+        return np.concatenate([np.flatnonzero(lab == o) for o in self.data.different_labels()]).astype(np.uint64)
+
+    def save(self, filename, use_native: bool = True) -> None:
+        """write_libsvm_model_data (libsvm_model_parsing.hpp:371-499).  The body is formatted by the library's multi-threaded writer
+        (csrc/model_io.hpp, ``lssvm_mi355_model_write_*``); the Python loop below writes the same bytes and is what is left when the library is not built."""
+        header, order = self.header_text(), self.class_order()
+        X = self.data.data()
+        alpha = np.ascontiguousarray(self.alpha, dtype=X.dtype)
+        if use_native and _save_native(filename, header, X, alpha, order):
+            return
         with open(filename, "w") as f:
-            f.write(f"# This model file has been created at {datetime.datetime.now():%Y-%m-%d %H:%M:%S}\n")
-            f.write(f"svm_type c_svc\nkernel_type {p.kernel_type}\n")
-            if p.kernel_type == KernelFunctionType.POLYNOMIAL:
-                f.write(f"degree {p.degree}\ngamma {p.gamma!r}\ncoef0 {p.coef0!r}\n")
-            elif p.kernel_type == KernelFunctionType.RBF:
-                f.write(f"gamma {p.gamma!r}\n")
-            f.write(f"nr_class 2\nlabel {' '.join(_fmt_label(o) for o in order)}\ntotal_sv {X.shape[0]}\n"
-                    f"nr_sv {' '.join(str(c) for c in counts)}\nrho {float(self.rho)!r}\nSV\n")
-            for o in order:
-                for i in range(X.shape[0]):
-                    if labels[i] == o:
-                        feats = " ".join(f"{j + 1}:{float(v):.10e}" for j, v in enumerate(X[i]) if v != 0)
-                        f.write(f"{float(self.alpha[i]):.10e} {feats} \n")
+            f.write(header)
+            for i in order.tolist():
+                f.write(f"{float(alpha[i]):.10e} " + "".join(f"{j + 1}:{float(v):.10e} " for j, v in enumerate(X[i]) if v != 0) + "\n")
 
     # ------------------------------------------------------------------ load
     @classmethod
-    def load(cls, filename, real_type=np.float64, label_type=float) -> "Model":
+    def load(cls, filename, real_type=np.float64, label_type=float, use_native: bool = True) -> "Model":
+        """parse_libsvm_model_header + the support vectors (libsvm_model_parsing.hpp:64-262, model.hpp:170-200).  Well-formed files are read by the
+        library's multi-threaded reader (``lssvm_mi355_model_open / _fill / _close``); whatever that declines is parsed -- and, where it is wrong, reported
+        in the reference's words -- by the code below."""
+        if use_native:
+            fast = _load_native(filename, np.dtype(real_type), label_type)
+            if fast is not None:
+                params, X, per_sv_labels, alphas, rho = fast
+                return cls(params, DataSet(X, per_sv_labels, real_type=real_type), alpha=alphas, rho=rho)
         lines = read_lines(filename)
         kernel = degree = gamma = coef0 = None
         svm_type_set = False

@@ -152,7 +152,7 @@ def test_generated_code_of_the_shipped_library_passes_the_audit():
     assert int(last.split()[0]) >= 40, last  # the hand-scheduled instantiations were found at all
 
 
-@pytest.mark.parametrize("exe_name, args", [("test_reader_sanitized", []), ("test_arff_reader_sanitized", []), ("test_csvm_sanitized", ["--no-gpu"])])
+@pytest.mark.parametrize("exe_name, args", [("test_reader_sanitized", []), ("test_arff_reader_sanitized", []), ("test_model_io_sanitized", []), ("test_csvm_sanitized", ["--no-gpu"])])
 def test_host_side_under_address_and_undefined_behaviour_sanitizers(exe_name, args):
     """CPU build only (GPU sanitizers are not available on this pool): the native LIBSVM reader on the shapes of the reference's
     invalid fixtures, every truncation and single-byte corruption of a valid file, overflowing indices, CR / CRLF, NUL bytes ... and the host side of
