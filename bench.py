@@ -50,7 +50,7 @@ PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6, "bf16": 16 * 157.3}  # dense M
 # the sources that decide how many bytes the tile kernel moves: profiles/hbm_traffic.json carries their hash, a stale entry is dropped
 TRAFFIC_SOURCES = ["plssvm_amd/csrc/lssvm_tile_f32_split.hip.hpp", "plssvm_amd/csrc/lssvm_tile_f32_pair.hip.hpp", "plssvm_amd/csrc/lssvm_s6w_groups.inc", "plssvm_amd/csrc/lssvm_tile_f32.hip.hpp",
                    "plssvm_amd/csrc/lssvm_tile_f32_wide.hip.hpp", "plssvm_amd/csrc/lssvm_tile_f64.hip.hpp", "plssvm_amd/csrc/lssvm_tile_f64_wide.hip.hpp", "plssvm_amd/csrc/lssvm_device_common.hip.hpp",
-                   "plssvm_amd/csrc/lssvm_kernels.hip.hpp", "plssvm_amd/csrc/lssvm_problem.hip", "plssvm_amd/csrc/lssvm_problem.hip.hpp", "plssvm_amd/csrc/lssvm_types.hpp",
+                   "plssvm_amd/csrc/lssvm_kernels.hip.hpp", "plssvm_amd/csrc/lssvm_problem.hip", "plssvm_amd/csrc/lssvm_solver.hip", "plssvm_amd/csrc/lssvm_exchange.hip", "plssvm_amd/csrc/lssvm_problem.hip.hpp", "plssvm_amd/csrc/lssvm_types.hpp",
                    "plssvm_amd/csrc/tile_launch_f32.hip", "plssvm_amd/csrc/tile_launch_f32h.hip", "plssvm_amd/csrc/tile_launch_f32s.hip", "plssvm_amd/csrc/tile_launch_f32d.hip",
                    "plssvm_amd/csrc/tile_launch_f32x.hip", "plssvm_amd/csrc/tile_launch_f64.hip", "plssvm_amd/csrc/tile_launch_f64x.hip"]  # (the launch and split sources belong here too)
 
@@ -226,11 +226,87 @@ def short_leg(name, steps, warmup, seed, device):
     pp = plane_products_of(gram_mode)
     peak = PEAK_TFLOPS["bf16"] if gram_mode != 0 else PEAK_TFLOPS[wl["dtype"]]
     kern_s = kern_ms * 1e-3
-    return {"workload": wl["desc"], "steps": done, "warmup": warmup, "ms_per_step": elapsed / max(done, 1) * 1e3, "value": 2.0 * n * n * d * done / elapsed / 1e9, "unit": "GFLOP/s",
+    return {"workload": wl["desc"], "steps": done, "warmup": warmup, "setup_ms": float(i1.get("setup_ms", 0.0)), "ms_per_step": elapsed / max(done, 1) * 1e3, "value": 2.0 * n * n * d * done / elapsed / 1e9, "unit": "GFLOP/s",
             "avg_launch_ms": kern_ms, "launches": launches, "launches_timed": timed, "tile_launches_per_matvec": int(i1.get("tile_launches_per_matvec", 1)),
             "frac": (2.0 * use_mac * d * pp / kern_s / 1e12 / peak) if kern_ms > 0 else None,
             "executed_frac": (2.0 * exe_mac * d * pp / kern_s / 1e12 / peak) if kern_ms > 0 else None, "peak": peak,
             "gram_mode": {0: "native", 1: "bf16x6", 2: "f16x3", 3: "f16 grid planes"}[gram_mode], "dtype": "f32" if wl["dtype"] == "float32" else "f64", "symmetric": symmetric}
+
+
+def predict_leg(seed, device, num_sv=50_000, num_points=200_000, d=128, calls=3):
+    """other_workloads.predict (VERDICT r05 item 2): csvm::predict_values (include/plssvm/csvm.hpp:204-208; GPU recipe gpu_csvm.hpp:656-730,
+    HIP/predict_kernel.hip.hpp:63-117) on `num_points` points against `num_sv` support vectors, rbf fp32 -- a RECTANGULAR instance of the tile kernel -- and the linear
+    kernel through w.  The entry point is one-shot like the reference's (it uploads both point sets and prepares them on every call), so the line carries two rates:
+    `kernel` (HIP events around the product kernel alone; `frac` prices it like the solve's tile kernel: 2 * num_sv * num_points * d multiply-adds-as-flop x plane
+    products over the 16-bit matrix-core peak) and `call` (host wall clock of the whole call from host buffers: PCIe and set-up included)."""
+    import numpy as np
+
+    from plssvm_amd import backend
+    from plssvm_amd.datagen import make_blobs_pm1
+    from plssvm_amd.parameter import Parameter
+
+    X, _ = make_blobs_pm1(num_sv + num_points, d, seed=seed + 1, dtype=np.float32)
+    sv, pts = np.ascontiguousarray(X[:num_sv]), np.ascontiguousarray(X[num_sv:])
+    alpha = np.random.default_rng(seed).standard_normal(num_sv).astype(np.float32)
+    out = {"workload": f"predict_values: {num_points} points x {num_sv} support vectors x {d} features, fp32", "calls": calls}
+    for kernel in ("rbf", "linear"):
+        prm = Parameter(kernel_type=kernel, gamma=None, cost=1.0)
+        infos, w = [], None
+        for k in range(calls + 1):  # the first call is the warm-up (code-object load, first allocations)
+            info = {}
+            t0 = time.perf_counter()
+            values, w = backend.predict_values(prm, sv, alpha, 0.25, w, pts, info_out=info)
+            info["wall_ms"] = (time.perf_counter() - t0) * 1e3
+            if k > 0:
+                infos.append(info)
+        kern_ms = sum(i["kernel_ms"] for i in infos) / len(infos)
+        call_ms = sum(i["total_ms"] for i in infos) / len(infos)
+        leg = {"kernel_ms": kern_ms, "call_ms": call_ms, "setup_ms": sum(i["setup_ms"] for i in infos) / len(infos), "points_per_s_call": num_points / (call_ms * 1e-3),
+               "finite": bool(np.all(np.isfinite(values)))}
+        if kernel == "rbf":
+            gm = int(infos[-1]["gram_mode"])
+            pp = plane_products_of(gm)
+            peak = PEAK_TFLOPS["bf16"] if gm != 0 else PEAK_TFLOPS["float32"]
+            flop = 2.0 * num_sv * num_points * d
+            leg.update({"gram_mode": {0: "native", 1: "bf16x6", 2: "f16x3", 3: "f16 grid planes"}[gm], "bound": "mfma", "peak": peak, "algorithmic_flop_per_launch": flop * pp,
+                        "achieved": flop * pp / (kern_ms * 1e-3) / 1e12, "frac": flop * pp / (kern_ms * 1e-3) / 1e12 / peak, "avg_launch_ms": kern_ms,
+                        "value": flop / (call_ms * 1e-3) / 1e9, "value_kernel_only": flop / (kern_ms * 1e-3) / 1e9, "unit": "GFLOP/s (2 * num_sv * num_points * d per call)",
+                        "f16_row_rel_error": infos[-1]["f16_row_rel_error"]})
+        else:
+            # w.x per point: one pass over the points, HBM bound -- algorithmic bytes = the points once + the outputs
+            nbytes = float(num_points) * d * 4 + num_points * 4
+            leg.update({"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "achieved": nbytes / (kern_ms * 1e-3) / 1e9, "frac": nbytes / (kern_ms * 1e-3) / 1e9 / 8000.0,
+                        "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": nbytes, "note": "w (calculate_w) is computed by the first call and handed back to the later ones"})
+        out[kernel] = leg
+    return out
+
+
+def e2e_leg(seed, workdir=None):
+    """The reference's tracker reports the file -> model wall clock beside cg/total_runtime (main_train.cpp:24-70, csvm.cpp:167-176): `python -m plssvm_amd.train` on a
+    configs[1]-shaped LIBSVM file (50 000 x 128, rbf, fp32, eps 1e-3 -- the reference's default), then `python -m plssvm_amd.predict` of the same file with the model --
+    run in this process through the command lines' own entry points, phases from plssvm_amd.cli.LAST_TIMINGS."""
+    import tempfile
+
+    from plssvm_amd import cli
+    from plssvm_amd.datagen import generate_libsvm_file
+
+    out = {}
+    with tempfile.TemporaryDirectory(dir=workdir) as tmp:
+        data_file, model_file, pred_file = os.path.join(tmp, "c2.libsvm"), os.path.join(tmp, "c2.libsvm.model"), os.path.join(tmp, "c2.libsvm.predict")
+        t0 = time.perf_counter()
+        generate_libsvm_file(data_file, 50_000, 128, seed=seed)
+        out["generate_and_write_data_s"] = time.perf_counter() - t0
+        out["data_bytes"] = os.path.getsize(data_file)
+        rc = cli.train_main(["-t", "2", "--use_float_as_real_type", "-e", "0.001", "-q", data_file, model_file])
+        if rc != 0:
+            return {"error": f"plssvm_amd.train returned {rc}"}
+        out["train"] = {k: v for k, v in cli.LAST_TIMINGS.items() if k != "task"}
+        rc = cli.predict_main(["--use_float_as_real_type", "-q", data_file, model_file, pred_file])
+        if rc != 0:
+            return {"error": f"plssvm_amd.predict returned {rc}"}
+        out["predict"] = {k: v for k, v in cli.LAST_TIMINGS.items() if k != "task"}
+    out["command"] = "python -m plssvm_amd.train -t 2 --use_float_as_real_type -e 0.001 c2.libsvm ; python -m plssvm_amd.predict --use_float_as_real_type c2.libsvm c2.libsvm.model"
+    return out
 
 
 def free_port() -> int:
@@ -561,6 +637,12 @@ def main():
     n = N - 1
     flop_step = 2.0 * n * n * d
     value = flop_step * steps_done / elapsed / 1e9
+    # every rank's tile-kernel time per matvec (rank order): on a real node the spread of the devices' pace, beside rank 0's figure that prices the roofline
+    kernel_ms_per_rank = None
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, float(kernel_ms_between(i0, i1)[2]))
+        kernel_ms_per_rank = gathered
 
     # roofline of the dominant kernel (the tile kernel of the implicit matvec), from HIP events on the solver stream(s); a process
     # that drives several shards reports the slowest shard's average launch
@@ -616,6 +698,7 @@ def main():
             else f"effective K*d GFLOP/s of the CG iteration, {wl['kernel']} {wl['dtype']}",
             "value": value, "unit": "GFLOP/s", "cg_iters_per_s": steps_done / elapsed,
             "n_gpus": n_gpus, "steps": steps_done, "warmup": args.warmup, "ms_per_step": elapsed / max(steps_done, 1) * 1e3,
+            "setup_ms": float(i1.get("setup_ms", 0.0)),  # upload of the data matrix + q, norms, operand planes, work-item lists (outside the timed region; lssvm_cg_info.setup_ms)
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if wl["dtype"] == "float32" else "f64", "data": "synthetic",
             "arithmetic": {1: "fp32 operands split exactly into 3 bf16 planes, 6 plane products per multiply-add accumulated in fp32 on the bf16 matrix cores",
@@ -624,7 +707,7 @@ def main():
                            3: "rbf with a large exponent scale: fp32 operands as 3 f16 planes (a grid plane + 2 rest planes), 6 plane products per multiply-add accumulated in fp32 "
                               "on the f16 matrix cores, the grid-plane products first so that the large terms cancel exactly"}.get(gram_mode, "native " + wl["dtype"] + " matrix-core fma chains"),
             "config": {"workload": wl["desc"], "num_points": N, "num_features": d, "kernel": wl["kernel"], "gamma": 1.0 / d, "cost": 1.0,
-                       "seed": args.seed, "library_options": args.option, "parallelism": parallelism, "shards": shards, "exchange": exchange_names.get(int(i1.get("exchange", 0)), "?"),
+                       "seed": args.seed, "library_options": args.option, "parallelism": parallelism, "shards": shards, "ranks": world, "exchange": exchange_names.get(int(i1.get("exchange", 0)), "?"),
                        "residuum_after_timed_steps": i1["residuum"], "residuum_bit_equal_on_all_ranks": ranks_agree,
                        # what RCCL itself reports for the communicator the partial vectors travelled over (ncclCommCount / ncclCommCuDevice on rank 0), and the
                        # file its entry points were resolved from -- null / 0 when no RCCL exchange ran
@@ -640,7 +723,7 @@ def main():
                                  "traffic_frac_of_hbm_peak": (traffic / kern_s / 1e12 / 8.0) if (traffic is not None and kern_ms > 0) else None},
                          "board_power": board_power,
                          "kernel": "lssvm::tile_matvec (implicit K*d tile kernel)", "launches": launches, "launches_timed": timed, "avg_launch_ms": kern_ms,
-                         "tile_launches_per_matvec": bands,
+                         "kernel_ms_per_rank": kernel_ms_per_rank, "tile_launches_per_matvec": bands,
                          "launch_note": "a 'launch' here is ONE implicit matvec = the sum of its row-block band launches of the tile kernel (rocprofv3 lists the bands one by one); "
                                         "where a matvec is short (< 1 ms by the library's shape rule) the HIP events bracket every 8th matvec only (never the first after cg_begin) -- avg_launch_ms is the summed time of the launches_timed bracketed matvecs over their count",
                          "algorithmic_flop_per_launch": useful_launch * plane_products, "symmetric": symmetric,
@@ -708,7 +791,15 @@ def main():
                     legs[name] = short_leg(name, k, w, args.seed, local_rank)
                 except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
                     legs[name] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                legs["predict"] = predict_leg(args.seed, local_rank)
+            except Exception as e:  # noqa: BLE001
+                legs["predict"] = {"error": f"{type(e).__name__}: {e}"}
             out["other_workloads"] = legs
+            try:
+                out["e2e"] = e2e_leg(args.seed)
+            except Exception as e:  # noqa: BLE001
+                out["e2e"] = {"error": f"{type(e).__name__}: {e}"}
         # the CPU legs come LAST: the OpenMP runtime's workers keep spinning after a parallel region and would slow the host side of
         # the GPU legs down (measured: 16 ms instead of 2.6 ms per c2 iteration in a native leg that followed them)
         if not args.no_cpu_baseline and shards == 1:

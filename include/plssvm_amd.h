@@ -28,8 +28,11 @@
 extern "C" {
 #endif
 
-#define PLSSVM_AMD_ABI_VERSION 3 /* 2: multi-device entry points (_multi), lssvm_cg_info grew local_devices / exchange; 3: lssvm_cg_info grew matvec_timed /
-                                  * matvec_kernel_ms_total / rccl_nranks / rccl_rank / rccl_device / persistent_launches */
+#define PLSSVM_AMD_ABI_VERSION 4 /* 2: multi-device entry points (_multi), lssvm_cg_info grew local_devices / exchange; 3: lssvm_cg_info grew matvec_timed /
+                                  * matvec_kernel_ms_total / rccl_nranks / rccl_rank / rccl_device / persistent_launches; 4: PER-CALL OPTIONS -- every entry point
+                                  * that creates a problem takes a trailing `const lssvm_mi355_options *` (NULL = the process defaults), predict_values reports
+                                  * lssvm_predict_info, lssvm_cg_info grew f16_row_rel_error, model / data file writers and the model reader, the shard-weight
+                                  * entry points moved to plssvm_amd_testing.h (experimental) */
 
 typedef enum lssvm_status {
     LSSVM_SUCCESS = 0,
@@ -91,7 +94,20 @@ typedef struct lssvm_cg_info {
     int32_t rccl_device;     /* exchange == 1: ncclCommCuDevice of that communicator; else -1 */
     int32_t persistent_launches; /* of tile_launches_per_matvec, the launches that are PERSISTENT: one workgroup per CU, the work items drawn from per-XCD counters instead of one
                                   * workgroup per item dealt by the hardware (256-row workgroups, launches of more items than CUs) */
+    double f16_row_rel_error; /* fp32, gram_mode 2 / 3: what the set-up MEASURED on this data -- the largest relative error (2-norm) of a row represented as two f16 planes;
+                               * mode 3 takes "f16x3" up to 2^-22 (rbf: or an absolute bound on the exponent), else "bf16x6".  -1 where the check did not run, NaN for a plane that overflows */
 } lssvm_cg_info;
+
+/* What a predict_values call reports (the reference tracks the whole call, gpu_csvm.hpp:656-730). */
+typedef struct lssvm_predict_info {
+    double total_ms;   /* host wall clock of the call: uploads, data preparation, the product, the read-back */
+    double setup_ms;   /* ... of which before the product kernel was enqueued (uploads of both point sets, centring, norms, operand planes) */
+    double kernel_ms;  /* device time of the kernel that evaluates the product (HIP events): the rectangular tile kernel, or w.x for the linear kernel */
+    double rbf_exponent_scale; /* as lssvm_cg_info */
+    double f16_row_rel_error;  /* as lssvm_cg_info, over support vectors and points */
+    int32_t gram_mode;         /* as lssvm_cg_info */
+    int32_t rbf_direct;        /* as lssvm_cg_info */
+} lssvm_predict_info;
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* library / device queries                                                                                           */
@@ -104,6 +120,20 @@ int lssvm_mi355_device_name(int device, char *buf, size_t buf_len);
 const char *lssvm_mi355_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------------------------ */
+/* options of ONE caller (ABI 4)                                                                                       */
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* The tuning knobs listed at the end of this header, held by the caller instead of the process: a plssvm::csvm object is a move-only object whose const
+ * virtuals share no state with other objects beyond `verbosity` (include/plssvm/csvm.hpp:50-83) -- two backend objects with different settings must be able to
+ * solve at the same time from two threads.  `create` copies the process-wide defaults of that moment (lssvm_mi355_set_option / LSSVM_MI355_OPTIONS); `set` / `get`
+ * take the names and ranges of lssvm_mi355_set_option.  Every entry point below that creates a problem takes a trailing `const lssvm_mi355_options *`:
+ * NULL = a snapshot of the process defaults (the behaviour of ABI 3); the object is read during the call only and may be changed or destroyed afterwards. */
+typedef struct lssvm_mi355_options lssvm_mi355_options; /* opaque */
+int lssvm_mi355_options_create(lssvm_mi355_options **out);
+int lssvm_mi355_options_set(lssvm_mi355_options *options, const char *name, int64_t value);
+int lssvm_mi355_options_get(const lssvm_mi355_options *options, const char *name, int64_t *value_out);
+int lssvm_mi355_options_destroy(lssvm_mi355_options *options);
+
+/* ------------------------------------------------------------------------------------------------------------------ */
 /* one-shot entry points: exactly what plssvm::csvm's pure virtuals need (include/plssvm/csvm.hpp:188-208)           */
 /* ------------------------------------------------------------------------------------------------------------------ */
 
@@ -111,9 +141,9 @@ const char *lssvm_mi355_last_error(void);
  * X: N x d row-major, y: N labels (+-1), alpha_out: N entries (alpha[N-1] = -sum(alpha[0..N-1))), rho_out = -bias.
  * Runs on device 0 of the calling process.  info may be NULL. */
 int lssvm_mi355_solve_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, const float *y,
-                          float eps, uint64_t max_iter, float *alpha_out, float *rho_out, lssvm_cg_info *info);
+                          float eps, uint64_t max_iter, float *alpha_out, float *rho_out, lssvm_cg_info *info, const lssvm_mi355_options *options);
 int lssvm_mi355_solve_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, const double *y,
-                          double eps, uint64_t max_iter, double *alpha_out, double *rho_out, lssvm_cg_info *info);
+                          double eps, uint64_t max_iter, double *alpha_out, double *rho_out, lssvm_cg_info *info, const lssvm_mi355_options *options);
 
 /* The same solve on SEVERAL devices of the calling process -- what a plssvm::csvm backend needs, since the reference drives all
  * its devices from one process behind csvm::fit (gpu_csvm.hpp:283-299 device split, :574-593 per-device launches, :449-475
@@ -126,20 +156,22 @@ int lssvm_mi355_solve_f64(const lssvm_params *params, const double *X, size_t nu
  *   exercised on a single-GPU machine. */
 int lssvm_mi355_solve_multi_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, const float *y,
                                 float eps, uint64_t max_iter, float *alpha_out, float *rho_out, lssvm_cg_info *info,
-                                const int *devices, int num_devices);
+                                const int *devices, int num_devices, const lssvm_mi355_options *options);
 int lssvm_mi355_solve_multi_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, const double *y,
                                 double eps, uint64_t max_iter, double *alpha_out, double *rho_out, lssvm_cg_info *info,
-                                const int *devices, int num_devices);
+                                const int *devices, int num_devices, const lssvm_mi355_options *options);
 
 /* csvm::predict_values (csvm.hpp:204, :208; recipe: backends/OpenMP/csvm.cpp:188-227, HIP/predict_kernel.hip.hpp:34-117).
  * w_inout has num_features entries; *w_valid != 0 on entry means it already holds w (linear kernel only), on exit it is
- * set to 1 when w was computed (calculate_w, csvm.cpp:255-280).  out: num_predict_points decision values. */
+ * set to 1 when w was computed (calculate_w, csvm.cpp:255-280).  out: num_predict_points decision values.  info (may be NULL): the timings of the call. */
 int lssvm_mi355_predict_values_f32(const lssvm_params *params, const float *support_vectors, size_t num_support_vectors,
                                    size_t num_features, const float *alpha, float rho, float *w_inout, int *w_valid,
-                                   const float *predict_points, size_t num_predict_points, float *out);
+                                   const float *predict_points, size_t num_predict_points, float *out, lssvm_predict_info *info,
+                                   const lssvm_mi355_options *options);
 int lssvm_mi355_predict_values_f64(const lssvm_params *params, const double *support_vectors, size_t num_support_vectors,
                                    size_t num_features, const double *alpha, double rho, double *w_inout, int *w_valid,
-                                   const double *predict_points, size_t num_predict_points, double *out);
+                                   const double *predict_points, size_t num_predict_points, double *out, lssvm_predict_info *info,
+                                   const lssvm_mi355_options *options);
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* fine-grained entry points for kernel-level parity tests: the protected members the reference's backend tests re-export  */
@@ -147,15 +179,15 @@ int lssvm_mi355_predict_values_f64(const lssvm_params *params, const double *sup
 /* ------------------------------------------------------------------------------------------------------------------ */
 
 /* gpu_csvm::generate_q (gpu_csvm.hpp:349-384) / openmp generate_q (csvm.cpp:232-251): q_out has N-1 entries */
-int lssvm_mi355_generate_q_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, float *q_out);
-int lssvm_mi355_generate_q_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, double *q_out);
+int lssvm_mi355_generate_q_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, float *q_out, const lssvm_mi355_options *options);
+int lssvm_mi355_generate_q_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, double *q_out, const lssvm_mi355_options *options);
 
 /* run_device_kernel (gpu_csvm.hpp:431-447 / csvm.cpp:283-306): ret[0..N-1) += add * Abar * d with
  * Abar_ij = k(x_i,x_j) + delta_ij / C + QA_cost - q_i - q_j; add must be +1 or -1 (svm_kernel.cpp:28). */
 int lssvm_mi355_run_device_kernel_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features,
-                                      const float *q, const float *d, float *ret_inout, float QA_cost, float add);
+                                      const float *q, const float *d, float *ret_inout, float QA_cost, float add, const lssvm_mi355_options *options);
 int lssvm_mi355_run_device_kernel_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features,
-                                      const double *q, const double *d, double *ret_inout, double QA_cost, double add);
+                                      const double *q, const double *d, double *ret_inout, double QA_cost, double add, const lssvm_mi355_options *options);
 
 /* calculate_w (gpu_csvm.hpp:386-429 / csvm.cpp:255-280): w[f] = sum_i alpha_i * sv[i][f] */
 int lssvm_mi355_calculate_w_f32(const float *support_vectors, size_t num_support_vectors, size_t num_features, const float *alpha, float *w_out);
@@ -189,19 +221,6 @@ typedef struct lssvm_shard {
  * dealt by equal AREA (boundary r = round(blocks * sqrt(r / world))); else equal contiguous runs.  The partition every
  * Problem uses (plssvm_amd/sharding.py restates it for the flop accounting of bench.py). */
 int lssvm_mi355_shard_blocks(size_t num_points, int world, int rank, int symmetric, int64_t *block_begin, int64_t *block_end);
-/* Devices of unequal pace (the MI355X boxes of one pool run the same kernel in 252 ... 277 ms): rank r of a sharded SYMMETRIC problem gets weights[r] / sum of the triangle's area
- * instead of 1 / world -- a process-wide default like the options below, snapshotted when a problem is created, applied when `count` equals the problem's world (any other
- * length, or count = 0: equal shares).  EVERY rank of a sharded solve must set the same weights (the partition is computed locally by every rank); the data is replicated on
- * every device, so a new partition costs a new problem, no data exchange.  bench.py --balance-shares measures the ranks' pace and sets them.  No counterpart in the reference
- * (its multi-device split is by features, gpu_csvm.hpp:283-299). */
-int lssvm_mi355_set_shard_weights(const double *weights, int count);
-/* The same for a LIVE problem, between two lssvm_mi355_cg_step calls: the shards' row blocks, work items and slabs are rebuilt for new shares; the data, the vectors and the
- * CG state stay (the implicit matrix does not change, only who evaluates which tiles).  weights == NULL, count == 0: shares by MEASURED pace -- every shard's tile-kernel time
- * per matvec so far against the area of its share; one process driving all devices knows them, one process per GPU gathers them over the library's RCCL communicator (every rank
- * must make the call; not over HIP IPC: explicit weights there, the same on every rank).  *changed_out = 0 where the times lie within 2 % of each other or the problem is not
- * sharded / not symmetric.  A solve that wants it: cg_begin, a few cg_step, problem_rebalance, the remaining cg_step. */
-int lssvm_mi355_problem_rebalance(lssvm_mi355_problem *p, const double *weights, int count, int *changed_out);
-
 /* RCCL bootstrap: rank 0 obtains a 128-byte unique id and hands it to the other ranks out of band
  * (bench.py / the Python launcher broadcast it with torch.distributed); every rank then calls comm_init.
  * One communicator per process.  Replaces the reference's host-staged device_reduction (gpu_csvm.hpp:449-475). */
@@ -225,11 +244,11 @@ int lssvm_mi355_problem_ipc_connect(lssvm_mi355_problem *p, const void *blobs, s
 
 /* upload X (N x d row-major, dtype per `dtype`), compute q, QA_cost and the per-row norms on `device`. */
 int lssvm_mi355_problem_create(lssvm_mi355_problem **out, const lssvm_params *params, int dtype, const void *X, int mem_kind,
-                               size_t num_points, size_t num_features, int device, const lssvm_shard *shard /* NULL = single GPU */);
+                               size_t num_points, size_t num_features, int device, const lssvm_shard *shard /* NULL = single GPU */, const lssvm_mi355_options *options);
 /* the same on several devices of this process (see lssvm_mi355_solve_multi_*); mem_kind LSSVM_MEM_DEVICE: X may live on any of them.
  * Every lssvm_mi355_problem_* / lssvm_mi355_cg_* call below accepts the handle. */
 int lssvm_mi355_problem_create_multi(lssvm_mi355_problem **out, const lssvm_params *params, int dtype, const void *X, int mem_kind,
-                                     size_t num_points, size_t num_features, const int *devices, int num_devices);
+                                     size_t num_points, size_t num_features, const int *devices, int num_devices, const lssvm_mi355_options *options);
 int lssvm_mi355_problem_destroy(lssvm_mi355_problem *p);
 
 /* read back q (N-1 entries, dtype of the problem) and QA_cost */
@@ -326,10 +345,10 @@ int lssvm_mi355_arff_fill_f32(lssvm_mi355_arff_file *file, float *X, uint64_t ld
 int lssvm_mi355_arff_fill_f64(lssvm_mi355_arff_file *file, double *X, uint64_t ldx, double *labels);
 int lssvm_mi355_arff_close(lssvm_mi355_arff_file *file);
 
-/* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT).  set_option changes the process-wide DEFAULTS;
- * every problem / solve takes a snapshot of them when it is created, so later changes never affect a live problem.  The defaults can
- * be preset from the environment: LSSVM_MI355_OPTIONS="name=value,name=value" (read once when the library is loaded).  Fourteen options here, two
- * testing aids in plssvm_amd_testing.h -- who sets each besides the tests: DESIGN.md section 4.5 (round 4 retired xcd_map, lds_extra_kb, item_order,
+/* tuning knobs, by name (all have defaults; unknown names -> LSSVM_ERR_INVALID_ARGUMENT).  set_option changes the process-wide DEFAULTS (thread safe);
+ * every problem / solve that is not handed a lssvm_mi355_options of its own takes a snapshot of them when it is created, so later changes never affect a live problem.  The defaults can
+ * be preset from the environment: LSSVM_MI355_OPTIONS="name=value,name=value" (read once when the library is loaded).  Thirteen options here, two
+ * testing aids and one experimental option in plssvm_amd_testing.h -- who sets each besides the tests: DESIGN.md section 4.5 (round 4 retired xcd_map, lds_extra_kb, item_order,
  * linear_panel_features, check_shards, rbf_direct_above and mfma_shape = 1: measured, decided, constants now):
  *   "rbf_form"      fp32 rbf: 0 = automatic (default): the norm expansion c_i + c_j + x_i'.x_j' on the matrix cores, unless
  *                   R2 = 2 gamma log2(e) max|x - mean|^2 exceeds 32 -- the expansion's exponent carries an absolute error of
@@ -381,8 +400,6 @@ int lssvm_mi355_arff_close(lssvm_mi355_arff_file *file);
  *                   the NEXT matvec are enqueued before the host reads the stop test of the current iteration, so the device never waits for
  *                   the host; they touch d and K*d only, so a converged solve ends exactly where the reference's does, one matvec is discarded.
  *                   0 = the host reads every stop test before it enqueues anything further
- *   "rebalance_after" lssvm_mi355_solve_multi_*: after this many CG iterations the shards get new shares of the triangle by their measured pace
- *                   (lssvm_mi355_problem_rebalance with weights = NULL); 0 (default) = never -- devices are taken to run at one pace
  */
 int lssvm_mi355_set_option(const char *name, int64_t value);
 int lssvm_mi355_get_option(const char *name, int64_t *value_out);

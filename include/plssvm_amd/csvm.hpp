@@ -350,6 +350,23 @@ class csvm : public ::plssvm_amd::csvm {
     }
     [[nodiscard]] int get_num_devices() const noexcept { return use_devices_; }
 
+    /* A tuning knob of THIS backend object (names and ranges: lssvm_mi355_set_option in plssvm_amd.h).  The object holds its own lssvm_mi355_options (ABI 4), created by
+     * the first call from the process defaults of that moment; nothing process-wide is touched, so two csvm objects with different settings can solve at the same time
+     * from two threads -- like the reference's backend objects, which share no state beyond `verbosity` (csvm.hpp:50-83). */
+    void set_option(const char *name, long long value) {
+        if (!options_) {
+            lssvm_mi355_options *o = nullptr;
+            detail::check(lssvm_mi355_options_create(&o));
+            options_.reset(o);
+        }
+        detail::check(lssvm_mi355_options_set(options_.get(), name, static_cast<int64_t>(value)));
+    }
+    [[nodiscard]] long long get_option(const char *name) const {
+        int64_t v = 0;
+        detail::check(options_ ? lssvm_mi355_options_get(options_.get(), name, &v) : lssvm_mi355_get_option(name, &v));
+        return static_cast<long long>(v);
+    }
+
     /* the tracking entries of the last solve in the layout of the reference's performance tracker (performance_tracker.cpp:139-190):
      * one YAML document with the groups `backend` (csvm.hip.cpp:59-60) and `cg` (csvm.cpp:167-174, csvm.hpp:318-320) */
     void write_tracking_yaml(std::ostream &out) const {
@@ -412,7 +429,7 @@ class csvm : public ::plssvm_amd::csvm {
         T rho{};
         // all devices of this process behind ONE call, like gpu_csvm::solve_system_of_linear_equations_impl (gpu_csvm.hpp:477-654)
         lssvm_cg_info info{};
-        detail::check(fn(&p, flat.data(), A.size(), A.front().size(), b.data(), eps, static_cast<uint64_t>(max_iter), alpha.data(), &rho, &info, nullptr, use_devices_));
+        detail::check(fn(&p, flat.data(), A.size(), A.front().size(), b.data(), eps, static_cast<uint64_t>(max_iter), alpha.data(), &rho, &info, nullptr, use_devices_, options_.get()));
         {
             const std::lock_guard<std::mutex> lock(info_mutex_);
             info_ = info;
@@ -442,11 +459,15 @@ class csvm : public ::plssvm_amd::csvm {
         int w_valid = w.empty() ? 0 : 1;
         std::vector<T> w_buf = w.empty() ? std::vector<T>(d) : w;
         std::vector<T> out(predict_points.size());
-        detail::check(fn(&p, sv.data(), support_vectors.size(), d, alpha.data(), rho, w_buf.data(), &w_valid, pts.data(), predict_points.size(), out.data()));
+        detail::check(fn(&p, sv.data(), support_vectors.size(), d, alpha.data(), rho, w_buf.data(), &w_valid, pts.data(), predict_points.size(), out.data(), nullptr, options_.get()));
         if (params.kernel_type == kernel_function_type::linear && w_valid != 0) w = std::move(w_buf);  // csvm.cpp:204-207: w is filled for the linear kernel only
         return out;
     }
 
+    struct options_deleter {
+        void operator()(lssvm_mi355_options *o) const noexcept { (void) lssvm_mi355_options_destroy(o); }
+    };
+    std::unique_ptr<lssvm_mi355_options, options_deleter> options_{};  // this object's own tuning knobs; empty = the process defaults (move-only, like the object)
     int num_devices_{ 0 };  // visible devices
     int use_devices_{ 1 };  // devices per solve: 1 by default (several devices are opt-in: plssvm_amd::num_devices = k, 0 = every visible device)
     mutable std::mutex info_mutex_;

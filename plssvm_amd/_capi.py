@@ -28,6 +28,7 @@ STATUS_NAMES = {0: "LSSVM_SUCCESS", -1: "LSSVM_ERR_INVALID_ARGUMENT", -2: "LSSVM
 # every symbol include/plssvm_amd.h declares (tests/test_capi_symbols.py checks the built library against this list AND the header)
 EXPORTED_SYMBOLS = [
     "lssvm_mi355_abi_version", "lssvm_mi355_device_count", "lssvm_mi355_device_name", "lssvm_mi355_last_error",
+    "lssvm_mi355_options_create", "lssvm_mi355_options_set", "lssvm_mi355_options_get", "lssvm_mi355_options_destroy",
     "lssvm_mi355_solve_f32", "lssvm_mi355_solve_f64", "lssvm_mi355_solve_multi_f32", "lssvm_mi355_solve_multi_f64", "lssvm_mi355_predict_values_f32", "lssvm_mi355_predict_values_f64",
     "lssvm_mi355_generate_q_f32", "lssvm_mi355_generate_q_f64", "lssvm_mi355_run_device_kernel_f32", "lssvm_mi355_run_device_kernel_f64",
     "lssvm_mi355_calculate_w_f32", "lssvm_mi355_calculate_w_f64",
@@ -52,7 +53,17 @@ class LssvmCgInfo(C.Structure):
                 ("target_residuum", C.c_double), ("epsilon", C.c_double), ("avg_iteration_ms", C.c_double), ("total_ms", C.c_double),
                 ("setup_ms", C.c_double), ("matvec_kernel_ms", C.c_double), ("matvec_launches", C.c_uint64), ("devices_used", C.c_int32),
                 ("converged", C.c_int32), ("symmetric", C.c_int32), ("gram_mode", C.c_int32), ("local_devices", C.c_int32), ("exchange", C.c_int32), ("tile_launches_per_matvec", C.c_int32), ("rbf_direct", C.c_int32), ("rbf_exponent_scale", C.c_double),
-                ("matvec_timed", C.c_uint64), ("matvec_kernel_ms_total", C.c_double), ("rccl_nranks", C.c_int32), ("rccl_rank", C.c_int32), ("rccl_device", C.c_int32), ("persistent_launches", C.c_int32)]
+                ("matvec_timed", C.c_uint64), ("matvec_kernel_ms_total", C.c_double), ("rccl_nranks", C.c_int32), ("rccl_rank", C.c_int32), ("rccl_device", C.c_int32), ("persistent_launches", C.c_int32),
+                ("f16_row_rel_error", C.c_double)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class LssvmPredictInfo(C.Structure):
+    """``lssvm_predict_info``: the timings of one ``predict_values`` call."""
+    _fields_ = [("total_ms", C.c_double), ("setup_ms", C.c_double), ("kernel_ms", C.c_double), ("rbf_exponent_scale", C.c_double), ("f16_row_rel_error", C.c_double),
+                ("gram_mode", C.c_int32), ("rbf_direct", C.c_int32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -129,7 +140,7 @@ def device_name(device: int = 0) -> str:
     return buf.value.decode()
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 LSSVM_IPC_BLOB_BYTES = 256
 # every tuning knob of lssvm_mi355_set_option (include/plssvm_amd.h)
 OPTION_NAMES = ["rbf_form", "rbf_fold", "j_chunk_tiles", "j_chunk_head", "symmetric", "tile_kernel", "gram_mode", "mfma_shape", "colslab_band_mb", "colslab_limit_mb", "force_collective", "skip_collective",
@@ -159,6 +170,46 @@ def set_shard_weights(weights=None) -> None:
     w = [float(v) for v in (weights or [])]
     arr = (C.c_double * len(w))(*w) if w else None
     check(lib.lssvm_mi355_set_shard_weights(arr, C.c_int(len(w))))
+
+
+class Options:
+    """``lssvm_mi355_options`` (ABI 4): the tuning knobs held by ONE caller instead of the process -- a private copy of the process defaults of the moment it is
+    created, changed with :meth:`set`, handed to the entry points that create a problem (``options=`` of ``plssvm_amd.backend``)."""
+
+    def __init__(self, **values):
+        self._h = C.c_void_p(None)
+        check(lib.lssvm_mi355_options_create(C.byref(self._h)))
+        for name, value in values.items():
+            self.set(name, value)
+
+    def set(self, name: str, value: int) -> "Options":
+        check(lib.lssvm_mi355_options_set(self._h, name.encode(), C.c_int64(int(value))))
+        return self
+
+    def get(self, name: str) -> int:
+        v = C.c_int64(0)
+        check(lib.lssvm_mi355_options_get(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
+    def close(self):
+        if self._h:
+            lib.lssvm_mi355_options_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def options_ptr(options):
+    """The ``const lssvm_mi355_options *`` argument: NULL (= the process defaults) for None."""
+    if options is None:
+        return None
+    if not isinstance(options, Options):
+        raise InvalidParameterError("options must be a plssvm_amd._capi.Options or None")
+    return options._h
 
 
 def set_option(name: str, value: int) -> None:

@@ -19,11 +19,11 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import LssvmCgInfo, LssvmParams, LssvmShard, check, ctype_of, lib, ptr, suffix_of
+from ._capi import LssvmCgInfo, LssvmParams, LssvmPredictInfo, LssvmShard, Options, check, ctype_of, lib, options_ptr, ptr, suffix_of
 from .exceptions import InvalidParameterError
 from .parameter import Parameter
 
-__all__ = ["solve_system_of_linear_equations", "predict_values", "generate_q", "run_device_kernel", "calculate_w", "ResidentProblem",
+__all__ = ["Options", "solve_system_of_linear_equations", "predict_values", "generate_q", "run_device_kernel", "calculate_w", "ResidentProblem",
            "comm_get_unique_id", "comm_init", "comm_destroy"]
 
 
@@ -42,11 +42,12 @@ def _as_matrix(A, dtype=None) -> np.ndarray:
     return A
 
 
-def solve_system_of_linear_equations(params: Parameter, A, b, eps: float, max_iter: int, devices=None, num_devices: int | None = None):
+def solve_system_of_linear_equations(params: Parameter, A, b, eps: float, max_iter: int, devices=None, num_devices: int | None = None, options: Options | None = None):
     """Returns ``(alpha[N], rho, info)`` -- ``csvm::solve_system_of_linear_equations`` (csvm.hpp:188-192).
 
     ``devices`` (a list of HIP ordinals; the same ordinal may repeat) or ``num_devices`` (0 = every visible device) select the
-    single-process multi-device solve ``lssvm_mi355_solve_multi_*``; with neither the solve runs on device 0."""
+    single-process multi-device solve ``lssvm_mi355_solve_multi_*``; with neither the solve runs on device 0.  ``options``: this call's own tuning knobs
+    (:class:`Options`); None = the process defaults."""
     A = _as_matrix(A)
     N, d = A.shape
     b = np.ascontiguousarray(b, dtype=A.dtype)
@@ -60,7 +61,7 @@ def solve_system_of_linear_equations(params: Parameter, A, b, eps: float, max_it
     if devices is None and num_devices is None:
         fn = getattr(lib, f"lssvm_mi355_solve_{suffix_of(A.dtype)}")
         fn.restype = C.c_int
-        check(fn(C.byref(ps), ptr(A), C.c_size_t(N), C.c_size_t(d), ptr(b), ct(eps), C.c_uint64(int(max_iter)), ptr(alpha), C.byref(rho), C.byref(info)))
+        check(fn(C.byref(ps), ptr(A), C.c_size_t(N), C.c_size_t(d), ptr(b), ct(eps), C.c_uint64(int(max_iter)), ptr(alpha), C.byref(rho), C.byref(info), options_ptr(options)))
     else:
         fn = getattr(lib, f"lssvm_mi355_solve_multi_{suffix_of(A.dtype)}")
         fn.restype = C.c_int
@@ -68,22 +69,22 @@ def solve_system_of_linear_equations(params: Parameter, A, b, eps: float, max_it
         if devices is None:
             ndev = int(num_devices)
         check(fn(C.byref(ps), ptr(A), C.c_size_t(N), C.c_size_t(d), ptr(b), ct(eps), C.c_uint64(int(max_iter)), ptr(alpha), C.byref(rho), C.byref(info),
-                 dev_arr, C.c_int(ndev)))
+                 dev_arr, C.c_int(ndev), options_ptr(options)))
     return alpha, A.dtype.type(rho.value), info.as_dict()
 
 
-def generate_q(params: Parameter, data):
+def generate_q(params: Parameter, data, options: Options | None = None):
     data = _as_matrix(data)
     N, d = data.shape
     q = np.zeros(N - 1, dtype=data.dtype)
     fn = getattr(lib, f"lssvm_mi355_generate_q_{suffix_of(data.dtype)}")
     fn.restype = C.c_int
     ps = _params_struct(params, d)
-    check(fn(C.byref(ps), ptr(data), C.c_size_t(N), C.c_size_t(d), ptr(q)))
+    check(fn(C.byref(ps), ptr(data), C.c_size_t(N), C.c_size_t(d), ptr(q), options_ptr(options)))
     return q
 
 
-def run_device_kernel(params: Parameter, q, ret, d, data, QA_cost: float, add: float):
+def run_device_kernel(params: Parameter, q, ret, d, data, QA_cost: float, add: float, options: Options | None = None):
     """``ret += add * Abar * d``; returns the updated copy of ``ret`` (gpu_csvm.hpp:431-447)."""
     data = _as_matrix(data)
     N, nf = data.shape
@@ -96,7 +97,7 @@ def run_device_kernel(params: Parameter, q, ret, d, data, QA_cost: float, add: f
     fn = getattr(lib, f"lssvm_mi355_run_device_kernel_{suffix_of(data.dtype)}")
     fn.restype = C.c_int
     ps = _params_struct(params, nf)
-    check(fn(C.byref(ps), ptr(data), C.c_size_t(N), C.c_size_t(nf), ptr(q), ptr(d), ptr(out), ct(QA_cost), ct(add)))
+    check(fn(C.byref(ps), ptr(data), C.c_size_t(N), C.c_size_t(nf), ptr(q), ptr(d), ptr(out), ct(QA_cost), ct(add), options_ptr(options)))
     return out
 
 
@@ -112,8 +113,9 @@ def calculate_w(support_vectors, alpha):
     return w
 
 
-def predict_values(params: Parameter, support_vectors, alpha, rho: float, w, predict_points):
-    """Returns ``(values[num_points], w)``; ``w`` is None for the polynomial / rbf kernels (csvm.hpp:204-208)."""
+def predict_values(params: Parameter, support_vectors, alpha, rho: float, w, predict_points, options: Options | None = None, info_out: dict | None = None):
+    """Returns ``(values[num_points], w)``; ``w`` is None for the polynomial / rbf kernels (csvm.hpp:204-208).  ``info_out``: a dict that receives the call's
+    ``lssvm_predict_info`` (timings, the Gram mode that ran)."""
     sv = _as_matrix(support_vectors)
     pts = _as_matrix(predict_points, dtype=sv.dtype)
     alpha = np.ascontiguousarray(alpha, dtype=sv.dtype)
@@ -131,7 +133,10 @@ def predict_values(params: Parameter, support_vectors, alpha, rho: float, w, pre
     fn = getattr(lib, f"lssvm_mi355_predict_values_{suffix_of(sv.dtype)}")
     fn.restype = C.c_int
     ps = _params_struct(params, nf)
-    check(fn(C.byref(ps), ptr(sv), C.c_size_t(nsv), C.c_size_t(nf), ptr(alpha), ct(rho), ptr(w_buf), C.byref(w_valid), ptr(pts), C.c_size_t(pts.shape[0]), ptr(out)))
+    pinfo = LssvmPredictInfo()
+    check(fn(C.byref(ps), ptr(sv), C.c_size_t(nsv), C.c_size_t(nf), ptr(alpha), ct(rho), ptr(w_buf), C.byref(w_valid), ptr(pts), C.c_size_t(pts.shape[0]), ptr(out), C.byref(pinfo), options_ptr(options)))
+    if info_out is not None:
+        info_out.update(pinfo.as_dict())
     return out, (w_buf if w_valid.value else None)
 
 
@@ -166,7 +171,7 @@ class ResidentProblem:
     """A data matrix resident in HBM plus the CG state on it (``lssvm_mi355_problem_*`` / ``lssvm_mi355_cg_*``)."""
 
     def __init__(self, params: Parameter, X, device: int = 0, rank: int = 0, world: int = 1, device_ptr: int | None = None, shape=None, dtype=None,
-                 devices=None):
+                 devices=None, options: Options | None = None):
         """``devices``: a list of HIP ordinals -> ONE process drives all of them (``lssvm_mi355_problem_create_multi``; an empty list = every
         visible device); otherwise ``device`` holds rank ``rank`` of a world of processes (one process per GPU, or a single GPU)."""
         self._h = C.c_void_p(None)
@@ -192,12 +197,12 @@ class ResidentProblem:
             dev_arr, ndev = _capi.int_array(list(devices) or None)
             lib.lssvm_mi355_problem_create_multi.restype = C.c_int
             check(lib.lssvm_mi355_problem_create_multi(C.byref(self._h), C.byref(ps), C.c_int(_capi.dtype_code(self.dtype)), src, C.c_int(kind), C.c_size_t(N),
-                                                       C.c_size_t(d), dev_arr, C.c_int(ndev)))
+                                                       C.c_size_t(d), dev_arr, C.c_int(ndev), options_ptr(options)))
         else:
             shard = LssvmShard(rank, world)
             lib.lssvm_mi355_problem_create.restype = C.c_int
             check(lib.lssvm_mi355_problem_create(C.byref(self._h), C.byref(ps), C.c_int(_capi.dtype_code(self.dtype)), src, C.c_int(kind), C.c_size_t(N), C.c_size_t(d),
-                                                 C.c_int(device), C.byref(shard)))
+                                                 C.c_int(device), C.byref(shard), options_ptr(options)))
         self._keep = None  # the library copied the data
 
     def close(self):

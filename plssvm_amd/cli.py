@@ -24,6 +24,10 @@ from .parameter import Parameter
 
 VERBOSITY = ("full", "timing", "libsvm", "quiet")
 
+# the phases of the last train_main / predict_main call of this process, in seconds: what the reference's tracker records as data_set_read / cg / model_write times
+# (main_train.cpp:24-70); bench.py prints them as its `e2e` block
+LAST_TIMINGS: dict = {}
+
 
 def _common(ap):
     ap.add_argument("-b", "--backend", default="automatic", help="choose the backend: automatic|mi355|hip (the reference's other backends are not built here)")
@@ -83,7 +87,9 @@ def train_main(argv=None) -> int:
         params = Parameter(kernel_type=args.kernel_type, degree=args.degree, gamma=args.gamma, coef0=args.coef0, cost=args.cost)
         _log(verb, ("full",), f"\ntask: training\nkernel_type: {params.kernel_type}\ncost: {params.cost}\nepsilon: {args.epsilon}\n"
                               f"real_type: {np.dtype(real_type).name}\ninput file (data set): '{args.input}'\noutput file (model): '{model_file}'\n")
+        t_r = time.perf_counter()
         data = DataSet(filename=args.input, real_type=real_type, label_type=str if args.use_strings_as_labels else float)
+        t_r = time.perf_counter() - t_r
         _log(verb, ("full", "timing"), f"Read {data.num_data_points()} data points with {data.num_features()} features using the libsvm parser from file '{args.input}'.")
         svm = make_csvm(args.backend, TargetPlatform(args.target_platform), params)
         _log(verb, ("full",), f"\nUsing MI355 as backend.\nFound {svm.num_devices} HIP device(s).\n")
@@ -97,6 +103,10 @@ def train_main(argv=None) -> int:
         model.save(model_file)
         t_w = time.perf_counter() - t_w
         _log(verb, ("full", "timing"), f"Write {model.num_support_vectors()} support vectors with {model.num_features()} features to the libsvm model file '{model_file}'.")
+        LAST_TIMINGS.clear()
+        LAST_TIMINGS.update({"task": "train", "read_s": t_r, "setup_ms": float(info.get("setup_ms", 0.0)), "solve_s": float(info.get("total_ms", 0.0)) * 1e-3,
+                             "fit_s": float(info["total_runtime_ms"]) * 1e-3, "write_s": t_w, "total_s": time.perf_counter() - t0, "iterations": int(info["iterations"]),
+                             "num_data_points": data.num_data_points(), "num_features": data.num_features(), "model_bytes": os.path.getsize(model_file)})
         if args.performance_tracking is not None:
             from .performance_tracker import PerformanceTracker
 
@@ -107,6 +117,7 @@ def train_main(argv=None) -> int:
             tr.add("data_set_read", "num_data_points", data.num_data_points())
             tr.add("data_set_read", "num_features", data.num_features())
             tr.add("data_set_read", "filename", args.input)
+            tr.add("data_set_read", "time", f"{t_r * 1e3:.0f}ms")
             tr.add("model_write", "num_support_vectors", model.num_support_vectors())
             tr.add("model_write", "rho", float(model.rho))  # model.hpp:221
             tr.add("model_write", "filename", model_file)
@@ -142,12 +153,23 @@ def predict_main(argv=None) -> int:
         t0 = time.perf_counter()
         real_type = np.float32 if args.use_float_as_real_type else np.float64
         label_type = str if args.use_strings_as_labels else float
+        t_r = time.perf_counter()
         data = DataSet(filename=args.test, real_type=real_type, label_type=label_type) if _has_two_labels(args.test, label_type) else _unlabeled(args.test, real_type, label_type)
+        t_r = time.perf_counter() - t_r
+        t_m = time.perf_counter()
         model = Model.load(args.model, real_type=real_type, label_type=label_type)
+        t_m = time.perf_counter() - t_m
         svm = make_csvm(args.backend, TargetPlatform(args.target_platform))
+        t_p = time.perf_counter()
         predicted = svm.predict(model, data)
+        t_p = time.perf_counter() - t_p
+        t_w = time.perf_counter()
         with open(out_file, "w") as f:
             f.write("\n".join(_fmt(p) for p in predicted))
+        t_w = time.perf_counter() - t_w
+        LAST_TIMINGS.clear()
+        LAST_TIMINGS.update({"task": "predict", "read_s": t_r, "model_read_s": t_m, "predict_s": t_p, "write_s": t_w, "num_data_points": data.num_data_points(),
+                             "num_support_vectors": model.num_support_vectors()})
         _log(verb, ("full", "timing"), f"Write {len(predicted)} predictions to the file '{out_file}'.")
         if data.has_labels():
             correct = sum(1 for p, c in zip(predicted, data.labels()) if p == c)

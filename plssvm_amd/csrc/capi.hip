@@ -10,9 +10,133 @@
 #include <memory>
 #include <new>
 
+/* the options of one caller (ABI 4): a private copy of the tuning knobs */
+struct lssvm_mi355_options {
+    lssvm::Options o;
+};
+
 namespace {
 
 using lssvm::guarded;
+
+/* the options by name: ONE rule book for the process defaults (lssvm_mi355_set_option) and for a caller's own object (lssvm_mi355_options_set) */
+void set_option_in(lssvm::Options &o, const char *name, int64_t value) {
+    const std::string n(name);
+    if (n == "rbf_form") {
+        LSSVM_REQUIRE(value >= 0 && value <= 3, "rbf_form must be 0 (automatic), 1 (direct), 2 (matrix cores, norm expansion) or 3 (matrix cores, grid planes)");
+        o.rbf_form = value;
+    } else if (n == "rbf_fold") {
+        o.rbf_fold = value != 0 ? 1 : 0;
+    } else if (n == "j_chunk_tiles") {
+        LSSVM_REQUIRE(value >= 0 && value <= (1 << 20), "j_chunk_tiles out of range");
+        o.j_chunk_tiles = value;
+    } else if (n == "j_chunk_head") {
+        LSSVM_REQUIRE(value >= 0 && value < (1 << 20), "j_chunk_head out of range (1024 count + tiles)");
+        o.j_chunk_head = value;
+    } else if (n == "symmetric") {
+        o.symmetric = value != 0 ? 1 : 0;
+    } else if (n == "tile_kernel") {
+        LSSVM_REQUIRE(value == 0 || value == 1, "tile_kernel must be 0 (automatic) or 1 (generic kernel)");
+        o.tile_kernel = value;
+    } else if (n == "debug_ablate") {
+#ifdef LSSVM_ENABLE_ABLATION
+        o.debug_ablate = value;
+#else
+        LSSVM_REQUIRE(value == 0, "debug_ablate exists in builds with -DLSSVM_ENABLE_ABLATION only");
+#endif
+    } else if (n == "force_collective") {
+        o.force_collective = value != 0 ? 1 : 0;
+    } else if (n == "gram_mode") {
+        LSSVM_REQUIRE(value >= 0 && value <= 3, "gram_mode must be 0 (v_mfma_f32), 1 (bf16x6), 2 (f16x3 unchecked) or 3 (f16x3 where the data allows, else bf16x6)");
+        o.gram_mode = value;
+    } else if (n == "mfma_shape") {
+        LSSVM_REQUIRE(value == 2 || value == 3, "mfma_shape must be 2 (128-row workgroups) or 3 (256-row workgroups in the symmetric variant where they apply)");
+        o.mfma_shape = value;
+    } else if (n == "item_order_dev") {
+#ifdef LSSVM_DEV_SUBSET
+        LSSVM_REQUIRE(value >= 0 && value <= 7, "item_order_dev must be 0 ... 7");
+        o.item_order_dev = value;
+#else
+        LSSVM_REQUIRE(value == 0, "item_order_dev exists in development builds (make DEV=1) only");
+#endif
+    } else if (n == "pair_lag") {
+#ifdef LSSVM_DEV_SUBSET
+        LSSVM_REQUIRE(value >= 0 && value <= 7 && value != 2, "pair_lag must be 0, 1, 3 (steps of lag) or 4 ... 7 (priority experiments)");
+        o.pair_lag = value;
+#else
+        LSSVM_REQUIRE(value == 0, "pair_lag exists in development builds (make DEV=1) only");
+#endif
+    } else if (n == "colslab_band_mb") {
+        LSSVM_REQUIRE(value >= 1, "colslab_band_mb must be positive");
+        o.colslab_band_mb = value;
+    } else if (n == "colslab_limit_mb") {
+        LSSVM_REQUIRE(value >= 0, "colslab_limit_mb must not be negative");
+        o.colslab_limit_mb = value;
+    } else if (n == "skip_collective") {
+        o.skip_collective = value != 0 ? 1 : 0;
+    } else if (n == "exchange") {
+        LSSVM_REQUIRE(value >= 0 && value <= 2, "exchange must be 0 (automatic), 1 (RCCL) or 2 (peer kernels)");
+        o.exchange = value;
+    } else if (n == "ipc_timeout_s") {
+        LSSVM_REQUIRE(value >= 1, "ipc_timeout_s must be at least 1");
+        o.ipc_timeout_s = value;
+    } else if (n == "enqueue_ahead_below_us") {
+        LSSVM_REQUIRE(value >= 0, "enqueue_ahead_below_us must not be negative");
+        o.enqueue_ahead_below_us = value;
+    } else if (n == "rebalance_after") {
+        LSSVM_REQUIRE(value >= 0, "rebalance_after must not be negative");
+        o.rebalance_after = value;
+    } else {
+        throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "unknown option '" + n + "'");
+    }
+}
+void get_option_from(const lssvm::Options &o, const char *name, int64_t *value_out) {
+    const std::string n(name);
+    if (n == "rbf_form") {
+        *value_out = o.rbf_form;
+    } else if (n == "rbf_fold") {
+        *value_out = o.rbf_fold;
+    } else if (n == "j_chunk_tiles") {
+        *value_out = o.j_chunk_tiles;
+    } else if (n == "j_chunk_head") {
+        *value_out = o.j_chunk_head;
+    } else if (n == "symmetric") {
+        *value_out = o.symmetric;
+    } else if (n == "tile_kernel") {
+        *value_out = o.tile_kernel;
+    } else if (n == "debug_ablate") {
+        *value_out = o.debug_ablate;
+    } else if (n == "force_collective") {
+        *value_out = o.force_collective;
+    } else if (n == "gram_mode") {
+        *value_out = o.gram_mode;
+    } else if (n == "mfma_shape") {
+        *value_out = o.mfma_shape;
+    } else if (n == "item_order_dev") {
+        *value_out = o.item_order_dev;
+    } else if (n == "pair_lag") {
+        *value_out = o.pair_lag;
+    } else if (n == "colslab_band_mb") {
+        *value_out = o.colslab_band_mb;
+    } else if (n == "colslab_limit_mb") {
+        *value_out = o.colslab_limit_mb;
+    } else if (n == "skip_collective") {
+        *value_out = o.skip_collective;
+    } else if (n == "exchange") {
+        *value_out = o.exchange;
+    } else if (n == "ipc_timeout_s") {
+        *value_out = o.ipc_timeout_s;
+    } else if (n == "enqueue_ahead_below_us") {
+        *value_out = o.enqueue_ahead_below_us;
+    } else if (n == "rebalance_after") {
+        *value_out = o.rebalance_after;
+    } else {
+        throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "unknown option '" + n + "'");
+    }
+}
+
+/* the options a call runs with: the caller's object, or a snapshot of the process defaults */
+lssvm::Options options_of(const lssvm_mi355_options *options) { return options != nullptr ? options->o : lssvm::options_snapshot(); }
 
 struct Handle {
     std::unique_ptr<lssvm::ProblemBase> impl;
@@ -25,7 +149,7 @@ lssvm::ProblemBase *impl_of(lssvm_mi355_problem *p) {
 
 template <typename T>
 void solve_one_shot(const lssvm_params *params, const T *X, size_t N, size_t d, const T *y, T eps, uint64_t max_iter, T *alpha_out, T *rho_out, lssvm_cg_info *info,
-                    const int *devices, int num_devices) {
+                    const int *devices, int num_devices, const lssvm_mi355_options *options) {
     lssvm::check_params(params);
     LSSVM_REQUIRE(X != nullptr && N > 0, "The data must not be empty!");                                                                  // csvm.cpp:73
     LSSVM_REQUIRE(d > 0, "The data points must contain at least one feature!");                                                           // csvm.cpp:74
@@ -33,10 +157,11 @@ void solve_one_shot(const lssvm_params *params, const T *X, size_t N, size_t d, 
     LSSVM_REQUIRE(eps > T(0), "The stopping criterion in the CG algorithm must be greater than 0.0, but is " + std::to_string(eps) + "!");  // csvm.cpp:77
     LSSVM_REQUIRE(max_iter > 0, "The number of CG iterations must be greater than 0!");                                                   // csvm.cpp:78
     LSSVM_REQUIRE(alpha_out != nullptr && rho_out != nullptr, "alpha_out / rho_out must not be NULL");
-    lssvm::Solver<T> prob(*params, X, LSSVM_MEM_HOST, N, d, lssvm::resolve_devices(devices, num_devices, N), nullptr);
+    const lssvm::Options opt = options_of(options);
+    lssvm::Solver<T> prob(opt, *params, X, LSSVM_MEM_HOST, N, d, lssvm::resolve_devices(devices, num_devices, N), nullptr);
     prob.cg_begin(y, static_cast<double>(eps));
     // option rebalance_after (several devices, symmetric variant): the first iterations measure every shard's pace, then the shares follow it (lssvm_mi355_problem_rebalance)
-    const uint64_t first = static_cast<uint64_t>(lssvm::options().rebalance_after);
+    const uint64_t first = static_cast<uint64_t>(opt.rebalance_after);
     if (first > 0 && first < max_iter) {
         prob.cg_step(first, nullptr);
         (void) prob.rebalance(nullptr, 0);
@@ -53,10 +178,10 @@ void solve_one_shot(const lssvm_params *params, const T *X, size_t N, size_t d, 
 }
 
 template <typename T>
-void generate_q_one_shot(const lssvm_params *params, const T *X, size_t N, size_t d, T *q_out) {
+void generate_q_one_shot(const lssvm_params *params, const T *X, size_t N, size_t d, T *q_out, const lssvm_mi355_options *options) {
     lssvm::check_params(params);
     LSSVM_REQUIRE(q_out != nullptr, "q_out must not be NULL");
-    lssvm::Solver<T> prob(*params, X, LSSVM_MEM_HOST, N, d, { 0 }, nullptr);
+    lssvm::Solver<T> prob(options_of(options), *params, X, LSSVM_MEM_HOST, N, d, { 0 }, nullptr);
     prob.get_q(q_out, nullptr);
 }
 
@@ -64,7 +189,7 @@ void generate_q_one_shot(const lssvm_params *params, const T *X, size_t N, size_
 
 extern "C" {
 
-static_assert(sizeof(lssvm_cg_info) == 160, "lssvm_cg_info changed: bump PLSSVM_AMD_ABI_VERSION and plssvm_amd/_capi.py (LssvmCgInfo) with it");
+static_assert(sizeof(lssvm_cg_info) == 168, "lssvm_cg_info changed: bump PLSSVM_AMD_ABI_VERSION and plssvm_amd/_capi.py (LssvmCgInfo) with it");
 int lssvm_mi355_abi_version(void) { return PLSSVM_AMD_ABI_VERSION; }
 
 const char *lssvm_mi355_last_error(void) { return lssvm::last_error_message().c_str(); }
@@ -92,63 +217,63 @@ int lssvm_mi355_device_name(int device, char *buf, size_t buf_len) {
 }
 
 int lssvm_mi355_solve_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, const float *y, float eps, uint64_t max_iter,
-                          float *alpha_out, float *rho_out, lssvm_cg_info *info) {
+                          float *alpha_out, float *rho_out, lssvm_cg_info *info, const lssvm_mi355_options *options) {
     static const int device0 = 0;
-    return guarded([&] { solve_one_shot<float>(params, X, num_points, num_features, y, eps, max_iter, alpha_out, rho_out, info, &device0, 1); });
+    return guarded([&] { solve_one_shot<float>(params, X, num_points, num_features, y, eps, max_iter, alpha_out, rho_out, info, &device0, 1, options); });
 }
 int lssvm_mi355_solve_multi_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, const float *y, float eps, uint64_t max_iter,
-                                float *alpha_out, float *rho_out, lssvm_cg_info *info, const int *devices, int num_devices) {
-    return guarded([&] { solve_one_shot<float>(params, X, num_points, num_features, y, eps, max_iter, alpha_out, rho_out, info, devices, num_devices); });
+                                float *alpha_out, float *rho_out, lssvm_cg_info *info, const int *devices, int num_devices, const lssvm_mi355_options *options) {
+    return guarded([&] { solve_one_shot<float>(params, X, num_points, num_features, y, eps, max_iter, alpha_out, rho_out, info, devices, num_devices, options); });
 }
 int lssvm_mi355_solve_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, const double *y, double eps, uint64_t max_iter,
-                          double *alpha_out, double *rho_out, lssvm_cg_info *info) {
+                          double *alpha_out, double *rho_out, lssvm_cg_info *info, const lssvm_mi355_options *options) {
     static const int device0 = 0;
-    return guarded([&] { solve_one_shot<double>(params, X, num_points, num_features, y, eps, max_iter, alpha_out, rho_out, info, &device0, 1); });
+    return guarded([&] { solve_one_shot<double>(params, X, num_points, num_features, y, eps, max_iter, alpha_out, rho_out, info, &device0, 1, options); });
 }
 int lssvm_mi355_solve_multi_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, const double *y, double eps, uint64_t max_iter,
-                                double *alpha_out, double *rho_out, lssvm_cg_info *info, const int *devices, int num_devices) {
-    return guarded([&] { solve_one_shot<double>(params, X, num_points, num_features, y, eps, max_iter, alpha_out, rho_out, info, devices, num_devices); });
+                                double *alpha_out, double *rho_out, lssvm_cg_info *info, const int *devices, int num_devices, const lssvm_mi355_options *options) {
+    return guarded([&] { solve_one_shot<double>(params, X, num_points, num_features, y, eps, max_iter, alpha_out, rho_out, info, devices, num_devices, options); });
 }
 
 int lssvm_mi355_predict_values_f32(const lssvm_params *params, const float *sv, size_t nsv, size_t nfeat, const float *alpha, float rho, float *w_inout,
-                                   int *w_valid, const float *points, size_t npoints, float *out) {
+                                   int *w_valid, const float *points, size_t npoints, float *out, lssvm_predict_info *info, const lssvm_mi355_options *options) {
     return guarded([&] {
         LSSVM_REQUIRE(params != nullptr, "params must not be NULL!");
-        lssvm::predict_values<float>(*params, sv, nsv, nfeat, alpha, rho, w_inout, w_valid, points, npoints, out);
+        lssvm::predict_values<float>(options_of(options), *params, sv, nsv, nfeat, alpha, rho, w_inout, w_valid, points, npoints, out, info);
     });
 }
 int lssvm_mi355_predict_values_f64(const lssvm_params *params, const double *sv, size_t nsv, size_t nfeat, const double *alpha, double rho, double *w_inout,
-                                   int *w_valid, const double *points, size_t npoints, double *out) {
+                                   int *w_valid, const double *points, size_t npoints, double *out, lssvm_predict_info *info, const lssvm_mi355_options *options) {
     return guarded([&] {
         LSSVM_REQUIRE(params != nullptr, "params must not be NULL!");
-        lssvm::predict_values<double>(*params, sv, nsv, nfeat, alpha, rho, w_inout, w_valid, points, npoints, out);
+        lssvm::predict_values<double>(options_of(options), *params, sv, nsv, nfeat, alpha, rho, w_inout, w_valid, points, npoints, out, info);
     });
 }
 
-int lssvm_mi355_generate_q_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, float *q_out) {
-    return guarded([&] { generate_q_one_shot<float>(params, X, num_points, num_features, q_out); });
+int lssvm_mi355_generate_q_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, float *q_out, const lssvm_mi355_options *options) {
+    return guarded([&] { generate_q_one_shot<float>(params, X, num_points, num_features, q_out, options); });
 }
-int lssvm_mi355_generate_q_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, double *q_out) {
-    return guarded([&] { generate_q_one_shot<double>(params, X, num_points, num_features, q_out); });
+int lssvm_mi355_generate_q_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, double *q_out, const lssvm_mi355_options *options) {
+    return guarded([&] { generate_q_one_shot<double>(params, X, num_points, num_features, q_out, options); });
 }
 
 int lssvm_mi355_run_device_kernel_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, const float *q, const float *d,
-                                      float *ret_inout, float QA_cost, float add) {
+                                      float *ret_inout, float QA_cost, float add, const lssvm_mi355_options *options) {
     return guarded([&] {
         lssvm::check_params(params);
         LSSVM_REQUIRE(q != nullptr, "The q array may not be empty!");  // csvm.cpp:284
         (void) QA_cost;  // q and QA_cost are functions of (X, params); they are recomputed on the device and must agree with the caller's
-        lssvm::Solver<float> prob(*params, X, LSSVM_MEM_HOST, num_points, num_features, { 0 }, nullptr);
+        lssvm::Solver<float> prob(options_of(options), *params, X, LSSVM_MEM_HOST, num_points, num_features, { 0 }, nullptr);
         prob.matvec(d, ret_inout, static_cast<double>(add));
     });
 }
 int lssvm_mi355_run_device_kernel_f64(const lssvm_params *params, const double *X, size_t num_points, size_t num_features, const double *q, const double *d,
-                                      double *ret_inout, double QA_cost, double add) {
+                                      double *ret_inout, double QA_cost, double add, const lssvm_mi355_options *options) {
     return guarded([&] {
         lssvm::check_params(params);
         LSSVM_REQUIRE(q != nullptr, "The q array may not be empty!");
         (void) QA_cost;
-        lssvm::Solver<double> prob(*params, X, LSSVM_MEM_HOST, num_points, num_features, { 0 }, nullptr);
+        lssvm::Solver<double> prob(options_of(options), *params, X, LSSVM_MEM_HOST, num_points, num_features, { 0 }, nullptr);
         prob.matvec(d, ret_inout, add);
     });
 }
@@ -166,7 +291,8 @@ int lssvm_mi355_shard_blocks(size_t num_points, int world, int rank, int symmetr
         LSSVM_REQUIRE(num_points >= 2 && num_points < (size_t(1) << 31) - 4 * lssvm::TILE, "invalid number of data points");
         LSSVM_REQUIRE(world >= 1 && rank >= 0 && rank < world, "invalid shard descriptor");
         int b = 0, e = 0;
-        lssvm::shard_blocks(static_cast<int>((num_points - 1 + lssvm::TILE - 1) / lssvm::TILE), world, rank, symmetric != 0, b, e, &lssvm::options().shard_weights);
+        const lssvm::Options opt = lssvm::options_snapshot();
+        lssvm::shard_blocks(static_cast<int>((num_points - 1 + lssvm::TILE - 1) / lssvm::TILE), world, rank, symmetric != 0, b, e, &opt.shard_weights);
         *block_begin = b;
         *block_end = e;
     });
@@ -180,6 +306,7 @@ int lssvm_mi355_set_shard_weights(const double *weights, int count) {
             LSSVM_REQUIRE(std::isfinite(weights[k]) && weights[k] > 0.0, "shard weights must be positive and finite");
             w.push_back(weights[k]);
         }
+        const std::lock_guard<std::mutex> lock(lssvm::options_mutex());
         lssvm::options().shard_weights = w;
     });
 }
@@ -239,7 +366,7 @@ int lssvm_mi355_comm_destroy(void) {
 
 /* ---- resident problem ---- */
 int lssvm_mi355_problem_create(lssvm_mi355_problem **out, const lssvm_params *params, int dtype, const void *X, int mem_kind, size_t num_points,
-                               size_t num_features, int device, const lssvm_shard *shard) {
+                               size_t num_features, int device, const lssvm_shard *shard, const lssvm_mi355_options *options) {
     return guarded([&] {
         LSSVM_REQUIRE(out != nullptr, "out must not be NULL");
         *out = nullptr;
@@ -248,15 +375,15 @@ int lssvm_mi355_problem_create(lssvm_mi355_problem **out, const lssvm_params *pa
         auto h = std::make_unique<Handle>();
         lssvm::select_device_checked(device);
         if (dtype == LSSVM_DTYPE_F32) {
-            h->impl = std::make_unique<lssvm::Solver<float>>(*params, X, mem_kind, num_points, num_features, std::vector<int>{ device }, shard);
+            h->impl = std::make_unique<lssvm::Solver<float>>(options_of(options), *params, X, mem_kind, num_points, num_features, std::vector<int>{ device }, shard);
         } else {
-            h->impl = std::make_unique<lssvm::Solver<double>>(*params, X, mem_kind, num_points, num_features, std::vector<int>{ device }, shard);
+            h->impl = std::make_unique<lssvm::Solver<double>>(options_of(options), *params, X, mem_kind, num_points, num_features, std::vector<int>{ device }, shard);
         }
         *out = reinterpret_cast<lssvm_mi355_problem *>(h.release());
     });
 }
 int lssvm_mi355_problem_create_multi(lssvm_mi355_problem **out, const lssvm_params *params, int dtype, const void *X, int mem_kind, size_t num_points,
-                                     size_t num_features, const int *devices, int num_devices) {
+                                     size_t num_features, const int *devices, int num_devices, const lssvm_mi355_options *options) {
     return guarded([&] {
         LSSVM_REQUIRE(out != nullptr, "out must not be NULL");
         *out = nullptr;
@@ -266,9 +393,9 @@ int lssvm_mi355_problem_create_multi(lssvm_mi355_problem **out, const lssvm_para
         const std::vector<int> devs = lssvm::resolve_devices(devices, num_devices, num_points);
         auto h = std::make_unique<Handle>();
         if (dtype == LSSVM_DTYPE_F32) {
-            h->impl = std::make_unique<lssvm::Solver<float>>(*params, X, mem_kind, num_points, num_features, devs, nullptr);
+            h->impl = std::make_unique<lssvm::Solver<float>>(options_of(options), *params, X, mem_kind, num_points, num_features, devs, nullptr);
         } else {
-            h->impl = std::make_unique<lssvm::Solver<double>>(*params, X, mem_kind, num_points, num_features, devs, nullptr);
+            h->impl = std::make_unique<lssvm::Solver<double>>(options_of(options), *params, X, mem_kind, num_points, num_features, devs, nullptr);
         }
         *out = reinterpret_cast<lssvm_mi355_problem *>(h.release());
     });
@@ -324,122 +451,39 @@ int lssvm_mi355_measure_bf16_mfma_ceiling(int device, int b_from_lds, double set
 int lssvm_mi355_set_option(const char *name, int64_t value) {
     return guarded([&] {
         LSSVM_REQUIRE(name != nullptr, "name must not be NULL");
-        const std::string n(name);
-        if (n == "rbf_form") {
-            LSSVM_REQUIRE(value >= 0 && value <= 3, "rbf_form must be 0 (automatic), 1 (direct), 2 (matrix cores, norm expansion) or 3 (matrix cores, grid planes)");
-            lssvm::options().rbf_form = value;
-        } else if (n == "rbf_fold") {
-            lssvm::options().rbf_fold = value != 0 ? 1 : 0;
-        } else if (n == "j_chunk_tiles") {
-            LSSVM_REQUIRE(value >= 0 && value <= (1 << 20), "j_chunk_tiles out of range");
-            lssvm::options().j_chunk_tiles = value;
-        } else if (n == "j_chunk_head") {
-            LSSVM_REQUIRE(value >= 0 && value < (1 << 20), "j_chunk_head out of range (1024 count + tiles)");
-            lssvm::options().j_chunk_head = value;
-        } else if (n == "symmetric") {
-            lssvm::options().symmetric = value != 0 ? 1 : 0;
-        } else if (n == "tile_kernel") {
-            LSSVM_REQUIRE(value == 0 || value == 1, "tile_kernel must be 0 (automatic) or 1 (generic kernel)");
-            lssvm::options().tile_kernel = value;
-        } else if (n == "debug_ablate") {
-#ifdef LSSVM_ENABLE_ABLATION
-            lssvm::options().debug_ablate = value;
-#else
-            LSSVM_REQUIRE(value == 0, "debug_ablate exists in builds with -DLSSVM_ENABLE_ABLATION only");
-#endif
-        } else if (n == "force_collective") {
-            lssvm::options().force_collective = value != 0 ? 1 : 0;
-        } else if (n == "gram_mode") {
-            LSSVM_REQUIRE(value >= 0 && value <= 3, "gram_mode must be 0 (v_mfma_f32), 1 (bf16x6), 2 (f16x3 unchecked) or 3 (f16x3 where the data allows, else bf16x6)");
-            lssvm::options().gram_mode = value;
-        } else if (n == "mfma_shape") {
-            LSSVM_REQUIRE(value == 2 || value == 3, "mfma_shape must be 2 (128-row workgroups) or 3 (256-row workgroups in the symmetric variant where they apply)");
-            lssvm::options().mfma_shape = value;
-        } else if (n == "item_order_dev") {
-#ifdef LSSVM_DEV_SUBSET
-            LSSVM_REQUIRE(value >= 0 && value <= 7, "item_order_dev must be 0 ... 7");
-            lssvm::options().item_order_dev = value;
-#else
-            LSSVM_REQUIRE(value == 0, "item_order_dev exists in development builds (make DEV=1) only");
-#endif
-        } else if (n == "pair_lag") {
-#ifdef LSSVM_DEV_SUBSET
-            LSSVM_REQUIRE(value >= 0 && value <= 7 && value != 2, "pair_lag must be 0, 1, 3 (steps of lag) or 4 ... 7 (priority experiments)");
-            lssvm::options().pair_lag = value;
-#else
-            LSSVM_REQUIRE(value == 0, "pair_lag exists in development builds (make DEV=1) only");
-#endif
-        } else if (n == "colslab_band_mb") {
-            LSSVM_REQUIRE(value >= 1, "colslab_band_mb must be positive");
-            lssvm::options().colslab_band_mb = value;
-        } else if (n == "colslab_limit_mb") {
-            LSSVM_REQUIRE(value >= 0, "colslab_limit_mb must not be negative");
-            lssvm::options().colslab_limit_mb = value;
-        } else if (n == "skip_collective") {
-            lssvm::options().skip_collective = value != 0 ? 1 : 0;
-        } else if (n == "exchange") {
-            LSSVM_REQUIRE(value >= 0 && value <= 2, "exchange must be 0 (automatic), 1 (RCCL) or 2 (peer kernels)");
-            lssvm::options().exchange = value;
-        } else if (n == "ipc_timeout_s") {
-            LSSVM_REQUIRE(value >= 1, "ipc_timeout_s must be at least 1");
-            lssvm::options().ipc_timeout_s = value;
-        } else if (n == "enqueue_ahead_below_us") {
-            LSSVM_REQUIRE(value >= 0, "enqueue_ahead_below_us must not be negative");
-            lssvm::options().enqueue_ahead_below_us = value;
-        } else if (n == "rebalance_after") {
-            LSSVM_REQUIRE(value >= 0, "rebalance_after must not be negative");
-            lssvm::options().rebalance_after = value;
-        } else {
-            throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "unknown option '" + n + "'");
-        }
+        const std::lock_guard<std::mutex> lock(lssvm::options_mutex());
+        set_option_in(lssvm::options(), name, value);
     });
 }
 int lssvm_mi355_get_option(const char *name, int64_t *value_out) {
     return guarded([&] {
         LSSVM_REQUIRE(name != nullptr && value_out != nullptr, "name / value_out must not be NULL");
-        const std::string n(name);
-        if (n == "rbf_form") {
-            *value_out = lssvm::options().rbf_form;
-        } else if (n == "rbf_fold") {
-            *value_out = lssvm::options().rbf_fold;
-        } else if (n == "j_chunk_tiles") {
-            *value_out = lssvm::options().j_chunk_tiles;
-        } else if (n == "j_chunk_head") {
-            *value_out = lssvm::options().j_chunk_head;
-        } else if (n == "symmetric") {
-            *value_out = lssvm::options().symmetric;
-        } else if (n == "tile_kernel") {
-            *value_out = lssvm::options().tile_kernel;
-        } else if (n == "debug_ablate") {
-            *value_out = lssvm::options().debug_ablate;
-        } else if (n == "force_collective") {
-            *value_out = lssvm::options().force_collective;
-        } else if (n == "gram_mode") {
-            *value_out = lssvm::options().gram_mode;
-        } else if (n == "mfma_shape") {
-            *value_out = lssvm::options().mfma_shape;
-        } else if (n == "item_order_dev") {
-            *value_out = lssvm::options().item_order_dev;
-        } else if (n == "pair_lag") {
-            *value_out = lssvm::options().pair_lag;
-        } else if (n == "colslab_band_mb") {
-            *value_out = lssvm::options().colslab_band_mb;
-        } else if (n == "colslab_limit_mb") {
-            *value_out = lssvm::options().colslab_limit_mb;
-        } else if (n == "skip_collective") {
-            *value_out = lssvm::options().skip_collective;
-        } else if (n == "exchange") {
-            *value_out = lssvm::options().exchange;
-        } else if (n == "ipc_timeout_s") {
-            *value_out = lssvm::options().ipc_timeout_s;
-        } else if (n == "enqueue_ahead_below_us") {
-            *value_out = lssvm::options().enqueue_ahead_below_us;
-        } else if (n == "rebalance_after") {
-            *value_out = lssvm::options().rebalance_after;
-        } else {
-            throw lssvm::Error(LSSVM_ERR_INVALID_ARGUMENT, "unknown option '" + n + "'");
-        }
+        const std::lock_guard<std::mutex> lock(lssvm::options_mutex());
+        get_option_from(lssvm::options(), name, value_out);
     });
+}
+
+/* ---- options of one caller (ABI 4) ---- */
+int lssvm_mi355_options_create(lssvm_mi355_options **out) {
+    return guarded([&] {
+        LSSVM_REQUIRE(out != nullptr, "out must not be NULL");
+        *out = new lssvm_mi355_options{ lssvm::options_snapshot() };
+    });
+}
+int lssvm_mi355_options_set(lssvm_mi355_options *options, const char *name, int64_t value) {
+    return guarded([&] {
+        LSSVM_REQUIRE(options != nullptr && name != nullptr, "options / name must not be NULL");
+        set_option_in(options->o, name, value);
+    });
+}
+int lssvm_mi355_options_get(const lssvm_mi355_options *options, const char *name, int64_t *value_out) {
+    return guarded([&] {
+        LSSVM_REQUIRE(options != nullptr && name != nullptr && value_out != nullptr, "options / name / value_out must not be NULL");
+        get_option_from(options->o, name, value_out);
+    });
+}
+int lssvm_mi355_options_destroy(lssvm_mi355_options *options) {
+    return guarded([&] { delete options; });
 }
 
 /* The process-wide option defaults can be preset from the environment, LSSVM_MI355_OPTIONS="name=value,name=value" (applied once when the

@@ -17,6 +17,9 @@
 
 #include "lssvm_device_common.hip.hpp"
 
+/* The kernels that are not templates are DEFINED by the one translation unit that launches them: lssvm_problem.hip (data set-up, record packing, k_finish2)
+ * defines LSSVM_KERNELS_SETUP before it includes this header, lssvm_solver.hip (k_finish_delta) LSSVM_KERNELS_CG.  The templates are instantiated where they are used. */
+
 namespace lssvm {
 
 
@@ -25,6 +28,7 @@ namespace lssvm {
  * accumulators from c_i alone (as the C operand of the first MFMA) and evaluates K_ij d_j = 2^acc * (2^c_j d_j); used only while
  * |c| <= 100, so neither factor leaves the fp32 range */
 /* folded == 2 (rbf on grid planes, KT_RBFG): dc[jt][0..127] = E_j * d_j, dc[jt][128..255] = cc_j = sigma^2 ch_j (the exact start value); E_j = efac[j] */
+#ifdef LSSVM_KERNELS_SETUP
 __global__ void k_pack_dc(const float *__restrict__ dvec, const float *__restrict__ cc, int ncols_padded, float *__restrict__ dc, int folded, float *__restrict__ zero, int nzero,
                           const float *__restrict__ efac) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -44,12 +48,14 @@ __global__ void k_pack_dc(const float *__restrict__ dvec, const float *__restric
         dc[static_cast<size_t>(jt) * 256 + 128 + l] = c;
     }
 }
+#endif  // LSSVM_KERNELS_SETUP
 
 /* operand planes [nplanes][rows][ldx16] (row-major, rows a multiple of 16, ldx16 of 64) -> the same data with every block of 16 rows x 32 features stored
  * as ONE MFMA A fragment (64 lanes x 8 halfs, lane 16 g + r holding features 8 g .. 8 g + 7 of row r), ordered
  * [plane][ldx16 / 64 chunks][rows / 16 blocks][2 k32 steps][64 lanes][8]: the 64-feature chunk OUTERMOST, so that the sixteen row blocks a workgroup
  * loads for one chunk are 32 KiB contiguous (with the row block outermost they lay a power of two apart whenever ldx16 is one: every wave on the same
  * L2 channels -- 100 000 x 385 measured 16 % slower that way).  One thread per 16-byte piece. */
+#ifdef LSSVM_KERNELS_SETUP
 __global__ void k_planes_fragment_major(const uint16_t *__restrict__ src, size_t plane_elems, int rows, int ldx16, int nplanes, uint16_t *__restrict__ dst) {
     const size_t piece = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const size_t per_plane = static_cast<size_t>(rows) * (ldx16 / 8);
@@ -62,12 +68,14 @@ __global__ void k_planes_fragment_major(const uint16_t *__restrict__ src, size_t
     const f32x4 v = *reinterpret_cast<const f32x4 *>(src + pl * plane_elems + static_cast<size_t>(row) * ldx16 + 8 * f8);
     *reinterpret_cast<f32x4 *>(dst + pl * plane_elems + (static_cast<size_t>(c64) * (rows / 16) + rb) * 1024 + kk * 512 + (16 * g + r) * 8) = v;
 }
+#endif  // LSSVM_KERNELS_SETUP
 
 /* fp64 data [rows][ldx] (row-major, rows a multiple of 16, ldx of 16) -> the same data with every block of 16 rows x 4 features stored as ONE A fragment of
  * v_mfma_f64_16x16x4 (64 lanes, lane 16 q + r = row r, feature q), ordered [ldx / 16 chunks][rows / 16 blocks][4 k-steps][64 lanes]: the 16-feature
  * chunk outermost, so that the eight row blocks a workgroup loads for one chunk are 16 KiB contiguous.  One thread per element.  (The
  * panels-inside-a-sub-tile kernel re-loads its row fragments at every sub-tile and panel -- 22 % of its time, row-major: 32 bytes of each of 16 lines
  * per load instruction.) */
+#ifdef LSSVM_KERNELS_SETUP
 __global__ void k_rows_fragment_major_f64(const double *__restrict__ src, int rows, int ldx, double *__restrict__ dst) {
     const size_t e = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (e >= static_cast<size_t>(rows) * ldx) return;
@@ -75,8 +83,10 @@ __global__ void k_rows_fragment_major_f64(const double *__restrict__ src, int ro
     const int rb = row >> 4, r = row & 15, chunk = f >> 4, s = (f >> 2) & 3, q = f & 3;
     dst[((static_cast<size_t>(chunk) * (rows / 16) + rb) * 4 + s) * 64 + 16 * q + r] = src[e];
 }
+#endif  // LSSVM_KERNELS_SETUP
 
 /* in place: the features of every aligned group of 8 are reordered to 0,2,4,6,1,3,5,7 (fp32 HBM layout, see above) */
+#ifdef LSSVM_KERNELS_SETUP
 __global__ void k_interleave_features(float *__restrict__ X, size_t ngroups) {
     const size_t g = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (g >= ngroups) return;
@@ -85,9 +95,11 @@ __global__ void k_interleave_features(float *__restrict__ X, size_t ngroups) {
     p[0] = f32x4{ lo.x, lo.z, hi.x, hi.z };
     p[1] = f32x4{ lo.y, lo.w, hi.y, hi.w };
 }
+#endif  // LSSVM_KERNELS_SETUP
 
 
 /* fp64 records of the v2 kernel: per 64-column sub-tile st: dc[st][0..63] = d, dc[st][64..127] = c */
+#ifdef LSSVM_KERNELS_SETUP
 __global__ void k_pack_dc_f64(const double *__restrict__ dvec, const double *__restrict__ cc, int ncols_padded, double *__restrict__ dc, double *__restrict__ zero, int nzero) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < nzero) zero[j] = 0.0;
@@ -96,6 +108,7 @@ __global__ void k_pack_dc_f64(const double *__restrict__ dvec, const double *__r
     dc[static_cast<size_t>(st) * 128 + l] = dvec[j];
     dc[static_cast<size_t>(st) * 128 + 64 + l] = (cc != nullptr) ? cc[j] : 0.0;
 }
+#endif  // LSSVM_KERNELS_SETUP
 
 /* =====================================================================================================================
  * O(n) / O(n d) helper kernels
@@ -155,6 +168,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_sum_and_qdot(const T *__restric
 }
 
 /* single block: out[slot0] = sum part[.][0], out[slot1] = sum part[.][1]  (fixed tree order) */
+#ifdef LSSVM_KERNELS_SETUP
 __global__ __launch_bounds__(RED_THREADS) void k_finish2(const double *__restrict__ part, double *__restrict__ sc, int slot0, int slot1) {
     __shared__ double lds[8];
     double acc[2] = { part[threadIdx.x * 2 + 0], part[threadIdx.x * 2 + 1] };
@@ -164,6 +178,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_finish2(const double *__restric
         if (slot1 >= 0) sc[slot1] = acc[1];
     }
 }
+#endif  // LSSVM_KERNELS_SETUP
 
 /* Kv[row_begin + i] = sum over column chunks of partial[c][i], chunks in ascending order (rows of this device only) */
 template <typename T>
@@ -326,6 +341,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_residual(const T *__restrict__ 
 }
 
 /* delta_old = delta ; delta = sum r^2 ; beta = delta / delta_old ; publish delta to the host-mapped word  (csvm.cpp:152-161) */
+#ifdef LSSVM_KERNELS_CG
 __global__ __launch_bounds__(RED_THREADS) void k_finish_delta(const double *__restrict__ part, double *__restrict__ sc, double *__restrict__ host_delta, int is_initial) {
     __shared__ double lds[8];
     double acc[2] = { part[threadIdx.x * 2 + 0], 0.0 };
@@ -343,6 +359,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_finish_delta(const double *__re
         *host_delta = acc[0];
     }
 }
+#endif  // LSSVM_KERNELS_CG
 
 __device__ __forceinline__ void pack_dc_entry(const PackDc<float> &pk, int j, float dj) {  // (the statements of k_pack_dc: the same bits)
     const int jt = j >> 7, l = j & 127;

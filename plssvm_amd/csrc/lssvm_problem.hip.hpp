@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -89,8 +90,19 @@ constexpr int ITEM_ORDER = 3;                 // symmetric variant: the work ite
                                               // workgroups round-robin over the 8 XCDs), the items cut short by the diagonal last, longest first.  Against plain
                                               // column-chunk major order (1): bit-identical results, fabric traffic 116 -> 97 GB per matvec at 1 000 000 x 128, time -0.3 %
                                               // (profiles/r04_ab_xcd_item_order.log)
-/* process-wide DEFAULTS (lssvm_mi355_set_option); every problem takes a snapshot when it is created */
+/* process-wide DEFAULTS (lssvm_mi355_set_option); every problem / solve that is not handed options of its own (lssvm_mi355_options, ABI 4) takes a snapshot when it is
+ * created.  The defaults are read and written under options_mutex() only: options_snapshot() for readers. */
 Options &options();
+std::mutex &options_mutex();
+inline Options options_snapshot() {
+    const std::lock_guard<std::mutex> lock(options_mutex());
+    return options();
+}
+/* fp32 rbf, rbf_form 0 (automatic): the grid planes were chosen from the exponent scale but do not represent THIS data -- the owner of the problem builds it again
+ * with the formula-exact kernel (Solver's constructor, predict_values); with an explicit rbf_form = 3 the error reaches the caller */
+struct GridPlanesUnfit : Error {
+    GridPlanesUnfit() : Error(LSSVM_ERR_INTERNAL, "the grid planes of the rbf kernel do not represent this data (option rbf_form = 1 selects the direct kernel)") {}
+};
 
 /* ------------------------------------------------------------------ RCCL (lazy) ------------------------------------------------------------------ */
 struct Comm {  // the RCCL entry points (dlopen'ed once) + the communicator of a one-process-per-GPU launch
@@ -112,6 +124,8 @@ struct Comm {  // the RCCL entry points (dlopen'ed once) + the communicator of a
 };
 Comm &comm();
 void comm_load();
+void nccl_check(ncclResult_t rc, const char *what);  // throws LSSVM_ERR_COMM with RCCL's own message
+constexpr int MAX_LOCAL_DEVICES = 16;                // shards one process drives / ranks the peer exchange sums
 
 inline double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -249,6 +263,7 @@ void shard_blocks(int num_tiles, int world, int rank, bool symmetric, int &begin
 
 /* fp32: a data matrix once more as operand planes of the split tile kernels (make_planes in lssvm_problem.hip) */
 struct PlaneSet {
+    double f16_row_rel_error = -1.0;  // what the representability check of the f16 planes measured (make_planes), -1 where it did not run
     DevBuf<uint16_t> buf;
     int ldx16 = 0;
     int mode = 0;   // 0 none, 1 bf16x6 (three bf16 planes), 2 f16x3 (two f16 planes)
@@ -337,6 +352,7 @@ class Problem {
     bool dc_folded_ = false;  // the (d_j | c_j) records carry (2^c_j d_j | 2^c_j): rbf on the 16x16x32 bf16x6 kernels
     bool pair_ = false;            // fp32 symmetric variant on the split kernels, <= 128 features per pass: 256-row workgroups on block pairs (lssvm_tile_f32_pair.hip.hpp)
     int part_blocks() const { return pair_ ? round_up(std::max(num_ib_, 1), 2) : std::max(num_ib_, 1); }  // row blocks of a row slab (whole pairs)
+    double f16_row_rel_error_ = -1.0;  // fp32, gram_mode 2 / 3: the largest relative error of a row under two f16 planes, as measured at set-up (-1: not measured)
     bool f16_probe_failed_ = false;  // the probe for the linear kernel's panel passes found the data unfit for two f16 planes
     bool wide_nl_ = false;         // fp32 rbf / polynomial on more features than the one-pass split kernels take: feature panels inside a tile (lssvm_tile_f32_wide.hip.hpp)
     bool wide_linear_ = false;     // linear kernel over feature panels, one tile-kernel pass per panel: fp32 f16x3 beyond linear_panel_features, fp64 beyond 256 features
@@ -377,6 +393,8 @@ class Problem {
     // statistics: HIP events around the tile kernel
     double matvec_ms_ = 0.0;       // tile-kernel time of the TIMED matvecs (HIP events around the band launches)
     uint64_t matvec_launches_ = 0; // matvecs enqueued
+    double pace_ms0_ = 0.0;        // matvec_ms_ / matvec_timed_ at the last reshard: a rebalance by measured pace looks at what came after it
+    uint64_t pace_timed0_ = 0;
     uint64_t matvec_timed_ = 0;    // ... of which timed: all of them where a matvec is long, every 8th where it is short (two event records cost ~6 us per
                                    // matvec on the stream: 9 % of a 10 000-point CG iteration, profiles/r04_event_record_cost.log)
     /* a rule on the shape only, like the enqueue-ahead decision: below ~1 ms per matvec the events are sampled */
@@ -454,6 +472,7 @@ struct LocalComms {
     std::vector<ncclComm_t> comms;
     ~LocalComms();
 };
+std::shared_ptr<LocalComms> local_comms_for(const std::vector<int> &devices);  // lssvm_exchange.hip
 
 /* Solver<T>: the CG driver (csvm.cpp:71-183 / gpu_csvm.hpp:477-654) over the shards that live in THIS process:
  *   - one shard, world 1: single GPU;
@@ -466,7 +485,8 @@ struct LocalComms {
 template <typename T>
 class Solver final : public ProblemBase {
   public:
-    Solver(const lssvm_params &params, const void *X, int mem_kind, size_t num_points, size_t num_features, const std::vector<int> &devices, const lssvm_shard *shard);
+    /* `opt`: the options of THIS solve (the caller's lssvm_mi355_options, or a snapshot of the process defaults) */
+    Solver(const Options &opt, const lssvm_params &params, const void *X, int mem_kind, size_t num_points, size_t num_features, const std::vector<int> &devices, const lssvm_shard *shard);
     ~Solver() override;
 
     void get_q(void *q_out, double *QA_cost_out) override;
@@ -497,6 +517,7 @@ class Solver final : public ProblemBase {
     uint64_t xseq_ = 0;              // implicit matvecs exchanged so far
     Event ev_delta_;                 // shard 0's stream: delta of the iteration is on the host
     int world_ = 1;  // shards of the problem in total (all processes)
+    int info_shard_ = -1;  // the shard whose tile-kernel times fill_info reports (-1: not chosen yet)
 
     // CG state (host side)
     double eps_ = 0.0;
@@ -513,8 +534,8 @@ void measure_bf16_mfma_ceiling(int device, int b_from_lds, double settle_ms, dou
 
 /* one-shot helpers used by the C ABI */
 template <typename T>
-void predict_values(const lssvm_params &params, const T *sv, size_t nsv, size_t nfeat, const T *alpha, T rho, T *w_inout, int *w_valid, const T *points,
-                    size_t npoints, T *out);
+void predict_values(const Options &opt, const lssvm_params &params, const T *sv, size_t nsv, size_t nfeat, const T *alpha, T rho, T *w_inout, int *w_valid, const T *points,
+                    size_t npoints, T *out, lssvm_predict_info *info);
 template <typename T>
 void calculate_w(const T *sv, size_t nsv, size_t nfeat, const T *alpha, T *w_out);
 

@@ -130,13 +130,24 @@ class MI355CSVM(CSVM):
         if not 0 <= int(num_devices) <= self.num_devices:
             raise BackendError(f"Requested {num_devices} devices, but only {self.num_devices} are available!")
         self.use_devices = int(num_devices)
+        self._options = None  # this object's own tuning knobs (ABI 4): created by the first set_option, None = the process defaults
+
+    def set_option(self, name: str, value: int) -> None:
+        """A tuning knob of THIS backend object (``lssvm_mi355_options``; names as ``lssvm_mi355_set_option``): other objects and the process defaults are not touched --
+        the reference's backend objects share no state beyond ``verbosity`` either (csvm.hpp:50-83)."""
+        if self._options is None:
+            self._options = _capi.Options()
+        self._options.set(name, value)
+
+    def get_option(self, name: str) -> int:
+        return self._options.get(name) if self._options is not None else _capi.get_option(name)
 
     def solve_system_of_linear_equations(self, params, A, b, eps, max_iter):
         # all devices of this process behind ONE call (gpu_csvm::solve_system_of_linear_equations_impl, gpu_csvm.hpp:477-654)
-        return backend.solve_system_of_linear_equations(params, A, b, eps, max_iter, num_devices=self.use_devices)
+        return backend.solve_system_of_linear_equations(params, A, b, eps, max_iter, num_devices=self.use_devices, options=self._options)
 
     def predict_values(self, params, support_vectors, alpha, rho, w, predict_points):
-        return backend.predict_values(params, support_vectors, alpha, rho, w, predict_points)
+        return backend.predict_values(params, support_vectors, alpha, rho, w, predict_points, options=self._options)
 
 
 def make_csvm(backend_type=BackendType.AUTOMATIC, *args, **kwargs) -> CSVM:

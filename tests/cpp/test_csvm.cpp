@@ -15,6 +15,8 @@
 #include <sstream>
 #include <string>
 #include <tuple>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 namespace pa = plssvm_amd;
@@ -191,13 +193,13 @@ static void test_multi_device_shards(pa::kernel_function_type kernel) {
     // the yardstick of an fp32 CG trajectory is its distance to the float64 solve (rounding noise is amplified from iteration to iteration)
     std::vector<double> Xd(X.begin(), X.end()), yd(y.begin(), y.end()), a64(N);
     double rho64{};
-    const int rc64 = lssvm_mi355_solve_f64(&prm, Xd.data(), N, d, yd.data(), 1e-9, 60, a64.data(), &rho64, nullptr);
+    const int rc64 = lssvm_mi355_solve_f64(&prm, Xd.data(), N, d, yd.data(), 1e-9, 60, a64.data(), &rho64, nullptr, nullptr);
     if constexpr (std::is_same_v<T, float>) {
-        rc1 = lssvm_mi355_solve_f32(&prm, X.data(), N, d, y.data(), T(1e-5), 60, a1.data(), &rho1, &i1);
-        rc3 = lssvm_mi355_solve_multi_f32(&prm, X.data(), N, d, y.data(), T(1e-5), 60, a3.data(), &rho3, &i3, devs, 3);
+        rc1 = lssvm_mi355_solve_f32(&prm, X.data(), N, d, y.data(), T(1e-5), 60, a1.data(), &rho1, &i1, nullptr);
+        rc3 = lssvm_mi355_solve_multi_f32(&prm, X.data(), N, d, y.data(), T(1e-5), 60, a3.data(), &rho3, &i3, devs, 3, nullptr);
     } else {
-        rc1 = lssvm_mi355_solve_f64(&prm, X.data(), N, d, y.data(), T(1e-9), 60, a1.data(), &rho1, &i1);
-        rc3 = lssvm_mi355_solve_multi_f64(&prm, X.data(), N, d, y.data(), T(1e-9), 60, a3.data(), &rho3, &i3, devs, 3);
+        rc1 = lssvm_mi355_solve_f64(&prm, X.data(), N, d, y.data(), T(1e-9), 60, a1.data(), &rho1, &i1, nullptr);
+        rc3 = lssvm_mi355_solve_multi_f64(&prm, X.data(), N, d, y.data(), T(1e-9), 60, a3.data(), &rho3, &i3, devs, 3, nullptr);
     }
     EXPECT_TRUE(rc1 == 0 && rc3 == 0 && rc64 == 0);
     if (rc3 != 0) std::printf("  %s\n", lssvm_mi355_last_error());
@@ -219,6 +221,74 @@ static void test_multi_device_shards(pa::kernel_function_type kernel) {
                     i1.gram_mode, i3.gram_mode, static_cast<double>(rho1), static_cast<double>(rho3), rho64);
     }
     EXPECT_TRUE(std::abs(static_cast<double>(rho3) - rho64) <= 2 * std::abs(static_cast<double>(rho1) - rho64) + 20 * tol * std::max(1.0, std::abs(rho64)));  // rho = -(y_N + QA_cost sum(x) - q.x) cancels
+}
+
+/* ABI 4: the tuning knobs belong to the csvm OBJECT.  Two objects with different gram_mode solve the same system at the same time from two threads, several times
+ * over: every solve must report its own object's mode (0 = native v_mfma_f32, 1 = bf16x6, 2 = f16x3), the process defaults must stay untouched, and a third thread
+ * that keeps flipping the process default must not leak into either (the boundary's semantics: include/plssvm/csvm.hpp:50-83 -- move-only objects, const virtuals,
+ * no shared state beyond `verbosity`). */
+static void test_two_objects_with_their_own_options_on_two_threads() {
+    std::mt19937 gen(5);
+    std::uniform_real_distribution<float> u(-1.0f, 1.0f);
+    const std::size_t N = 1500, d = 40;
+    std::vector<std::vector<float>> X(N, std::vector<float>(d));
+    std::vector<float> y(N);
+    for (auto &row : X) for (auto &v : row) v = u(gen);
+    for (std::size_t i = 0; i < N; ++i) y[i] = (i % 2 == 0) ? 1.0f : -1.0f;
+    mock_mi355_csvm a{ pa::kernel_type = pa::kernel_function_type::rbf, pa::gamma = 0.05 };
+    mock_mi355_csvm b{ pa::kernel_type = pa::kernel_function_type::rbf, pa::gamma = 0.05 };
+    a.set_option("gram_mode", 1);
+    b.set_option("gram_mode", 0);
+    int64_t before = -1, after = -1;
+    EXPECT_TRUE(lssvm_mi355_get_option("gram_mode", &before) == 0);
+    EXPECT_TRUE(a.get_option("gram_mode") == 1 && b.get_option("gram_mode") == 0 && before == 3);
+    pa::detail::parameter<float> prm{};
+    prm.kernel_type = pa::kernel_function_type::rbf;
+    prm.set_gamma(0.05f);
+    std::atomic<int> wrong{ 0 };
+    std::atomic<bool> stop{ false };
+    std::vector<float> alpha_a, alpha_b;
+    const auto run = [&](const mock_mi355_csvm &svm, int want, std::vector<float> &keep) {
+        try {
+            for (int rep = 0; rep < 6; ++rep) {
+                auto res = svm.solve_system_of_linear_equations(prm, X, y, 1e-4f, 40);
+                if (svm.last_cg_info().gram_mode != want) ++wrong;
+                keep = std::move(res.first);
+            }
+        } catch (const std::exception &e) {
+            std::printf("  thread for mode %d: %s\n", want, e.what());
+            wrong += 100;
+        }
+    };
+    std::thread flip([&] {  // the process default changes under both: neither may see it
+        int64_t v = 2;
+        while (!stop.load()) {
+            (void) lssvm_mi355_set_option("gram_mode", v);
+            v = v == 2 ? 3 : 2;
+            std::this_thread::yield();
+        }
+        (void) lssvm_mi355_set_option("gram_mode", 3);
+    });
+    std::thread ta(run, std::cref(a), 1, std::ref(alpha_a)), tb(run, std::cref(b), 0, std::ref(alpha_b));
+    ta.join();
+    tb.join();
+    stop.store(true);
+    flip.join();
+    EXPECT_TRUE(wrong.load() == 0);
+    EXPECT_TRUE(lssvm_mi355_get_option("gram_mode", &after) == 0 && after == 3);
+    // the two paths solve the same system: they agree as two converged fp32 solves do
+    double diff = 0, scale = 0;
+    for (std::size_t i = 0; i < alpha_a.size() && i < alpha_b.size(); ++i) {
+        diff = std::max(diff, std::abs(static_cast<double>(alpha_a[i]) - alpha_b[i]));
+        scale = std::max(scale, std::abs(static_cast<double>(alpha_a[i])));
+    }
+    EXPECT_TRUE(alpha_a.size() == N && alpha_b.size() == N && diff <= 5e-3 * scale);
+    // an object that never set an option follows the process defaults; option errors are the library's
+    mock_mi355_csvm c{ pa::kernel_type = pa::kernel_function_type::rbf, pa::gamma = 0.05 };
+    (void) c.solve_system_of_linear_equations(prm, X, y, 1e-4f, 5);
+    EXPECT_TRUE(c.last_cg_info().gram_mode == 2 || c.last_cg_info().gram_mode == 1);
+    EXPECT_THROW_WHAT(c.set_option("no_such_option", 1), pa::invalid_parameter_exception, "unknown option");
+    EXPECT_THROW_WHAT(c.set_option("gram_mode", 9), pa::invalid_parameter_exception, "gram_mode must be");
 }
 
 static void test_factory_and_exceptions(bool have_gpu) {
@@ -276,6 +346,7 @@ int main(int argc, char **argv) {
             test_multi_device_shards<float>(k);
             test_multi_device_shards<double>(k);
         }
+        test_two_objects_with_their_own_options_on_two_threads();
     }
     std::printf("%d checks, %d failed\n", g_checks, g_failed);
     return g_failed;

@@ -1,6 +1,6 @@
 """GPU (-m gpu): the product's RCCL exchange with MORE THAN ONE RANK -- on one device, through a stand-in for RCCL.
 
-`Solver<T>::exchange` (plssvm_amd/csrc/lssvm_problem.hip) combines the row-block shards' partial K*v once per implicit matvec with
+`Solver<T>::exchange` (plssvm_amd/csrc/lssvm_exchange.hip) combines the row-block shards' partial K*v once per implicit matvec with
 ncclAllReduce (symmetric variant) or an in-place ncclAllGather (full square); it replaces the reference's host-staged
 gpu_csvm::device_reduction (include/plssvm/backends/gpu_csvm.hpp:449-475, tested there on whatever devices exist by
 tests/backends/generic_csvm_tests.hpp:495-540).  The real RCCL refuses two ranks on one device and this pool's boxes have one MI355X, so until
@@ -129,6 +129,24 @@ def test_bench_line_of_four_ranks_reports_what_rccl_saw(tmp_path):
     assert cfg["rccl_nranks"] == 4 and cfg["rccl_rank0_device"] == 0 and cfg["rccl_is_stand_in"] and os.path.samefile(cfg["rccl_library"], STAND_IN)
     assert cfg["shards"] == 4 and cfg["exchange"] == "RCCL all-reduce" and line["steps"] == 6 and line["n_gpus"] == 1
     assert np.isfinite(cfg["residuum_after_timed_steps"]) and line["value"] > 0 and cfg["residuum_bit_equal_on_all_ranks"] is True
+
+
+def test_bench_line_of_eight_ranks_is_first_contact_ready(tmp_path):
+    """What the first real SCALE record will be checked against, field by field: bench.py --gpus 8 with one process per rank and the DEFAULT exchange
+    -- eight ranks on device 0 through the stand-in here -- prints ranks = 8, rccl_nranks = 8 (from ncclCommCount), the residuum as the same bits on every rank, and every
+    rank's tile-kernel time per matvec.  n_gpus stays the number of DISTINCT devices (1 on this box, 8 on a node): no scaling number is made from one device."""
+    _need_stand_in()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FAKE_RCCL_TIMEOUT_S="120")
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--rank-devices", "0,0,0,0,0,0,0,0", "--rccl-stand-in", STAND_IN, "--workload", "c2", "--steps", "6",
+                         "--warmup", "2", "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    line = json.loads(pr.stdout.strip().splitlines()[-1])
+    cfg, roof = line["config"], line["roofline"]
+    assert cfg["ranks"] == 8 and cfg["shards"] == 8 and cfg["rccl_nranks"] == 8 and cfg["rccl_is_stand_in"] and cfg["exchange"] == "RCCL all-reduce"
+    assert line["n_gpus"] == 1 and line["steps"] == 6 and line["scaling"] == "strong" and line["value"] > 0 and line["setup_ms"] > 0
+    assert cfg["residuum_bit_equal_on_all_ranks"] is True and np.isfinite(cfg["residuum_after_timed_steps"])
+    per_rank = roof["kernel_ms_per_rank"]
+    assert isinstance(per_rank, list) and len(per_rank) == 8 and all(t > 0 for t in per_rank) and roof["avg_launch_ms"] == pytest.approx(per_rank[0])
 
 
 def test_bench_rebalances_the_shares_by_measured_pace(tmp_path):

@@ -1,0 +1,261 @@
+"""Round 6: per-call options (ABI 4), the predict timings, what the representability check does to data that is not blobs, and the two ADVICE r05 findings
+(a rebalance that grows the band list; grid planes that do not represent the data).  All through the C ABI on a real MI355X."""
+
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from plssvm_amd import _capi, backend
+from plssvm_amd._capi import Options
+from plssvm_amd.csvm import make_csvm
+from plssvm_amd.data_set import DataSet
+from plssvm_amd.datagen import make_blobs_pm1
+from plssvm_amd.exceptions import PlssvmError
+from plssvm_amd.parameter import Parameter
+
+pytestmark = pytest.mark.gpu
+
+EPS32 = np.finfo(np.float32).eps
+
+
+def _rows_vs_oracle(oracle, prob, kernel, X, gamma, rows):
+    """|implicit matvec - float64 oracle| on `rows`, on the scale of each row's summands (as tests/test_gpu_parity.py::_sampled_rows_vs_oracle)"""
+    n = X.shape[0] - 1
+    rhs = np.random.default_rng(0).uniform(-1, 1, size=n).astype(X.dtype)
+    q, QA = prob.q()
+    got = prob.matvec(rhs, np.zeros(n, X.dtype), 1.0)
+    X64, q64, rhs64 = X.astype(np.float64), q.astype(np.float64), rhs.astype(np.float64)
+    want = np.zeros(n)
+    for r in rows:
+        want = oracle.matvec_rows(kernel, X64, q64, rhs64, want, float(QA), 1.0, 1.0, int(r), int(r) + 1, degree=3, gamma=gamma, coef0=0.0)
+    G = X64[rows] @ X64[:n].T
+    if kernel == "rbf":
+        sq = np.einsum("ij,ij->i", X64, X64)
+        K = np.exp(-gamma * np.maximum(sq[rows, None] + sq[None, :n] - 2.0 * G, 0.0))
+    else:
+        K = np.abs(G)
+    absd = np.abs(rhs64)
+    scale = K @ absd + (abs(float(QA)) + np.abs(q64[rows])) * absd.sum() + np.abs(q64) @ absd + absd[rows]
+    return float(np.max(np.abs(got[rows] - want[rows]) / scale)), got
+
+
+# ------------------------------------------------------------------------------------------------------------ per-call options (ABI 4)
+def test_options_object_is_a_private_copy_of_the_defaults():
+    a = Options()
+    assert a.get("gram_mode") == _capi.get_option("gram_mode") == 3
+    a.set("gram_mode", 1).set("symmetric", 0)
+    b = Options(gram_mode=0)
+    assert (a.get("gram_mode"), a.get("symmetric"), b.get("gram_mode"), b.get("symmetric")) == (1, 0, 0, 1)
+    assert _capi.get_option("gram_mode") == 3 and _capi.get_option("symmetric") == 1  # the process defaults are untouched
+    _capi.set_option("mfma_shape", 2)
+    assert Options().get("mfma_shape") == 2 and a.get("mfma_shape") == 3  # a snapshot of the defaults of the moment it was created
+    with pytest.raises(PlssvmError, match="unknown option"):
+        a.set("no_such_option", 1)
+    with pytest.raises(PlssvmError, match="gram_mode must be"):
+        a.set("gram_mode", 7)
+
+
+def test_two_problems_with_their_own_options_side_by_side(oracle):
+    """Two resident problems on the same data, each created with its own options: each runs ITS Gram mode / variant (lssvm_cg_info), the process defaults are never
+    touched, and both agree with the float64 oracle."""
+    X, y = make_blobs_pm1(9000, 96, seed=3, dtype=np.float32)
+    prm = Parameter(kernel_type="rbf")
+    rows = np.arange(0, 8999, 301)
+    with backend.ResidentProblem(prm, X, options=Options(gram_mode=1)) as p1, backend.ResidentProblem(prm, X, options=Options(gram_mode=0, symmetric=0)) as p2, \
+            backend.ResidentProblem(prm, X) as p3:
+        i1, i2, i3 = p1.info(), p2.info(), p3.info()
+        assert (i1["gram_mode"], i1["symmetric"]) == (1, 1) and (i2["gram_mode"], i2["symmetric"]) == (0, 0) and (i3["gram_mode"], i3["symmetric"]) == (2, 1)
+        for p in (p1, p2, p3):
+            err, _ = _rows_vs_oracle(oracle, p, "rbf", X, 1.0 / 96, rows)
+            assert err < 4 * EPS32, err / EPS32
+    assert _capi.get_option("gram_mode") == 3 and _capi.get_option("symmetric") == 1
+
+
+def test_two_csvm_objects_with_different_options_solve_at_the_same_time():
+    """The Python mirror of tests/cpp/test_csvm.cpp's two-thread case: two backend objects, each with its own gram_mode, fit the same data from two threads while a third
+    thread keeps flipping the process default -- every solve reports its own object's mode (plssvm::csvm: move-only objects, const virtuals, no shared state beyond
+    `verbosity`, include/plssvm/csvm.hpp:50-83)."""
+    X, y = make_blobs_pm1(3000, 64, seed=5, dtype=np.float32)
+    data = DataSet(X, [int(v) for v in y], real_type=np.float32)
+    svm_a, svm_b = make_csvm("mi355", params=Parameter(kernel_type="rbf")), make_csvm("mi355", params=Parameter(kernel_type="rbf"))
+    svm_a.set_option("gram_mode", 1)
+    svm_b.set_option("gram_mode", 0)
+    seen = {"a": [], "b": []}
+    alphas = {}
+    stop = threading.Event()
+
+    def run(tag, svm):
+        for _ in range(5):
+            model = svm.fit(data, epsilon=1e-4, max_iter=40)
+            seen[tag].append(int(svm.last_cg_info["gram_mode"]))
+            alphas[tag] = model.alpha
+
+    def flip():
+        v = 2
+        while not stop.is_set():
+            _capi.set_option("gram_mode", v)
+            v = 5 - v
+        _capi.set_option("gram_mode", 3)
+
+    threads = [threading.Thread(target=run, args=("a", svm_a)), threading.Thread(target=run, args=("b", svm_b)), threading.Thread(target=flip)]
+    for t in threads:
+        t.start()
+    threads[0].join()
+    threads[1].join()
+    stop.set()
+    threads[2].join()
+    assert seen["a"] == [1] * 5 and seen["b"] == [0] * 5, seen
+    assert np.max(np.abs(alphas["a"] - alphas["b"])) <= 5e-3 * np.max(np.abs(alphas["a"]))
+    assert svm_a.get_option("gram_mode") == 1 and svm_b.get_option("gram_mode") == 0 and _capi.get_option("gram_mode") == 3
+
+
+# ------------------------------------------------------------------------------------------------------------ predict_values: timings, options
+def test_predict_values_reports_its_timings_and_follows_the_callers_options(oracle):
+    X, _ = make_blobs_pm1(6000 + 20000, 128, seed=9, dtype=np.float32)
+    sv, pts = X[:6000], X[6000:]
+    alpha = np.random.default_rng(1).standard_normal(6000).astype(np.float32)
+    prm = Parameter(kernel_type="rbf")
+    info, info0 = {}, {}
+    backend.predict_values(prm, sv, alpha, 0.5, None, pts)  # warm-up: code objects, first allocations
+    got, w = backend.predict_values(prm, sv, alpha, 0.5, None, pts, info_out=info)
+    got0, _ = backend.predict_values(prm, sv, alpha, 0.5, None, pts, options=Options(gram_mode=0), info_out=info0)
+    assert w is None and info["gram_mode"] == 2 and info0["gram_mode"] == 0 and info["rbf_direct"] == 0
+    assert 0 < info["kernel_ms"] < info["total_ms"] and 0 < info["setup_ms"] < info["total_ms"] and 0 < info["f16_row_rel_error"] <= 2.0 ** -22
+    assert info0["kernel_ms"] > info["kernel_ms"]  # native v_mfma_f32 chains against three f16 plane products on the 16-bit matrix cores
+    sample = np.arange(0, 20000, 997)
+    want, _ = oracle.predict_values("rbf", sv.astype(np.float64), alpha.astype(np.float64), 0.5, pts[sample].astype(np.float64), gamma=1.0 / 128)
+    scale = np.abs(alpha).sum()
+    assert np.max(np.abs(got[sample] - want)) < 16 * EPS32 * scale and np.max(np.abs(got0[sample] - want)) < 16 * EPS32 * scale
+    assert np.max(np.abs(got - got0)) < 16 * EPS32 * np.abs(alpha).sum()
+    # the linear kernel: w is computed once and handed back; the timed kernel is the w.x pass
+    lin = {}
+    vals, w = backend.predict_values(Parameter(kernel_type="linear"), sv, alpha, 0.5, None, pts, info_out=lin)
+    assert w is not None and lin["kernel_ms"] > 0 and lin["gram_mode"] == 0
+    vals2, _ = backend.predict_values(Parameter(kernel_type="linear"), sv, alpha, 0.5, w, pts)
+    assert np.array_equal(vals, vals2)
+
+
+# ------------------------------------------------------------------------------------------------------------ the Gram mode by data
+@pytest.mark.parametrize("name", ["plus_minus_one", "small_integers", "sparse01"])
+@pytest.mark.parametrize("kernel", ["linear", "rbf"])
+def test_exactly_representable_data_takes_f16x3_and_matches_the_float64_oracle(oracle, name, kernel):
+    """Data whose entries ARE f16 numbers (0 / +-1, small integers; rbf: after the centring by the column means, which leaves them within two f16 planes): the
+    representability check passes, the solve runs f16x3 (gram_mode 2), and a row of the implicit matvec is within 1 eps of the float64 oracle on the scale of its summands."""
+    rng = np.random.default_rng(11)
+    N, d = 12000, 128
+    if name == "plus_minus_one":
+        X = rng.choice([-1.0, 0.0, 1.0], size=(N, d)).astype(np.float32)
+    elif name == "small_integers":
+        X = rng.integers(-20, 21, size=(N, d)).astype(np.float32)
+    else:
+        X = (rng.random((N, d)) < 0.05).astype(np.float32)
+    gamma = 1.0 / (d * max(1.0, float(np.abs(X).max()) ** 2))  # keeps the rbf exponent scale small (the kernel's usual range) whatever the data's magnitude
+    rows = np.sort(rng.choice(N - 1, size=40, replace=False))
+    with backend.ResidentProblem(Parameter(kernel_type=kernel, gamma=gamma), X) as prob:
+        info = prob.info()
+        err, _ = _rows_vs_oracle(oracle, prob, kernel, X, gamma, rows)
+    assert info["gram_mode"] == 2 and info["rbf_direct"] == 0, info
+    assert 0 <= info["f16_row_rel_error"] <= 2.0 ** -22
+    if kernel == "linear":
+        assert info["f16_row_rel_error"] == 0.0  # one f16 plane holds every entry exactly
+    assert err < 1 * EPS32, err / EPS32
+
+
+@pytest.mark.parametrize("kernel", ["linear", "rbf"])
+def test_data_that_fails_the_representability_check_reports_bf16x6(oracle, kernel):
+    """Columns of very different magnitude (N(0, 1) x 10^U(-6, 6) per feature, unscaled): two f16 planes lose the small columns beside the large ones, the check
+    says so (lssvm_cg_info.f16_row_rel_error above 2^-22), the solve runs bf16x6 -- gram_mode = 1 in lssvm_cg_info -- and keeps the fp32-class accuracy; forcing f16x3
+    (gram_mode 2, no check) on the same data shows what the check prevents."""
+    rng = np.random.default_rng(12)
+    N, d = 12000, 128
+    X = (rng.normal(0, 1, size=(N, d)) * 10.0 ** rng.uniform(-6, 6, size=(1, d))).astype(np.float32)
+    X64 = X.astype(np.float64)
+    gamma = 1.0 / float(np.max(np.einsum("ij,ij->i", X64, X64)))  # rbf: an exponent scale of a few units
+    rows = np.sort(rng.choice(N - 1, size=40, replace=False))
+    with backend.ResidentProblem(Parameter(kernel_type=kernel, gamma=gamma), X) as prob:
+        info = prob.info()
+        err, _ = _rows_vs_oracle(oracle, prob, kernel, X, gamma, rows)
+    if kernel == "linear":
+        assert info["gram_mode"] == 1 and info["f16_row_rel_error"] > 2.0 ** -22, info
+    else:
+        # rbf accepts f16 planes under an ABSOLUTE bound on the exponent's error as well (the small columns do not matter to a distance the large ones dominate)
+        assert info["gram_mode"] in (1, 2) and info["rbf_direct"] == 0, info
+    assert err < 4 * EPS32, err / EPS32
+    if kernel == "linear":
+        with backend.ResidentProblem(Parameter(kernel_type=kernel, gamma=gamma), X, options=Options(gram_mode=2)) as forced:
+            assert forced.info()["gram_mode"] == 2
+            err_forced, _ = _rows_vs_oracle(oracle, forced, kernel, X, gamma, rows)
+        print(f"\nwide-range columns, linear: bf16x6 (chosen) {err / EPS32:.2f} eps, f16x3 forced {err_forced / EPS32:.2f} eps")
+
+
+# ------------------------------------------------------------------------------------------------------------ ADVICE r05
+def test_a_rebalance_that_needs_one_more_band_keeps_timing_its_launches(oracle):
+    """reshard() -> build_shard_lists() grows the event list when a shard's new share needs one more column-slab band; the new pairs had no
+    events and the first timed launch that picked one threw on that shard only.  Two shards on device 0, colslab_band_mb = 1: shard 0 goes from one band to two when it is
+    handed 85 % of the triangle; the timed cg_steps after it must run, the counters lssvm_cg_info reports must keep running, and the solve must end where the
+    single-device solve ends."""
+    X, y = make_blobs_pm1(9100, 64, seed=21, dtype=np.float32)
+    prm = Parameter(kernel_type="polynomial", degree=3)
+    a_ref, _, _ = backend.solve_system_of_linear_equations(prm, X, y, 1e-30, 14)
+    with backend.ResidentProblem(prm, X, devices=[0, 0], options=Options(colslab_band_mb=1)) as prob:
+        prob.cg_begin(y, 1e-30)
+        prob.cg_step(4)
+        before = prob.info()
+        assert prob.rebalance([0.85, 0.15]) is True
+        after = prob.info()
+        assert after["tile_launches_per_matvec"] > before["tile_launches_per_matvec"] >= 1, (before, after)
+        prob.cg_step(10)
+        end = prob.info()
+        alpha, rho, info = prob.cg_finish()
+    assert end["matvec_timed"] > before["matvec_timed"] and end["matvec_kernel_ms_total"] > before["matvec_kernel_ms_total"] > 0  # (never reset, never negative: ADVICE r05 low)
+    assert info["iterations"] == 14 and np.all(np.isfinite(alpha))
+    a64, _, _ = oracle.solve("polynomial", X.astype(np.float64), y.astype(np.float64), 1e-30, 14, degree=3, gamma=1.0 / 64, coef0=0.0, cost=1.0)
+    e_ref, e_got = np.max(np.abs(a_ref - a64)), np.max(np.abs(alpha - a64))
+    assert e_got <= 2 * e_ref + 1e-4 * np.max(np.abs(a64)), (e_got, e_ref)
+
+
+def test_grid_planes_that_do_not_represent_the_data_fall_back_to_the_direct_kernel(monkeypatch):
+    """with the default rbf_form = 0 an exponent scale of 32 ... 4096 selects the grid planes; if the planes then turn out not to represent the data
+    the solve (and predict_values) must run the formula-exact kernel like before the grid planes existed -- only an explicit rbf_form = 3 may fail.  No valid input is known
+    to trip the check, so the test trips it through the library's test hook."""
+    X, y = make_blobs_pm1(2500, 128, seed=8, dtype=np.float32)
+    prm = Parameter(kernel_type="rbf", gamma=4.0)
+    v = np.random.default_rng(2).uniform(-1, 1, size=2499).astype(np.float32)
+    with backend.ResidentProblem(prm, X) as prob:
+        assert prob.info()["gram_mode"] == 3 and 32 < prob.info()["rbf_exponent_scale"] <= 4096
+    with backend.ResidentProblem(prm, X, options=Options(rbf_form=1)) as prob:
+        want = prob.matvec(v, np.zeros(2499, np.float32), 1.0)
+    pts = X[:500]
+    alpha = np.random.default_rng(3).standard_normal(2500).astype(np.float32)
+    want_p, _ = backend.predict_values(prm, X, alpha, 0.1, None, pts, options=Options(rbf_form=1))
+    monkeypatch.setenv("LSSVM_MI355_TEST_GRID_UNFIT", "1")
+    with backend.ResidentProblem(prm, X) as prob:
+        info = prob.info()
+        got = prob.matvec(v, np.zeros(2499, np.float32), 1.0)
+    assert info["rbf_direct"] == 1 and info["gram_mode"] == 0 and np.array_equal(got, want)
+    with backend.ResidentProblem(prm, X, devices=[0, 0, 0]) as prob:  # every shard takes the same turn
+        assert prob.info()["rbf_direct"] == 1
+        assert np.allclose(prob.matvec(v, np.zeros(2499, np.float32), 1.0), want, rtol=0, atol=64 * EPS32 * np.max(np.abs(want)))
+    pinfo = {}
+    got_p, _ = backend.predict_values(prm, X, alpha, 0.1, None, pts, info_out=pinfo)
+    assert pinfo["rbf_direct"] == 1 and np.array_equal(got_p, want_p)
+    with pytest.raises(PlssvmError, match="grid planes"):
+        backend.ResidentProblem(prm, X, options=Options(rbf_form=3))
+    with pytest.raises(PlssvmError, match="grid planes"):
+        backend.predict_values(prm, X, alpha, 0.1, None, pts, options=Options(rbf_form=3))
+
+
+def test_the_first_matvec_after_cg_begin_is_never_timed():
+    """with long matvecs every launch is event-bracketed -- except launch 0, the cold first matvec of cg_begin."""
+    X, y = make_blobs_pm1(60000, 128, seed=4, dtype=np.float64)  # fp64 at this size: > 1 ms per matvec by the library's shape rule -> stride 1
+    with backend.ResidentProblem(Parameter(kernel_type="rbf"), X) as prob:
+        prob.cg_begin(y, 1e-30)
+        prob.synchronize()
+        i0 = prob.info()
+        prob.cg_step(3)
+        prob.synchronize()
+        i1 = prob.info()
+    assert i0["matvec_launches"] == 1 and i0["matvec_timed"] == 0
+    assert i1["matvec_launches"] == 4 and i1["matvec_timed"] == 3

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """ONE process driving several shards (lssvm_mi355_problem_create_multi) over RCCL group calls -- Exchange::local_rccl in
-plssvm_amd/csrc/lssvm_problem.hip -- with all shards on ONE device, through the tests' stand-in for RCCL (the real one refuses repeated
+plssvm_amd/csrc/lssvm_exchange.hip -- with all shards on ONE device, through the tests' stand-in for RCCL (the real one refuses repeated
 devices).  Started as a fresh child process by tests/test_gpu_fake_rccl.py: the stand-in is loaded FIRST, so the product library's own
 dlopen("librccl.so.1") resolves to it by SONAME.  The same problem then runs over the product's peer kernels (exchange = 2: the same fixed
 rank-order sum -> the same bits) and on a single shard; everything is written to --out as JSON."""
