@@ -151,7 +151,7 @@ __device__ __forceinline__ double fast_exp_f64(double x) {
  * |r| <= 1/2, 2^r by a degree-10 polynomial -- the interpolant of 2^r in the Chebyshev nodes of [-1/2, 1/2] (near-minimax: 1.4 eps of truncation with the
  * coefficients rounded to double; the Taylor polynomial of rounds 1-4 needed degree 12 for 0.8 eps) --, v_ldexp_f64 for the scale (underflow to 0 included).
  * 14 vector instructions per element; every one of them costs matrix-core time beside v_mfma_f64 -- on gfx950 NO vector instruction overlaps with an fp64 MFMA,
- * integer and fp32 ones included (profiles/r01_microbench_mfma_beside_valu.log: 4 v_fma_f64 per MFMA 77 -> 55 TFLOP/s, 4 integer instructions 77 -> 59), which
+ * integer and fp32 ones included (profiles/archive/r01_microbench_mfma_beside_valu.log: 4 v_fma_f64 per MFMA 77 -> 55 TFLOP/s, 4 integer instructions 77 -> 59), which
  * is why a v_exp_f32 seed corrected in fp64 cannot pay: a seed of 24 bits leaves the correction a full-length polynomial, and the
  * instructions it would move to the fp32 pipe cost the same issue time.  What is left is the count: 16 -> 14 here (p(0) = 1 exactly: K_ii = 1).
  * (A 64-entry table + degree-5 polynomial needs 13, but its per-lane LDS gathers serialise in the register-bound epilogue: measured 16 % SLOWER.) */

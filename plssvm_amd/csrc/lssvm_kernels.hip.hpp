@@ -506,25 +506,45 @@ __global__ void k_half_neg_norms(const T *__restrict__ X, int ldx, int nrows_tot
     if (lane == 0) c[row] = T(-0.5) * s;
 }
 
-/* w[f] = sum_i alpha_i X[i][f]   (calculate_w, csvm.cpp:255-280 / HIP/predict_kernel.hip.hpp:34-45): sequential fma chain
- * over the points per feature like the reference; coalesced because consecutive threads own consecutive features */
+/* w[f] = sum_i alpha_i X[i][f]   (calculate_w, csvm.cpp:255-280 / HIP/predict_kernel.hip.hpp:34-45).  Stage 1: block (b, c) sums rows [b R, (b + 1) R) of the features
+ * [256 c, 256 c + 256) in double, coalesced across the features; stage 2 adds the blocks of a feature in ascending order -- a fixed order, reproducible run to run. */
 template <typename T>
-__global__ void k_calculate_w(const T *__restrict__ X, int ldx, int dfeat, int npoints, const T *__restrict__ alpha, T *__restrict__ w) {
+__global__ void k_calculate_w_stage1(const T *__restrict__ X, int ldx, int npoints, int rows_per_block, const T *__restrict__ alpha, double *__restrict__ part /* [gridDim.x][ldx] */) {
+    const int f = blockIdx.y * blockDim.x + threadIdx.x;
+    if (f >= ldx) return;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, npoints);
+    double s = 0.0;
+    for (int i = r0; i < r1; ++i) s = fma(static_cast<double>(alpha[i]), static_cast<double>(X[static_cast<size_t>(i) * ldx + f]), s);
+    part[static_cast<size_t>(blockIdx.x) * ldx + f] = s;
+}
+template <typename T>
+__global__ void k_calculate_w_stage2(const double *__restrict__ part, int nblocks, int ldx, int dfeat, T *__restrict__ w) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= dfeat) return;
-    T s = T(0);
-    for (int i = 0; i < npoints; ++i) s = fma(alpha[i], X[static_cast<size_t>(i) * ldx + f], s);
-    w[f] = s;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += part[static_cast<size_t>(b) * ldx + f];
+    w[f] = static_cast<T>(s);
 }
-/* out_p = w . x_p - rho  (linear predict, csvm.cpp:213): one thread per point, sequential fma chain */
-template <typename T>
-__global__ void k_predict_linear(const T *__restrict__ P, int ldx, int dfeat, int npoints, const T *__restrict__ w, T rho, T *__restrict__ out) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npoints) return;
-    const T *x = P + static_cast<size_t>(p) * ldx;
+/* out_p = w . x_p - rho  (linear predict, csvm.cpp:213): L lanes per point, 16-byte loads, the lanes' partial chains added by a butterfly */
+template <typename T, int L>
+__global__ void k_predict_linear_rows(const T *__restrict__ P, int ldx, int npoints, const T *__restrict__ w, T rho, T *__restrict__ out) {
+    constexpr int V = 16 / static_cast<int>(sizeof(T));
+    using vec = T __attribute__((ext_vector_type(V)));
+    const int sub = threadIdx.x % L;
+    const int p = blockIdx.x * (blockDim.x / L) + threadIdx.x / L;
     T s = T(0);
-    for (int f = 0; f < dfeat; ++f) s = fma(w[f], x[f], s);
-    out[p] = s - rho;
+    if (p < npoints) {
+        const vec *x = reinterpret_cast<const vec *>(P + static_cast<size_t>(p) * ldx);
+        const vec *wv = reinterpret_cast<const vec *>(w);
+        for (int k = sub; k < ldx / V; k += L) {
+            const vec xv = x[k], ww = wv[k];
+#pragma unroll
+            for (int e = 0; e < V; ++e) s = fma(ww[e], xv[e], s);
+        }
+    }
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (p < npoints && sub == 0) out[p] = s - rho;
 }
 /* out_p = Kv_p - rho */
 template <typename T>

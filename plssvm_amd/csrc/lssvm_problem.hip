@@ -1164,6 +1164,25 @@ template class Problem<float>;
 template class Problem<double>;
 
 /* ------------------------------------------------------------------ predict path ------------------------------------------------------------------ */
+/* out_p = w . x_p - rho: one pass over the points, HBM bound.  A group of L lanes (a power of two, at most 64) owns a point and reads its row in 16-byte pieces, so
+ * that a wave's load instruction covers 1 KiB of consecutive memory wherever a row has at least 16 bytes x L. */
+template <typename T>
+static void launch_predict_linear(const DeviceMatrix<T> &P, const T *w, T rho, T *out, hipStream_t s) {
+    constexpr int V = 16 / static_cast<int>(sizeof(T));  // elements per 16-byte piece
+    const int pieces = P.ldx / V;                         // (ldx is a multiple of the k-chunk: 32 floats / 16 doubles)
+    int L = 1;
+    while (2 * L <= std::min(pieces, 64)) L *= 2;
+    const int rows_per_block = 256 / L;
+    const dim3 grid(static_cast<unsigned>((P.rows + rows_per_block - 1) / rows_per_block));
+    switch (L) {
+        case 4: hipLaunchKernelGGL((k_predict_linear_rows<T, 4>), grid, dim3(256), 0, s, P.data.p, P.ldx, P.rows, w, rho, out); break;
+        case 8: hipLaunchKernelGGL((k_predict_linear_rows<T, 8>), grid, dim3(256), 0, s, P.data.p, P.ldx, P.rows, w, rho, out); break;
+        case 16: hipLaunchKernelGGL((k_predict_linear_rows<T, 16>), grid, dim3(256), 0, s, P.data.p, P.ldx, P.rows, w, rho, out); break;
+        case 32: hipLaunchKernelGGL((k_predict_linear_rows<T, 32>), grid, dim3(256), 0, s, P.data.p, P.ldx, P.rows, w, rho, out); break;
+        default: hipLaunchKernelGGL((k_predict_linear_rows<T, 64>), grid, dim3(256), 0, s, P.data.p, P.ldx, P.rows, w, rho, out); break;
+    }
+}
+
 template <typename T>
 void calculate_w(const T *sv, size_t nsv, size_t nfeat, const T *alpha, T *w_out) {
     LSSVM_REQUIRE(sv != nullptr && nsv > 0, "The support vectors may not be empty!");                       // csvm.cpp:256
@@ -1177,7 +1196,14 @@ void calculate_w(const T *sv, size_t nsv, size_t nfeat, const T *alpha, T *w_out
     a.alloc_zero(nsv, s);
     w.alloc_zero(nfeat, s);
     LSSVM_HIP_CHECK(hipMemcpyAsync(a.p, alpha, nsv * sizeof(T), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_calculate_w<T>, dim3((S.dfeat + 63) / 64), dim3(64), 0, s, S.data.p, S.ldx, S.dfeat, S.rows, a.p, w.p);
+    // w[f] = sum_i alpha_i sv[i][f]: partial sums over blocks of 256 support vectors (coalesced across the features), then the blocks in order -- the reference's chain
+    // (csvm.cpp:255-280) is one sequential fma chain per feature; 128 threads walking 50 000 rows each took 10 ms where the matrix is read in 10 us
+    const int rows_per_block = 256;
+    const int nblocks = (S.rows + rows_per_block - 1) / rows_per_block;
+    DevBuf<double> part;
+    part.alloc_zero(static_cast<size_t>(nblocks) * S.ldx, s);
+    hipLaunchKernelGGL(k_calculate_w_stage1<T>, dim3(nblocks, (S.ldx + 255) / 256), dim3(256), 0, s, S.data.p, S.ldx, S.rows, rows_per_block, a.p, part.p);
+    hipLaunchKernelGGL(k_calculate_w_stage2<T>, dim3((S.dfeat + 255) / 256), dim3(256), 0, s, part.p, nblocks, S.ldx, S.dfeat, w.p);
     LSSVM_HIP_CHECK(hipGetLastError());
     LSSVM_HIP_CHECK(hipMemcpyAsync(w_out, w.p, nfeat * sizeof(T), hipMemcpyDeviceToHost, s));
     LSSVM_HIP_CHECK(hipStreamSynchronize(s));
@@ -1214,13 +1240,13 @@ static void predict_values_impl(const Options &opt, const lssvm_params &params, 
         DeviceMatrix<T> P;
         P.upload(points, LSSVM_MEM_HOST, npoints, nfeat, 0, s);
         DevBuf<T> w, o;
-        w.alloc_zero(nfeat, s);
+        w.alloc_zero(static_cast<size_t>(P.ldx), s);  // (zero padded like the points' rows: the kernel reads whole 16-byte pieces)
         o.alloc_zero(npoints, s);
         LSSVM_HIP_CHECK(hipMemcpyAsync(w.p, w_inout, nfeat * sizeof(T), hipMemcpyHostToDevice, s));
         LSSVM_HIP_CHECK(hipStreamSynchronize(s));
         const double t_kernel = now_ms();
         LSSVM_HIP_CHECK(hipEventRecord(ev_a.e, s));
-        hipLaunchKernelGGL(k_predict_linear<T>, dim3((P.rows + 127) / 128), dim3(128), 0, s, P.data.p, P.ldx, P.dfeat, P.rows, w.p, rho, o.p);
+        launch_predict_linear<T>(P, w.p, rho, o.p, s);
         LSSVM_HIP_CHECK(hipEventRecord(ev_b.e, s));
         LSSVM_HIP_CHECK(hipGetLastError());
         LSSVM_HIP_CHECK(hipMemcpyAsync(out, o.p, npoints * sizeof(T), hipMemcpyDeviceToHost, s));
@@ -1232,7 +1258,8 @@ static void predict_values_impl(const Options &opt, const lssvm_params &params, 
     // polynomial / rbf: out_p = sum_i alpha_i k(sv_i, p) - rho : a rectangular instance of the tile kernel
     DeviceMatrix<T> S, P;
     S.upload(sv, LSSVM_MEM_HOST, nsv, nfeat, 0, s);
-    P.upload(points, LSSVM_MEM_HOST, npoints, nfeat, 0, s);
+    // (the points padded to whole PAIRS of row blocks: the rectangular 256-row kernel below works on pairs; the padding is zero rows whose sums nobody reads)
+    P.upload(points, LSSVM_MEM_HOST, npoints, nfeat, static_cast<size_t>(round_up(static_cast<long>(npoints), 2 * TILE)), s);
     DevBuf<T> cS, cP;
     double rbf_r2 = 0.0;
     bool rbf_direct = rbf_wants_direct_form<T>(opt, params, S, &P, s, &rbf_r2);  // same rule as the training matvec (Problem<T>)
@@ -1285,10 +1312,22 @@ static void predict_values_impl(const Options &opt, const lssvm_params &params, 
     interleave_features<T>(P, s);
     const int num_jt = S.rows_alloc / TILE;
     const int num_ib = P.rows_alloc / TILE;
-    // column tiles per work item: the option, or automatically about 4096 work items (see Problem<T>'s constructor)
+    // Round 6: from 64 row blocks of points on, on at most 128 features, the RECTANGULAR 256-row kernel (tile_matvec_f32_pair_rect, lssvm_tile_f32_pair.hip.hpp) -- eight
+    // waves of a pair of row blocks share one stream of the support vectors' planes, in persistent launches that draw their items from per-XCD counters, like the
+    // training matvec's kernel; the 128-row full-square kernels ran this product at 0.49 of the 16-bit peak where the solve's kernel reaches 0.57 (200 000 points x
+    // 50 000 support vectors x 128, gpurun_out/r06_bench_default_1.json).  Same conditions as Problem<float>'s pair_: a split mode, no run-time integer power, rbf
+    // with both exponent terms folded (|c| <= PAIR_FOLD_MAX_C).
+    bool rect = false;
+    if constexpr (std::is_same_v<T, float>) {
+        const bool poly_generic = params.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params.degree != 2 && params.degree != 3;
+        const bool rbf_ok = params.kernel_type != LSSVM_KERNEL_RBF || (dc_folded != 0 && rbf_r2 <= 2.0 * PAIR_FOLD_MAX_C);
+        rect = v2 && !wide && !rbf_grid && !rbf_direct && planesS.mode != 0 && planesS.ldx16 <= 128 && !poly_generic && rbf_ok && opt.mfma_shape >= 3 && num_ib >= PAIR_MIN_TILES;
+    }
+    // column tiles per work item: the option, or automatically about 4096 work items (see Problem<T>'s constructor); 256-row items: about eight per CU, at most 64 tiles
+    const long rect_tiles = std::min<long>(64, std::max<long>(4, (static_cast<long>(num_ib / 2) * num_jt + 1024) / 2048));
     const int jc_tiles = opt.j_chunk_tiles > 0
                              ? static_cast<int>(opt.j_chunk_tiles)
-                             : static_cast<int>(std::min<long>(16, std::max<long>(2, (static_cast<long>(num_ib) * num_jt + 2048) / 4096)));
+                             : (rect ? static_cast<int>(rect_tiles) : static_cast<int>(std::min<long>(16, std::max<long>(2, (static_cast<long>(num_ib) * num_jt + 2048) / 4096))));
     const int num_jc = (num_jt + jc_tiles - 1) / jc_tiles;
     DevBuf<T> a, partial, Kv, o;
     a.alloc_zero(S.rows_alloc, s);
@@ -1339,6 +1378,58 @@ static void predict_values_impl(const Options &opt, const lssvm_params &params, 
     }
     ta.wide_panels = wide ? 1 : 0;
     set_launch_options(ta, opt);
+    DevBuf<uint16_t> planesP_frag;
+    DevBuf<int2> items_dev;
+    DevBuf<unsigned> queue;
+    if constexpr (std::is_same_v<T, float>) {
+        if (rect) {
+            // the row side once more fragment-major (a wave's load instruction reads 1 KiB in one piece), the item list of the whole rectangle in the lane order of the
+            // training kernel -- list position 8 k + x belongs to XCD lane x, and a lane works through ONE column chunk at a time, so that the workgroups of an XCD share
+            // their column stream in its L2 --, and the counters of a persistent launch
+            const size_t plane_elems = static_cast<size_t>(P.rows_alloc) * planesP.ldx16;
+            planesP_frag.alloc_zero(static_cast<size_t>(planesP.nplanes) * plane_elems, s);
+            const size_t pieces = static_cast<size_t>(planesP.nplanes) * P.rows_alloc * (planesP.ldx16 / 8);
+            hipLaunchKernelGGL(k_planes_fragment_major, dim3(static_cast<unsigned>((pieces + 255) / 256)), dim3(256), 0, s, planesP.buf.p, plane_elems, static_cast<int>(P.rows_alloc), planesP.ldx16,
+                               planesP.nplanes, planesP_frag.p);
+            LSSVM_HIP_CHECK(hipGetLastError());
+            const int pairs = num_ib / 2;
+            std::vector<int2> items;
+            items.reserve(static_cast<size_t>(pairs) * num_jc);
+            std::vector<int> lane_chunk(8, -1), lane_pos(8, 0);
+            int next_chunk = 0;
+            const size_t total = static_cast<size_t>(pairs) * num_jc;
+            while (items.size() < total) {
+                for (int x = 0; x < 8 && items.size() < total; ++x) {
+                    if (lane_chunk[x] == -2) continue;
+                    if (lane_chunk[x] < 0 || lane_pos[x] >= pairs) {
+                        if (next_chunk >= num_jc) {
+                            lane_chunk[x] = -2;  // (this lane has run out of chunks: its positions go to the others)
+                            continue;
+                        }
+                        lane_chunk[x] = next_chunk++;
+                        lane_pos[x] = 0;
+                    }
+                    items.push_back(make_int2(2 * lane_pos[x]++, lane_chunk[x]));
+                }
+            }
+            items_dev.alloc_zero(items.size(), s);
+            LSSVM_HIP_CHECK(hipMemcpyAsync(items_dev.p, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+            LSSVM_HIP_CHECK(hipStreamSynchronize(s));  // `items` goes out of scope
+            int cus = 256;
+            LSSVM_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+            ta.items = items_dev.p;
+            ta.num_items = static_cast<int>(items.size());
+            if (ta.num_items > cus) {
+                queue.alloc_zero(512, s);
+                ta.queue = queue.p;
+                ta.queue_next = queue.p + 256;
+                ta.queue_grid = cus;
+            }
+            ta.Xr16f = planesP_frag.p;
+            ta.row_pair = 1;
+            ta.rect = 1;
+        }
+    }
     LSSVM_HIP_CHECK(hipStreamSynchronize(s));
     const double t_kernel = now_ms();
     LSSVM_HIP_CHECK(hipEventRecord(ev_a.e, s));

@@ -44,8 +44,12 @@ __device__ unsigned long long *lssvm_item_trace = nullptr;  // [num_items][8]: e
 #endif
 
 /* HALF: 0 = waves 0-3 (row block 2p), 1 = waves 4-7 (row block 2p + 1; LAGT = 0, the shipped form: in lock step with the first half).  Both halves
- * execute the same number of barriers. */
-template <int KT, int NK64, int PL, int HALF, int LAGT>
+ * execute the same number of barriers.
+ * RECT (round 6): the RECTANGULAR product of predict_values (rows = the points to predict, columns = the support vectors; reference shape
+ * include/plssvm/backends/HIP/predict_kernel.hip.hpp:63-117) -- the same eight waves on one column stream, the same MFMA groups and LDS image, but every tile of the
+ * item's column chunk is evaluated in full (no diagonal), and there are no mirrored column sums: no d_i, no column butterflies, no records to flush; the epilogue is
+ * the kernel function and one fma per element. */
+template <int KT, int NK64, int PL, int HALF, int LAGT, bool RECT = false>
 __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int item_pos) {
     static_assert(PL == 3 || PL == 2, "three bf16 planes (bf16x6) or two f16 planes (f16x3)");
     static_assert(NK64 <= 2, "the hand-scheduled groups assume the 256-register budget of two waves per SIMD");
@@ -85,7 +89,8 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int it
     const int my_ib = ib0 + HALF;
     const int row0 = ib0 * TILE;
     const int jt_begin = chunk_begin(jc, a.jc_tiles, a.jc_head_tiles, a.jc_head_count);
-    const int jt_end = min(min(jt_begin + chunk_len(jc, a.jc_tiles, a.jc_head_tiles, a.jc_head_count), ib0 + 2), a.num_jt);
+    const int jt_end = RECT ? min(jt_begin + chunk_len(jc, a.jc_tiles, a.jc_head_tiles, a.jc_head_count), a.num_jt)
+                            : min(min(jt_begin + chunk_len(jc, a.jc_tiles, a.jc_head_tiles, a.jc_head_count), ib0 + 2), a.num_jt);
     const int ntiles = jt_end - jt_begin;
     if (ntiles <= 0) return;
     const int nsteps = ntiles * NKC;
@@ -200,7 +205,7 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int it
     // only while |c| <= PAIR_FOLD_MAX_C keeps e and the partial sums inside the fp32 range.
     if constexpr (HALF == 0) {
         if constexpr (KT == KT_RBFF) cis[tid] = __builtin_amdgcn_exp2f(a.cr[row0 + tid]);
-    } else {
+    } else if constexpr (!RECT) {
         const float dv = a.dvec[row0 + tid - PR_ROWS];
         if constexpr (KT == KT_RBFF) {
             dis[tid - PR_ROWS] = dv * __builtin_amdgcn_exp2f(a.cr[row0 + tid - PR_ROWS]);
@@ -267,7 +272,9 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int it
                     // BOTH halves retire their LDS traffic before the hand-over barrier that precedes flush_cols(t - 1): the colred stores of tile t - 1 (all eight waves)
                     // must have landed when waves 4 and 5 read them.  (For waves 0-3 the wait is already implied by the lgkmcnt(0) at the head of the two groups in
                     // front of it; spelled out so that a re-schedule of the groups cannot turn it into a race -- ADVICE r04.)
-                    if (kc == 0 && t > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if constexpr (!RECT) {
+                        if (kc == 0 && t > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
                     if constexpr (!decltype(checked)::value) {
                         if (!LSSVM_DBG(a, 16)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                         if (!LSSVM_DBG(a, 8)) __builtin_amdgcn_s_barrier();  // ablation bit 8: no hand-over barrier in the steady state
@@ -276,7 +283,7 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int it
                     } else {
                         handover_checked(step + LAG);
                     }
-                    if constexpr (HALF == 1) {
+                    if constexpr (HALF == 1 && !RECT) {
                         if (kc == 0 && t > 0 && J - 1 < ib0 + 1) flush_cols(t - 1);
                     }
                 }
@@ -310,8 +317,22 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int it
         // on and above it with two factors in {0, 1} -- the wave then adds exact zeros (K is finite), and the first half's zeros for tile
         // (2p + 1, 2p), which the second half does flush, need no code of their own.  (With several epilogue variants behind branches in one
         // loop the register allocator spills row-panel fragments for the whole kernel, and a scratch reload drains the LDS-DMA queue.)
-        constexpr bool MASKED = decltype(checked)::value;
-        if (!LSSVM_DBG(a, 4)) {  // ablation bit 4: no epilogue
+        constexpr bool MASKED = decltype(checked)::value && !RECT;
+        if constexpr (RECT) {
+            // the rectangular product: K_ij (alpha_j e_j) summed over the tile's columns, nothing mirrored
+            const float *dcr = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                const float djv = dcr[cb * 16 + r];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float kv = apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(acc[rb][cb][e], a);
+                        rowpart[4 * rb + e] = fmaf(kv, djv, rowpart[4 * rb + e]);
+                    }
+            }
+        } else if (!LSSVM_DBG(a, 4)) {  // ablation bit 4: no epilogue
             f32x4 di[2];
             using f32x2 = float __attribute__((ext_vector_type(2)));
             float colacc[8];
@@ -359,7 +380,7 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int it
     // steady-state tiles: the DMA three steps ahead needs no bounds AND the tile is strictly below the diagonal for both halves (J < ib0), so that
     // the loop carries exactly one epilogue (with both variants in it the register allocator spills the row panel around the epilogues, and a
     // scratch reload in the loop drains the LDS-DMA queue)
-    const int nmain = max(0, min(ntiles - TAIL_TILES, ib0 - jt_begin));
+    const int nmain = RECT ? max(0, ntiles - TAIL_TILES) : max(0, min(ntiles - TAIL_TILES, ib0 - jt_begin));
     int t = 0;
     LSSVM_TRACE(2);
     for (; t < nmain; ++t) tile_body(t, std::false_type{});
@@ -373,7 +394,9 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int it
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (jt_begin + ntiles - 1 < ib0 + 1) flush_cols(ntiles - 1);
+    if constexpr (!RECT) {
+        if (jt_begin + ntiles - 1 < ib0 + 1) flush_cols(ntiles - 1);
+    }
 
     // every lane group owns its rows: reduce over the 16 columns of the group and store
 #pragma unroll
@@ -427,6 +450,20 @@ __global__ __launch_bounds__(PR_THREADS, 2) LSSVM_HAND_VGPR_CAP void tile_matvec
             pair_body<KT, NK64, PL, 0, LAGT>(ai, pos);
         } else {
             pair_body<KT, NK64, PL, 1, LAGT>(ai, pos);
+        }
+    });
+}
+
+/* The rectangular instance (predict_values): one work item = a pair of row blocks of the points x a chunk of the support vectors' column tiles; the item list covers the
+ * whole rectangle (Problem-less: lssvm_problem.hip, predict_values_impl builds it), persistent launches as above. */
+template <int KT, int NK64, int PL>
+__global__ __launch_bounds__(PR_THREADS, 2) LSSVM_HAND_VGPR_CAP void tile_matvec_f32_pair_rect(const TileArgs<float> a) {
+    const bool first_half = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6) < 4;
+    for_each_work_item(a, [&](const auto &ai, int pos) {
+        if (first_half) {
+            pair_body<KT, NK64, PL, 0, 0, true>(ai, pos);
+        } else {
+            pair_body<KT, NK64, PL, 1, 0, true>(ai, pos);
         }
     });
 }

@@ -40,7 +40,7 @@ __device__ __forceinline__ f32x4 plane_mfma(const bf16x8 &av, const bf16x8 &bv, 
 /*
  * The split kernel on v_mfma_f32_16x16x32_{bf16,f16}.  (Round 1's 32x32x16 form of it -- each wave 4 accumulators of 32 x 32 -- was retired in
  * round 3: same matrix-core cycles, but in the power-bound regime this kernel runs in MI355X holds a higher clock on the 16x16x32 shape,
- * MI355X_MICROARCH.md "DVFS give-back" (7); measured 511 against 477 ms at 1 000 000 x 128, profiles/r02_ab_mfma_shape_c5.log.)
+ * MI355X_MICROARCH.md "DVFS give-back" (7); measured 511 against 477 ms at 1 000 000 x 128, profiles/archive/r02_ab_mfma_shape_c5.log.)
  * A wave's 32 rows x 128 columns are 2 x 8 blocks of 16 x 16 (64 accumulator registers), one B fragment (16 columns x 32 features, one
  * ds_read_b128) feeds up to 6 MFMAs (2 row blocks x up to 3 row planes).
  * Operand maps (cdna_hip_programming.md section 3): lane l holds A[row l & 15][k = 8 (l >> 4) + j] and B[k = 8 (l >> 4) + j][col l & 15], j = 0..7;

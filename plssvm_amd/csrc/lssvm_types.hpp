@@ -80,6 +80,7 @@ struct TileArgs {
     int jc_head_tiles;  // 256-row workgroups only (0 elsewhere): the FIRST jc_head_count column chunks have this many tiles instead of jc_tiles -- short items that
     int jc_head_count;  // every row pair has, dispatched last: they fill the final dispatch round of a small launch (chunk_begin / chunk_len below)
     int row_pair;     // host side only: != 0 selects the 256-row-workgroup kernels (items = block pairs, lssvm_tile_f32_pair.hip.hpp)
+    int rect;         // host side only: with row_pair, != 0 selects the RECTANGULAR 256-row kernel of predict_values (every tile in full, no mirrored column sums)
     int pair_lag;     // host side only: steps the second half of such a workgroup runs behind the first
     int mfma_shape;   // host side only: option mfma_shape (2 = 128-row workgroups, 3 = 256-row workgroups where they apply)
     int dbg;          // diagnostic ablations (timing only, results wrong): 1 = no global re-loads, 2 = no kernel function in the epilogue

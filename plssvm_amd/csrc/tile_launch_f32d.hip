@@ -59,9 +59,60 @@ static void launch_pair(const TileArgs<float> &a, int kernel_type, hipStream_t s
     }
 }
 
+/* the rectangular instance (predict_values): polynomial of degree 2 / 3 and rbf with folded records, at most 128 features, both plane kinds */
+template <int KT, int PL>
+static void launch_rect_kt(const TileArgs<float> &a, hipStream_t s) {
+    const dim3 grid = sym_grid(a, 1), block(PR_THREADS);
+    switch (a.nk64) {
+#ifndef LSSVM_DEV_SUBSET
+        case 1:
+            ensure_dynamic_lds(tile_matvec_f32_pair_rect<KT, 1, PL>, PR_LDS_BYTES);
+            hipLaunchKernelGGL((tile_matvec_f32_pair_rect<KT, 1, PL>), grid, block, PR_LDS_BYTES, s, a);
+            break;
+#endif
+        case 2:
+            ensure_dynamic_lds(tile_matvec_f32_pair_rect<KT, 2, PL>, PR_LDS_BYTES);
+            hipLaunchKernelGGL((tile_matvec_f32_pair_rect<KT, 2, PL>), grid, block, PR_LDS_BYTES, s, a);
+            break;
+        default: throw Error(LSSVM_ERR_INTERNAL, "no rectangular 256-row tile kernel for this number of features");
+    }
+}
+template <int PL>
+static void launch_rect(const TileArgs<float> &a, int kernel_type, hipStream_t s) {
+    switch (kernel_type) {
+        case KT_POLY:
+            if (a.degree == 3) {
+                launch_rect_kt<KT_POLY3, PL>(a, s);
+            } else if (a.degree == 2) {
+                launch_rect_kt<KT_POLY2, PL>(a, s);
+            } else {
+                throw Error(LSSVM_ERR_INTERNAL, "no rectangular 256-row tile kernel for the run-time integer power");
+            }
+            break;
+        case KT_RBF:
+            if (a.dc_folded == 0) throw Error(LSSVM_ERR_INTERNAL, "the rectangular 256-row rbf kernel needs the folded records");
+            launch_rect_kt<KT_RBFF, PL>(a, s);
+            break;
+        default: throw Error(LSSVM_ERR_INTERNAL, "no rectangular 256-row tile kernel for this kernel function");  // (the linear kernel predicts through w)
+    }
+}
+
 void launch_pair_tile_kernel(const TileArgs<float> &a, int kernel_type, hipStream_t s) {
     if (a.items == nullptr || a.num_items <= 0) return;
     if (a.Xr16f == nullptr) throw Error(LSSVM_ERR_INTERNAL, "the 256-row tile kernel needs the fragment-major row planes");
+    if (a.rect != 0) {
+        if (a.planes_f16 != 0) {
+            launch_rect<2>(a, kernel_type, s);
+        } else {
+#ifdef LSSVM_DEV_SUBSET
+            throw Error(LSSVM_ERR_INTERNAL, "development build: 256-row kernels for the f16 planes only");
+#else
+            launch_rect<3>(a, kernel_type, s);
+#endif
+        }
+        LSSVM_HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (a.planes_f16 != 0) {
         launch_pair<2>(a, kernel_type, s);
     } else {

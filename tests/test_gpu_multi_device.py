@@ -16,7 +16,7 @@ within the kernel-level bar (64 eps of the vector's scale); the full-square vari
 independent of the number of shards (row-owned sums), asserted with array_equal.  CG trajectories are compared after THREE
 iterations: with the reference's start vector x0 = 1 the residual falls by ten orders of magnitude in the first iterations and the
 recursion then amplifies a 1e-16 re-association to 1e-3 within two more steps -- in float64, for one device against itself with another
-chunking just the same (measured: delta_4 equal to 9 digits, delta_5 to 3; profiles/r02_sharded_cg_sensitivity.log); converged
+chunking just the same (measured: delta_4 equal to 9 digits, delta_5 to 3; profiles/archive/r02_sharded_cg_sensitivity.log); converged
 solves are compared at the accuracy the stop criterion defines.
 """
 

@@ -52,7 +52,7 @@ def test_generate_q_and_run_device_kernel_vs_golden(golden, inputs, name, tag, p
     else:
         assert ol.rel_inf(q, golden[key + "/q"]) < 8 * eps
     # the reference's own criterion, ELEMENT-wise |a - b| < 128 eps (|a| + |b|) (EXPECT_FLOATING_POINT_VECTOR_NEAR,
-    # tests/custom_test_macros.hpp:114-137), held at 16 eps here (measured: q <= 0.5, matvec <= 4.8, profiles/r02_golden_elementwise.log)
+    # tests/custom_test_macros.hpp:114-137), held at 16 eps here (measured: q <= 0.5, matvec <= 4.8, profiles/archive/r02_golden_elementwise.log)
     assert ol.float_near(q, golden[key + "/q"], 16)
     rhs = golden[key + "/rhs"]
     QA = float(golden[key + "/QA_cost"])
@@ -115,7 +115,7 @@ def _rho_from_alpha(kernel, X, y, alpha, P, oracle):
 def test_solve_f32_tight_goldens_traces_and_rho(golden, inputs, oracle, name, kernel, mode):
     """The fp32 `cg_tight` goldens (eps = 1e-5) and the per-iteration delta traces of the reference, for both Gram modes.
 
-    What can be held tightly in fp32, measured on MI355X (profiles/r02_golden_elementwise.log): delta_0 agrees with the reference to
+    What can be held tightly in fp32, measured on MI355X (profiles/archive/r02_golden_elementwise.log): delta_0 agrees with the reference to
     <= 2e-6 and delta_1 to <= 6e-5 relative; from delta_2 on the trajectories of ANY two fp32 implementations separate (up to 0.23 at
     delta_2, order 1 at delta_3: x0 = 1 makes delta_0 ~ 1e8, every step amplifies rounding noise -- the reference's own 8-thread run
     leaves its 1-thread run the same way).  Asserted: delta_0 < 1e-5, delta_1 < 1e-3; the iteration count within 2 of the
@@ -154,7 +154,7 @@ def test_solve_f32_tight_goldens_traces_and_rho(golden, inputs, oracle, name, ke
 @pytest.mark.parametrize("kernel", ["linear", "rbf"])
 def test_rho_of_both_gram_modes_at_4096x128(oracle, kernel):
     """at 16384 x 128 (linear) the bf16x6 mode's rho looked 20x worse than the native mode's.  The number was a RELATIVE error
-    of a rho that happens to be ~1e-2 there; over seeds neither mode is systematically better (profiles/r02_rho_study_8192.log,
+    of a rho that happens to be ~1e-2 there; over seeds neither mode is systematically better (profiles/archive/r02_rho_study_8192.log,
     r02_rho_study_16384.log: |drho| 7.6e-2 vs 8.9e-3, 9.3e-3 vs 6.9e-3, 9.4e-2 vs 1.3e-1, 4.0e-2 vs 1.1e-3, 1.3e-1 vs 1.2e-1 ...; the
     reference's own fp32 solve: 4e-2 ... 7e-2).  What IS deterministic is asserted here for both modes at 4096 x 128: rho is consistent
     with the returned alpha, and its distance to the float64 solve is explained by alpha's distance (same linear functional)."""

@@ -137,6 +137,35 @@ def test_predict_values_reports_its_timings_and_follows_the_callers_options(orac
     assert np.array_equal(vals, vals2)
 
 
+@pytest.mark.parametrize("kernel, degree, npts, nsv, d, gram_mode, chunk", [
+    ("rbf", 3, 8192, 3001, 128, 3, 0), ("rbf", 3, 8300, 5000, 64, 3, 5), ("rbf", 3, 9001, 2900, 100, 1, 0), ("polynomial", 3, 8192, 3001, 128, 3, 0),
+    ("polynomial", 2, 8450, 4000, 33, 1, 7), ("polynomial", 3, 16500, 700, 128, 3, 3), ("rbf", 3, 20000, 129, 20, 3, 0), ("rbf", 3, 8193, 128, 128, 3, 1)])
+def test_predict_values_on_the_rectangular_256_row_kernel(oracle, kernel, degree, npts, nsv, d, gram_mode, chunk):
+    """Round 6: from 64 row blocks of points on, on at most 128 features, predict_values runs `tile_matvec_f32_pair_rect` -- the 256-row, shared
+    column stream, persistent-launch form of the training kernel for the RECTANGULAR product (rows = points, columns = support vectors; the reference's shape:
+    include/plssvm/backends/HIP/predict_kernel.hip.hpp:63-117).  Ragged point and support-vector counts (pairs of row blocks padded with zero rows, a last column tile
+    of one support vector), one and several column chunks per item (option j_chunk_tiles), both plane kinds: against the float64 oracle on sampled points at the bar
+    of the 128-row kernels (16 eps of the summands' scale), and against the 128-row kernels themselves (option mfma_shape = 2) on ALL points."""
+    rng = np.random.default_rng(npts + nsv)
+    X, _ = make_blobs_pm1(nsv + npts, d, seed=13, dtype=np.float32)
+    sv, pts = X[:nsv], X[nsv:]
+    alpha = rng.standard_normal(nsv).astype(np.float32)
+    kw = dict(degree=degree, gamma=1.0 / d, coef0=0.5)
+    prm = Parameter(kernel_type=kernel, degree=degree, gamma=1.0 / d, coef0=0.5)
+    info, info128 = {}, {}
+    got, _ = backend.predict_values(prm, sv, alpha, 0.125, None, pts, options=Options(gram_mode=gram_mode, j_chunk_tiles=chunk), info_out=info)
+    got128, _ = backend.predict_values(prm, sv, alpha, 0.125, None, pts, options=Options(gram_mode=gram_mode, mfma_shape=2), info_out=info128)
+    assert info["gram_mode"] == (2 if gram_mode == 3 else gram_mode) and info128["gram_mode"] == info["gram_mode"]
+    sample = np.unique(np.concatenate([np.arange(0, npts, 211), [0, 127, 128, 255, 256, npts - 1]]))
+    want, _ = oracle.predict_values(kernel, sv.astype(np.float64), alpha.astype(np.float64), 0.125, pts[sample].astype(np.float64), **kw)
+    scale = np.abs(alpha).sum() * (1.0 if kernel == "rbf" else float(np.max(np.abs(1.0 / d * (pts[sample].astype(np.float64) @ sv.astype(np.float64).T) + 0.5)) ** degree))
+    assert np.max(np.abs(got[sample] - want)) < 16 * EPS32 * scale, np.max(np.abs(got[sample] - want)) / (EPS32 * scale)
+    assert np.max(np.abs(got128[sample] - want)) < 16 * EPS32 * scale
+    assert np.max(np.abs(got - got128)) < 16 * EPS32 * scale  # every point, the padded pair included
+    again, _ = backend.predict_values(prm, sv, alpha, 0.125, None, pts, options=Options(gram_mode=gram_mode, j_chunk_tiles=chunk))
+    assert np.array_equal(got, again)  # which CU evaluates an item changes no result
+
+
 # ------------------------------------------------------------------------------------------------------------ the Gram mode by data (VERDICT r05 item 4)
 @pytest.mark.parametrize("name", ["plus_minus_one", "small_integers", "sparse01"])
 @pytest.mark.parametrize("kernel", ["linear", "rbf"])
@@ -165,14 +194,15 @@ def test_exactly_representable_data_takes_f16x3_and_matches_the_float64_oracle(o
 
 @pytest.mark.parametrize("kernel", ["linear", "rbf"])
 def test_data_that_fails_the_representability_check_reports_bf16x6(oracle, kernel):
-    """Columns of very different magnitude (N(0, 1) x 10^U(-6, 6) per feature, unscaled): two f16 planes lose the small columns beside the large ones, the check
-    says so (lssvm_cg_info.f16_row_rel_error above 2^-22), the solve runs bf16x6 -- gram_mode = 1 in lssvm_cg_info -- and keeps the fp32-class accuracy; forcing f16x3
-    (gram_mode 2, no check) on the same data shows what the check prevents."""
+    """POINTS of very different magnitude (N(0, 1) x 10^U(-4, 4) per ROW, unscaled): the planes carry ONE power-of-two scale for the whole matrix, so the small rows'
+    mid plane falls into f16's subnormal range and loses bits -- the check measures it (lssvm_cg_info.f16_row_rel_error above 2^-22), the solve runs bf16x6 (gram_mode = 1
+    in lssvm_cg_info) and keeps the fp32-class accuracy; forcing f16x3 (gram_mode 2: no check) on the same data shows what the check prevents.  (Columns of different
+    magnitude do NOT fail it: a row's error is measured against the row's norm, which its large entries dominate -- tests/tools/gram_mode_by_data.py, "wide_range".)"""
     rng = np.random.default_rng(12)
     N, d = 12000, 128
-    X = (rng.normal(0, 1, size=(N, d)) * 10.0 ** rng.uniform(-6, 6, size=(1, d))).astype(np.float32)
+    X = (rng.normal(0, 1, size=(N, d)) * 10.0 ** rng.uniform(-4, 4, size=(N, 1))).astype(np.float32)
     X64 = X.astype(np.float64)
-    gamma = 1.0 / float(np.max(np.einsum("ij,ij->i", X64, X64)))  # rbf: an exponent scale of a few units
+    gamma = 8.0 / float(np.max(np.einsum("ij,ij->i", X64, X64)))  # rbf: an exponent scale of a few units
     rows = np.sort(rng.choice(N - 1, size=40, replace=False))
     with backend.ResidentProblem(Parameter(kernel_type=kernel, gamma=gamma), X) as prob:
         info = prob.info()
@@ -180,14 +210,14 @@ def test_data_that_fails_the_representability_check_reports_bf16x6(oracle, kerne
     if kernel == "linear":
         assert info["gram_mode"] == 1 and info["f16_row_rel_error"] > 2.0 ** -22, info
     else:
-        # rbf accepts f16 planes under an ABSOLUTE bound on the exponent's error as well (the small columns do not matter to a distance the large ones dominate)
+        # rbf accepts f16 planes under an ABSOLUTE bound on the exponent's error as well (a small row is a point near the centre: its exponent needs no relative accuracy)
         assert info["gram_mode"] in (1, 2) and info["rbf_direct"] == 0, info
     assert err < 4 * EPS32, err / EPS32
     if kernel == "linear":
         with backend.ResidentProblem(Parameter(kernel_type=kernel, gamma=gamma), X, options=Options(gram_mode=2)) as forced:
             assert forced.info()["gram_mode"] == 2
             err_forced, _ = _rows_vs_oracle(oracle, forced, kernel, X, gamma, rows)
-        print(f"\nwide-range columns, linear: bf16x6 (chosen) {err / EPS32:.2f} eps, f16x3 forced {err_forced / EPS32:.2f} eps")
+        print(f"\nrows of different magnitude, linear: bf16x6 (chosen) {err / EPS32:.2f} eps, f16x3 forced {err_forced / EPS32:.2f} eps")
 
 
 # ------------------------------------------------------------------------------------------------------------ ADVICE r05

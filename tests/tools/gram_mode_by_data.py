@@ -13,6 +13,7 @@ other shapes, 50 000 x 128 each unless noted:
     lognormal      exp(N(0, 1.5^2)) per entry, unscaled, heavy tailed (entries from 1e-3 to 1e3)
     lognormal_mm   the same, min-max scaled to [-1, 1] per feature (what plssvm-scale would hand to plssvm-train)
     wide_range     N(0, 1) x 10^U(-6, 6) per FEATURE: columns of very different magnitude, unscaled
+    row_scales     N(0, 1) x 10^U(-4, 4) per POINT: rows of very different magnitude, unscaled (the one shape here that two f16 planes with ONE scale cannot hold)
     ref500x200     the reference's own tests/data/libsvm/500x200.libsvm (from the committed golden inputs; 500 x 200)
 
 Per data set and kernel (linear; rbf with gamma = 1 / num_features): the representability statistic the library measured (lssvm_cg_info.f16_row_rel_error; accepted up
@@ -59,6 +60,7 @@ def data_sets(n, d, seed=7):
     yield "lognormal", logn.astype(np.float32), y
     yield "lognormal_mm", minmax(logn), y
     yield "wide_range", (rng.normal(0, 1, size=(n, d)) * 10.0 ** rng.uniform(-6, 6, size=(1, d))).astype(np.float32), y
+    yield "row_scales", (rng.normal(0, 1, size=(n, d)) * 10.0 ** rng.uniform(-4, 4, size=(n, 1))).astype(np.float32), y
     inputs = np.load(os.path.join(ROOT, "tests", "golden", "inputs.npz"))
     if "500x200_X" in inputs:
         yield "ref500x200", inputs["500x200_X"].astype(np.float32), inputs["500x200_y"].astype(np.float32)
