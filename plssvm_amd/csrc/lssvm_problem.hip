@@ -1432,6 +1432,14 @@ static void predict_values_impl(const Options &opt, const lssvm_params &params, 
     }
     LSSVM_HIP_CHECK(hipStreamSynchronize(s));
     const double t_kernel = now_ms();
+    // (measurement aid: LSSVM_MI355_PREDICT_REPEAT=k in the environment launches the product kernel k times -- it overwrites its slabs, the result is the same -- and times
+    // the LAST launch: what the kernel takes once the chip's clocks have settled, beside the first launch after the set-up's idle gaps that a single call measures)
+    int repeat = 1;
+    if (const char *rep = std::getenv("LSSVM_MI355_PREDICT_REPEAT"); rep != nullptr) repeat = std::min(std::max(std::atoi(rep), 1), 64);
+    for (int k = 0; k + 1 < repeat; ++k) {
+        launch_tile_kernel<T>(ta, params.kernel_type, rbf_direct, num_jc, s);
+        if (ta.queue != nullptr) std::swap(ta.queue, ta.queue_next);  // (a persistent launch zeroes the OTHER set of counters)
+    }
     LSSVM_HIP_CHECK(hipEventRecord(ev_a.e, s));
     launch_tile_kernel<T>(ta, params.kernel_type, rbf_direct, num_jc, s);
     LSSVM_HIP_CHECK(hipEventRecord(ev_b.e, s));

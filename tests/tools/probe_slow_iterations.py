@@ -15,7 +15,7 @@ for name,(X,kernel,gm) in cases.items():
     with backend.ResidentProblem(Parameter(kernel_type=kernel,gamma=1.0/d),X,options=Options(gram_mode=gm)) as prob:
         prob.cg_begin(y,1e-30)
         i_prev=prob.info()
-        for it in range(14):
+        for it in range(30):
             t0=time.perf_counter(); prob.cg_step(1); prob.synchronize(); dt=(time.perf_counter()-t0)*1e3
             i=prob.info()
             print(f" it {it:2d} wall {dt:7.3f} ms  delta {i['residuum']:.4e}  timed {i['matvec_timed']} kern_total {i['matvec_kernel_ms_total']:.3f} gram {i['gram_mode']} direct {i['rbf_direct']} sym {i['symmetric']} launches/mv {i['tile_launches_per_matvec']} persistent {i['persistent_launches']}")
