@@ -5,7 +5,9 @@
 WL=${1:-c2}; STEPS=${2:-5}; OUT=${3:-gpurun_out/pmc_$WL}; if [ $# -ge 3 ]; then shift 3; else shift $#; fi; EXTRA="$@"
 export TMPDIR=/tmp
 mkdir -p "$OUT"
-run() { name=$1; shift; timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py --workload "$WL" --steps "$STEPS" --warmup 1 --no-cpu-baseline --no-native-reference --no-ceiling --no-other-workloads $EXTRA > "$OUT/$name.log" 2>&1; echo "$name rc=$?"; }
+# WL = predict: the predict leg on its own (tests/tools/predict_bench.py) instead of a CG workload of bench.py
+if [ "$WL" = predict ]; then PROG="tests/tools/predict_bench.py 200000 50000 2"; else PROG="bench.py --workload $WL --steps $STEPS --warmup 1 --no-cpu-baseline --no-native-reference --no-ceiling --no-other-workloads $EXTRA"; fi
+run() { name=$1; shift; timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 $PROG > "$OUT/$name.log" 2>&1; echo "$name rc=$?"; }
 [ -n "$PMC_SQ_ONLY" ] || run fetch FETCH_SIZE
 [ -n "$PMC_SQ_ONLY" ] || run write WRITE_SIZE
 run sq1 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE

@@ -33,6 +33,16 @@ for wl in $PWLS; do
   [ -n "$f" ] && cp "$f" $O/${TAG}_rocprofv3_kernel_stats_bench_${wl}.csv
   grep "^{" $O/prof_$wl.log | tail -1 > $O/${TAG}_rocprofv3_bench_line_${wl}.json
 done
+# predict_values (other_workloads.predict): the same two kinds of passes around the predict leg alone
+rm -rf $O/prof_predict
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_predict -- python3 tests/tools/predict_bench.py > $O/prof_predict.log 2>&1
+f=$(find $O/prof_predict -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp "$f" $O/${TAG}_rocprofv3_kernel_stats_predict.csv
+grep "^{" $O/prof_predict.log | tail -1 > $O/${TAG}_rocprofv3_bench_line_predict.json
+rm -rf $O/pmc_predict
+bash tests/tools/pmc_passes.sh predict 2 $O/pmc_predict
+python3 tests/tools/pmc_summarize.py predict $O/pmc_predict > $O/${TAG}_pmc_predict.txt 2>&1
+rm -rf $O/pmc_predict
 [ -z "$PROFILE_ONLY" ] && : > $O/${TAG}_pmc_tile_matvec.txt
 for wl in $PWLS; do
   rm -rf $O/pmc_$wl
