@@ -154,7 +154,7 @@ def predict_main(argv=None) -> int:
         real_type = np.float32 if args.use_float_as_real_type else np.float64
         label_type = str if args.use_strings_as_labels else float
         t_r = time.perf_counter()
-        data = DataSet(filename=args.test, real_type=real_type, label_type=label_type) if _has_two_labels(args.test, label_type) else _unlabeled(args.test, real_type, label_type)
+        data = _test_data(args.test, real_type, label_type)  # (the file is parsed ONCE: until round 6 a first pass looked at its labels only)
         t_r = time.perf_counter() - t_r
         t_m = time.perf_counter()
         model = Model.load(args.model, real_type=real_type, label_type=label_type)
@@ -262,19 +262,13 @@ def _parse_by_extension(filename, dtype, label_type):
     return parse_libsvm_data(filename, dtype=dtype, label_type=label_type)
 
 
-def _has_two_labels(filename, label_type):
-    _, labels = _parse_by_extension(filename, np.float64, label_type)
-    return labels is not None and len(set(labels)) == 2
-
-
-class _Unlabeled(DataSet):
-    pass
-
-
-def _unlabeled(filename, real_type, label_type=float):
-    """a test file without labels, or with a single class: usable for prediction only (labels kept for the accuracy line, parsed with the
-    label type the command line asked for: --use_strings_as_labels must not turn "cat" into a float conversion error)"""
+def _test_data(filename, real_type, label_type=float):
+    """The test file of plssvm-predict: a labelled data set where it holds exactly two classes; without labels, or with a single class, it is usable for
+    prediction only (labels kept for the accuracy line, parsed with the label type the command line asked for: --use_strings_as_labels must not turn "cat" into
+    a float conversion error)."""
     X, labels = _parse_by_extension(filename, real_type, label_type)
+    if labels is not None and len(set(labels)) == 2:
+        return DataSet(X, labels, real_type=real_type, label_type=label_type)
     ds = DataSet(X, None, real_type=real_type)
     ds._labels = labels
     return ds

@@ -862,9 +862,10 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         const bool poly_generic = tile_params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && tile_params_.degree != 2 && tile_params_.degree != 3;
         const bool narrow = wide_linear_ ? true : (round_up(static_cast<long>(num_features), 64) <= 128 && v2_eligible(opt_, ldx_probe, rbf_direct_));
         // (rbf: that kernel folds BOTH exponent terms out of the chain -- only while |c| = R2 / 2 stays small and the folded records are on)
-        const bool rbf_ok = tile_params_.kernel_type != LSSVM_KERNEL_RBF || (opt_.rbf_fold != 0 && rbf_r2_ <= 2.0 * PAIR_FOLD_MAX_C);
+        // (round 6: rbf on GRID planes has its 256-row form too -- start values instead of folded terms, so neither condition applies to it)
+        const bool rbf_ok = tile_params_.kernel_type != LSSVM_KERNEL_RBF || rbf_grid_ || (opt_.rbf_fold != 0 && rbf_r2_ <= 2.0 * PAIR_FOLD_MAX_C);
         // (below 64 row blocks -- 8 192 points -- the 128-row workgroups have more items to spread over the chip: 3 000 points 13.8 against 19.7 us)
-        pair_ = sym_ && opt_.gram_mode != 0 && opt_.mfma_shape >= 3 && !wide_nl_ && !poly_generic && narrow && rbf_ok && num_tiles_ >= PAIR_MIN_TILES && !rbf_grid_;
+        pair_ = sym_ && opt_.gram_mode != 0 && opt_.mfma_shape >= 3 && !wide_nl_ && !poly_generic && narrow && rbf_ok && num_tiles_ >= PAIR_MIN_TILES;
     }
     choose_shard_geometry();
     // 256-row workgroups: PERSISTENT launches, the work items drawn from per-XCD counters (for_each_work_item, lssvm_device_common.hip.hpp) instead of one workgroup per

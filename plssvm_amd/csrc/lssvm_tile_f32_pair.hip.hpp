@@ -53,10 +53,17 @@ template <int KT, int NK64, int PL, int HALF, int LAGT, bool RECT = false>
 __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int item_pos) {
     static_assert(PL == 3 || PL == 2, "three bf16 planes (bf16x6) or two f16 planes (f16x3)");
     static_assert(NK64 <= 2, "the hand-scheduled groups assume the 256-register budget of two waves per SIMD");
-    static_assert(KT != KT_RBF, "rbf runs here with BOTH exponent terms folded (KT_RBFF, see below); the unfolded form stays on the 128-row kernels");
+    static_assert(KT != KT_RBF, "rbf runs here with BOTH exponent terms folded (KT_RBFF, see below) or on grid planes (KT_RBFG); the unfolded form stays on the 128-row kernels");
     static_assert(LAGT >= 0 && LAGT <= 7, "0 ... 3: steps of lag; 4 ... 7: priority experiments of the development builds");
     constexpr bool F16 = PL == 2;
-    constexpr int NKC = PL * NK64;
+    // KT_RBFG (round 6: rbf with a large exponent scale in the 256-row form; s6w_body has the 128-row form and the derivation): three f16 column planes (h | s1 | s2) and FOUR
+    // phases per tile, each over all 64-feature chunks -- h x h, h x (s1, s2), s1 x (h, s1), s2 x h -- with the accumulators started from sigma^2 (ch_i + ch_j), an exact sum
+    constexpr bool GRID = KT == KT_RBFG;
+    static_assert(!GRID || (PL == 2 && !RECT), "the grid-plane kernel exists with f16 planes, symmetric variant");
+    constexpr int NKC = GRID ? 4 * NK64 : PL * NK64;
+    constexpr auto col_plane_of = [](int kc) constexpr { return GRID ? (kc / NK64 == 0 ? 0 : kc / NK64 - 1) : kc % PL; };
+    constexpr auto chunk_of = [](int kc) constexpr { return GRID ? kc % NK64 : kc / PL; };
+    constexpr auto nq_of = [](int kc) constexpr { return GRID ? ((kc / NK64 == 1 || kc / NK64 == 2) ? 2 : 1) : PL - kc % PL; };
     // LAGT = 0, the shipped form: lock step, and the second-dispatched half of the workgroup (waves 4-7, the loser of the SIMD's issue arbitration by age) at
     // s_setprio 1 for the whole kernel (MI355X_MICROARCH.md, Two waves per SIMD, item 4): 265.0 -> 262.1 ms at 1 000 000 x 128 rbf, neutral for the linear
     // kernel (profiles/r04_ab_pair_priority.log).  Development builds also carry 1, 3 = steps of lag (no priority); 4 = lock step WITHOUT the priority;
@@ -64,8 +71,15 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int it
     constexpr int PRIO = (LAGT == 0 || LAGT == 6) ? (HALF == 1 ? 1 : 0) : (LAGT == 5 ? (HALF == 1 ? 3 : 0) : (LAGT == 7 ? (HALF == 0 ? 1 : 0) : 0));
     constexpr int LAGE = LAGT == 6 ? 1 : (LAGT >= 4 ? 0 : LAGT);
     constexpr int LAG = HALF ? LAGE : 0;  // this half's distance behind the global step counter
-    constexpr int PLA = F16 ? ((KT == KT_RBF || KT == KT_RBFF) ? 3 : 2) : 3;
+    constexpr int PLA = F16 ? ((KT == KT_RBF || KT == KT_RBFF || GRID) ? 3 : 2) : 3;
     constexpr auto row_plane = [](int p, int q) constexpr { return (F16 && PLA == 3) ? (p == 0 ? (q == 0 ? 2 : 1) : 0) : q; };
+    constexpr auto row_plane_of = [row_plane](int kc, int q) constexpr {  // row plane of the q-th product of step kc (grid planes: by phase)
+        if (GRID) {
+            const int ph = kc / NK64;
+            return ph == 0 ? 0 : (ph == 1 ? (q == 0 ? 1 : 2) : (ph == 2 ? (q == 0 ? 0 : 1) : 0));
+        }
+        return row_plane(kc % PL, q);
+    };
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char *ring = smem_raw;                                               // [PR_RING][128 columns][128 B]
     char *dcs = smem_raw + PR_RING * V2_SLOT_BYTES;                      // [V2_DC_SLOTS][256 floats]
@@ -110,7 +124,7 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int it
     auto issue_chunk = [&](int step) {  // generic form (prologue, last tiles)
         const int t = step / NKC;
         const int kc = step - t * NKC;
-        const char *base = sgpr_ptr(a.Xc16 + (kc % PL) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + (kc / PL) * 64);
+        const char *base = sgpr_ptr(a.Xc16 + col_plane_of(kc) * a.plane_stride + static_cast<size_t>(jt_begin + t) * TILE * a.ldx16 + chunk_of(kc) * 64);
         const unsigned slot = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(dma_lds + static_cast<unsigned>(step & (PR_RING - 1)) * V2_SLOT_BYTES)));
         static_for<0, 2>([&](auto i_c) { lds_dma16<decltype(i_c)::value * 1024>(dma_off[decltype(i_c)::value], base, slot); });
     };
@@ -122,7 +136,7 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int it
         constexpr int KC = KC3 % NKC;
         constexpr int i = decltype(i_c)::value;
         if (LSSVM_DBG(a, 16)) return;  // ablation: no LDS-DMA after the prologue
-        const char *base = xc_tile + (KC3 / NKC) * tile_bytes + (KC % PL) * plane_bytes + (KC / PL) * 128;
+        const char *base = xc_tile + (KC3 / NKC) * tile_bytes + col_plane_of(KC) * plane_bytes + chunk_of(KC) * 128;
         lds_dma16<i * 1024>(dma_off[i], sgpr_ptr(base), dma_lds + slot_idx * V2_SLOT_BYTES);
     };
     auto issue_dc = [&](int t) {  // the record of column tile t: by the second half (four waves x 256 B)
@@ -177,7 +191,7 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int it
     // same product the same way) -- so two planes are loaded and the third is derived in registers: a third less of the row panel, whose load is most of a work
     // item's start (192 -> 128 KiB per item at ~11 B / cycle / CU).  Bit-identical; 1 000 000 x 128: 267.8 -> 266.7 ms, 50 000 x 128: 0.759 -> 0.755 ms per
     // iteration, same box, interleaved (profiles/r05_ab_mfma_order_and_derived_row_plane.log, "lib_v_derive")
-    constexpr int P_FIRST = (F16 && PLA == 3) ? 1 : 0;
+    constexpr int P_FIRST = (F16 && PLA == 3 && !GRID) ? 1 : 0;  // (grid planes: h, s1, s2 are three planes of their own)
     const size_t frag_chunk = a.plane_stride_r / static_cast<size_t>(a.ldx16) / 16 * 1024;  // elements between the 64-feature chunks of a fragment-major plane
 #pragma unroll
     for (int p = P_FIRST; p < PLA; ++p) {
@@ -205,10 +219,13 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int it
     // only while |c| <= PAIR_FOLD_MAX_C keeps e and the partial sums inside the fp32 range.
     if constexpr (HALF == 0) {
         if constexpr (KT == KT_RBFF) cis[tid] = __builtin_amdgcn_exp2f(a.cr[row0 + tid]);
+        if constexpr (GRID) cis[tid] = a.cr[row0 + tid];  // sigma^2 ch_i: the start value
     } else if constexpr (!RECT) {
         const float dv = a.dvec[row0 + tid - PR_ROWS];
         if constexpr (KT == KT_RBFF) {
             dis[tid - PR_ROWS] = dv * __builtin_amdgcn_exp2f(a.cr[row0 + tid - PR_ROWS]);
+        } else if constexpr (GRID) {
+            dis[tid - PR_ROWS] = dv * a.er[row0 + tid - PR_ROWS];  // the row's folded factor E_i rides on d_i
         } else {
             dis[tid - PR_ROWS] = dv;
         }
@@ -256,17 +273,31 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int it
         const int s0 = t * NKC;
         const int J = jt_begin + t;
         const unsigned phase = static_cast<unsigned>(s0) & (PR_RING - 1);
+        if constexpr (GRID) {  // the accumulators start at sigma^2 (ch_i + ch_j), an exact sum (s6w_body)
+            const float *dcr0 = reinterpret_cast<const float *>(dcs + (t % V2_DC_SLOTS) * 1024);
+            f32x4 civ[2];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) civ[rb] = *reinterpret_cast<const f32x4 *>(cis + wave * 32 + 16 * rb + 4 * g);
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                const float cjv = dcr0[128 + cb * 16 + r];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[rb][cb][e] = civ[rb][e] + cjv;
+            }
+        }
         static_for<0, NKC>([&](auto kc_c) {
             constexpr int kc = decltype(kc_c)::value;
-            constexpr int chunk = kc / PL, plane = kc % PL;
+            constexpr int chunk = chunk_of(kc);
             const int step = s0 + kc;
             const unsigned slot_off = ((phase + kc) & (PR_RING - 1)) * V2_SLOT_BYTES;
             const unsigned slot_next_off = ((phase + kc + 1) & (PR_RING - 1)) * V2_SLOT_BYTES;
             static_for<0, 4>([&](auto mm_c) {
                 constexpr int mm = decltype(mm_c)::value;
                 constexpr int kk = mm >> 1, cbh = mm & 1;
-                constexpr int NQ = PL - plane;
-                constexpr int Z = (kc == 0 && kk == 0) ? 1 : 0;  // first MFMA of every accumulator of this column half: C = 0
+                constexpr int NQ = nq_of(kc);
+                constexpr int Z = (!GRID && kc == 0 && kk == 0) ? 1 : 0;  // first MFMA of every accumulator of this column half: C = 0 (grid planes: the start values above)
                 constexpr int CUR = mm & 1;
                 if constexpr (mm == 2) {
                     // BOTH halves retire their LDS traffic before the hand-over barrier that precedes flush_cols(t - 1): the colred stores of tile t - 1 (all eight waves)
@@ -292,7 +323,7 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int it
                 constexpr int PO = mm < 3 ? 4 * NH * 2048 : 0;
                 f32x4 &c0 = acc[0][4 * cbh + 0], &c1 = acc[1][4 * cbh + 0], &c2 = acc[0][4 * cbh + 1], &c3 = acc[1][4 * cbh + 1];
                 f32x4 &c4 = acc[0][4 * cbh + 2], &c5 = acc[1][4 * cbh + 2], &c6 = acc[0][4 * cbh + 3], &c7 = acc[1][4 * cbh + 3];
-                constexpr int P0 = row_plane(plane, 0), P1 = NQ >= 2 ? row_plane(plane, 1) : P0, P2 = NQ >= 3 ? row_plane(plane, 2) : P0;
+                constexpr int P0 = row_plane_of(kc, 0), P1 = NQ >= 2 ? row_plane_of(kc, 1) : P0, P2 = NQ >= 3 ? row_plane_of(kc, 2) : P0;
                 const bf16x8 &a00 = afrag[P0][2 * chunk + kk][0], &a01 = afrag[P0][2 * chunk + kk][1];
                 const bf16x8 &a10 = afrag[P1][2 * chunk + kk][0], &a11 = afrag[P1][2 * chunk + kk][1];
                 const bf16x8 &a20 = afrag[P2][2 * chunk + kk][0], &a21 = afrag[P2][2 * chunk + kk][1];
@@ -353,7 +384,7 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int it
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float kv = apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(acc[rb][cb][e], a);
+                        const float kv = apply_kernel_function<v2_base_kt(KT), v2_degree_class(KT)>(GRID ? acc[rb][cb][e] * a.gamma : acc[rb][cb][e], a);  // (grid planes: the chain carries sigma^2, gamma = sigma^-2)
                         rowpart[4 * rb + e] = fmaf(kv, djv, rowpart[4 * rb + e]);
                         kvp[e & 1] = kv;
                         if (e & 1) {
@@ -418,6 +449,10 @@ __device__ __forceinline__ void pair_body(const TileArgs<float> &a, const int it
 #pragma unroll
             for (int e = 0; e < 4; ++e) rowpart[4 * rb + e] *= ei[e];
         }
+    }
+    if constexpr (GRID) {  // the row's folded factor E_i, once per work item
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rowpart[i] *= a.er[row0 + wave * 32 + 16 * (i >> 2) + 4 * g + (i & 3)];
     }
     if (r == 0) {
         float *dst = a.partial + static_cast<size_t>(jc) * a.part_stride + ibl * TILE + wave * 32 + 4 * g;

@@ -53,6 +53,14 @@ static void launch_pair(const TileArgs<float> &a, int kernel_type, hipStream_t s
             }
             break;
         default:
+            if (a.rbf_grid != 0) {  // rbf on grid planes (round 6): f16 planes only
+                if constexpr (PL == 2) {
+                    launch_pair_kt<KT_RBFG, PL>(a, s);
+                } else {
+                    throw Error(LSSVM_ERR_INTERNAL, "the grid planes of the rbf kernel are f16 planes");
+                }
+                break;
+            }
             if (a.dc_folded == 0) throw Error(LSSVM_ERR_INTERNAL, "the 256-row rbf kernel needs the folded records");  // (Problem<float> does not choose block pairs otherwise)
             launch_pair_kt<KT_RBFF, PL>(a, s);
             break;

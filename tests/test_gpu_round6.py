@@ -166,6 +166,60 @@ def test_predict_values_on_the_rectangular_256_row_kernel(oracle, kernel, degree
     assert np.array_equal(got, again)  # which CU evaluates an item changes no result
 
 
+# ------------------------------------------------------------------------------------------------------------ rbf on grid planes in the 256-row form
+@pytest.mark.parametrize("d, gamma, devices", [(128, 4.0, None), (128, 30.0, None), (64, 8.0, None), (100, 2.0, [0, 0, 0]), (40, 60.0, None)])
+def test_rbf_on_grid_planes_in_the_256_row_kernel(oracle, d, gamma, devices):
+    """Round 6: from 64 row blocks on, rbf with an exponent scale of 32 ... 4 096 runs `tile_matvec_f32_pair<KT_RBFG, ...>` -- the grid planes (x = h + s1 + s2,
+    accumulators started from the exact grid norms, the h.h products first) in the 256-row, shared column stream, persistent-launch form.  The bar of
+    test_rbf_on_grid_planes_keeps_the_direct_forms_accuracy_on_the_matrix_cores, unchanged, on 8 704 points with near-duplicate pairs: against the float64 oracle on the scale of
+    each row's K.v summands, beside the direct kernel (rbf_form 1) and the 128-row grid kernel (mfma_shape 2), symmetric and full square, one device and three shards."""
+    rng = np.random.default_rng(5)
+    N = 8704
+    X, y = make_blobs_pm1(N, d, seed=6, dtype=np.float32)
+    X[1::2] = (X[0::2] + rng.normal(0, 2e-3, size=X[0::2].shape)).astype(np.float32)  # near-duplicate pairs: the pairs that lose digits in the norm expansion
+    p = Parameter(kernel_type="rbf", gamma=gamma)
+    n = N - 1
+    X64 = X.astype(np.float64)
+    q64 = oracle.q("rbf", X64, gamma=gamma)
+    v64 = rng.uniform(-1, 1, size=n)
+    basis = np.linalg.qr(np.stack([np.ones(n), q64], axis=1))[0]  # a right-hand side orthogonal to 1 and q: the rank-1 terms vanish, the comparison sees K itself
+    for _ in range(2):
+        v64 = v64 - basis @ (basis.T @ v64)
+    v = v64.astype(np.float32)
+    v64 = v.astype(np.float64)
+    want = oracle.matvec("rbf", X64, q64, v64, np.zeros(n), 2.0, 1.0, 1.0, gamma=gamma)
+    sq = np.einsum("ij,ij->i", X64, X64)
+    absv = np.abs(v64)
+    scale_k = np.zeros(n)
+    for lo in range(0, n, 2048):  # K |v| in row blocks (the full 8 703 x 8 703 matrix in float64 is 600 MB)
+        hi = min(n, lo + 2048)
+        K = np.exp(-gamma * np.maximum(sq[lo:hi, None] + sq[None, :n] - 2.0 * (X64[lo:hi] @ X64[:n].T), 0.0))
+        scale_k[lo:hi] = K @ absv
+    scale_k += absv + (2.0 + np.abs(q64)) * abs(v64.sum()) + abs(q64 @ v64)
+    errs = {}
+    for name, opts in (("256-row grid planes", {}), ("256-row grid planes, again", {}), ("128-row grid planes", dict(mfma_shape=2)), ("direct", dict(rbf_form=1)), ("norm expansion", dict(rbf_form=2)),
+                       ("full square", dict(symmetric=0))):
+        with backend.ResidentProblem(p, X, devices=devices, options=Options(**opts)) as prob:
+            info = prob.info()
+            got = prob.matvec(v, np.zeros(n, np.float32), 1.0)
+        if name.startswith("256-row"):
+            assert info["gram_mode"] == 3 and info["rbf_direct"] == 0 and info["symmetric"] == 1 and 32 < info["rbf_exponent_scale"] <= 4096, info
+            if devices is None:
+                assert info["persistent_launches"] >= 1, info  # the 256-row kernels' launches (the 128-row grid kernel has one workgroup per item)
+        if name == "128-row grid planes":
+            assert info["gram_mode"] == 3 and info["persistent_launches"] == 0
+        errs[name] = (float(np.max(np.abs(got - want) / scale_k)), got)
+    print(f"\n{N} x {d}, gamma {gamma:g}, exponent scale {info['rbf_exponent_scale']:.0f}: " + ", ".join(f"{k} {e / EPS32:.2f} eps" for k, (e, _) in errs.items()))
+    assert np.array_equal(errs["256-row grid planes"][1], errs["256-row grid planes, again"][1])
+    assert errs["256-row grid planes"][0] < 16 * EPS32 and errs["128-row grid planes"][0] < 16 * EPS32 and errs["direct"][0] < 16 * EPS32 and errs["full square"][0] < 16 * EPS32
+    assert errs["256-row grid planes"][0] < max(4 * errs["direct"][0], 8 * EPS32)
+    assert errs["norm expansion"][0] > 2 * errs["256-row grid planes"][0]  # what the grid planes are for
+    # a CG solve on the 256-row grid kernel ends where the direct kernel's ends
+    a_grid, rho_grid, i_grid = backend.solve_system_of_linear_equations(p, X, y, 1e-5, 300, devices=devices)
+    a_dir, rho_dir, _ = backend.solve_system_of_linear_equations(p, X, y, 1e-5, 300, devices=devices, options=Options(rbf_form=1))
+    assert i_grid["gram_mode"] == 3 and np.max(np.abs(a_grid - a_dir)) <= 5e-3 * np.max(np.abs(a_dir)) and abs(float(rho_grid) - float(rho_dir)) <= 5e-3 * max(1.0, abs(float(rho_dir)))
+
+
 # ------------------------------------------------------------------------------------------------------------ BASELINE configs at full size vs the reference's compiled kernels
 FULL_SIZE = None
 
