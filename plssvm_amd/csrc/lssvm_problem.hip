@@ -455,6 +455,52 @@ static std::vector<int> band_edges(int ib_begin, int ib_end_all, size_t real_siz
     return edge;
 }
 
+/* The work items of a launch, given chunk by chunk, in XCD-LANE order: list position 8 k + x belongs to lane x (the persistent workgroups of XCD x draw from it first,
+ * for_each_work_item; the hardware's own deal is round-robin too), and a lane works through one UNIT -- a run of items of ONE column chunk -- at a time, the units dealt
+ * to the lanes as they run dry.  Round 6: a unit used to be a whole chunk.  A lane that found no chunk left gave its list positions to the others, which shifts every
+ * later item to another lane: with FEWER CHUNKS THAN A FEW PER LANE the mapping was scrambled for most of the list -- predict_values at 200 000 x 50 000 has 7 chunks for
+ * 8 lanes: L2 hit rate 0.19, 17 GB of fabric reads per 5 ms launch (profiles/r06_pmc_predict.txt); 50 000 x 128 training: 8 chunks of unequal length, 0.77.  Now a launch
+ * of fewer than 64 chunks cuts its chunks into pieces (of at least 32 items: the CUs of one XCD) so that there are about 64 units: the lanes stay aligned until the last
+ * unit of the list.  Launches of 64 chunks and more (1 000 000 x 128: 123 per band) are dealt as before. */
+static std::vector<int2> xcd_lane_order(const std::vector<std::vector<int2>> &by_chunk) {
+    size_t total = 0;
+    for (const auto &c : by_chunk) total += c.size();
+    const size_t pieces = by_chunk.size() < 64 ? (64 + by_chunk.size() - 1) / std::max<size_t>(by_chunk.size(), 1) : 1;
+    struct Unit {
+        const int2 *begin;
+        size_t count;
+    };
+    std::vector<Unit> units;
+    for (const auto &c : by_chunk) {
+        if (c.empty()) continue;
+        const size_t n_pieces = std::max<size_t>(1, std::min(pieces, c.size() / 32));
+        for (size_t k = 0; k < n_pieces; ++k) {
+            const size_t lo = c.size() * k / n_pieces, hi = c.size() * (k + 1) / n_pieces;
+            units.push_back({ c.data() + lo, hi - lo });
+        }
+    }
+    std::vector<int2> out;
+    out.reserve(total);
+    size_t next_unit = 0;
+    std::vector<long> lane_unit(8, -1);  // -1: none yet, -2: the list of units is exhausted
+    std::vector<size_t> lane_pos(8, 0);
+    while (out.size() < total) {
+        for (int x = 0; x < 8 && out.size() < total; ++x) {
+            while (lane_unit[x] == -1 || (lane_unit[x] >= 0 && lane_pos[x] >= units[static_cast<size_t>(lane_unit[x])].count)) {
+                if (next_unit >= units.size()) {
+                    lane_unit[x] = -2;
+                    break;
+                }
+                lane_unit[x] = static_cast<long>(next_unit++);
+                lane_pos[x] = 0;
+            }
+            if (lane_unit[x] == -2) continue;  // (this lane has run out of units: its positions go to the others -- the last round of the list only)
+            out.push_back(units[static_cast<size_t>(lane_unit[x])].begin[lane_pos[x]++]);
+        }
+    }
+    return out;
+}
+
 /* The (row block, column chunk) work items of one band in DISPATCH order: column chunk major (concurrent workgroups share the chunk; the
    hardware dispatches workgroups in item order as CU slots free up).  order >= 1 (ITEM_ORDER): the items cut short by the diagonal go last in
    their band, longest first, so that the final dispatch round is made of the shortest items.  .x = absolute row block, .y = chunk. */
@@ -507,32 +553,11 @@ static std::vector<int2> band_items(int band_begin, int band_end, int jc_tiles, 
     if (order == 3) {
         // XCD-aware: the hardware deals consecutive workgroups round-robin over the 8 XCDs (observed, a speed matter only), each with an L2 of its own.
         // In column-chunk major order the workgroups that stream one chunk are spread over all eight L2s, which each fetch it from the fabric; here list
-        // position 8 k + x belongs to "lane" x, and a lane works through ONE column chunk at a time (the chunks dealt to the lanes as they run dry),
-        // so that an XCD's workgroups share their column stream in ITS L2.
+        // position 8 k + x belongs to "lane" x, and a lane works through ONE column chunk at a time, so that an XCD's workgroups share their column
+        // stream in ITS L2 (xcd_lane_order below).
         std::vector<std::vector<int2>> by_chunk(static_cast<size_t>(num_jc));
         for (const int2 &it : full) by_chunk[static_cast<size_t>(it.y)].push_back(it);
-        std::vector<int2> out;
-        out.reserve(full.size());
-        int next_chunk = 0;
-        std::vector<int> lane_chunk(8, -1);
-        std::vector<size_t> lane_pos(8, 0);
-        size_t emitted = 0;
-        while (emitted < full.size()) {
-            for (int x = 0; x < 8 && emitted < full.size(); ++x) {
-                while (lane_chunk[x] < 0 || lane_pos[x] >= by_chunk[static_cast<size_t>(lane_chunk[x])].size()) {
-                    if (next_chunk >= num_jc) {
-                        lane_chunk[x] = -2;
-                        break;
-                    }
-                    lane_chunk[x] = next_chunk++;
-                    lane_pos[x] = 0;
-                }
-                if (lane_chunk[x] == -2) continue;  // (this lane has run out of chunks: its positions go to the others)
-                out.push_back(by_chunk[static_cast<size_t>(lane_chunk[x])][lane_pos[x]++]);
-                ++emitted;
-            }
-        }
-        full.swap(out);
+        full = xcd_lane_order(by_chunk);
     }
     full.insert(full.end(), cut.begin(), cut.end());
     return full;
@@ -1394,25 +1419,12 @@ static void predict_values_impl(const Options &opt, const lssvm_params &params, 
                                planesP.nplanes, planesP_frag.p);
             LSSVM_HIP_CHECK(hipGetLastError());
             const int pairs = num_ib / 2;
-            std::vector<int2> items;
-            items.reserve(static_cast<size_t>(pairs) * num_jc);
-            std::vector<int> lane_chunk(8, -1), lane_pos(8, 0);
-            int next_chunk = 0;
-            const size_t total = static_cast<size_t>(pairs) * num_jc;
-            while (items.size() < total) {
-                for (int x = 0; x < 8 && items.size() < total; ++x) {
-                    if (lane_chunk[x] == -2) continue;
-                    if (lane_chunk[x] < 0 || lane_pos[x] >= pairs) {
-                        if (next_chunk >= num_jc) {
-                            lane_chunk[x] = -2;  // (this lane has run out of chunks: its positions go to the others)
-                            continue;
-                        }
-                        lane_chunk[x] = next_chunk++;
-                        lane_pos[x] = 0;
-                    }
-                    items.push_back(make_int2(2 * lane_pos[x]++, lane_chunk[x]));
-                }
+            std::vector<std::vector<int2>> by_chunk(static_cast<size_t>(num_jc));
+            for (int jc = 0; jc < num_jc; ++jc) {
+                by_chunk[static_cast<size_t>(jc)].reserve(static_cast<size_t>(pairs));
+                for (int pr = 0; pr < pairs; ++pr) by_chunk[static_cast<size_t>(jc)].push_back(make_int2(2 * pr, jc));
             }
+            const std::vector<int2> items = xcd_lane_order(by_chunk);
             items_dev.alloc_zero(items.size(), s);
             LSSVM_HIP_CHECK(hipMemcpyAsync(items_dev.p, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice, s));
             LSSVM_HIP_CHECK(hipStreamSynchronize(s));  // `items` goes out of scope
