@@ -621,9 +621,13 @@ def main():
         sampler.stop()
         watts, ghz = sampler.window(w0, w1)
         if watts:
+            # energy of the WHOLE timed region (the settled samples alone leave the ramp at its start out): trapezoid rule over every sample in [w0, w1]
+            allw, _ = sampler.window(w0, w1, settle=0.0)
+            energy = sum(allw) / len(allw) * (w1 - w0) if allw else None
             board_power = {"median_w": median(watts), "max_w": max(watts), "cap_w": sampler.cap_watts(), "shader_clock_ghz_median": median(ghz), "samples": len(watts),
-                           "source": f"amdgpu hwmon of PCI {sampler.bus}, every 20 ms over the last 70 % of the timed region",
-                           "energy_j_per_step": sum(watts) / len(watts) * (w1 - w0) / max(args.steps, 1), "throttle": throttle}
+                           "source": f"amdgpu hwmon of PCI {sampler.bus}, every 20 ms: median / max over the last 70 % of the timed region, energy over all of it",
+                           "energy_j_per_step": (energy / max(args.steps, 1)) if energy is not None else None, "energy_samples": len(allw),
+                           "throttle": throttle if throttle is not None else {"unavailable": "amd-smi metric --json gave no reading (tool missing, profiled run, or no amdsmi module for this interpreter)"}}
 
     elapsed = t1 - t0
     if dist is not None:

@@ -76,7 +76,56 @@ def grid_case(seed: int, index: int) -> dict:
                 gamma=float(rng.choice([60.0, 300.0, 1500.0, 3500.0])) / d, coef0=0.0, data_seed=700 + index, v_seed=int(rng.integers(1 << 30)), orthogonal_v=True)
 
 
+def grid_pair_case(seed: int, index: int) -> dict:
+    """rbf with a large exponent scale in the 256-ROW form (round 6: tile_matvec_f32_pair<KT_RBFG>): from 64 row blocks on, at most 128 features, symmetric variant --
+    odd and even block counts, chunk lengths from one tile, bands, shards; gamma d from 60 to 3 500 as grid_case."""
+    rng = np.random.default_rng([seed, index, 6])
+    N = int(rng.integers(8194, 13000))
+    d = int(rng.choice([3, 17, 64, 65, 100, 128]))
+    opts = dict(gram_mode=int(rng.choice([3, 3, 1])), j_chunk_tiles=int(rng.choice([0, 0, 1, 2, 3, 5, 7])), symmetric=1, colslab_band_mb=int(rng.choice([2048, 1])), rbf_fold=int(rng.choice([1, 0])), mfma_shape=3)
+    return dict(family="grid_pair", dtype="float32", kernel="rbf", N=N, d=d, opts=opts, shards=int(rng.choice([1, 1, 2, 3, 8])), degree=3,
+                gamma=float(rng.choice([60.0, 300.0, 1500.0, 3500.0])) / d, coef0=0.0, data_seed=900 + index, v_seed=int(rng.integers(1 << 30)), orthogonal_v=True)
+
+
+def rect_case(seed: int, index: int) -> dict:
+    """predict_values on the RECTANGULAR 256-row kernel (round 6: tile_matvec_f32_pair_rect): at least 64 row blocks of points, at most 128 features, rbf (folded records)
+    and the polynomial kernel of degree 2 / 3, both plane kinds; ragged point and support-vector counts, chunk lengths from one tile."""
+    rng = np.random.default_rng([seed, index, 7])
+    kernel = ("rbf", "polynomial")[int(rng.integers(2))]
+    return dict(family="rect", kernel=kernel, npts=int(rng.integers(8065, 20000)), nsv=int(rng.choice([1, 2, 127, 128, 129, 1000, 2500, 6001])), d=int(rng.choice([1, 17, 64, 65, 100, 128])),
+                degree=int(rng.choice([2, 3])), gamma_d=float(rng.choice([1.0, 0.3])), coef0=float(rng.choice([0.0, 1.0])),
+                opts=dict(gram_mode=int(rng.choice([3, 3, 2, 1])), j_chunk_tiles=int(rng.choice([0, 0, 1, 2, 5, 9])), mfma_shape=3), data_seed=1100 + index, a_seed=int(rng.integers(1 << 30)))
+
+
+def run_rect_case(case: dict) -> dict:
+    """predict_values against the float64 sum on every point, on the scale of each point's summands; the 128-row kernels (mfma_shape = 2) as the yardstick"""
+    from plssvm_amd._capi import Options
+
+    npts, nsv, d = case["npts"], case["nsv"], case["d"]
+    X, _ = make_blobs_pm1(nsv + npts, d, seed=case["data_seed"], dtype=np.float32)
+    sv, pts = X[:nsv], X[nsv:]
+    alpha = np.random.default_rng(case["a_seed"]).standard_normal(nsv).astype(np.float32)
+    gamma = case["gamma_d"] / d
+    p = Parameter(kernel_type=case["kernel"], gamma=gamma, degree=case["degree"], coef0=case["coef0"], cost=1.0)
+    info = {}
+    got, _ = backend.predict_values(p, sv, alpha, 0.5, None, pts, options=Options(**case["opts"]), info_out=info)
+    ref, _ = backend.predict_values(p, sv, alpha, 0.5, None, pts, options=Options(**{**case["opts"], "mfma_shape": 2}))
+    S, P, a64 = sv.astype(np.float64), pts.astype(np.float64), alpha.astype(np.float64)
+    G = P @ S.T
+    if case["kernel"] == "rbf":
+        K = np.exp(-gamma * np.maximum(np.einsum("ij,ij->i", P, P)[:, None] + np.einsum("ij,ij->i", S, S)[None, :] - 2.0 * G, 0.0))
+    else:
+        K = (gamma * G + case["coef0"]) ** case["degree"]
+    truth = K @ a64 - 0.5
+    scale = np.abs(K) @ np.abs(a64) + 0.5
+    eps = float(np.finfo(np.float32).eps)
+    err, err_ref = float(np.max(np.abs(got - truth) / scale)) / eps, float(np.max(np.abs(ref - truth) / scale)) / eps
+    return dict(err=err, err_generic=err_ref, ok=bool(np.all(np.isfinite(got))) and err < max(4.0 * err_ref, 16.0), gram_mode=info["gram_mode"], symmetric=0)
+
+
 def describe(case: dict) -> str:
+    if case["family"] == "rect":
+        return f"rect {case['kernel']} points {case['npts']} support vectors {case['nsv']} d {case['d']} degree {case['degree']} coef0 {case['coef0']} gamma*d {case['gamma_d']} {case['opts']}"
     return (f"{case['family']} {case['dtype']} {case['kernel']} N {case['N']} d {case['d']} degree {case['degree']} coef0 {case['coef0']} gamma*d {case['gamma'] * case['d']:.1f} "
             f"shards {case['shards']} {case['opts']}")
 
