@@ -288,6 +288,24 @@ def predict_leg(seed, device, num_sv=50_000, num_points=200_000, d=128, calls=3)
             leg.update({"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "achieved": nbytes / (kern_ms * 1e-3) / 1e9, "frac": nbytes / (kern_ms * 1e-3) / 1e9 / 8000.0,
                         "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": nbytes, "note": "w (calculate_w) is computed by the first call and handed back to the later ones"})
         out[kernel] = leg
+    # the model RESIDENT in HBM (lssvm_mi355_predictor_*, round 6): what a call costs when the support vectors are not uploaded and prepared again -- the whole batch, and a
+    # small batch of 1 000 points, whose one-shot call is almost entirely the support vectors' set-up
+    prm = Parameter(kernel_type="rbf", gamma=None, cost=1.0)
+    res = {}
+    with backend.Predictor(prm, sv, alpha, 0.25) as pred:
+        for label, batch in (("batch_all_points", pts), ("batch_1000_points", pts[:1000])):
+            calls_ms, resident = [], None
+            for k in range(calls + 1):
+                info = {}
+                pred.predict(batch, info_out=info)
+                if k > 0:
+                    calls_ms.append(info["total_ms"])
+                    resident = int(info["resident"])
+            one = {}
+            backend.predict_values(prm, sv, alpha, 0.25, None, batch, info_out=one)
+            res[label] = {"points": int(batch.shape[0]), "resident_call_ms": sum(calls_ms) / len(calls_ms), "one_shot_call_ms": one["total_ms"], "ran_resident": resident,
+                          "points_per_s_resident": batch.shape[0] / (sum(calls_ms) / len(calls_ms) * 1e-3)}
+    out["resident_predictor_rbf"] = res
     return out
 
 

@@ -107,6 +107,8 @@ typedef struct lssvm_predict_info {
     double f16_row_rel_error;  /* as lssvm_cg_info, over support vectors and points */
     int32_t gram_mode;         /* as lssvm_cg_info */
     int32_t rbf_direct;        /* as lssvm_cg_info */
+    int32_t resident;          /* lssvm_mi355_predictor_predict: 1 if the batch ran against the RESIDENT support vectors, 0 if it took the one-shot path (same result) */
+    int32_t reserved;
 } lssvm_predict_info;
 
 /* ------------------------------------------------------------------------------------------------------------------ */
@@ -172,6 +174,19 @@ int lssvm_mi355_predict_values_f64(const lssvm_params *params, const double *sup
                                    size_t num_features, const double *alpha, double rho, double *w_inout, int *w_valid,
                                    const double *predict_points, size_t num_predict_points, double *out, lssvm_predict_info *info,
                                    const lssvm_mi355_options *options);
+
+/* The same prediction with the MODEL RESIDENT in HBM across calls (no counterpart in the reference, whose predict_values uploads the support vectors on every call --
+ * gpu_csvm.hpp:656-730 -- which is the whole cost of a small batch): `create` uploads the support vectors and prepares them once (centring, norms, operand planes,
+ * packed records; the linear kernel: w), `predict` uploads a batch of points (host memory, num_points x num_features row-major of the predictor's dtype), prepares
+ * it alike and writes num_points decision values.  fp32 rbf / polynomial models of at most 128 features run against the resident form; everything else, and any batch
+ * the resident form cannot take (it lies further from the support vectors' centre than the norm expansion allows, or two f16 planes do not represent it), goes through
+ * the one-shot path with the copies the predictor keeps -- the values are the same either way, lssvm_predict_info.resident says which.  Device 0, like predict_values;
+ * calls on one handle are not re-entrant. */
+typedef struct lssvm_mi355_predictor lssvm_mi355_predictor; /* opaque */
+int lssvm_mi355_predictor_create(lssvm_mi355_predictor **out, const lssvm_params *params, int dtype, const void *support_vectors, size_t num_support_vectors,
+                                 size_t num_features, const void *alpha, double rho, const lssvm_mi355_options *options);
+int lssvm_mi355_predictor_predict(lssvm_mi355_predictor *predictor, const void *predict_points, size_t num_predict_points, void *out, lssvm_predict_info *info);
+int lssvm_mi355_predictor_destroy(lssvm_mi355_predictor *predictor);
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* fine-grained entry points for kernel-level parity tests: the protected members the reference's backend tests re-export  */

@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = [
     "lssvm_mi355_abi_version", "lssvm_mi355_device_count", "lssvm_mi355_device_name", "lssvm_mi355_last_error",
     "lssvm_mi355_options_create", "lssvm_mi355_options_set", "lssvm_mi355_options_get", "lssvm_mi355_options_destroy",
     "lssvm_mi355_solve_f32", "lssvm_mi355_solve_f64", "lssvm_mi355_solve_multi_f32", "lssvm_mi355_solve_multi_f64", "lssvm_mi355_predict_values_f32", "lssvm_mi355_predict_values_f64",
+    "lssvm_mi355_predictor_create", "lssvm_mi355_predictor_predict", "lssvm_mi355_predictor_destroy",
     "lssvm_mi355_generate_q_f32", "lssvm_mi355_generate_q_f64", "lssvm_mi355_run_device_kernel_f32", "lssvm_mi355_run_device_kernel_f64",
     "lssvm_mi355_calculate_w_f32", "lssvm_mi355_calculate_w_f64",
     "lssvm_mi355_shard_blocks", "lssvm_mi355_set_shard_weights", "lssvm_mi355_problem_rebalance", "lssvm_mi355_comm_get_unique_id", "lssvm_mi355_comm_init", "lssvm_mi355_comm_destroy",
@@ -63,10 +64,10 @@ class LssvmCgInfo(C.Structure):
 class LssvmPredictInfo(C.Structure):
     """``lssvm_predict_info``: the timings of one ``predict_values`` call."""
     _fields_ = [("total_ms", C.c_double), ("setup_ms", C.c_double), ("kernel_ms", C.c_double), ("rbf_exponent_scale", C.c_double), ("f16_row_rel_error", C.c_double),
-                ("gram_mode", C.c_int32), ("rbf_direct", C.c_int32)]
+                ("gram_mode", C.c_int32), ("rbf_direct", C.c_int32), ("resident", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):
-        return {name: getattr(self, name) for name, _ in self._fields_}
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
 
 
 class LssvmModelInfo(C.Structure):

@@ -23,7 +23,7 @@ from ._capi import LssvmCgInfo, LssvmParams, LssvmPredictInfo, LssvmShard, Optio
 from .exceptions import InvalidParameterError
 from .parameter import Parameter
 
-__all__ = ["Options", "solve_system_of_linear_equations", "predict_values", "generate_q", "run_device_kernel", "calculate_w", "ResidentProblem",
+__all__ = ["Options", "Predictor", "solve_system_of_linear_equations", "predict_values", "generate_q", "run_device_kernel", "calculate_w", "ResidentProblem",
            "comm_get_unique_id", "comm_init", "comm_destroy"]
 
 
@@ -138,6 +138,50 @@ def predict_values(params: Parameter, support_vectors, alpha, rho: float, w, pre
     if info_out is not None:
         info_out.update(pinfo.as_dict())
     return out, (w_buf if w_valid.value else None)
+
+
+class Predictor:
+    """A model resident in HBM across predict calls (``lssvm_mi355_predictor_*``): the support vectors are uploaded and prepared once, every :meth:`predict` uploads only
+    its batch of points.  Same values as :func:`predict_values`; ``info_out["resident"]`` says whether a batch ran against the resident form or took the one-shot path."""
+
+    def __init__(self, params: Parameter, support_vectors, alpha, rho: float, options: Options | None = None):
+        sv = _as_matrix(support_vectors)
+        alpha = np.ascontiguousarray(alpha, dtype=sv.dtype)
+        if alpha.size != sv.shape[0]:
+            raise InvalidParameterError(f"The number of support vectors ({sv.shape[0]}) and number of weights ({alpha.size}) must be the same!")
+        self.dtype, self.num_features = sv.dtype, int(sv.shape[1])
+        self._h = C.c_void_p(None)
+        ps = _params_struct(params, sv.shape[1])
+        check(lib.lssvm_mi355_predictor_create(C.byref(self._h), C.byref(ps), C.c_int(_capi.dtype_code(sv.dtype)), ptr(sv), C.c_size_t(sv.shape[0]), C.c_size_t(sv.shape[1]), ptr(alpha),
+                                               C.c_double(float(rho)), options_ptr(options)))
+
+    def predict(self, predict_points, info_out: dict | None = None):
+        pts = _as_matrix(predict_points, dtype=self.dtype)
+        if pts.shape[1] != self.num_features:
+            raise InvalidParameterError(f"The number of features in the support vectors ({self.num_features}) must be the same as in the data points to predict ({pts.shape[1]})!")
+        out = np.zeros(pts.shape[0], dtype=self.dtype)
+        pinfo = LssvmPredictInfo()
+        check(lib.lssvm_mi355_predictor_predict(self._h, ptr(pts), C.c_size_t(pts.shape[0]), ptr(out), C.byref(pinfo)))
+        if info_out is not None:
+            info_out.update(pinfo.as_dict())
+        return out
+
+    def close(self):
+        if self._h:
+            lib.lssvm_mi355_predictor_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -250,6 +250,31 @@ int lssvm_mi355_predict_values_f64(const lssvm_params *params, const double *sv,
     });
 }
 
+struct lssvm_mi355_predictor {
+    std::unique_ptr<lssvm::PredictorBase> impl;
+};
+int lssvm_mi355_predictor_create(lssvm_mi355_predictor **out, const lssvm_params *params, int dtype, const void *support_vectors, size_t num_support_vectors,
+                                 size_t num_features, const void *alpha, double rho, const lssvm_mi355_options *options) {
+    return guarded([&] {
+        LSSVM_REQUIRE(out != nullptr, "out must not be NULL");
+        *out = nullptr;
+        lssvm::check_params(params);
+        LSSVM_REQUIRE(dtype == LSSVM_DTYPE_F32 || dtype == LSSVM_DTYPE_F64, "dtype must be LSSVM_DTYPE_F32 or LSSVM_DTYPE_F64");
+        auto h = std::make_unique<lssvm_mi355_predictor>();
+        h->impl = lssvm::make_predictor(options_of(options), *params, dtype, support_vectors, num_support_vectors, num_features, alpha, rho);
+        *out = h.release();
+    });
+}
+int lssvm_mi355_predictor_predict(lssvm_mi355_predictor *predictor, const void *predict_points, size_t num_predict_points, void *out, lssvm_predict_info *info) {
+    return guarded([&] {
+        LSSVM_REQUIRE(predictor != nullptr, "predictor handle must not be NULL");
+        predictor->impl->predict(predict_points, num_predict_points, out, info);
+    });
+}
+int lssvm_mi355_predictor_destroy(lssvm_mi355_predictor *predictor) {
+    return guarded([&] { delete predictor; });
+}
+
 int lssvm_mi355_generate_q_f32(const lssvm_params *params, const float *X, size_t num_points, size_t num_features, float *q_out, const lssvm_mi355_options *options) {
     return guarded([&] { generate_q_one_shot<float>(params, X, num_points, num_features, q_out, options); });
 }

@@ -1190,6 +1190,45 @@ template class Problem<float>;
 template class Problem<double>;
 
 /* ------------------------------------------------------------------ predict path ------------------------------------------------------------------ */
+/* What the rectangular 256-row kernel (tile_matvec_f32_pair_rect) needs besides the planes: the row side once more fragment-major (a wave's load instruction reads
+ * 1 KiB in one piece), the item list of the whole rectangle in XCD-lane order (xcd_lane_order: the workgroups of an XCD share their column stream in its L2), and the
+ * counters of a persistent launch.  Used by the one-shot predict_values and by the resident predictor. */
+struct RectSetup {
+    DevBuf<uint16_t> frag;
+    DevBuf<int2> items;
+    DevBuf<unsigned> queue;
+};
+static void setup_rect_launch(TileArgs<float> &ta, RectSetup &rs, const PlaneSet &planesP, int rows_alloc, int num_ib, int num_jc, hipStream_t s) {
+    const size_t plane_elems = static_cast<size_t>(rows_alloc) * planesP.ldx16;
+    rs.frag.alloc_zero(static_cast<size_t>(planesP.nplanes) * plane_elems, s);
+    const size_t pieces = static_cast<size_t>(planesP.nplanes) * rows_alloc * (planesP.ldx16 / 8);
+    hipLaunchKernelGGL(k_planes_fragment_major, dim3(static_cast<unsigned>((pieces + 255) / 256)), dim3(256), 0, s, planesP.buf.p, plane_elems, rows_alloc, planesP.ldx16, planesP.nplanes, rs.frag.p);
+    LSSVM_HIP_CHECK(hipGetLastError());
+    const int pairs = num_ib / 2;
+    std::vector<std::vector<int2>> by_chunk(static_cast<size_t>(num_jc));
+    for (int jc = 0; jc < num_jc; ++jc) {
+        by_chunk[static_cast<size_t>(jc)].reserve(static_cast<size_t>(pairs));
+        for (int pr = 0; pr < pairs; ++pr) by_chunk[static_cast<size_t>(jc)].push_back(make_int2(2 * pr, jc));
+    }
+    const std::vector<int2> items = xcd_lane_order(by_chunk);
+    rs.items.alloc_zero(items.size(), s);
+    LSSVM_HIP_CHECK(hipMemcpyAsync(rs.items.p, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+    LSSVM_HIP_CHECK(hipStreamSynchronize(s));  // `items` goes out of scope
+    int cus = 256;
+    LSSVM_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+    ta.items = rs.items.p;
+    ta.num_items = static_cast<int>(items.size());
+    if (ta.num_items > cus) {
+        rs.queue.alloc_zero(512, s);
+        ta.queue = rs.queue.p;
+        ta.queue_next = rs.queue.p + 256;
+        ta.queue_grid = cus;
+    }
+    ta.Xr16f = rs.frag.p;
+    ta.row_pair = 1;
+    ta.rect = 1;
+}
+
 /* out_p = w . x_p - rho: one pass over the points, HBM bound.  A group of L lanes (a power of two, at most 64) owns a point and reads its row in 16-byte pieces, so
  * that a wave's load instruction covers 1 KiB of consecutive memory wherever a row has at least 16 bytes x L. */
 template <typename T>
@@ -1404,44 +1443,9 @@ static void predict_values_impl(const Options &opt, const lssvm_params &params, 
     }
     ta.wide_panels = wide ? 1 : 0;
     set_launch_options(ta, opt);
-    DevBuf<uint16_t> planesP_frag;
-    DevBuf<int2> items_dev;
-    DevBuf<unsigned> queue;
+    RectSetup rect_setup;
     if constexpr (std::is_same_v<T, float>) {
-        if (rect) {
-            // the row side once more fragment-major (a wave's load instruction reads 1 KiB in one piece), the item list of the whole rectangle in the lane order of the
-            // training kernel -- list position 8 k + x belongs to XCD lane x, and a lane works through ONE column chunk at a time, so that the workgroups of an XCD share
-            // their column stream in its L2 --, and the counters of a persistent launch
-            const size_t plane_elems = static_cast<size_t>(P.rows_alloc) * planesP.ldx16;
-            planesP_frag.alloc_zero(static_cast<size_t>(planesP.nplanes) * plane_elems, s);
-            const size_t pieces = static_cast<size_t>(planesP.nplanes) * P.rows_alloc * (planesP.ldx16 / 8);
-            hipLaunchKernelGGL(k_planes_fragment_major, dim3(static_cast<unsigned>((pieces + 255) / 256)), dim3(256), 0, s, planesP.buf.p, plane_elems, static_cast<int>(P.rows_alloc), planesP.ldx16,
-                               planesP.nplanes, planesP_frag.p);
-            LSSVM_HIP_CHECK(hipGetLastError());
-            const int pairs = num_ib / 2;
-            std::vector<std::vector<int2>> by_chunk(static_cast<size_t>(num_jc));
-            for (int jc = 0; jc < num_jc; ++jc) {
-                by_chunk[static_cast<size_t>(jc)].reserve(static_cast<size_t>(pairs));
-                for (int pr = 0; pr < pairs; ++pr) by_chunk[static_cast<size_t>(jc)].push_back(make_int2(2 * pr, jc));
-            }
-            const std::vector<int2> items = xcd_lane_order(by_chunk);
-            items_dev.alloc_zero(items.size(), s);
-            LSSVM_HIP_CHECK(hipMemcpyAsync(items_dev.p, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice, s));
-            LSSVM_HIP_CHECK(hipStreamSynchronize(s));  // `items` goes out of scope
-            int cus = 256;
-            LSSVM_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
-            ta.items = items_dev.p;
-            ta.num_items = static_cast<int>(items.size());
-            if (ta.num_items > cus) {
-                queue.alloc_zero(512, s);
-                ta.queue = queue.p;
-                ta.queue_next = queue.p + 256;
-                ta.queue_grid = cus;
-            }
-            ta.Xr16f = planesP_frag.p;
-            ta.row_pair = 1;
-            ta.rect = 1;
-        }
+        if (rect) setup_rect_launch(ta, rect_setup, planesP, P.rows_alloc, num_ib, num_jc, s);
     }
     LSSVM_HIP_CHECK(hipStreamSynchronize(s));
     const double t_kernel = now_ms();
@@ -1492,5 +1496,241 @@ template void predict_values<float>(const Options &, const lssvm_params &, const
 template void predict_values<double>(const Options &, const lssvm_params &, const double *, size_t, size_t, const double *, double, double *, int *, const double *, size_t, double *, lssvm_predict_info *);
 template void calculate_w<float>(const float *, size_t, size_t, const float *, float *);
 template void calculate_w<double>(const double *, size_t, size_t, const double *, double *);
+
+/* ------------------------------------------------------------------ the resident predictor ------------------------------------------------------------------ */
+template <typename T>
+class Predictor final : public PredictorBase {
+  public:
+    Predictor(const Options &opt, const lssvm_params &params, const T *sv, size_t nsv, size_t nfeat, const T *alpha, T rho) :
+        opt_(opt), params_(params), nsv_(nsv), nfeat_(nfeat), rho_(rho), sv_host_(sv, sv + nsv * nfeat), alpha_host_(alpha, alpha + nsv) {
+        dtype = std::is_same_v<T, float> ? LSSVM_DTYPE_F32 : LSSVM_DTYPE_F64;
+        check_params(&params_);
+        LSSVM_REQUIRE(sv != nullptr && nsv > 0, "The support vectors must not be empty!");   // csvm.cpp:189
+        LSSVM_REQUIRE(nfeat > 0, "The support vectors must contain at least one feature!");  // csvm.cpp:190
+        LSSVM_REQUIRE(alpha != nullptr, "The number of support vectors and number of weights must be the same!");
+        select_device_checked(0);
+        hipStream_t s = nullptr;
+        if (params_.kernel_type == LSSVM_KERNEL_LINEAR) {
+            // the linear kernel predicts through w = sum_i alpha_i sv_i (csvm.cpp:204-213): computed once, resident zero padded like a row of points
+            w_host_.assign(nfeat, T(0));
+            calculate_w<T>(sv, nsv, nfeat, alpha, w_host_.data());
+            w_.alloc_zero(static_cast<size_t>(padded_features<T>(nfeat)), s);
+            LSSVM_HIP_CHECK(hipMemcpyAsync(w_.p, w_host_.data(), nfeat * sizeof(T), hipMemcpyHostToDevice, s));
+            LSSVM_HIP_CHECK(hipStreamSynchronize(s));
+            return;
+        }
+        if constexpr (std::is_same_v<T, float>) prepare_resident(s);
+    }
+
+    void predict(const void *points_v, size_t npoints, void *out_v, lssvm_predict_info *info) override {
+        const T *points = static_cast<const T *>(points_v);
+        T *out = static_cast<T *>(out_v);
+        LSSVM_REQUIRE(points != nullptr && npoints > 0, "The data points to predict must not be empty!");  // csvm.cpp:194
+        LSSVM_REQUIRE(out != nullptr, "out must not be NULL");
+        lssvm_predict_info local{};
+        local.f16_row_rel_error = -1.0;
+        bool done = false;
+        if (params_.kernel_type == LSSVM_KERNEL_LINEAR) {
+            predict_linear(points, npoints, out, local);
+            done = true;
+        } else if constexpr (std::is_same_v<T, float>) {
+            if (resident_) done = predict_resident(points, npoints, out, local);
+        }
+        if (!done) {
+            // what the resident form does not cover (fp64, more than 128 features, exponent scales beyond the norm expansion, a batch whose planes fail the f16 check or
+            // that lies further from the support vectors' centre than the form chosen for them allows): the one-shot path, same result
+            int w_valid = 0;
+            std::vector<T> w_tmp(nfeat_);
+            predict_values<T>(opt_, params_, sv_host_.data(), nsv_, nfeat_, alpha_host_.data(), rho_, w_tmp.data(), &w_valid, points, npoints, out, &local);
+            local.resident = 0;
+        }
+        if (info != nullptr) *info = local;
+    }
+
+  private:
+    void predict_linear(const T *points, size_t npoints, T *out, lssvm_predict_info &info) {
+        select_device_checked(0);
+        hipStream_t s = nullptr;
+        const double t0 = now_ms();
+        Event ev_a, ev_b;
+        ev_a.create(true);
+        ev_b.create(true);
+        DeviceMatrix<T> P;
+        P.upload(points, LSSVM_MEM_HOST, npoints, nfeat_, 0, s);
+        DevBuf<T> o;
+        o.alloc_zero(npoints, s);
+        LSSVM_HIP_CHECK(hipStreamSynchronize(s));
+        const double t_kernel = now_ms();
+        LSSVM_HIP_CHECK(hipEventRecord(ev_a.e, s));
+        launch_predict_linear<T>(P, w_.p, rho_, o.p, s);
+        LSSVM_HIP_CHECK(hipEventRecord(ev_b.e, s));
+        LSSVM_HIP_CHECK(hipGetLastError());
+        LSSVM_HIP_CHECK(hipMemcpyAsync(out, o.p, npoints * sizeof(T), hipMemcpyDeviceToHost, s));
+        LSSVM_HIP_CHECK(hipStreamSynchronize(s));
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ev_a.e, ev_b.e) == hipSuccess) info.kernel_ms = ms;
+        info.total_ms = now_ms() - t0;
+        info.setup_ms = t_kernel - t0;
+        info.resident = 1;
+    }
+
+    /* fp32, rbf / polynomial, at most 128 features, a split Gram mode: the support vectors' side of the product, once */
+    void prepare_resident(hipStream_t s) {
+        if (round_up(static_cast<long>(nfeat_), 64) > 128 || opt_.gram_mode == 0 || opt_.tile_kernel == 1) return;
+        S_.upload(sv_host_.data(), LSSVM_MEM_HOST, nsv_, nfeat_, 0, s);
+        if (!v2_eligible(opt_, S_.ldx, false)) return;
+        const bool rbf = params_.kernel_type == LSSVM_KERNEL_RBF;
+        if (rbf) {
+            if (opt_.rbf_form == 1 || opt_.rbf_form == 3) return;  // (the direct kernel / the grid planes asked for: the one-shot path has them)
+            column_means<float>(S_, mean_, s);
+            const double sq = max_centred_sqnorm<float>(S_, mean_, s);
+            r2_sv_ = 2.0 * static_cast<double>(static_cast<float>(params_.gamma)) * 1.4426950408889634 * sq;
+            if (!(r2_sv_ <= RBF_DIRECT_ABOVE) && opt_.rbf_form != 2) return;  // (beyond the norm expansion's range: grid planes or the direct kernel, one-shot)
+            scale_ = rbf_prescale<float>(params_, false);
+            hipLaunchKernelGGL(k_center<float>, dim3((S_.dfeat + 255) / 256, S_.rows), dim3(256), 0, s, S_.data.p, S_.ldx, S_.dfeat, S_.rows, mean_.p, scale_);
+            LSSVM_HIP_CHECK(hipGetLastError());
+            half_neg_norms<float>(S_, cS_, s);
+        }
+        make_planes(opt_, params_, false, S_, nullptr, planesS_, nullptr, s);
+        if (planesS_.mode == 0) return;
+        num_jt_ = S_.rows_alloc / TILE;
+        a_.alloc_zero(S_.rows_alloc, s);
+        LSSVM_HIP_CHECK(hipMemcpyAsync(a_.p, alpha_host_.data(), nsv_ * sizeof(float), hipMemcpyHostToDevice, s));
+        // the (alpha_j | c_j) records: folded for rbf while the exponent terms stay small -- decided per batch from ITS exponent scale too, so both forms are kept
+        const int ncols = num_jt_ * TILE;
+        dc_.alloc_zero(static_cast<size_t>(num_jt_) * 256, s);
+        hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, s, a_.p, cS_.p, ncols, dc_.p, 0, static_cast<float *>(nullptr), 0, static_cast<const float *>(nullptr));
+        if (rbf && opt_.rbf_fold != 0) {
+            dc_folded_.alloc_zero(static_cast<size_t>(num_jt_) * 256, s);
+            hipLaunchKernelGGL(k_pack_dc, dim3((ncols + 255) / 256), dim3(256), 0, s, a_.p, cS_.p, ncols, dc_folded_.p, 1, static_cast<float *>(nullptr), 0, static_cast<const float *>(nullptr));
+        }
+        LSSVM_HIP_CHECK(hipGetLastError());
+        LSSVM_HIP_CHECK(hipStreamSynchronize(s));
+        resident_ = true;
+    }
+
+    /* a batch of points against the resident support vectors; false = this batch needs the one-shot path */
+    bool predict_resident(const float *points, size_t npoints, float *out, lssvm_predict_info &info) {
+        select_device_checked(0);
+        hipStream_t s = nullptr;
+        const double t0 = now_ms();
+        const bool rbf = params_.kernel_type == LSSVM_KERNEL_RBF;
+        DeviceMatrix<float> P;
+        P.upload(points, LSSVM_MEM_HOST, npoints, nfeat_, static_cast<size_t>(round_up(static_cast<long>(npoints), 2 * TILE)), s);
+        DevBuf<float> cP;
+        double r2 = r2_sv_;
+        if (rbf) {
+            const double sq = max_centred_sqnorm<float>(P, mean_, s);  // (against the SUPPORT VECTORS' means: the centre the resident side was prepared with)
+            r2 = std::max(r2, 2.0 * static_cast<double>(static_cast<float>(params_.gamma)) * 1.4426950408889634 * sq);
+            if (!(r2 <= RBF_DIRECT_ABOVE) && opt_.rbf_form != 2) return false;  // this batch reaches beyond the norm expansion's range
+            hipLaunchKernelGGL(k_center<float>, dim3((P.dfeat + 255) / 256, P.rows), dim3(256), 0, s, P.data.p, P.ldx, P.dfeat, P.rows, mean_.p, scale_);
+            LSSVM_HIP_CHECK(hipGetLastError());
+            half_neg_norms<float>(P, cP, s);
+        }
+        // the batch's planes: the kind and the scale of the support vectors' planes; two f16 planes must represent THIS batch too
+        PlaneSet planesP;
+        planesP.ldx16 = planesS_.ldx16;
+        planesP.nplanes = planesS_.nplanes;
+        planesP.mode = planesS_.mode;
+        planesP.shift = planesS_.shift;
+        planesP.buf.alloc_zero(static_cast<size_t>(planesP.nplanes) * P.rows_alloc * planesP.ldx16, s);
+        if (planesS_.mode == 2) {
+            DevBuf<unsigned> stats;
+            stats.alloc_zero(4, s);
+            split_f16_planes(P.data.p, P.ldx, P.dfeat, static_cast<size_t>(P.rows_alloc), planesP.ldx16, std::ldexp(1.0f, planesS_.shift), rbf ? F16_RBF_SHIFT : 0, planesP.buf.p,
+                             static_cast<size_t>(P.rows_alloc) * planesP.ldx16, stats.p, s);
+            unsigned host[4] = { 0, 0, 0, 0 };
+            LSSVM_HIP_CHECK(hipMemcpyAsync(host, stats.p, sizeof(host), hipMemcpyDeviceToHost, s));
+            LSSVM_HIP_CHECK(hipStreamSynchronize(s));
+            float rel2 = 0.0f, rest2 = 0.0f, x2 = 0.0f;
+            std::memcpy(&rel2, &host[0], sizeof(float));
+            std::memcpy(&rest2, &host[1], sizeof(float));
+            std::memcpy(&x2, &host[2], sizeof(float));
+            bool ok = rel2 <= F16_REL2_MAX;
+            if (!ok && rbf) ok = std::isfinite(rel2) && 2.0 * std::sqrt(static_cast<double>(rest2) * static_cast<double>(x2)) <= static_cast<double>(F16_ABS_MAX);
+            info.f16_row_rel_error = std::max(planesS_.f16_row_rel_error, std::sqrt(static_cast<double>(rel2)));
+            if (!ok && opt_.gram_mode != 2) return false;  // the support vectors' planes are f16, this batch needs bf16: one-shot (which splits both sides alike)
+        } else {
+            split_bf16_planes(P.data.p, P.ldx, P.dfeat, static_cast<size_t>(P.rows_alloc), planesP.ldx16, planesP.buf.p, static_cast<size_t>(P.rows_alloc) * planesP.ldx16, s);
+        }
+        const int num_ib = P.rows_alloc / TILE;
+        const bool folded = rbf && dc_folded_.p != nullptr && r2 <= FOLD_MAX_R2;
+        const bool poly_generic = params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree != 2 && params_.degree != 3;
+        const bool rbf_ok = !rbf || (folded && r2 <= 2.0 * PAIR_FOLD_MAX_C);
+        const bool rect = !poly_generic && rbf_ok && opt_.mfma_shape >= 3 && num_ib >= PAIR_MIN_TILES;
+        const long rect_tiles = std::min<long>(64, std::max<long>(4, (static_cast<long>(num_ib / 2) * num_jt_ + 1024) / 2048));
+        const int jc_tiles = opt_.j_chunk_tiles > 0 ? static_cast<int>(opt_.j_chunk_tiles)
+                                                   : (rect ? static_cast<int>(rect_tiles) : static_cast<int>(std::min<long>(16, std::max<long>(2, (static_cast<long>(num_ib) * num_jt_ + 2048) / 4096))));
+        const int num_jc = (num_jt_ + jc_tiles - 1) / jc_tiles;
+        DevBuf<float> partial, Kv, o;
+        partial.alloc_zero(static_cast<size_t>(num_jc) * P.rows_alloc, s);
+        Kv.alloc_zero(P.rows_alloc, s);
+        o.alloc_zero(npoints, s);
+        TileArgs<float> ta{};
+        ta.Xr = P.data.p;
+        ta.Xc = S_.data.p;
+        ta.cr = cP.p;
+        ta.cc = cS_.p;
+        ta.dvec = a_.p;
+        ta.dc = folded ? dc_folded_.p : dc_.p;
+        ta.dc_folded = folded ? 1 : 0;
+        ta.partial = partial.p;
+        ta.part_stride = P.rows_alloc;
+        ta.ldx = S_.ldx;
+        ta.kchunks = S_.ldx / F32_KC;
+        ta.num_ib = num_ib;
+        ta.num_jt = num_jt_;
+        ta.jc_tiles = jc_tiles;
+        ta.ncols_valid = S_.rows;
+        set_kernel_scalars(ta, params_, false);
+        set_plane_args(ta, params_, planesS_, planesP, static_cast<size_t>(S_.rows_alloc), static_cast<size_t>(P.rows_alloc));
+        set_launch_options(ta, opt_);
+        RectSetup rect_setup;
+        if (rect) setup_rect_launch(ta, rect_setup, planesP, P.rows_alloc, num_ib, num_jc, s);
+        Event ev_a, ev_b;
+        ev_a.create(true);
+        ev_b.create(true);
+        LSSVM_HIP_CHECK(hipStreamSynchronize(s));
+        const double t_kernel = now_ms();
+        LSSVM_HIP_CHECK(hipEventRecord(ev_a.e, s));
+        launch_tile_kernel<float>(ta, params_.kernel_type, false, num_jc, s);
+        LSSVM_HIP_CHECK(hipEventRecord(ev_b.e, s));
+        hipLaunchKernelGGL(k_reduce_partials<float>, dim3((P.rows_alloc + 255) / 256), dim3(256), 0, s, partial.p, ta.part_stride, num_jc, 0, P.rows_alloc, Kv.p);
+        hipLaunchKernelGGL(k_sub_rho<float>, dim3((P.rows + 255) / 256), dim3(256), 0, s, Kv.p, P.rows, rho_, o.p);
+        LSSVM_HIP_CHECK(hipGetLastError());
+        LSSVM_HIP_CHECK(hipMemcpyAsync(out, o.p, npoints * sizeof(float), hipMemcpyDeviceToHost, s));
+        LSSVM_HIP_CHECK(hipStreamSynchronize(s));
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ev_a.e, ev_b.e) == hipSuccess) info.kernel_ms = ms;
+        info.total_ms = now_ms() - t0;
+        info.setup_ms = t_kernel - t0;
+        info.gram_mode = planesS_.mode;
+        info.rbf_direct = 0;
+        info.rbf_exponent_scale = r2;
+        if (info.f16_row_rel_error < 0.0) info.f16_row_rel_error = planesS_.f16_row_rel_error;
+        info.resident = 1;
+        return true;
+    }
+
+    Options opt_;
+    lssvm_params params_;
+    size_t nsv_, nfeat_;
+    T rho_;
+    std::vector<T> sv_host_, alpha_host_, w_host_;  // the one-shot path's inputs
+    DevBuf<T> w_;
+    // fp32 resident form
+    bool resident_ = false;
+    DeviceMatrix<float> S_;
+    DevBuf<float> mean_, cS_, a_, dc_, dc_folded_;
+    PlaneSet planesS_;
+    double r2_sv_ = 0.0;
+    float scale_ = 1.0f;
+    int num_jt_ = 0;
+};
+
+std::unique_ptr<PredictorBase> make_predictor(const Options &opt, const lssvm_params &params, int dtype, const void *sv, size_t nsv, size_t nfeat, const void *alpha, double rho) {
+    if (dtype == LSSVM_DTYPE_F32) return std::make_unique<Predictor<float>>(opt, params, static_cast<const float *>(sv), nsv, nfeat, static_cast<const float *>(alpha), static_cast<float>(rho));
+    return std::make_unique<Predictor<double>>(opt, params, static_cast<const double *>(sv), nsv, nfeat, static_cast<const double *>(alpha), rho);
+}
 
 }  // namespace lssvm

@@ -539,6 +539,17 @@ void predict_values(const Options &opt, const lssvm_params &params, const T *sv,
 template <typename T>
 void calculate_w(const T *sv, size_t nsv, size_t nfeat, const T *alpha, T *w_out);
 
+/* The resident predictor (round 6; lssvm_mi355_predictor_*): a model kept in HBM across predict calls -- csvm::predict_values (csvm.hpp:204-208) uploads and prepares the
+ * support vectors on every call, which is the whole cost of a small batch.  create() prepares them once (centring, norms, operand planes, packed records; the linear
+ * kernel: w); predict() uploads a batch of points, prepares it alike and runs the product.  What a batch cannot do on the resident form (see Predictor<T>::predict) goes
+ * through the one-shot path with the host copies kept here: the result is the same either way. */
+struct PredictorBase {
+    int dtype = 0;
+    virtual ~PredictorBase() = default;
+    virtual void predict(const void *points, size_t npoints, void *out, lssvm_predict_info *info) = 0;
+};
+std::unique_ptr<PredictorBase> make_predictor(const Options &opt, const lssvm_params &params, int dtype, const void *sv, size_t nsv, size_t nfeat, const void *alpha, double rho);
+
 void check_params(const lssvm_params *params);
 int select_device_checked(int device);
 /* `num_devices` == 0: automatic (all visible devices, but at least 32 row blocks per device); `devices` may be NULL (0 .. num_devices-1) */

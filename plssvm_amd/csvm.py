@@ -149,6 +149,20 @@ class MI355CSVM(CSVM):
     def predict_values(self, params, support_vectors, alpha, rho, w, predict_points):
         return backend.predict_values(params, support_vectors, alpha, rho, w, predict_points, options=self._options)
 
+    def predict(self, model: Model, data: DataSet):
+        """csvm::predict (csvm.hpp:322-342) with the model RESIDENT in HBM from the first call on (``lssvm_mi355_predictor_*``): later calls with the same model upload only
+        their points.  Same labels as the base class's one-shot ``predict_values``."""
+        if model.num_features() != data.num_features():
+            raise InvalidParameterError(f"Number of features per data point ({data.num_features()}) must match the number of features per support vector of the "
+                                        f"provided model ({model.num_features()})!")
+        cached = getattr(model, "_predictor", None)
+        if cached is None or cached[0] is not self:
+            cached = (self, backend.Predictor(model.params, model.support_vectors(), model.alpha, float(model.rho), options=self._options))
+            model._predictor = cached
+        values = cached[1].predict(data.data())
+        mapper = model.data.mapping
+        return [mapper.label_of(1 if v > 0 else -1) for v in values]  # operators.hpp:180-182 sign, csvm.hpp:337-340
+
 
 def make_csvm(backend_type=BackendType.AUTOMATIC, *args, **kwargs) -> CSVM:
     """plssvm::make_csvm (csvm_factory.hpp:123-171).  ``automatic`` / ``mi355`` / ``hip`` select the MI355X backend; every other

@@ -75,7 +75,7 @@ def test_abi_version_and_struct_layout():
     assert C.sizeof(_capi.LssvmParams) == 32
     assert C.sizeof(_capi.LssvmShard) == 8
     assert C.sizeof(_capi.LssvmCgInfo) == 168  # ABI 4 (static_assert in capi.hip)
-    assert C.sizeof(_capi.LssvmPredictInfo) == 48 and C.sizeof(_capi.LssvmModelInfo) == 80
+    assert C.sizeof(_capi.LssvmPredictInfo) == 56 and C.sizeof(_capi.LssvmModelInfo) == 80
 
 
 has_gpu = _capi.device_count() > 0

@@ -166,6 +166,71 @@ def test_predict_values_on_the_rectangular_256_row_kernel(oracle, kernel, degree
     assert np.array_equal(got, again)  # which CU evaluates an item changes no result
 
 
+# ------------------------------------------------------------------------------------------------------------ the resident predictor
+@pytest.mark.parametrize("kernel, degree, dt", [("rbf", 3, np.float32), ("polynomial", 2, np.float32), ("polynomial", 3, np.float32), ("linear", 3, np.float32), ("linear", 3, np.float64),
+                                                ("rbf", 3, np.float64), ("polynomial", 5, np.float32)])
+def test_resident_predictor_equals_the_one_shot_predict_values(oracle, kernel, degree, dt):
+    """lssvm_mi355_predictor_* (round 6): the support vectors stay in HBM, prepared once; batches of one point, of a hundred, and of more than 64 row blocks (the rectangular
+    256-row kernel) give the values of csvm::predict_values (csvm.hpp:204-208) -- bit for bit where the one-shot call prepares the batch the same way (rbf: the same centre,
+    the same plane scale), within the kernel-level bar elsewhere (the polynomial planes' power-of-two scale comes from the support vectors alone here, from both sides
+    there) -- and lssvm_predict_info.resident says which path a batch took: fp32 rbf / polynomial(2, 3) / linear models up to 128 features run resident, fp64 rbf does not."""
+    rng = np.random.default_rng(17)
+    nsv, d = 3001, 100
+    X, _ = make_blobs_pm1(nsv + 9000, d, seed=23, dtype=dt)
+    sv, pool = X[:nsv], X[nsv:]
+    alpha = rng.standard_normal(nsv).astype(dt)
+    prm = Parameter(kernel_type=kernel, degree=degree, gamma=1.0 / d, coef0=0.5)
+    eps = np.finfo(dt).eps
+    scale = np.abs(alpha).sum() * (1.0 if kernel == "rbf" else (float(np.max(np.abs(1.0 / d * (pool.astype(np.float64) @ sv.astype(np.float64).T) + 0.5)) ** degree) if kernel == "polynomial"
+                                                               else float(np.max(np.abs(pool.astype(np.float64) @ sv.astype(np.float64).T)))))
+    with backend.Predictor(prm, sv, alpha, 0.125) as pred:
+        for npts in (1, 100, 9000):
+            pts = pool[:npts]
+            info, info1 = {}, {}
+            got = pred.predict(pts, info_out=info)
+            want, _ = backend.predict_values(prm, sv, alpha, 0.125, None, pts, info_out=info1)
+            expect_resident = dt == np.float32 or kernel == "linear"
+            assert info["resident"] == (1 if expect_resident else 0), (kernel, dt, npts, info)
+            assert info["kernel_ms"] > 0 and info["total_ms"] >= info["kernel_ms"]
+            if kernel == "rbf" or not expect_resident:
+                assert np.array_equal(got, want), (kernel, npts, np.max(np.abs(got - want)))
+            else:
+                assert np.max(np.abs(got - want)) <= 16 * eps * scale, (kernel, npts, np.max(np.abs(got - want)) / (eps * scale))
+            if expect_resident and npts >= 100 and kernel != "linear":
+                assert info["total_ms"] < info1["total_ms"]  # the support vectors were not uploaded and prepared again
+        again = pred.predict(pool[:9000])
+        assert np.array_equal(again, got)
+    ref, _ = oracle.predict_values(kernel, sv.astype(np.float64), alpha.astype(np.float64), 0.125, pool[:200].astype(np.float64), degree=degree, gamma=1.0 / d, coef0=0.5)
+    assert np.max(np.abs(got[:200] - ref)) <= 16 * eps * scale
+
+
+def test_resident_predictor_hands_irregular_batches_to_the_one_shot_path():
+    """A batch the resident form cannot take still gets the one-shot call's values: rbf points far outside the support vectors' range (an exponent scale beyond the norm
+    expansion's: the one-shot path moves to the grid planes), and polynomial points whose rows differ by eight orders of magnitude (two f16 planes with the support vectors'
+    scale do not represent them: the one-shot path splits BOTH sides as bf16x6)."""
+    rng = np.random.default_rng(19)
+    nsv, d = 2000, 64
+    X, _ = make_blobs_pm1(nsv + 9000, d, seed=29, dtype=np.float32)
+    sv, pts = X[:nsv], X[nsv:]
+    alpha = rng.standard_normal(nsv).astype(np.float32)
+    prm = Parameter(kernel_type="rbf", gamma=1.0 / d)
+    far = (pts * 12.0).astype(np.float32)
+    with backend.Predictor(prm, sv, alpha, 0.0) as pred:
+        info, info_far, one = {}, {}, {}
+        pred.predict(pts, info_out=info)
+        got = pred.predict(far, info_out=info_far)
+        want, _ = backend.predict_values(prm, sv, alpha, 0.0, None, far, info_out=one)
+        assert info["resident"] == 1 and info_far["resident"] == 0 and info_far["rbf_exponent_scale"] > 32 and np.array_equal(got, want) and one["gram_mode"] == info_far["gram_mode"]
+    prm = Parameter(kernel_type="polynomial", degree=2, gamma=1.0 / d, coef0=1.0)
+    wild = (pts * 10.0 ** rng.uniform(-6, 0, size=(pts.shape[0], 1))).astype(np.float32)
+    with backend.Predictor(prm, sv, alpha, 0.0) as pred:
+        info, info_wild, one = {}, {}, {}
+        pred.predict(pts, info_out=info)
+        got = pred.predict(wild, info_out=info_wild)
+        want, _ = backend.predict_values(prm, sv, alpha, 0.0, None, wild, info_out=one)
+        assert info["resident"] == 1 and info["gram_mode"] == 2 and info_wild["resident"] == 0 and info_wild["gram_mode"] == 1 and np.array_equal(got, want)
+
+
 # ------------------------------------------------------------------------------------------------------------ rbf on grid planes in the 256-row form (VERDICT r05 item 7)
 @pytest.mark.parametrize("d, gamma, devices", [(128, 4.0, None), (128, 30.0, None), (64, 8.0, None), (100, 5.0, [0, 0, 0]), (40, 60.0, None)])
 def test_rbf_on_grid_planes_in_the_256_row_kernel(oracle, d, gamma, devices):
