@@ -23,6 +23,14 @@
 namespace lssvm {
 
 
+/* out_i = v_i * s_i (row-scaled f16 planes of the linear kernel: s = 2^-k_i per row; in place where out == v) */
+#ifdef LSSVM_KERNELS_SETUP
+__global__ void k_scale_vector(const float *v, const float *__restrict__ s, int n, float *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v[i] * s[i];
+}
+#endif  // LSSVM_KERNELS_SETUP
+
 /* dc[jt][0..127] = d of tile jt, dc[jt][128..255] = c (rbf: -|x_j|^2/2, else unused): one 1-KiB LDS-DMA record per tile */
 /* folded != 0 (rbf on the 16x16x32 bf16x6 kernels): dc[jt][0..127] = 2^c_j * d_j, dc[jt][128..255] = 2^c_j -- the tile kernel then starts its
  * accumulators from c_i alone (as the C operand of the first MFMA) and evaluates K_ij d_j = 2^acc * (2^c_j d_j); used only while

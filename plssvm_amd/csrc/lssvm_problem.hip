@@ -353,6 +353,30 @@ static void make_planes(const Options &o, const lssvm_params &p, bool rbf_direct
             }
             return;
         }
+        // Round 6, linear kernel (training): what ONE scale for the matrix cannot hold is data whose ROWS differ by orders of magnitude (tests/tools/gram_mode_by_data.py:
+        // the only shape that failed) -- the small rows' mid plane falls into f16's subnormals.  A power-of-two scale PER ROW holds them: K = D (Xs Xs^T) D with D = diag(2^-k_i),
+        // so the tile kernels run unchanged on Xs and Problem<float> multiplies the vector by D in front of the product and the result by D behind it (two O(n) launches)
+        // instead of running twice the matrix-core work as bf16x6.
+        if (p.kernel_type == LSSVM_KERNEL_LINEAR && M2 == nullptr && o.gram_mode == 3 && std::isfinite(rel2)) {
+            out.row_inv_scale.alloc_zero(static_cast<size_t>(M.rows_alloc), s);
+            LSSVM_HIP_CHECK(hipMemsetAsync(stats.p, 0, 4 * sizeof(unsigned), s));
+            split_f16_planes(M.data.p, M.ldx, M.dfeat, static_cast<size_t>(M.rows_alloc), ldx16, 1.0f, 0, out.buf.p, static_cast<size_t>(M.rows_alloc) * ldx16, stats.p, s, out.row_inv_scale.p);
+            LSSVM_HIP_CHECK(hipMemcpyAsync(host, stats.p, sizeof(host), hipMemcpyDeviceToHost, s));
+            LSSVM_HIP_CHECK(hipStreamSynchronize(s));
+            float rel2_rows = 0.0f;
+            std::memcpy(&rel2_rows, &host[0], sizeof(float));
+            if (const char *dbg = std::getenv("LSSVM_MI355_DEBUG"); dbg != nullptr && dbg[0] == '1') {
+                std::fprintf(stderr, "[plssvm_amd] f16 planes with a scale per row: max relative representation error of a row %.3g -> %s\n", std::sqrt(static_cast<double>(rel2_rows)),
+                             rel2_rows <= F16_REL2_MAX ? "f16x3 (row scaled)" : "bf16x6");
+            }
+            if (rel2_rows <= F16_REL2_MAX) {
+                out.mode = 2;
+                out.shift = 0;
+                out.f16_row_rel_error = std::sqrt(static_cast<double>(rel2_rows));
+                return;
+            }
+            out.row_inv_scale.release();
+        }
         out.buf.release();
         if (out2 != nullptr) out2->buf.release();
     }
@@ -952,6 +976,8 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
             grid_sigma_ = make_grid_planes(X_, rbf_r2_, planes_, c_.p, efac_, st, wide_nl_);
         } else if (!wide_linear_) make_planes(opt_, tile_params_, rbf_direct_, X_, nullptr, planes_, nullptr, st, wide_nl_, false, f16_probe_failed_);
         f16_row_rel_error_ = planes_.f16_row_rel_error;
+        row_scaled_ = planes_.row_inv_scale.p != nullptr;
+        if (row_scaled_) vs_.alloc_zero(static_cast<size_t>(nvec_) + TILE, st);
         if ((wide_nl_ || pair_) && planes_.mode == 0) throw Error(LSSVM_ERR_INTERNAL, "no operand planes for a path that was chosen from the shape alone");
         if ((wide_nl_ && sym_) || pair_) {
             // the row side of the panels-inside-a-tile kernel: the planes once more, every 16 x 32 block stored as the A fragment a wave loads
@@ -1075,6 +1101,12 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
     // symmetric variant: row sums of the device's blocks and the mirrored column sums of every band are ADDED into K*v (and, sharded, every rank
     // adds into all earlier rows): start from zero -- by the kernel that packs the records where there is one, by a memset otherwise
     const bool clear = zero_first || sym_;
+    if constexpr (std::is_same_v<T, float>) {
+        if (row_scaled_) {  // K v = D (Xs Xs^T) (D v): the tile kernels see D v (make_planes: a power-of-two scale per row)
+            hipLaunchKernelGGL(k_scale_vector, dim3((nvec_ + 255) / 256), dim3(256), 0, st, v_dev, planes_.row_inv_scale.p, nvec_, vs_.p);
+            v_dev = vs_.p;
+        }
+    }
     const bool prepacked = d_packed_ && v_dev == d_.p;  // k_update_d has left the records of d_ and cleared K*v (pack_for_d)
     d_packed_ = false;                                  // (either they are consumed now, or dc_ is about to hold another vector's)
     const bool pack = dc_.p != nullptr && num_ib_ > 0 && !prepacked;
@@ -1157,6 +1189,10 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
         }
         hipLaunchKernelGGL(k_reduce_partials<T>, dim3((nrows + 255) / 256), dim3(256), 0, st, partial_.p, a.part_stride, num_jc_, ib_begin_ * TILE, nrows, Kv_.p);
     }
+    if constexpr (std::is_same_v<T, float>) {
+        // (every entry this shard has added into: the symmetric variant mirrors into the rows of earlier blocks too; a sharded solve exchanges the scaled partial vectors)
+        if (row_scaled_) hipLaunchKernelGGL(k_scale_vector, dim3((nvec_ + 255) / 256), dim3(256), 0, st, Kv_.p, planes_.row_inv_scale.p, nvec_, Kv_.p);
+    }
     LSSVM_HIP_CHECK(hipGetLastError());
 }
 
@@ -1165,7 +1201,7 @@ void Problem<T>::enqueue_apply_K_local(const T *v_dev, bool zero_first) {
 template <typename T>
 PackDc<T> Problem<T>::pack_for_d(bool zero_first) {
     PackDc<T> pk;
-    if (dc_.p == nullptr || num_ib_ <= 0) return pk;
+    if (dc_.p == nullptr || num_ib_ <= 0 || row_scaled_) return pk;  // (row-scaled planes: the records are those of D d, packed per matvec)
     pk.dc = dc_.p;
     pk.cc = c_.p;
     pk.ncols = num_tiles_ * TILE;

@@ -255,7 +255,8 @@ void split_bf16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx1
  * statistics {max rel^2, max |rest|^2, max |y|^2} as float bits */
 void split_grid_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, float g, float sigma, uint16_t *planes, size_t plane_stride, float *chg, float *efac, unsigned *stats,
                        hipStream_t s);  // tile_launch_f32h.hip
-void split_f16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, float scale, int shift, uint16_t *planes, size_t plane_stride, unsigned *stats, hipStream_t s);  // tile_launch_f32h.hip
+void split_f16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, float scale, int shift, uint16_t *planes, size_t plane_stride, unsigned *stats, hipStream_t s,
+                      float *row_inv_scale = nullptr);  // row_inv_scale != NULL: a power-of-two scale per ROW, its inverse stored there  // tile_launch_f32h.hip
 void absmax_f32(const float *X, int ldx, int dfeat, size_t rows, unsigned *out, hipStream_t s);  // tile_launch_f32h.hip
 bool v2_eligible_f64(const Options &o, int ldx);
 int sym_block_boundary(int num_tiles, int r, int world, const std::vector<double> *weights = nullptr);
@@ -263,6 +264,7 @@ void shard_blocks(int num_tiles, int world, int rank, bool symmetric, int &begin
 
 /* fp32: a data matrix once more as operand planes of the split tile kernels (make_planes in lssvm_problem.hip) */
 struct PlaneSet {
+    DevBuf<float> row_inv_scale;     // f16x3, linear kernel, round 6: 2^-k_i per row where the planes carry a scale PER ROW (empty: one scale for the matrix)
     double f16_row_rel_error = -1.0;  // what the representability check of the f16 planes measured (make_planes), -1 where it did not run
     DevBuf<uint16_t> buf;
     int ldx16 = 0;
@@ -353,6 +355,8 @@ class Problem {
     bool pair_ = false;            // fp32 symmetric variant on the split kernels, <= 128 features per pass: 256-row workgroups on block pairs (lssvm_tile_f32_pair.hip.hpp)
     int part_blocks() const { return pair_ ? round_up(std::max(num_ib_, 1), 2) : std::max(num_ib_, 1); }  // row blocks of a row slab (whole pairs)
     double f16_row_rel_error_ = -1.0;  // fp32, gram_mode 2 / 3: the largest relative error of a row under two f16 planes, as measured at set-up (-1: not measured)
+    bool row_scaled_ = false;        // fp32 linear kernel: the f16 planes carry a power-of-two scale per ROW (planes_.row_inv_scale): K v = D (Xs Xs^T) (D v)
+    DevBuf<T> vs_;                   // ... D v, the vector the tile kernel multiplies
     bool f16_probe_failed_ = false;  // the probe for the linear kernel's panel passes found the data unfit for two f16 planes
     bool wide_nl_ = false;         // fp32 rbf / polynomial on more features than the one-pass split kernels take: feature panels inside a tile (lssvm_tile_f32_wide.hip.hpp)
     bool wide_linear_ = false;     // linear kernel over feature panels, one tile-kernel pass per panel: fp32 f16x3 beyond linear_panel_features, fp64 beyond 256 features

@@ -25,11 +25,24 @@ namespace lssvm {
  * stats[0] = max over the rows of |rest|^2 / |y|^2 (rest = y - hi - mid: relative representation error of a row, squared), stats[1] = max |rest|^2,
  * stats[2] = max |y|^2 -- as float bit patterns combined with atomicMax (non-negative floats order like their bit patterns; a NaN stays on top).
  * X: [rows][ldx] fp32, features in natural order; planes zero padded. */
+/* row_inv != NULL (round 6, linear kernel): every ROW gets a power-of-two scale of its own -- 2^k_i moves the row's largest entry to [2^14, 2^15) -- and row_inv[row]
+ * receives 2^-k_i: K = D (Xs Xs^T) D with Xs the scaled rows and D = diag(2^-k_i), so the caller multiplies the vector by D in front of the product and the result by D
+ * behind it (Problem<float>: row_scaled_).  One scale for the whole matrix loses the small ROWS of data whose points differ by orders of magnitude. */
 __global__ void k_split_f16x2(const float *__restrict__ X, int ldx, int dfeat, size_t rows, int ldx16, float scale, int shift, uint16_t *__restrict__ planes,
-                              size_t plane_stride, unsigned *__restrict__ stats) {
+                              size_t plane_stride, unsigned *__restrict__ stats, float *__restrict__ row_inv) {
     const size_t row = static_cast<size_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
+    if (row_inv != nullptr) {
+        float m = 0.0f;
+        for (int f = lane; f < dfeat; f += 64) m = fmaxf(m, fabsf(X[row * ldx + f]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        int k = 0;
+        if (m > 0.0f && m <= 3.0e38f) k = min(max(14 - ilogbf(m), -40), 40);  // (F16_TARGET_EXP, F16_MAX_SHIFT of lssvm_problem.hip)
+        scale = ldexpf(1.0f, k);
+        if (lane == 0) row_inv[row] = ldexpf(1.0f, -k);
+    }
     const float up = __builtin_ldexpf(1.0f, shift), down = __builtin_ldexpf(1.0f, -shift);
     float sr = 0.0f, sx = 0.0f;
     bool overflow = false;
@@ -225,8 +238,9 @@ void launch_f16_tile_kernel(const TileArgs<float> &a, int kernel_type, dim3 grid
     LSSVM_HIP_CHECK(hipGetLastError());
 }
 
-void split_f16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, float scale, int shift, uint16_t *planes, size_t plane_stride, unsigned *stats, hipStream_t s) {
-    hipLaunchKernelGGL(k_split_f16x2, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, X, ldx, dfeat, rows, ldx16, scale, shift, planes, plane_stride, stats);
+void split_f16_planes(const float *X, int ldx, int dfeat, size_t rows, int ldx16, float scale, int shift, uint16_t *planes, size_t plane_stride, unsigned *stats, hipStream_t s,
+                      float *row_inv_scale) {
+    hipLaunchKernelGGL(k_split_f16x2, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, X, ldx, dfeat, rows, ldx16, scale, shift, planes, plane_stride, stats, row_inv_scale);
     LSSVM_HIP_CHECK(hipGetLastError());
 }
 

@@ -367,32 +367,71 @@ def test_exactly_representable_data_takes_f16x3_and_matches_the_float64_oracle(o
     assert err < 1 * EPS32, err / EPS32
 
 
-@pytest.mark.parametrize("kernel", ["linear", "rbf"])
-def test_data_that_fails_the_representability_check_reports_bf16x6(oracle, kernel):
-    """POINTS of very different magnitude (N(0, 1) x 10^U(-4, 4) per ROW, unscaled): the planes carry ONE power-of-two scale for the whole matrix, so the small rows'
-    mid plane falls into f16's subnormal range and loses bits -- the check measures it (lssvm_cg_info.f16_row_rel_error above 2^-22), the solve runs bf16x6 (gram_mode = 1
-    in lssvm_cg_info) and keeps the fp32-class accuracy; forcing f16x3 (gram_mode 2: no check) on the same data shows what the check prevents.  (Columns of different
-    magnitude do NOT fail it: a row's error is measured against the row's norm, which its large entries dominate -- tests/tools/gram_mode_by_data.py, "wide_range".)"""
+@pytest.mark.parametrize("kernel", ["linear", "polynomial", "rbf"])
+def test_data_that_fails_the_representability_check_of_one_scale(oracle, kernel):
+    """POINTS of very different magnitude (N(0, 1) x 10^U(-4, 4) per ROW, unscaled): planes with ONE power-of-two scale for the whole matrix push the small rows' mid plane into
+    f16's subnormal range -- the check measures it (a row error far above 2^-22).  (Columns of different magnitude do NOT fail it: a row's error is measured against the row's
+    norm, which its large entries dominate -- tests/tools/gram_mode_by_data.py, "wide_range".)
+      * polynomial: the solve runs bf16x6 -- gram_mode = 1 in lssvm_cg_info -- and keeps the fp32-class accuracy; forcing f16x3 (gram_mode 2: no check) shows what the check prevents;
+      * LINEAR (round 6): the planes get a power-of-two scale PER ROW instead -- K = D (Xs Xs^T) D, the vector scaled in front of the product and the result behind it -- and stay
+        f16x3 (gram_mode 2, row error back below 2^-22) at the f16x3 kernels' speed and accuracy; one device and three shards agree, three CG iterations agree with the bf16x6 solve's;
+      * rbf accepts f16 planes under an ABSOLUTE bound on the exponent's error as well (a small row is a point near the centre: its exponent needs no relative accuracy)."""
     rng = np.random.default_rng(12)
     N, d = 12000, 128
     X = (rng.normal(0, 1, size=(N, d)) * 10.0 ** rng.uniform(-4, 4, size=(N, 1))).astype(np.float32)
+    y = np.where(np.arange(N) % 2 == 0, 1.0, -1.0).astype(np.float32)
     X64 = X.astype(np.float64)
-    gamma = 8.0 / float(np.max(np.einsum("ij,ij->i", X64, X64)))  # rbf: an exponent scale of a few units
+    top = float(np.max(np.einsum("ij,ij->i", X64, X64)))
+    gamma = 8.0 / top if kernel == "rbf" else 1.0 / top  # rbf: an exponent scale of a few units; polynomial: gamma x.y of order one
+    prm = Parameter(kernel_type=kernel, gamma=gamma, degree=2, coef0=1.0)
     rows = np.sort(rng.choice(N - 1, size=40, replace=False))
-    with backend.ResidentProblem(Parameter(kernel_type=kernel, gamma=gamma), X) as prob:
+
+    def rows_err(prob):
+        n = N - 1
+        rhs = np.random.default_rng(0).uniform(-1, 1, size=n).astype(np.float32)
+        q, QA = prob.q()
+        got = prob.matvec(rhs, np.zeros(n, np.float32), 1.0)
+        q64, rhs64 = q.astype(np.float64), rhs.astype(np.float64)
+        want = np.zeros(n)
+        for r in rows:
+            want = oracle.matvec_rows(kernel, X64, q64, rhs64, want, float(QA), 1.0, 1.0, int(r), int(r) + 1, degree=2, gamma=gamma, coef0=1.0)
+        G = X64[rows] @ X64[:n].T
+        if kernel == "rbf":
+            sq = np.einsum("ij,ij->i", X64, X64)
+            K = np.exp(-gamma * np.maximum(sq[rows, None] + sq[None, :n] - 2.0 * G, 0.0))
+        elif kernel == "polynomial":
+            K = np.abs(gamma * G + 1.0) ** 2
+        else:
+            K = np.abs(G)
+        absd = np.abs(rhs64)
+        scale = K @ absd + (abs(float(QA)) + np.abs(q64[rows])) * absd.sum() + np.abs(q64) @ absd + absd[rows]
+        return float(np.max(np.abs(got[rows] - want[rows]) / scale)), got
+
+    with backend.ResidentProblem(prm, X) as prob:
         info = prob.info()
-        err, _ = _rows_vs_oracle(oracle, prob, kernel, X, gamma, rows)
-    if kernel == "linear":
+        err, got = rows_err(prob)
+    with backend.ResidentProblem(prm, X, options=Options(gram_mode=1)) as exact:
+        err_bf16, got_bf16 = rows_err(exact)
+    print(f"\nrows of different magnitude, {kernel}: default gram mode {info['gram_mode']} (row error {info['f16_row_rel_error']:.2e}) {err / EPS32:.2f} eps, bf16x6 {err_bf16 / EPS32:.2f} eps")
+    assert err < 4 * EPS32 and err_bf16 < 4 * EPS32
+    if kernel == "polynomial":
         assert info["gram_mode"] == 1 and info["f16_row_rel_error"] > 2.0 ** -22, info
-    else:
-        # rbf accepts f16 planes under an ABSOLUTE bound on the exponent's error as well (a small row is a point near the centre: its exponent needs no relative accuracy)
-        assert info["gram_mode"] in (1, 2) and info["rbf_direct"] == 0, info
-    assert err < 4 * EPS32, err / EPS32
-    if kernel == "linear":
-        with backend.ResidentProblem(Parameter(kernel_type=kernel, gamma=gamma), X, options=Options(gram_mode=2)) as forced:
+        with backend.ResidentProblem(prm, X, options=Options(gram_mode=2)) as forced:
             assert forced.info()["gram_mode"] == 2
-            err_forced, _ = _rows_vs_oracle(oracle, forced, kernel, X, gamma, rows)
-        print(f"\nrows of different magnitude, linear: bf16x6 (chosen) {err / EPS32:.2f} eps, f16x3 forced {err_forced / EPS32:.2f} eps")
+    elif kernel == "linear":
+        assert info["gram_mode"] == 2 and 0 <= info["f16_row_rel_error"] <= 2.0 ** -22, info
+        with backend.ResidentProblem(prm, X, devices=[0, 0, 0]) as sharded:
+            assert sharded.info()["gram_mode"] == 2
+            _, got3 = rows_err(sharded)
+        assert np.max(np.abs(got3 - got)) <= 64 * EPS32 * np.max(np.abs(got))
+        # the CG loop runs on it like on any other planes (the records are packed per matvec, the enqueue-ahead path included); the kernel matrix of such data spans sixteen orders
+        # of magnitude, so only the first iterations are comparable between two Gram modes
+        a1, rho1, i1 = backend.solve_system_of_linear_equations(prm, X, y, 1e-30, 3)
+        a2, rho2, i2 = backend.solve_system_of_linear_equations(prm, X, y, 1e-30, 3, options=Options(gram_mode=1))
+        assert i1["gram_mode"] == 2 and i2["gram_mode"] == 1 and i1["iterations"] == 3 and np.all(np.isfinite(a1))
+        assert np.max(np.abs(a1 - a2)) <= 1e-2 * np.max(np.abs(a2)), (np.max(np.abs(a1 - a2)), np.max(np.abs(a2)))
+    else:
+        assert info["gram_mode"] in (1, 2) and info["rbf_direct"] == 0, info
 
 
 # ------------------------------------------------------------------------------------------------------------ ADVICE r05
