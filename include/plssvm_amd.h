@@ -393,7 +393,8 @@ int lssvm_mi355_arff_close(lssvm_mi355_arff_file *file);
  *                   3 (default) = "f16x3" where the data allows, else "bf16x6"; 2 = "f16x3": every operand as TWO f16 planes (hi + mid; rbf: shifted by
  *                   2^-6 / 2^6, others pre-scaled by a power of two), three plane products on v_mfma_f32_16x16x32_f16; num_features <= 512 (rbf 384)
  *                   in one pass, beyond that over feature panels of 128 (linear: one launch per panel; rbf / polynomial: inside a tile, symmetric variant)
- *                   -- without the check whether two f16 planes represent THIS data as well as fp32 does, which mode 3 makes at set-up;
+ *                   -- without the check whether two f16 planes represent THIS data as well as fp32 does, which mode 3 makes at set-up (linear kernel, round 6: where ONE
+ *                   power-of-two scale for the matrix fails that check -- points that differ by orders of magnitude -- mode 3 gives every ROW its own scale and stays f16x3);
  *                   1 = "bf16x6": exact split into THREE bf16 planes, six plane products on v_mfma_f32_16x16x32_bf16, num_features <= 384 in one
  *                   pass (rbf / polynomial beyond that: feature panels inside a tile);
  *                   0 = Gram tiles on v_mfma_f32_32x32x2_f32 (exact fmaf chains)
