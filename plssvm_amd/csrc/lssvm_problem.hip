@@ -1538,7 +1538,7 @@ template <typename T>
 class Predictor final : public PredictorBase {
   public:
     Predictor(const Options &opt, const lssvm_params &params, const T *sv, size_t nsv, size_t nfeat, const T *alpha, T rho) :
-        opt_(opt), params_(params), nsv_(nsv), nfeat_(nfeat), rho_(rho), sv_host_(sv, sv + nsv * nfeat), alpha_host_(alpha, alpha + nsv) {
+        opt_(opt), params_(params), nsv_(nsv), nfeat_(nfeat), rho_(rho) {
         dtype = std::is_same_v<T, float> ? LSSVM_DTYPE_F32 : LSSVM_DTYPE_F64;
         check_params(&params_);
         LSSVM_REQUIRE(sv != nullptr && nsv > 0, "The support vectors must not be empty!");   // csvm.cpp:189
@@ -1555,7 +1555,17 @@ class Predictor final : public PredictorBase {
             LSSVM_HIP_CHECK(hipStreamSynchronize(s));
             return;
         }
-        if constexpr (std::is_same_v<T, float>) prepare_resident(s);
+        alpha_host_.assign(alpha, alpha + nsv);
+        if constexpr (std::is_same_v<T, float>) prepare_resident(sv, s);
+        // the one-shot path's input: a host copy where nothing is resident; a resident model keeps its support vectors as they came in HBM and fetches them if a batch ever asks
+        if (!resident_) {
+            sv_host_.assign(sv, sv + nsv * nfeat);
+            S_.data.release();  // (whatever prepare_resident had built before it found the model outside the resident form)
+            raw_.release();
+            planesS_.buf.release();
+            cS_.release();
+            mean_.release();
+        }
     }
 
     void predict(const void *points_v, size_t npoints, void *out_v, lssvm_predict_info *info) override {
@@ -1577,6 +1587,7 @@ class Predictor final : public PredictorBase {
             // that lies further from the support vectors' centre than the form chosen for them allows): the one-shot path, same result
             int w_valid = 0;
             std::vector<T> w_tmp(nfeat_);
+            if (sv_host_.empty()) fetch_support_vectors();
             predict_values<T>(opt_, params_, sv_host_.data(), nsv_, nfeat_, alpha_host_.data(), rho_, w_tmp.data(), &w_valid, points, npoints, out, &local);
             local.resident = 0;
         }
@@ -1611,18 +1622,21 @@ class Predictor final : public PredictorBase {
     }
 
     /* fp32, rbf / polynomial, at most 128 features, a split Gram mode: the support vectors' side of the product, once */
-    void prepare_resident(hipStream_t s) {
+    void prepare_resident(const float *sv, hipStream_t s) {
         if (round_up(static_cast<long>(nfeat_), 64) > 128 || opt_.gram_mode == 0 || opt_.tile_kernel == 1) return;
-        S_.upload(sv_host_.data(), LSSVM_MEM_HOST, nsv_, nfeat_, 0, s);
+        if (params_.kernel_type == LSSVM_KERNEL_RBF && (opt_.rbf_form == 1 || opt_.rbf_form == 3)) return;  // (the direct kernel / the grid planes asked for: the one-shot path has them)
+        S_.upload(sv, LSSVM_MEM_HOST, nsv_, nfeat_, 0, s);
         if (!v2_eligible(opt_, S_.ldx, false)) return;
         const bool rbf = params_.kernel_type == LSSVM_KERNEL_RBF;
         if (rbf) {
-            if (opt_.rbf_form == 1 || opt_.rbf_form == 3) return;  // (the direct kernel / the grid planes asked for: the one-shot path has them)
             column_means<float>(S_, mean_, s);
             const double sq = max_centred_sqnorm<float>(S_, mean_, s);
             r2_sv_ = 2.0 * static_cast<double>(static_cast<float>(params_.gamma)) * 1.4426950408889634 * sq;
             if (!(r2_sv_ <= RBF_DIRECT_ABOVE) && opt_.rbf_form != 2) return;  // (beyond the norm expansion's range: grid planes or the direct kernel, one-shot)
             scale_ = rbf_prescale<float>(params_, false);
+            // S_ is centred and scaled in place below: the support vectors as they came stay beside it (the one-shot path's input, should a batch need it)
+            raw_.alloc_zero(S_.data.count, s);
+            LSSVM_HIP_CHECK(hipMemcpyAsync(raw_.p, S_.data.p, S_.data.count * sizeof(float), hipMemcpyDeviceToDevice, s));
             hipLaunchKernelGGL(k_center<float>, dim3((S_.dfeat + 255) / 256, S_.rows), dim3(256), 0, s, S_.data.p, S_.ldx, S_.dfeat, S_.rows, mean_.p, scale_);
             LSSVM_HIP_CHECK(hipGetLastError());
             half_neg_norms<float>(S_, cS_, s);
@@ -1645,14 +1659,36 @@ class Predictor final : public PredictorBase {
         resident_ = true;
     }
 
+    /* the support vectors back on the host, as they came (a resident model keeps no host copy until a batch needs the one-shot path) */
+    void fetch_support_vectors() {
+        if constexpr (std::is_same_v<T, float>) {
+            select_device_checked(0);
+            const float *src = raw_.p != nullptr ? raw_.p : S_.data.p;
+            LSSVM_REQUIRE(src != nullptr, "the predictor holds no support vectors");
+            sv_host_.resize(nsv_ * nfeat_);
+            LSSVM_HIP_CHECK(hipMemcpy2D(sv_host_.data(), nfeat_ * sizeof(float), src, static_cast<size_t>(S_.ldx) * sizeof(float), nfeat_ * sizeof(float), nsv_, hipMemcpyDeviceToHost));
+        }
+    }
+
     /* a batch of points against the resident support vectors; false = this batch needs the one-shot path */
     bool predict_resident(const float *points, size_t npoints, float *out, lssvm_predict_info &info) {
         select_device_checked(0);
         hipStream_t s = nullptr;
         const double t0 = now_ms();
+        const char *dbg_env = std::getenv("LSSVM_MI355_DEBUG");
+        const bool dbg = dbg_env != nullptr && dbg_env[0] == '1';
+        double t_last = t0;
+        auto lap = [&](const char *what) {  // LSSVM_MI355_DEBUG=1: where a call's time goes (the stream is drained at every lap, so the laps add up)
+            if (!dbg) return;
+            (void) hipStreamSynchronize(s);
+            const double t = now_ms();
+            std::fprintf(stderr, "[plssvm_amd] predictor: %-28s %8.3f ms\n", what, t - t_last);
+            t_last = t;
+        };
         const bool rbf = params_.kernel_type == LSSVM_KERNEL_RBF;
         DeviceMatrix<float> P;
         P.upload(points, LSSVM_MEM_HOST, npoints, nfeat_, static_cast<size_t>(round_up(static_cast<long>(npoints), 2 * TILE)), s);
+        lap("points uploaded");
         DevBuf<float> cP;
         double r2 = r2_sv_;
         if (rbf) {
@@ -1663,6 +1699,7 @@ class Predictor final : public PredictorBase {
             LSSVM_HIP_CHECK(hipGetLastError());
             half_neg_norms<float>(P, cP, s);
         }
+        lap("centred, norms");
         // the batch's planes: the kind and the scale of the support vectors' planes; two f16 planes must represent THIS batch too
         PlaneSet planesP;
         planesP.ldx16 = planesS_.ldx16;
@@ -1689,6 +1726,7 @@ class Predictor final : public PredictorBase {
         } else {
             split_bf16_planes(P.data.p, P.ldx, P.dfeat, static_cast<size_t>(P.rows_alloc), planesP.ldx16, planesP.buf.p, static_cast<size_t>(P.rows_alloc) * planesP.ldx16, s);
         }
+        lap("operand planes");
         const int num_ib = P.rows_alloc / TILE;
         const bool folded = rbf && dc_folded_.p != nullptr && r2 <= FOLD_MAX_R2;
         const bool poly_generic = params_.kernel_type == LSSVM_KERNEL_POLYNOMIAL && params_.degree != 2 && params_.degree != 3;
@@ -1727,6 +1765,7 @@ class Predictor final : public PredictorBase {
         ev_a.create(true);
         ev_b.create(true);
         LSSVM_HIP_CHECK(hipStreamSynchronize(s));
+        lap(rect ? "slabs, 256-row launch set up" : "slabs");
         const double t_kernel = now_ms();
         LSSVM_HIP_CHECK(hipEventRecord(ev_a.e, s));
         launch_tile_kernel<float>(ta, params_.kernel_type, false, num_jc, s);
@@ -1734,8 +1773,10 @@ class Predictor final : public PredictorBase {
         hipLaunchKernelGGL(k_reduce_partials<float>, dim3((P.rows_alloc + 255) / 256), dim3(256), 0, s, partial.p, ta.part_stride, num_jc, 0, P.rows_alloc, Kv.p);
         hipLaunchKernelGGL(k_sub_rho<float>, dim3((P.rows + 255) / 256), dim3(256), 0, s, Kv.p, P.rows, rho_, o.p);
         LSSVM_HIP_CHECK(hipGetLastError());
+        lap("product, row sums");
         LSSVM_HIP_CHECK(hipMemcpyAsync(out, o.p, npoints * sizeof(float), hipMemcpyDeviceToHost, s));
         LSSVM_HIP_CHECK(hipStreamSynchronize(s));
+        lap("values downloaded");
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, ev_a.e, ev_b.e) == hipSuccess) info.kernel_ms = ms;
         info.total_ms = now_ms() - t0;
@@ -1757,7 +1798,7 @@ class Predictor final : public PredictorBase {
     // fp32 resident form
     bool resident_ = false;
     DeviceMatrix<float> S_;
-    DevBuf<float> mean_, cS_, a_, dc_, dc_folded_;
+    DevBuf<float> mean_, cS_, a_, dc_, dc_folded_, raw_;
     PlaneSet planesS_;
     double r2_sv_ = 0.0;
     float scale_ = 1.0f;

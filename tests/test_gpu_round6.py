@@ -197,7 +197,16 @@ def test_resident_predictor_equals_the_one_shot_predict_values(oracle, kernel, d
             else:
                 assert np.max(np.abs(got - want)) <= 16 * eps * scale, (kernel, npts, np.max(np.abs(got - want)) / (eps * scale))
             if expect_resident and npts >= 100 and kernel != "linear":
-                assert info["total_ms"] < info1["total_ms"]  # the support vectors were not uploaded and prepared again
+                # the support vectors were not uploaded and prepared again (the best of three calls each: now and then one call of a long-lived process takes
+                # tens of milliseconds longer than its kernels)
+                t_res, t_one = [info["total_ms"]], [info1["total_ms"]]
+                for _ in range(2):
+                    a, b = {}, {}
+                    pred.predict(pts, info_out=a)
+                    backend.predict_values(prm, sv, alpha, 0.125, None, pts, info_out=b)
+                    t_res.append(a["total_ms"])
+                    t_one.append(b["total_ms"])
+                assert min(t_res) < min(t_one), (t_res, t_one)
         again = pred.predict(pool[:9000])
         assert np.array_equal(again, got)
     ref, _ = oracle.predict_values(kernel, sv.astype(np.float64), alpha.astype(np.float64), 0.125, pool[:200].astype(np.float64), degree=degree, gamma=1.0 / d, coef0=0.5)
