@@ -180,7 +180,8 @@ int lssvm_mi355_predict_values_f64(const lssvm_params *params, const double *sup
  * packed records; the linear kernel: w), `predict` uploads a batch of points (host memory, num_points x num_features row-major of the predictor's dtype), prepares
  * it alike and writes num_points decision values.  fp32 rbf / polynomial models of at most 128 features run against the resident form; everything else, and any batch
  * the resident form cannot take (it lies further from the support vectors' centre than the norm expansion allows, or two f16 planes do not represent it), goes through
- * the one-shot path with the copies the predictor keeps -- the values are the same either way, lssvm_predict_info.resident says which.  Device 0, like predict_values;
+ * the one-shot path (a resident model keeps no host copy: its support vectors come back from HBM the first time that happens) -- the values are the same either way,
+ * lssvm_predict_info.resident says which.  Device 0, like predict_values;
  * calls on one handle are not re-entrant. */
 typedef struct lssvm_mi355_predictor lssvm_mi355_predictor; /* opaque */
 int lssvm_mi355_predictor_create(lssvm_mi355_predictor **out, const lssvm_params *params, int dtype, const void *support_vectors, size_t num_support_vectors,
