@@ -168,8 +168,8 @@ def predict_main(argv=None) -> int:
             f.write("\n".join(_fmt(p) for p in predicted))
         t_w = time.perf_counter() - t_w
         LAST_TIMINGS.clear()
-        LAST_TIMINGS.update({"task": "predict", "read_s": t_r, "model_read_s": t_m, "predict_s": t_p, "write_s": t_w, "num_data_points": data.num_data_points(),
-                             "num_support_vectors": model.num_support_vectors()})
+        LAST_TIMINGS.update({"task": "predict", "read_s": t_r, "model_read_s": t_m, "predict_s": t_p, "predict_phases": dict(getattr(svm, "last_predict_phases", {})), "write_s": t_w,
+                             "num_data_points": data.num_data_points(), "num_support_vectors": model.num_support_vectors()})
         _log(verb, ("full", "timing"), f"Write {len(predicted)} predictions to the file '{out_file}'.")
         if data.has_labels():
             correct = sum(1 for p, c in zip(predicted, data.labels()) if p == c)

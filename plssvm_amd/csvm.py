@@ -155,13 +155,21 @@ class MI355CSVM(CSVM):
         if model.num_features() != data.num_features():
             raise InvalidParameterError(f"Number of features per data point ({data.num_features()}) must match the number of features per support vector of the "
                                         f"provided model ({model.num_features()})!")
+        t0 = time.perf_counter()
         cached = getattr(model, "_predictor", None)
         if cached is None or cached[0] is not self:
             cached = (self, backend.Predictor(model.params, model.support_vectors(), model.alpha, float(model.rho), options=self._options))
             model._predictor = cached
-        values = cached[1].predict(data.data())
+        t1 = time.perf_counter()
+        info = {}
+        values = cached[1].predict(data.data(), info_out=info)
+        t2 = time.perf_counter()
         mapper = model.data.mapping
-        return [mapper.label_of(1 if v > 0 else -1) for v in values]  # operators.hpp:180-182 sign, csvm.hpp:337-340
+        labels = [mapper.label_of(1 if v > 0 else -1) for v in values]  # operators.hpp:180-182 sign, csvm.hpp:337-340
+        # where the call's time went, in seconds (the command line's timing block and bench.py's `e2e` print it)
+        self.last_predict_phases = {"model_to_hbm_s": t1 - t0, "values_s": t2 - t1, "library_total_ms": float(info.get("total_ms", 0.0)), "kernel_ms": float(info.get("kernel_ms", 0.0)),
+                                    "labels_s": time.perf_counter() - t2}
+        return labels
 
 
 def make_csvm(backend_type=BackendType.AUTOMATIC, *args, **kwargs) -> CSVM:
