@@ -9,7 +9,8 @@
  * reference's, included from /root/reference/include.  The only restated part is the ~100-line CG driver
  * (src/plssvm/backends/OpenMP/csvm.cpp:71-183) and predict_values (:188-227): their translation unit needs the
  * un-vendored `igor` named-argument library (CMakeLists.txt:192-220) and therefore cannot be compiled here; the
- * restatement below calls the reference's compiled kernels and the reference's operators.hpp line by line.
+ * restatement below calls the reference's compiled kernels and the reference's operators.hpp line by line.  (Plus sampled_rows: one ROW of the implicit matvec as a
+ * loop around the reference's kernel_function<>, for inputs whose full triangle would take the reference hours.)
  *
  * The only third-party header needed is {fmt} (assert message formatting, include/plssvm/detail/assert.hpp:18-19);
  * the copy shipped inside this image's PyTorch is used (a real {fmt}, not a stand-in).
@@ -73,6 +74,26 @@ void run_kernel(int kernel_type, int degree, T gamma, T coef0, T inv_cost, const
         case 0: plssvm::openmp::device_kernel_linear(q, ret, d, data, QA_cost, inv_cost, add); break;
         case 1: plssvm::openmp::device_kernel_polynomial(q, ret, d, data, QA_cost, inv_cost, add, degree, gamma, coef0); break;
         default: plssvm::openmp::device_kernel_rbf(q, ret, d, data, QA_cost, inv_cost, add, gamma); break;
+    }
+}
+
+// SAMPLED ROWS of one implicit matvec, for inputs whose full lower triangle takes the reference hours (BASELINE configs[4], 1 000 000 points): row i of
+// ret += add * Abar * d as the sum over j of the reference's own per-pair expression (svm_kernel.cpp:45-52: temp = (kernel_function(data[i], data[j]) + QA_cost - q[i] - q[j]) * add,
+// the diagonal with "+ cost * add"), with the reference's COMPILED kernel_function<> -- only the loop over one row instead of the triangle is written here.  The sum runs in
+// j order in T, so a float64 call is the yardstick (the triangle's own order differs from it in the last digits of a double).
+template <typename T>
+void sampled_rows(int kernel_type, int degree, T gamma, T coef0, T inv_cost, const std::vector<T> &q, const std::vector<T> &d, const std::vector<std::vector<T>> &data, T QA_cost,
+                  T add, const std::uint64_t *rows, std::size_t nrows, T *out) {
+    const std::size_t n = data.size() - 1;
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (std::size_t k = 0; k < nrows; ++k) {
+        const std::size_t i = static_cast<std::size_t>(rows[k]);
+        T sum{ 0.0 };
+        for (std::size_t j = 0; j < n; ++j) {
+            const T temp = (kf<T>(kernel_type, degree, gamma, coef0, data[i], data[j]) + QA_cost - q[i] - q[j]) * add;
+            sum += (i == j ? temp + inv_cost * add : temp) * d[j];
+        }
+        out[k] = sum;
     }
 }
 
@@ -206,6 +227,10 @@ void predict(int kernel_type, int degree, T gamma, T coef0, const T *sv, std::si
         std::vector<T> rv(ret, ret + N - 1);                                                                                                       \
         run_kernel<T>(kt, degree, gamma, coef0, cost, qv, rv, dv, to_rows(X, N, d), QA_cost, add);                                                 \
         std::copy(rv.begin(), rv.end(), ret);                                                                                                      \
+    }                                                                                                                                              \
+    extern "C" void ref_matvec_sampled_rows_##SUF(int kt, int degree, T gamma, T coef0, const T *X, std::size_t N, std::size_t d, const T *q, const T *dvec, T QA_cost, T cost,   \
+                                                  T add, const std::uint64_t *rows, std::size_t nrows, T *out) {                                   \
+        sampled_rows<T>(kt, degree, gamma, coef0, cost, std::vector<T>(q, q + N - 1), std::vector<T>(dvec, dvec + N - 1), to_rows(X, N, d), QA_cost, add, rows, nrows, out);   \
     }                                                                                                                                              \
     extern "C" int ref_solve_##SUF(int kt, int degree, T gamma, T coef0, T cost, const T *X, std::size_t N, std::size_t d, const T *y, T eps,      \
                                    std::uint64_t max_iter, T *alpha, T *rho, oracle_cg_info *info, double *trace, std::size_t cap) {               \

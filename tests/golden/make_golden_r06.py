@@ -13,7 +13,10 @@ is computed by the reference in the configuration's own precision AND, for the f
 rounding); stored: QA_cost, q and the result at 512 seeded rows (first and last row included), the largest |result|, and the SHA-256 of the input matrix.  All
 cores are used (a 50 000-point matvec takes a minute on 8): the reference's float64 sums are stable across thread counts to >= 9 digits, its fp32 sums
 differ between thread counts by what `omp atomic` reorders -- the test holds the GPU to the float64 rows and to the fp32 rows only as far as the reference's own fp32
-run is from ITS float64 run.  configs[4] (1 000 000 x 128) would take the reference four hours per matvec here: it stays on the restated row function.
+run is from ITS float64 run.  configs[4] (1 000 000 x 128, `--with-c5`) would take the reference four hours per matvec here: its fixture holds q (the reference's q kernel,
+fp32) and the 512 sampled rows in float64 as sums of the reference's compiled kernel_function<> over ONE ROW each, in the per-pair expression of svm_kernel.cpp:45-52
+(oracle/ref_shim.cpp, sampled_rows: only the loop over a row instead of the triangle is written there) -- at configs[1] these row sums and the full run's rows agree to
+3e-14 of the largest entry, which this script checks before it trusts them.
 
 Run in the build container only (needs /root/reference):   make -C oracle ref && python tests/golden/make_golden_r06.py [--with-c3]"""
 
@@ -32,6 +35,7 @@ import oracle_lib  # noqa: E402
 from plssvm_amd.datagen import make_blobs_pm1  # noqa: E402
 
 CASES = {"c2": ("rbf", 50_000, 128, np.float32), "c3": ("linear", 200_000, 256, np.float32), "c4": ("polynomial", 100_000, 64, np.float64)}
+CASES5 = ("rbf", 1_000_000, 128, np.float32)  # configs[4]: sampled row sums only (--with-c5)
 DATA_SEED, RHS_SEED, ROWS_SEED, NROWS = 42, 606, 6, 512
 
 
@@ -51,7 +55,7 @@ def main():
     ref = oracle_lib.ref()
     path = os.path.join(HERE, "full_size_rows.npz")
     out = dict(np.load(path)) if os.path.isfile(path) else {}
-    names = ["c2", "c4"] + (["c3"] if "--with-c3" in sys.argv else [])
+    names = [] if "--only-c5" in sys.argv else ["c2", "c4"] + (["c3"] if "--with-c3" in sys.argv else [])
     for name in names:
         kernel, X, rhs, rows = inputs(name)
         N, d = X.shape
@@ -75,6 +79,36 @@ def main():
         if dt == np.float32:
             e = float(np.max(np.abs(out[f"{name}/matvec_p1_rows"].astype(np.float64) - out[f"{name}/matvec_p1_rows64"]))) / float(out[f"{name}/matvec_p1_absmax"])
             print(f"{name}: the reference's fp32 run against its float64 run at the sampled rows: {e / np.finfo(np.float32).eps:.1f} eps of the largest entry", flush=True)
+        np.savez_compressed(path, **out)
+    if "--with-c5" in sys.argv:
+        # the row sums against the full run where both exist
+        kernel, X, rhs, rows = inputs("c2")
+        X64, kw = X.astype(np.float64), dict(degree=3, gamma=1.0 / X.shape[1], coef0=0.0)
+        q = ref.q(kernel, X64, **kw)
+        QA = np.float64(ref.kernel_function(kernel, X64[-1], X64[-1], **kw)) + 1.0
+        got = ref.matvec_sampled_rows(kernel, X64, q, rhs.astype(np.float64), QA, 1.0, 1.0, rows, **kw)
+        dev = float(np.max(np.abs(got - out["c2/matvec_p1_rows64"]))) / float(out["c2/matvec_p1_absmax"])
+        print(f"c2: row sums of the reference's kernel_function against the rows of its full run: {dev:.1e} of the largest entry", flush=True)
+        assert dev < 1e-12
+        name, (kernel, N, d, dt) = "c5", CASES5
+        X, _ = make_blobs_pm1(N, d, seed=DATA_SEED, dtype=dt)
+        n = N - 1
+        rhs = np.random.default_rng(RHS_SEED).uniform(-1.0, 1.0, size=n).astype(dt)
+        rows = np.sort(np.random.default_rng(ROWS_SEED).choice(n, size=NROWS, replace=False))
+        rows[0], rows[-1] = 0, n - 1
+        kw = dict(degree=3, gamma=1.0 / d, coef0=0.0)
+        t0 = time.perf_counter()
+        q32 = ref.q(kernel, X, **kw)
+        QA32 = np.float32(ref.kernel_function(kernel, X[-1], X[-1], **kw)) + np.float32(1.0)
+        X64 = X.astype(np.float64)
+        q64 = ref.q(kernel, X64, **kw)
+        QA64 = np.float64(ref.kernel_function(kernel, X64[-1], X64[-1], **kw)) + 1.0
+        r64 = ref.matvec_sampled_rows(kernel, X64, q64, rhs.astype(np.float64), QA64, 1.0, 1.0, rows, **kw)
+        print(f"c5: {N} x {d} {kernel}: q (fp32, float64) and {NROWS} row sums in float64 in {time.perf_counter() - t0:.1f} s", flush=True)
+        out["c5/rows"], out["c5/q_rows"], out["c5/QA_cost"] = rows, q32[rows], np.asarray(QA32, np.float32)
+        out["c5/q_rows64"], out["c5/QA_cost64"], out["c5/matvec_p1_rows64"] = q64[rows], np.asarray(QA64), r64
+        out["c5/matvec_p1_absmax"] = np.asarray(np.max(np.abs(r64)))  # (of the sampled rows: no full run)
+        out["c5/X_sha256"] = np.frombuffer(hashlib.sha256(X.tobytes()).digest(), dtype=np.uint8)
         np.savez_compressed(path, **out)
     print("full_size_rows.npz", os.path.getsize(path), "bytes")
 

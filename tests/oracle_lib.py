@@ -99,6 +99,21 @@ class CpuPath:
            row_begin, row_end)
         return out
 
+    def matvec_sampled_rows(self, kernel, X, q, dvec, QA_cost, cost, add, rows, degree=3, gamma=1.0, coef0=0.0):
+        """(reference library only) rows `rows` of add * Abar * dvec: the reference's per-pair expression summed over one row each (ref_shim.cpp, sampled_rows)."""
+        X = np.ascontiguousarray(X)
+        suf, ct = _suffix(X.dtype)
+        N, d = X.shape
+        q = np.ascontiguousarray(q, dtype=X.dtype)
+        dvec = np.ascontiguousarray(dvec, dtype=X.dtype)
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.zeros(rows.size, dtype=X.dtype)
+        fn = self._fn("matvec_sampled_rows", suf)
+        fn.restype = None
+        fn.argtypes = [C.c_int, C.c_int, ct, ct, C.POINTER(ct), C.c_size_t, C.c_size_t, C.POINTER(ct), C.POINTER(ct), ct, ct, ct, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(ct)]
+        fn(self._kt(kernel), degree, gamma, coef0, _ptr(X, ct), N, d, _ptr(q, ct), _ptr(dvec, ct), QA_cost, cost, add, rows.ctypes.data_as(C.POINTER(C.c_uint64)), rows.size, _ptr(out, ct))
+        return out
+
     def solve(self, kernel, X, y, eps, max_iter, degree=3, gamma=1.0, coef0=0.0, cost=1.0, trace=False):
         """Returns (alpha[N], rho, info dict[, delta_trace])."""
         X = np.ascontiguousarray(X)

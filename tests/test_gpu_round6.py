@@ -296,13 +296,17 @@ def test_rbf_on_grid_planes_in_the_256_row_kernel(oracle, d, gamma, devices):
 FULL_SIZE = None
 
 
-@pytest.mark.parametrize("name, kernel, N, d, dt", [("c2", "rbf", 50_000, 128, np.float32), ("c3", "linear", 200_000, 256, np.float32), ("c4", "polynomial", 100_000, 64, np.float64)])
+@pytest.mark.parametrize("name, kernel, N, d, dt", [("c2", "rbf", 50_000, 128, np.float32), ("c3", "linear", 200_000, 256, np.float32), ("c4", "polynomial", 100_000, 64, np.float64),
+                                                    ("c5", "rbf", 1_000_000, 128, np.float32)])
 def test_baseline_configs_at_full_size_vs_the_references_own_kernels(name, kernel, N, d, dt):
     """VERDICT r05 ("what's weak" 1): until round 6 the largest input pinned to the reference's COMPILED kernels was 8 704 points.  tests/golden/full_size_rows.npz holds
     QA_cost, q and 512 sampled rows of ONE implicit matvec of the reference's own OpenMP kernels (oracle/_ref/liblssvm_ref.so: svm_kernel.cpp:33-54, q_kernel.cpp:18-55;
     generator tests/golden/make_golden_r06.py) on BASELINE.json's configs[1], [2] and [3] AT FULL SIZE -- the bench's own data -- in the configuration's precision
     and, for the fp32 ones, in float64 as well.  Bars, on the scale of each row's summands: fp64 4 eps; fp32 within 1 eps of the reference's float64 rows, no further
-    from them than the reference's own fp32 rows are, and as close to its fp32 rows as its own rounding allows."""
+    from them than the reference's own fp32 rows are, and as close to its fp32 rows as its own rounding allows.
+    configs[4] (the headline, 1 000 000 x 128: four hours per matvec for the reference): q from the reference's q kernel, and the 512 rows in float64 as sums of the reference's
+    COMPILED kernel_function<> over one row each in the expression of svm_kernel.cpp:45-52 (oracle/ref_shim.cpp sampled_rows; at configs[1] those sums and the full run's rows
+    agree to 3e-14 of the largest entry) -- the GPU's fp32 rows within 1 eps of them."""
     global FULL_SIZE
     if FULL_SIZE is None:
         FULL_SIZE = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_rows.npz"))
@@ -341,6 +345,12 @@ def test_baseline_configs_at_full_size_vs_the_references_own_kernels(name, kerne
         e = float(np.max(np.abs(got[rows] - G[f"{name}/matvec_p1_rows"]) / scale))
         print(f"\n{name}: sampled rows vs the reference's kernels: {e / eps:.2f} eps of the row's summands")
         assert e < 4 * eps
+    elif f"{name}/matvec_p1_rows" not in G:  # (no full fp32 run of the reference at this size: the float64 row sums alone)
+        ref64 = G[f"{name}/matvec_p1_rows64"]
+        e_gpu = float(np.max(np.abs(got[rows] - ref64) / scale))
+        print(f"\n{name}: sampled rows vs float64 row sums of the reference's kernel_function: {e_gpu / eps:.3f} eps of the row's summands "
+              f"({float(np.max(np.abs(got[rows] - ref64))) / float(G[f'{name}/matvec_p1_absmax']) / eps:.1f} eps of the largest sampled entry)")
+        assert e_gpu <= 1 * eps
     else:
         ref32, ref64 = G[f"{name}/matvec_p1_rows"].astype(np.float64), G[f"{name}/matvec_p1_rows64"]
         e_ref, e_gpu, e_vs = float(np.max(np.abs(ref32 - ref64) / scale)), float(np.max(np.abs(got[rows] - ref64) / scale)), float(np.max(np.abs(got[rows] - ref32) / scale))
