@@ -165,7 +165,8 @@ class MI355CSVM(CSVM):
         values = cached[1].predict(data.data(), info_out=info)
         t2 = time.perf_counter()
         mapper = model.data.mapping
-        labels = [mapper.label_of(1 if v > 0 else -1) for v in values]  # operators.hpp:180-182 sign, csvm.hpp:337-340
+        pos, neg = mapper.label_of(1), mapper.label_of(-1)
+        labels = [pos if p else neg for p in (np.asarray(values) > 0).tolist()]  # operators.hpp:180-182 sign, csvm.hpp:337-340
         # where the call's time went, in seconds (the command line's timing block and bench.py's `e2e` print it)
         self.last_predict_phases = {"model_to_hbm_s": t1 - t0, "values_s": t2 - t1, "library_total_ms": float(info.get("total_ms", 0.0)), "kernel_ms": float(info.get("kernel_ms", 0.0)),
                                     "labels_s": time.perf_counter() - t2}
