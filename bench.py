@@ -305,6 +305,22 @@ def predict_leg(seed, device, num_sv=50_000, num_points=200_000, d=128, calls=3)
             backend.predict_values(prm, sv, alpha, 0.25, None, batch, info_out=one)
             res[label] = {"points": int(batch.shape[0]), "resident_call_ms": sum(calls_ms) / len(calls_ms), "one_shot_call_ms": one["total_ms"], "ran_resident": resident,
                           "points_per_s_resident": batch.shape[0] / (sum(calls_ms) / len(calls_ms) * 1e-3)}
+            try:  # the batch and the values in HBM as well (LSSVM_MEM_DEVICE): no PCIe in the call
+                import torch
+
+                pd = torch.from_numpy(np.ascontiguousarray(batch)).cuda()
+                od = torch.zeros(batch.shape[0], dtype=torch.float32, device="cuda")
+                torch.cuda.synchronize()
+                hbm_ms = []
+                for k in range(calls + 1):
+                    info = {}
+                    pred.predict_device(pd.data_ptr(), batch.shape[0], od.data_ptr(), info_out=info)
+                    if k > 0:
+                        hbm_ms.append(info["total_ms"])
+                res[label].update({"batch_in_hbm_call_ms": sum(hbm_ms) / len(hbm_ms), "points_per_s_batch_in_hbm": batch.shape[0] / (sum(hbm_ms) / len(hbm_ms) * 1e-3)})
+                del pd, od
+            except Exception as e:  # noqa: BLE001  (torch is plumbing here: the leg stands without it)
+                res[label]["batch_in_hbm_error"] = f"{type(e).__name__}: {e}"
     out["resident_predictor_rbf"] = res
     return out
 

@@ -181,12 +181,13 @@ int lssvm_mi355_predict_values_f64(const lssvm_params *params, const double *sup
  * it alike and writes num_points decision values.  fp32 rbf / polynomial models of at most 128 features run against the resident form; everything else, and any batch
  * the resident form cannot take (it lies further from the support vectors' centre than the norm expansion allows, or two f16 planes do not represent it), goes through
  * the one-shot path (a resident model keeps no host copy: its support vectors come back from HBM the first time that happens) -- the values are the same either way,
- * lssvm_predict_info.resident says which.  Device 0, like predict_values;
- * calls on one handle are not re-entrant. */
+ * lssvm_predict_info.resident says which.  `mem_kind` (LSSVM_MEM_HOST / LSSVM_MEM_DEVICE, as lssvm_mi355_problem_create's) says where BOTH `predict_points` and `out`
+ * live: with LSSVM_MEM_DEVICE they are memory of device 0 (e.g. torch tensors' data_ptr) and a batch crosses no PCIe at all.  Device 0, like predict_values; calls on
+ * one handle are not re-entrant. */
 typedef struct lssvm_mi355_predictor lssvm_mi355_predictor; /* opaque */
 int lssvm_mi355_predictor_create(lssvm_mi355_predictor **out, const lssvm_params *params, int dtype, const void *support_vectors, size_t num_support_vectors,
                                  size_t num_features, const void *alpha, double rho, const lssvm_mi355_options *options);
-int lssvm_mi355_predictor_predict(lssvm_mi355_predictor *predictor, const void *predict_points, size_t num_predict_points, void *out, lssvm_predict_info *info);
+int lssvm_mi355_predictor_predict(lssvm_mi355_predictor *predictor, const void *predict_points, int mem_kind, size_t num_predict_points, void *out, lssvm_predict_info *info);
 int lssvm_mi355_predictor_destroy(lssvm_mi355_predictor *predictor);
 
 /* ------------------------------------------------------------------------------------------------------------------ */

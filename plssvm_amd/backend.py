@@ -161,10 +161,18 @@ class Predictor:
             raise InvalidParameterError(f"The number of features in the support vectors ({self.num_features}) must be the same as in the data points to predict ({pts.shape[1]})!")
         out = np.zeros(pts.shape[0], dtype=self.dtype)
         pinfo = LssvmPredictInfo()
-        check(lib.lssvm_mi355_predictor_predict(self._h, ptr(pts), C.c_size_t(pts.shape[0]), ptr(out), C.byref(pinfo)))
+        check(lib.lssvm_mi355_predictor_predict(self._h, ptr(pts), C.c_int(_capi.LSSVM_MEM_HOST), C.c_size_t(pts.shape[0]), ptr(out), C.byref(pinfo)))
         if info_out is not None:
             info_out.update(pinfo.as_dict())
         return out
+
+    def predict_device(self, points_ptr: int, num_points: int, out_ptr: int, info_out: dict | None = None) -> None:
+        """The same with the batch AND the values in memory of device 0 (``LSSVM_MEM_DEVICE``): ``points_ptr`` -> ``num_points`` x ``num_features`` row-major of the predictor's
+        dtype (e.g. a contiguous torch tensor's ``data_ptr()``, complete when the call is made), ``out_ptr`` -> ``num_points`` values, written when the call returns."""
+        pinfo = LssvmPredictInfo()
+        check(lib.lssvm_mi355_predictor_predict(self._h, C.c_void_p(int(points_ptr)), C.c_int(_capi.LSSVM_MEM_DEVICE), C.c_size_t(int(num_points)), C.c_void_p(int(out_ptr)), C.byref(pinfo)))
+        if info_out is not None:
+            info_out.update(pinfo.as_dict())
 
     def close(self):
         if self._h:

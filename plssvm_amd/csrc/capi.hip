@@ -265,10 +265,11 @@ int lssvm_mi355_predictor_create(lssvm_mi355_predictor **out, const lssvm_params
         *out = h.release();
     });
 }
-int lssvm_mi355_predictor_predict(lssvm_mi355_predictor *predictor, const void *predict_points, size_t num_predict_points, void *out, lssvm_predict_info *info) {
+int lssvm_mi355_predictor_predict(lssvm_mi355_predictor *predictor, const void *predict_points, int mem_kind, size_t num_predict_points, void *out, lssvm_predict_info *info) {
     return guarded([&] {
         LSSVM_REQUIRE(predictor != nullptr, "predictor handle must not be NULL");
-        predictor->impl->predict(predict_points, num_predict_points, out, info);
+        LSSVM_REQUIRE(mem_kind == LSSVM_MEM_HOST || mem_kind == LSSVM_MEM_DEVICE, "invalid mem_kind");
+        predictor->impl->predict(predict_points, mem_kind, num_predict_points, out, info);
     });
 }
 int lssvm_mi355_predictor_destroy(lssvm_mi355_predictor *predictor) {

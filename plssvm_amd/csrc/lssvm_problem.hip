@@ -1568,7 +1568,7 @@ class Predictor final : public PredictorBase {
         }
     }
 
-    void predict(const void *points_v, size_t npoints, void *out_v, lssvm_predict_info *info) override {
+    void predict(const void *points_v, int mem_kind, size_t npoints, void *out_v, lssvm_predict_info *info) override {
         const T *points = static_cast<const T *>(points_v);
         T *out = static_cast<T *>(out_v);
         LSSVM_REQUIRE(points != nullptr && npoints > 0, "The data points to predict must not be empty!");  // csvm.cpp:194
@@ -1577,10 +1577,10 @@ class Predictor final : public PredictorBase {
         local.f16_row_rel_error = -1.0;
         bool done = false;
         if (params_.kernel_type == LSSVM_KERNEL_LINEAR) {
-            predict_linear(points, npoints, out, local);
+            predict_linear(points, mem_kind, npoints, out, local);
             done = true;
         } else if constexpr (std::is_same_v<T, float>) {
-            if (resident_) done = predict_resident(points, npoints, out, local);
+            if (resident_) done = predict_resident(points, mem_kind, npoints, out, local);
         }
         if (!done) {
             // what the resident form does not cover (fp64, more than 128 features, exponent scales beyond the norm expansion, a batch whose planes fail the f16 check or
@@ -1588,14 +1588,22 @@ class Predictor final : public PredictorBase {
             int w_valid = 0;
             std::vector<T> w_tmp(nfeat_);
             if (sv_host_.empty()) fetch_support_vectors();
-            predict_values<T>(opt_, params_, sv_host_.data(), nsv_, nfeat_, alpha_host_.data(), rho_, w_tmp.data(), &w_valid, points, npoints, out, &local);
+            if (mem_kind == LSSVM_MEM_DEVICE) {  // (the one-shot entry point takes host buffers: a batch in HBM makes the round trip here -- the rare path)
+                select_device_checked(0);
+                std::vector<T> points_host(npoints * nfeat_), out_host(npoints);
+                LSSVM_HIP_CHECK(hipMemcpy(points_host.data(), points, points_host.size() * sizeof(T), hipMemcpyDeviceToHost));
+                predict_values<T>(opt_, params_, sv_host_.data(), nsv_, nfeat_, alpha_host_.data(), rho_, w_tmp.data(), &w_valid, points_host.data(), npoints, out_host.data(), &local);
+                LSSVM_HIP_CHECK(hipMemcpy(out, out_host.data(), npoints * sizeof(T), hipMemcpyHostToDevice));
+            } else {
+                predict_values<T>(opt_, params_, sv_host_.data(), nsv_, nfeat_, alpha_host_.data(), rho_, w_tmp.data(), &w_valid, points, npoints, out, &local);
+            }
             local.resident = 0;
         }
         if (info != nullptr) *info = local;
     }
 
   private:
-    void predict_linear(const T *points, size_t npoints, T *out, lssvm_predict_info &info) {
+    void predict_linear(const T *points, int mem_kind, size_t npoints, T *out, lssvm_predict_info &info) {
         select_device_checked(0);
         hipStream_t s = nullptr;
         const double t0 = now_ms();
@@ -1603,7 +1611,7 @@ class Predictor final : public PredictorBase {
         ev_a.create(true);
         ev_b.create(true);
         DeviceMatrix<T> P;
-        P.upload(points, LSSVM_MEM_HOST, npoints, nfeat_, 0, s);
+        P.upload(points, mem_kind, npoints, nfeat_, 0, s);
         DevBuf<T> o;
         o.alloc_zero(npoints, s);
         LSSVM_HIP_CHECK(hipStreamSynchronize(s));
@@ -1612,7 +1620,7 @@ class Predictor final : public PredictorBase {
         launch_predict_linear<T>(P, w_.p, rho_, o.p, s);
         LSSVM_HIP_CHECK(hipEventRecord(ev_b.e, s));
         LSSVM_HIP_CHECK(hipGetLastError());
-        LSSVM_HIP_CHECK(hipMemcpyAsync(out, o.p, npoints * sizeof(T), hipMemcpyDeviceToHost, s));
+        LSSVM_HIP_CHECK(hipMemcpyAsync(out, o.p, npoints * sizeof(T), mem_kind == LSSVM_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
         LSSVM_HIP_CHECK(hipStreamSynchronize(s));
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, ev_a.e, ev_b.e) == hipSuccess) info.kernel_ms = ms;
@@ -1671,7 +1679,7 @@ class Predictor final : public PredictorBase {
     }
 
     /* a batch of points against the resident support vectors; false = this batch needs the one-shot path */
-    bool predict_resident(const float *points, size_t npoints, float *out, lssvm_predict_info &info) {
+    bool predict_resident(const float *points, int mem_kind, size_t npoints, float *out, lssvm_predict_info &info) {
         select_device_checked(0);
         hipStream_t s = nullptr;
         const double t0 = now_ms();
@@ -1687,8 +1695,8 @@ class Predictor final : public PredictorBase {
         };
         const bool rbf = params_.kernel_type == LSSVM_KERNEL_RBF;
         DeviceMatrix<float> P;
-        P.upload(points, LSSVM_MEM_HOST, npoints, nfeat_, static_cast<size_t>(round_up(static_cast<long>(npoints), 2 * TILE)), s);
-        lap("points uploaded");
+        P.upload(points, mem_kind, npoints, nfeat_, static_cast<size_t>(round_up(static_cast<long>(npoints), 2 * TILE)), s);
+        lap(mem_kind == LSSVM_MEM_DEVICE ? "points copied in HBM" : "points uploaded");
         DevBuf<float> cP;
         double r2 = r2_sv_;
         if (rbf) {
@@ -1774,7 +1782,7 @@ class Predictor final : public PredictorBase {
         hipLaunchKernelGGL(k_sub_rho<float>, dim3((P.rows + 255) / 256), dim3(256), 0, s, Kv.p, P.rows, rho_, o.p);
         LSSVM_HIP_CHECK(hipGetLastError());
         lap("product, row sums");
-        LSSVM_HIP_CHECK(hipMemcpyAsync(out, o.p, npoints * sizeof(float), hipMemcpyDeviceToHost, s));
+        LSSVM_HIP_CHECK(hipMemcpyAsync(out, o.p, npoints * sizeof(float), mem_kind == LSSVM_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
         LSSVM_HIP_CHECK(hipStreamSynchronize(s));
         lap("values downloaded");
         float ms = 0.0f;

@@ -550,7 +550,7 @@ void calculate_w(const T *sv, size_t nsv, size_t nfeat, const T *alpha, T *w_out
 struct PredictorBase {
     int dtype = 0;
     virtual ~PredictorBase() = default;
-    virtual void predict(const void *points, size_t npoints, void *out, lssvm_predict_info *info) = 0;
+    virtual void predict(const void *points, int mem_kind, size_t npoints, void *out, lssvm_predict_info *info) = 0;  // points AND out of mem_kind
 };
 std::unique_ptr<PredictorBase> make_predictor(const Options &opt, const lssvm_params &params, int dtype, const void *sv, size_t nsv, size_t nfeat, const void *alpha, double rho);
 

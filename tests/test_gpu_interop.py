@@ -39,6 +39,39 @@ print('OK')
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_resident_predictor_with_the_batch_and_the_values_in_hbm():
+    """lssvm_mi355_predictor_predict with LSSVM_MEM_DEVICE: the points and the values are torch tensors on device 0 -- the same bits as the call from host buffers, for a
+    batch on the resident path (rbf, linear), for fp64 (the one-shot path inside the predictor: a round trip through the host) and for a batch the resident form declines."""
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')
+import torch
+from plssvm_amd import backend
+from plssvm_amd.parameter import Parameter
+from plssvm_amd.datagen import make_blobs_pm1
+rng = np.random.default_rng(5)
+for kernel, dt in (('rbf', np.float32), ('linear', np.float32), ('polynomial', np.float32), ('rbf', np.float64)):
+    X, _ = make_blobs_pm1(2500 + 9000, 96, seed=3, dtype=dt)
+    sv, pts = X[:2500], X[2500:]
+    alpha = rng.standard_normal(2500).astype(dt)
+    with backend.Predictor(Parameter(kernel_type=kernel, degree=2, gamma=1.0 / 96, coef0=1.0), sv, alpha, 0.25) as pred:
+        for batch in (pts, pts[:77], (pts * 12.0).astype(dt)):
+            info_h, info_d = {}, {}
+            want = pred.predict(batch, info_out=info_h)
+            Pd = torch.from_numpy(np.ascontiguousarray(batch)).cuda()
+            Od = torch.full((batch.shape[0],), float('nan'), dtype=Pd.dtype, device='cuda')
+            torch.cuda.synchronize()
+            pred.predict_device(Pd.data_ptr(), batch.shape[0], Od.data_ptr(), info_out=info_d)
+            got = Od.cpu().numpy()
+            assert np.array_equal(got, want), (kernel, dt, batch.shape, float(np.max(np.abs(got - want))))
+            assert info_d['resident'] == info_h['resident'], (kernel, dt, info_d, info_h)
+            assert np.array_equal(Pd.cpu().numpy(), batch)  # the caller's tensor is read only
+print('OK')
+""" % (ROOT, ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_bench_json_contract_small_workload():
     env = dict(os.environ)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c2", "--steps", "3", "--warmup", "1", "--cpu-sample-rows", "2048"],

@@ -34,9 +34,10 @@ def main():
     res = ow["predict"].get("resident_predictor_rbf")
     if res:
         rep.update({"R06_RES_ALL": f"{res['batch_all_points']['resident_call_ms']:.1f} ms", "R06_ONE_ALL": f"{res['batch_all_points']['one_shot_call_ms']:.1f} ms",
-                    "R06_RES_1K": f"{res['batch_1000_points']['resident_call_ms']:.2f} ms", "R06_ONE_1K": f"{res['batch_1000_points']['one_shot_call_ms']:.2f} ms"})
+                    "R06_RES_1K": f"{res['batch_1000_points']['resident_call_ms']:.2f} ms", "R06_ONE_1K": f"{res['batch_1000_points']['one_shot_call_ms']:.2f} ms",
+                    "R06_HBM_ALL": (f"{res['batch_all_points']['batch_in_hbm_call_ms']:.1f} ms" if "batch_in_hbm_call_ms" in res["batch_all_points"] else "n/a")})
     else:
-        rep.update({"R06_RES_ALL": "n/a", "R06_ONE_ALL": "n/a", "R06_RES_1K": "n/a", "R06_ONE_1K": "n/a"})
+        rep.update({"R06_RES_ALL": "n/a", "R06_ONE_ALL": "n/a", "R06_RES_1K": "n/a", "R06_ONE_1K": "n/a", "R06_HBM_ALL": "n/a"})
     for name, unit in (("c2", "TFLOP/s"), ("c3", "TFLOP/s"), ("c4", "TFLOP/s")):
         w = ow[name]
         up = name.upper()

@@ -39,6 +39,22 @@ for rep in range(3):
     t4 = time.perf_counter()
     pr.close()
     print(f"predictor create {1e3 * (t1 - t0):.2f} ms, first batch {1e3 * (t2 - t1):.2f} ms, second {1e3 * (t3 - t2):.2f} ms, 100 points {1e3 * (t4 - t3):.2f} ms, resident {info['resident']}", flush=True)
+try:  # the batch and the values in HBM (LSSVM_MEM_DEVICE): torch holds the tensors
+    import torch
+
+    Pd = torch.from_numpy(pts).cuda()
+    Od = torch.zeros(npts, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    with backend.Predictor(p, sv, alpha, 0.1) as pr:
+        for rep in range(4):
+            info = {}
+            t0 = time.perf_counter()
+            pr.predict_device(Pd.data_ptr(), npts, Od.data_ptr(), info)
+            t1 = time.perf_counter()
+            print(f"batch and values in HBM: call {1e3 * (t1 - t0):.2f} ms (library {info['total_ms']:.2f} ms, kernel {info['kernel_ms']:.2f} ms), same values {np.array_equal(Od.cpu().numpy(), v2)}",
+                  flush=True)
+except ImportError:
+    pass
 for rep in range(3):
     t0 = time.perf_counter()
     v, w = backend.predict_values(p, sv, alpha, 0.1, None, pts)
