@@ -20,7 +20,10 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <exception>
+#include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -47,13 +50,29 @@ void io_parallel(unsigned nt, std::size_t n, F &&body) {
         body(0u, std::size_t(0), n);
         return;
     }
+    // an exception of a worker (std::bad_alloc of its buffer) is carried to the caller instead of ending the process; a thread that cannot be started has its range run here
     std::vector<std::thread> pool;
     pool.reserve(nt);
+    std::exception_ptr failure;
+    std::mutex failure_mutex;
+    auto guarded_body = [&](unsigned t, std::size_t lo, std::size_t hi) {
+        try {
+            body(t, lo, hi);
+        } catch (...) {
+            const std::lock_guard<std::mutex> lock(failure_mutex);
+            if (!failure) failure = std::current_exception();
+        }
+    };
     for (unsigned t = 0; t < nt; ++t) {
         const std::size_t lo = n / nt * t + std::min<std::size_t>(t, n % nt), hi = n / nt * (t + 1) + std::min<std::size_t>(t + 1, n % nt);
-        pool.emplace_back([&body, t, lo, hi] { body(t, lo, hi); });
+        try {
+            pool.emplace_back([&guarded_body, t, lo, hi] { guarded_body(t, lo, hi); });
+        } catch (const std::system_error &) {
+            guarded_body(t, lo, hi);
+        }
     }
     for (std::thread &th : pool) th.join();
+    if (failure) std::rethrow_exception(failure);
 }
 
 class TextFile {
