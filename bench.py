@@ -328,27 +328,47 @@ def predict_leg(seed, device, num_sv=50_000, num_points=200_000, d=128, calls=3)
 def e2e_leg(seed, workdir=None):
     """The reference's tracker reports the file -> model wall clock beside cg/total_runtime (main_train.cpp:24-70, csvm.cpp:167-176): `python -m plssvm_amd.train` on a
     configs[1]-shaped LIBSVM file (50 000 x 128, rbf, fp32, eps 1e-3 -- the reference's default), then `python -m plssvm_amd.predict` of the same file with the model --
-    run in this process through the command lines' own entry points, phases from plssvm_amd.cli.LAST_TIMINGS."""
+    run in this process through the command lines' own entry points, phases from plssvm_amd.cli.LAST_TIMINGS.
+    This process has run every other leg by now, and a full collection of Python's cyclic garbage collector over what they left behind took 51 ms when it fell into the
+    6 ms predict phase: the command lines in their own processes have no such heap, so it is set aside first (gc.freeze) and the collector's pauses during the two
+    commands are reported beside the phases."""
+    import gc
     import tempfile
 
     from plssvm_amd import cli
     from plssvm_amd.datagen import generate_libsvm_file
 
     out = {}
+    pauses, started = [], [0.0]
+
+    def on_gc(phase, info):
+        if phase == "start":
+            started[0] = time.perf_counter()
+        else:
+            pauses.append({"generation": int(info.get("generation", -1)), "s": time.perf_counter() - started[0]})
+
     with tempfile.TemporaryDirectory(dir=workdir) as tmp:
         data_file, model_file, pred_file = os.path.join(tmp, "c2.libsvm"), os.path.join(tmp, "c2.libsvm.model"), os.path.join(tmp, "c2.libsvm.predict")
         t0 = time.perf_counter()
         generate_libsvm_file(data_file, 50_000, 128, seed=seed)
         out["generate_and_write_data_s"] = time.perf_counter() - t0
         out["data_bytes"] = os.path.getsize(data_file)
-        rc = cli.train_main(["-t", "2", "--use_float_as_real_type", "-e", "0.001", "-q", data_file, model_file])
-        if rc != 0:
-            return {"error": f"plssvm_amd.train returned {rc}"}
-        out["train"] = {k: v for k, v in cli.LAST_TIMINGS.items() if k != "task"}
-        rc = cli.predict_main(["--use_float_as_real_type", "-q", data_file, model_file, pred_file])
-        if rc != 0:
-            return {"error": f"plssvm_amd.predict returned {rc}"}
-        out["predict"] = {k: v for k, v in cli.LAST_TIMINGS.items() if k != "task"}
+        gc.collect()
+        gc.freeze()
+        gc.callbacks.append(on_gc)
+        try:
+            rc = cli.train_main(["-t", "2", "--use_float_as_real_type", "-e", "0.001", "-q", data_file, model_file])
+            if rc != 0:
+                return {"error": f"plssvm_amd.train returned {rc}"}
+            out["train"] = {k: v for k, v in cli.LAST_TIMINGS.items() if k != "task"}
+            rc = cli.predict_main(["--use_float_as_real_type", "-q", data_file, model_file, pred_file])
+            if rc != 0:
+                return {"error": f"plssvm_amd.predict returned {rc}"}
+            out["predict"] = {k: v for k, v in cli.LAST_TIMINGS.items() if k != "task"}
+        finally:
+            gc.callbacks.remove(on_gc)
+            gc.unfreeze()
+    out["python_gc"] = {"pauses_s": sum(p["s"] for p in pauses), "full_collections": sum(1 for p in pauses if p["generation"] == 2)}
     out["command"] = "python -m plssvm_amd.train -t 2 --use_float_as_real_type -e 0.001 c2.libsvm ; python -m plssvm_amd.predict --use_float_as_real_type c2.libsvm c2.libsvm.model"
     return out
 
