@@ -21,6 +21,7 @@ def main():
     ow, roof = b["other_workloads"], b["roofline"]
     pr, pl = ow["predict"]["rbf"], ow["predict"]["linear"]
     e2e = b["e2e"]["train"]
+    e2p = b["e2e"]["predict"]
     rep = {
         "R06_C5_MS": f"{b['ms_per_step']:.1f} ms", "R06_C5_KERN": f"{roof['avg_launch_ms']:.1f} ms = {roof['tile_launches_per_matvec']} band launches", "R06_C5_FRAC": f"{roof['frac']:.3f}",
         "R06_C5_VALUE": f"{b['value'] / 1e3:.0f}", "R06_C5_SETUP": f"{b['setup_ms']:.0f} ms",
@@ -30,6 +31,8 @@ def main():
         "R06_PL_CALL": f"{pl['call_ms']:.1f} ms", "R06_PL_KERN": f"{pl['kernel_ms'] * 1e3:.0f} µs", "R06_PL_FRAC": f"{pl['frac']:.2f}", "R06_PL_TBPS": f"{pl['achieved'] / 1e3:.1f}",
         "R06_E2E_READ": f"{e2e['read_s'] * 1e3:.0f} ms", "R06_E2E_SETUP": f"{e2e['setup_ms']:.1f} ms", "R06_E2E_SOLVE": f"{e2e['solve_s'] * 1e3:.1f} ms", "R06_E2E_ITS": str(e2e["iterations"]),
         "R06_E2E_WRITE": f"{e2e['write_s'] * 1e3:.0f} ms",
+        "R06_E2P_READ": f"{e2p['read_s'] * 1e3:.0f} ms", "R06_E2P_MODEL": f"{e2p['model_read_s'] * 1e3:.0f} ms", "R06_E2P_PREDICT": f"{e2p['predict_s'] * 1e3:.1f} ms",
+        "R06_E2P_WRITE": f"{e2p['write_s'] * 1e3:.0f} ms",
     }
     res = ow["predict"].get("resident_predictor_rbf")
     if res:
