@@ -16,8 +16,10 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <thread>
+#include <tuple>
 
 namespace lssvm {
 
@@ -611,7 +613,25 @@ static int num_chunks(int num_tiles, int tiles, int head_tiles, int head_count) 
  *   - with the PERSISTENT launches that draw their items from per-XCD counters (pair_queue_fetch; profiles/r05_queue_chunk_sweep.log, r05_queue_head_large.log):
  *     -5.4 % at 20 000 points, -4.5 % at 30 000, -3.5 % at 40 000, -2.6 % at 50 000, -0.9 % at 70 000, -1.6 % at 100 000, -1.0 % at 150 000, nothing at 250 000.
  * So heads are the default since the launches are persistent. */
+static PairChunks choose_pair_chunk_by_replay(int ib_begin, int ib_end, int num_tiles, size_t real_size, const Options &o, int slots);
+/* The replay is a pure function of the shard's shape and three options, and it costs 1.6 of the 4 ms a 50 000-point problem takes to set up: a process that creates
+ * problems of one shape again and again (a parameter search over C and gamma, predict after train) replays once. */
 static PairChunks choose_pair_chunk(int ib_begin, int ib_end, int num_tiles, size_t real_size, const Options &o, int slots) {
+    using Key = std::tuple<int, int, int, size_t, int, int64_t, int64_t, int64_t>;
+    static std::mutex cache_mutex;
+    static std::map<Key, PairChunks> cache;
+    const Key key{ ib_begin, ib_end, num_tiles, real_size, slots, o.j_chunk_head, o.colslab_band_mb, o.colslab_limit_mb };
+    {
+        const std::lock_guard<std::mutex> lock(cache_mutex);
+        if (const auto it = cache.find(key); it != cache.end()) return it->second;
+    }
+    const PairChunks chosen = choose_pair_chunk_by_replay(ib_begin, ib_end, num_tiles, real_size, o, slots);
+    const std::lock_guard<std::mutex> lock(cache_mutex);
+    if (cache.size() >= 4096) cache.clear();  // (bounded: shapes, not problems)
+    cache.emplace(key, chosen);
+    return chosen;
+}
+static PairChunks choose_pair_chunk_by_replay(int ib_begin, int ib_end, int num_tiles, size_t real_size, const Options &o, int slots) {
     const int cap = 64;
     PairChunks best_c;
     const long area = (static_cast<long>(ib_end) * (ib_end + 1) - static_cast<long>(ib_begin) * (ib_begin + 1)) / 4;  // pair-tiles, about
@@ -824,7 +844,18 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     const double t0 = now_ms();
     stream_.create();
     hipStream_t st = stream_.s;
+    const char *dbg_env = std::getenv("LSSVM_MI355_DEBUG");
+    const bool dbg_laps = dbg_env != nullptr && dbg_env[0] == '1' && rank_ == 0;
+    double t_lap = t0;
+    auto lap = [&](const char *what) {  // LSSVM_MI355_DEBUG=1: where the set-up's time goes (the stream is drained at every lap, so the laps add up)
+        if (!dbg_laps) return;
+        (void) hipStreamSynchronize(st);
+        const double t = now_ms();
+        std::fprintf(stderr, "[plssvm_amd] set-up: %-44s %8.3f ms\n", what, t - t_lap);
+        t_lap = t;
+    };
 
+    lap("stream");
     N_ = num_points;
     n_ = static_cast<int>(num_points - 1);
     num_tiles_ = (n_ + TILE - 1) / TILE;
@@ -833,6 +864,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     // data matrix: all N points (the last one is row n; it takes part in q and QA_cost only)
     // (+ TILE: an odd number of row blocks ends in a block pair whose second block is zero padding -- the 256-row workgroups read its rows, d_i and c_i)
     X_.upload(X, mem_kind, num_points, num_features, static_cast<size_t>(nvec_) + TILE, st);
+    lap("data into the padded layout");
     // fp32 rbf: matrix cores (norm expansion) or the formula-exact vector-ALU kernel?  (every shard sees the same data: same decision)
     rbf_direct_ = rbf_wants_direct_form<T>(opt_, params_, X_, nullptr, st, &rbf_r2_);
     // Large exponent scales (round 5): between RBF_DIRECT_ABOVE and RBF_GRID_MAX_R2, at any width, with operand planes allowed, the matrix cores run the
@@ -916,7 +948,9 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         // (below 64 row blocks -- 8 192 points -- the 128-row workgroups have more items to spread over the chip: 3 000 points 13.8 against 19.7 us)
         pair_ = sym_ && opt_.gram_mode != 0 && opt_.mfma_shape >= 3 && !wide_nl_ && !poly_generic && narrow && rbf_ok && num_tiles_ >= PAIR_MIN_TILES;
     }
+    lap("exponent scale, path decisions");
     choose_shard_geometry();
+    lap("shard geometry (chunk choice by replay)");
     // 256-row workgroups: PERSISTENT launches, the work items drawn from per-XCD counters (for_each_work_item, lssvm_device_common.hip.hpp) instead of one workgroup per
     // item dealt by the hardware -- whose deal is static per XCD (every eighth workgroup, whatever the XCD's pace: the eight clocks of one chip differ by 3-5 %) and in
     // order.  Same box, interleaved, bit-identical: 1 000 000 x 128 rbf 264.9 -> 256.8 ms per iteration (-3.0 %), 200 000 x 256 linear 20.05 -> 19.49 (-3.0 %),
@@ -942,6 +976,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     host_sc_.alloc(SC_COUNT);
     host_delta_.alloc_mapped(1);
 
+    lap("QA_cost, vectors");
     // q from the raw (un-centred) data: bit-compatible fma chains (q_kernel.cpp:18-55)
     {
         const T *xlast = X_.data.p + static_cast<size_t>(n_) * X_.ldx;
@@ -954,11 +989,13 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         }
         LSSVM_HIP_CHECK(hipGetLastError());
     }
+    lap("q");
     // rbf on the matrix cores: centre the data, then c_i = -|x_i|^2 / 2
     if (params_.kernel_type == LSSVM_KERNEL_RBF && !rbf_direct_) {
         center_columns<T>(X_, nullptr, rbf_prescale<T>(params_, v2_eligible_f64(opt_, X_.ldx) || wide_nl_), st);
         half_neg_norms<T>(X_, c_, st);
     }
+    lap("centring, norms");
     // polynomial in fp64 on the v2 kernel: fold gamma into the data (x' = sqrt(gamma) x, after q was computed from the raw data), so
     // that the MFMA chain leaves gamma * <x_i, x_j> and the epilogue is the bare integer power -- every vector ALU instruction
     // beside v_mfma_f64 costs matrix-core time (gamma > 0 is a precondition of the kernel, parameter.hpp / csvm.cpp:77)
@@ -993,6 +1030,7 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
         // rbf: folded records while the exponent terms stay small (rbf_r2_ = 2 max|c| in the exponent's unit)
         if (planes_.mode != 0) dc_folded_ = tile_params_.kernel_type == LSSVM_KERNEL_RBF && opt_.rbf_fold != 0 && rbf_r2_ <= FOLD_MAX_R2 && !rbf_grid_;
     }
+    lap("operand planes, fragment-major copy");
     interleave_features<T>(X_, st);
     if constexpr (std::is_same_v<T, double>) {
         if (wide_nl_ && sym_) {
@@ -1007,7 +1045,9 @@ Problem<T>::Problem(const Options &opt, const lssvm_params &params, const void *
     if ((std::is_same_v<T, float> && (v2_eligible(opt_, X_.ldx, rbf_direct_) || wide_linear_ || wide_nl_)) || (std::is_same_v<T, double> && (v2_eligible_f64(opt_, X_.ldx) || wide_linear_ || wide_nl_))) {
         dc_.alloc_zero(static_cast<size_t>(std::max(num_tiles_, 1)) * 256, st);  // (d_j | c_j) records: 256 reals per 128 columns
     }
+    lap("interleave, records");
     build_shard_lists(st);
+    lap("work-item lists, slabs, events");
     ev_ready_.create(false);
     ev_consumed_.create(false);
     LSSVM_HIP_CHECK(hipStreamSynchronize(st));

@@ -27,6 +27,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -195,15 +196,49 @@ struct DeviceMatrix {
 };
 
 /* ------------------------------------------------------------------ more RAII: stream, events, pinned host words ------------------------------------------------------------------ */
+/* A non-blocking stream of the CURRENT device.  Creating one costs 2-4 ms on this runtime (a hardware queue behind it) -- more than everything else in the set-up of a
+ * 50 000-point problem -- so an idle stream goes back to a small per-device pool instead of being destroyed, and the next problem takes it from there. */
 struct Stream {
     hipStream_t s = nullptr;
+    int device = -1;
     Stream() = default;
     Stream(const Stream &) = delete;
     Stream &operator=(const Stream &) = delete;
     ~Stream() {
-        if (s != nullptr) (void) hipStreamDestroy(s);
+        if (s == nullptr) return;
+        if (hipStreamSynchronize(s) == hipSuccess) {  // (only an idle stream without a pending error is kept)
+            const std::lock_guard<std::mutex> lock(pool_mutex());
+            std::vector<hipStream_t> &idle = pool()[device];
+            if (idle.size() < 8) {
+                idle.push_back(s);
+                return;
+            }
+        }
+        (void) hipStreamDestroy(s);
     }
-    void create() { LSSVM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); }
+    void create() {
+        LSSVM_HIP_CHECK(hipGetDevice(&device));
+        {
+            const std::lock_guard<std::mutex> lock(pool_mutex());
+            std::vector<hipStream_t> &idle = pool()[device];
+            if (!idle.empty()) {
+                s = idle.back();
+                idle.pop_back();
+                return;
+            }
+        }
+        LSSVM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    }
+
+  private:
+    static std::mutex &pool_mutex() {
+        static std::mutex m;
+        return m;
+    }
+    static std::map<int, std::vector<hipStream_t>> &pool() {
+        static std::map<int, std::vector<hipStream_t>> *p = new std::map<int, std::vector<hipStream_t>>();  // (never destroyed: streams outlive static destruction order)
+        return *p;
+    }
 };
 struct Event {
     hipEvent_t e = nullptr;
