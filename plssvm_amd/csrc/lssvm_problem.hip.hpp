@@ -561,6 +561,8 @@ class Solver final : public ProblemBase {
     // CG state (host side)
     double eps_ = 0.0;
     double delta0_ = 0.0, delta_ = 0.0;
+    double delta_before_ = 0.0;  // the residuum one iteration before delta_ (0 = none yet): the stop test's forecast, cg_step
+    int held_back_ = 0;          // iterations in a row whose next matvec was NOT enqueued ahead of the stop test because of that forecast
     double y_last_ = 0.0;
     uint64_t iter_ = 0;  // iterations done
     bool converged_ = false;

@@ -279,6 +279,8 @@ void Solver<T>::cg_begin(const void *y, double eps) {
     sync_all();
     delta0_ = static_cast<double>(static_cast<T>(p0.host_sc_.p[SC_DELTA0]));
     delta_ = delta0_;
+    delta_before_ = 0.0;
+    held_back_ = 0;
     begun_ = true;
     cg_wall_ms_ += now_ms() - t0;
 }
@@ -341,8 +343,19 @@ void Solver<T>::cg_step(uint64_t iterations, int *done_out) {
         // than the option says, each converged solve then paying one discarded matvec of that length).  Every input is the same on all ranks.
         const double n_d = static_cast<double>(p0.n_);
         const double matvec_us = 2.0 * n_d * n_d * static_cast<double>(p0.X_.dfeat) / static_cast<double>(world_) / p0.nominal_full_square_rate() * 1e6;
+        // Round 6: ... unless this iteration is forecast to be the last.  The discarded matvec is a third of a solve that converges after two iterations (the
+        // reference's default epsilon on BASELINE configs[1]: 3.2 ms of CG where 2.4 are needed).  With the residuum falling by rho = delta / delta_before per
+        // iteration, the stop test is about to succeed once delta rho^2 <= target -- this iteration or the next: for those (at most four in a row, should the
+        // residuum stall there) the host waits for delta before it enqueues anything, as it does for long matvecs.  delta, its predecessor and the target are the
+        // same bits on every rank, so every rank decides alike (see above); matvecs shorter than 100 us are not worth a host round trip and always go ahead.
+        bool last_iterations = false;
+        if (matvec_us >= 100.0 && delta_before_ > 0.0 && delta_ > 0.0 && held_back_ < 4) {
+            const double rho = std::min(delta_ / delta_before_, 1.0);
+            last_iterations = delta_ * rho * rho <= static_cast<double>(target);
+        }
+        held_back_ = last_iterations ? held_back_ + 1 : 0;
         const bool ahead = opt_.enqueue_ahead_below_us > 0 && matvec_us < static_cast<double>(opt_.enqueue_ahead_below_us) && k + 1 < iterations
-                           && exchange_ != Exchange::process_peer;
+                           && exchange_ != Exchange::process_peer && !last_iterations;
         if (ahead) {
             enqueue_direction_update();
             apply_K(Vec::d);
@@ -351,6 +364,7 @@ void Solver<T>::cg_step(uint64_t iterations, int *done_out) {
         LSSVM_HIP_CHECK(hipEventSynchronize(ev_delta_.e));
         for (auto &p : shards_) p->drain_events();
         ++iter_;
+        delta_before_ = delta_;
         delta_ = static_cast<double>(static_cast<T>(*static_cast<volatile double *>(p0.host_delta_.p)));
         if (static_cast<T>(delta_) <= target) {  // csvm.cpp:155-158: tested BEFORE the direction update
             converged_ = true;

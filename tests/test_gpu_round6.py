@@ -522,3 +522,28 @@ def test_the_first_matvec_after_cg_begin_is_never_timed():
         i1 = prob.info()
     assert i0["matvec_launches"] == 1 and i0["matvec_timed"] == 0
     assert i1["matvec_launches"] == 4 and i1["matvec_timed"] == 3
+
+
+def test_a_solve_forecast_to_stop_does_not_discard_a_matvec():
+    """Short matvecs are enqueued AHEAD of the stop test (option enqueue_ahead_below_us), at the price of one discarded matvec when the test fires -- a third of a solve that
+    converges after two iterations, as BASELINE configs[1]'s data does at the reference's default epsilon.  Round 6: from the second iteration on the host forecasts the test
+    (delta rho^2 <= target, rho the last reduction) and waits for delta in the iterations forecast to be the last: same bits, same stop, no discarded matvec -- and a solve
+    that converges slowly still goes ahead everywhere else (one refresh-free run of 40 iterations: every matvec used)."""
+    X, y = make_blobs_pm1(40_000, 128, seed=42, dtype=np.float32)
+    p = Parameter(kernel_type="rbf")
+    runs = {}
+    for ahead in (0, 5000):
+        _capi.set_option("enqueue_ahead_below_us", ahead)
+        try:
+            runs[ahead] = (backend.solve_system_of_linear_equations(p, X, y, 1e-3, 40_000), backend.solve_system_of_linear_equations(p, X, y, 1e-30, 40))
+        finally:
+            _capi.set_option("enqueue_ahead_below_us", 5000)
+    (c0, f0), (c1, f1) = runs[0], runs[5000]
+    for (a, rho, info), (b, rho_b, info_b) in ((c0, c1), (f0, f1)):
+        assert np.array_equal(a, b) and rho == rho_b and info["iterations"] == info_b["iterations"] and info["residuum"] == info_b["residuum"]
+    its = c1[2]["iterations"]
+    print(f"\nconverged after {its} iterations: {c1[2]['matvec_launches']} matvecs with the forecast, {c0[2]['matvec_launches']} in the synchronous loop; "
+          f"{c1[2]['total_ms']:.2f} ms against {c0[2]['total_ms']:.2f} ms")
+    assert c1[2]["converged"] == 1 and 2 <= its < 50
+    assert c1[2]["matvec_launches"] == c0[2]["matvec_launches"] == its + 1  # the initial residual and one per iteration: nothing discarded
+    assert f1[2]["matvec_launches"] == f0[2]["matvec_launches"] == 40 + 1
