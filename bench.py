@@ -50,7 +50,7 @@ PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6, "bf16": 16 * 157.3}  # dense M
 # the sources that decide how many bytes the tile kernel moves: profiles/hbm_traffic.json carries their hash, a stale entry is dropped
 TRAFFIC_SOURCES = ["plssvm_amd/csrc/lssvm_tile_f32_split.hip.hpp", "plssvm_amd/csrc/lssvm_tile_f32_pair.hip.hpp", "plssvm_amd/csrc/lssvm_s6w_groups.inc", "plssvm_amd/csrc/lssvm_tile_f32.hip.hpp",
                    "plssvm_amd/csrc/lssvm_tile_f32_wide.hip.hpp", "plssvm_amd/csrc/lssvm_tile_f64.hip.hpp", "plssvm_amd/csrc/lssvm_tile_f64_wide.hip.hpp", "plssvm_amd/csrc/lssvm_device_common.hip.hpp",
-                   "plssvm_amd/csrc/lssvm_kernels.hip.hpp", "plssvm_amd/csrc/lssvm_problem.hip", "plssvm_amd/csrc/lssvm_solver.hip", "plssvm_amd/csrc/lssvm_exchange.hip", "plssvm_amd/csrc/lssvm_problem.hip.hpp", "plssvm_amd/csrc/lssvm_types.hpp",
+                   "plssvm_amd/csrc/lssvm_kernels.hip.hpp", "plssvm_amd/csrc/lssvm_problem.hip", "plssvm_amd/csrc/lssvm_predict.hip", "plssvm_amd/csrc/lssvm_solver.hip", "plssvm_amd/csrc/lssvm_exchange.hip", "plssvm_amd/csrc/lssvm_problem.hip.hpp", "plssvm_amd/csrc/lssvm_types.hpp",
                    "plssvm_amd/csrc/tile_launch_f32.hip", "plssvm_amd/csrc/tile_launch_f32h.hip", "plssvm_amd/csrc/tile_launch_f32s.hip", "plssvm_amd/csrc/tile_launch_f32d.hip",
                    "plssvm_amd/csrc/tile_launch_f32x.hip", "plssvm_amd/csrc/tile_launch_f64.hip", "plssvm_amd/csrc/tile_launch_f64x.hip"]  # (the launch and split sources belong here too)
 

@@ -596,4 +596,43 @@ int select_device_checked(int device);
 /* `num_devices` == 0: automatic (all visible devices, but at least 32 row blocks per device); `devices` may be NULL (0 .. num_devices-1) */
 std::vector<int> resolve_devices(const int *devices, int num_devices, size_t num_points);
 
+/* ------------------------------------------------------------------ shared by lssvm_problem.hip and lssvm_predict.hip ------------------------------------------------------------------ */
+constexpr double FOLD_MAX_R2 = 200.0;    // folded rbf records (KT_RBFF) only while |c| = R2 / 2 <= 100: 2^c and 2^acc stay far inside the fp32 range
+constexpr double PAIR_FOLD_MAX_C = 32.0; // 256-row kernels, rbf: row AND column term folded (K = e_i 2^(x_i.x_j) e_j) only while |c| <= 32: the partial sums then carry at most 2^32 of
+                                         // extra scale (RBF_DIRECT_ABOVE = 32 keeps the automatic choice at |c| <= 16)
+constexpr int PAIR_MIN_TILES = 64;       // 256-row workgroups from this many row blocks on (a rule on the global shape: every rank decides alike)
+constexpr int SPLIT_MAX_FEATURES = 384;  // the bf16x6 kernels exist for 1 ... 6 chunks of 64 features (row panel = 3 planes in registers)
+constexpr int F16_MAX_FEATURES = 512;    // the f16x3 kernels exist for 1 ... 8 chunks of 64 features (row panel = 2 planes in registers)
+constexpr int F16_LINEAR_MAX_FEATURES = 1 << 20;
+constexpr int F16_RBF_MAX_FEATURES = 384;  // ... rbf: 1 ... 6 chunks (three row planes in registers: the shifted planes, see make_planes)
+constexpr int F16_RBF_SHIFT = 6;         // rbf: the planes are (2^-6 hi, 2^6 mid, 2^6 hi)
+constexpr int F16_TARGET_EXP = 14;       // f16x3, linear / polynomial: the planes carry 2^k x with max |2^k x| in [2^14, 2^15) (f16 overflows at 65504)
+constexpr int F16_MAX_SHIFT = 40;        // |k| is clamped here (2^(-2k) must stay a normal float beside gamma)
+constexpr float F16_REL2_MAX = 0x1p-44f; // accepted relative representation error of a row, squared: |x - (hi + mid)| <= 2^-22 |x| in the 2-norm
+constexpr float F16_ABS_MAX = 0x1p-22f;  // rbf: accepted bound on the ABSOLUTE error of the exponent from the representation, 2 max|rest| max|x|
+
+template <typename T>
+T rbf_prescale(const lssvm_params &p, bool fp64_v2);
+bool wide_nonlinear_f64(const Options &o, const lssvm_params &p, size_t num_features);
+bool wide_nonlinear(const Options &o, const lssvm_params &p, bool rbf_direct, size_t num_features);
+template <typename T>
+void set_kernel_scalars(TileArgs<T> &a, const lssvm_params &p, bool rbf_direct);
+template <typename T>
+void set_launch_options(TileArgs<T> &a, const Options &o);
+template <typename T>
+void column_means(const DeviceMatrix<T> &M, DevBuf<T> &mean, hipStream_t s);
+template <typename T>
+double max_centred_sqnorm(const DeviceMatrix<T> &M, const DevBuf<T> &mean, hipStream_t s);
+template <typename T>
+bool rbf_wants_direct_form(const Options &o, const lssvm_params &p, const DeviceMatrix<T> &M, const DeviceMatrix<T> *M2, hipStream_t s, double *r2_out);
+void make_planes(const Options &o, const lssvm_params &p, bool rbf_direct, const DeviceMatrix<float> &M, const DeviceMatrix<float> *M2, PlaneSet &out, PlaneSet *out2, hipStream_t s,
+                 bool wide_nl = false, bool linear_panels = false, bool f16_known_bad = false);
+bool rbf_wants_grid_planes(const Options &o, const lssvm_params &p, size_t num_features, double r2);
+float make_grid_planes(const DeviceMatrix<float> &M, double r2_in, PlaneSet &out, float *chg, DevBuf<float> &efac, hipStream_t s, bool wide_nl);
+void set_plane_args(TileArgs<float> &a, const lssvm_params &p, const PlaneSet &cols, const PlaneSet &rows, size_t col_rows_alloc, size_t row_rows_alloc);
+std::vector<int2> xcd_lane_order(const std::vector<std::vector<int2>> &by_chunk);
+void enqueue_pack_records(const float *dvec, const float *cc, int ncols_padded, float *dc, int folded, const float *efac, hipStream_t s);
+void enqueue_pack_records(const double *dvec, const double *cc, int ncols_padded, double *dc, int folded, const double *efac, hipStream_t s);
+void enqueue_planes_fragment_major(const uint16_t *planes, size_t plane_elems, int rows_alloc, int ldx16, int nplanes, uint16_t *frag, hipStream_t s);
+
 }  // namespace lssvm
