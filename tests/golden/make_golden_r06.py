@@ -55,7 +55,7 @@ def main():
     ref = oracle_lib.ref()
     path = os.path.join(HERE, "full_size_rows.npz")
     out = dict(np.load(path)) if os.path.isfile(path) else {}
-    names = [] if "--only-c5" in sys.argv else ["c2", "c4"] + (["c3"] if "--with-c3" in sys.argv else [])
+    names = [] if ("--only-c5" in sys.argv or "--only-predict" in sys.argv) else ["c2", "c4"] + (["c3"] if "--with-c3" in sys.argv else [])
     for name in names:
         kernel, X, rhs, rows = inputs(name)
         N, d = X.shape
@@ -109,6 +109,24 @@ def main():
         out["c5/q_rows64"], out["c5/QA_cost64"], out["c5/matvec_p1_rows64"] = q64[rows], np.asarray(QA64), r64
         out["c5/matvec_p1_absmax"] = np.asarray(np.max(np.abs(r64)))  # (of the sampled rows: no full run)
         out["c5/X_sha256"] = np.frombuffer(hashlib.sha256(X.tobytes()).digest(), dtype=np.uint8)
+        np.savez_compressed(path, **out)
+    if "--with-predict" in sys.argv:
+        # bench.py's predict leg at full size (other_workloads.predict: 200 000 points x 50 000 support vectors x 128, rbf fp32; the leg's own data): the decision values of
+        # 512 seeded points from the restated predict_values around the reference's compiled kernel_function (oracle/ref_shim.cpp, csvm.cpp:188-227) -- every point's value
+        # is its own sum over the support vectors, so the sampled points ARE what a full run gives for them -- in fp32 and in float64
+        nsv, npts, d, seed = 50_000, 200_000, 128, 42
+        X, _ = make_blobs_pm1(nsv + npts, d, seed=seed + 1, dtype=np.float32)
+        sv, pts = np.ascontiguousarray(X[:nsv]), np.ascontiguousarray(X[nsv:])
+        alpha = np.random.default_rng(seed).standard_normal(nsv).astype(np.float32)
+        idx = np.sort(np.random.default_rng(ROWS_SEED).choice(npts, size=NROWS, replace=False))
+        idx[0], idx[-1] = 0, npts - 1
+        t0 = time.perf_counter()
+        v32, _ = ref.predict_values("rbf", sv, alpha, np.float32(0.25), pts[idx], gamma=1.0 / d)
+        v64, _ = ref.predict_values("rbf", sv.astype(np.float64), alpha.astype(np.float64), 0.25, pts[idx].astype(np.float64), gamma=1.0 / d)
+        print(f"predict: {NROWS} of {npts} points x {nsv} support vectors x {d}: the reference's kernel_function sums in fp32 and float64 in {time.perf_counter() - t0:.1f} s; "
+              f"fp32 against float64: {float(np.max(np.abs(v32 - v64))):.3e} (largest |value| {float(np.max(np.abs(v64))):.3e})", flush=True)
+        out["predict/points"], out["predict/values"], out["predict/values64"] = idx, v32, v64
+        out["predict/X_sha256"] = np.frombuffer(hashlib.sha256(X.tobytes()).digest(), dtype=np.uint8)
         np.savez_compressed(path, **out)
     print("full_size_rows.npz", os.path.getsize(path), "bytes")
 

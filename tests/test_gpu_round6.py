@@ -360,6 +360,41 @@ def test_baseline_configs_at_full_size_vs_the_references_own_kernels(name, kerne
         assert e_gpu <= 1 * eps and e_vs <= e_ref + 1 * eps and e_gpu <= e_ref
 
 
+def test_the_bench_predict_leg_at_full_size_vs_the_references_kernel_function():
+    """bench.py's `other_workloads.predict` input (200 000 points x 50 000 support vectors x 128, rbf fp32, the leg's own data): tests/golden/full_size_rows.npz holds the decision
+    values of 512 seeded points as sums of the reference's COMPILED kernel_function in the order of csvm.cpp:188-227 (oracle/ref_shim.cpp `predict`; fp32 and float64).  The
+    one-shot predict_values -- the rectangular 256-row kernel at this size -- and the resident predictor: within 1 eps of the float64 values on the scale of a point's summands,
+    no further from them than the reference's own fp32 values, and the two entry points bit-equal."""
+    global FULL_SIZE
+    if FULL_SIZE is None:
+        FULL_SIZE = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_rows.npz"))
+    G = FULL_SIZE
+    if "predict/points" not in G:
+        pytest.skip("tests/golden/full_size_rows.npz holds no predict values (python tests/golden/make_golden_r06.py --only-predict --with-predict)")
+    import hashlib
+
+    nsv, npts, d, seed = 50_000, 200_000, 128, 42
+    X, _ = make_blobs_pm1(nsv + npts, d, seed=seed + 1, dtype=np.float32)
+    assert np.array_equal(np.frombuffer(hashlib.sha256(X.tobytes()).digest(), dtype=np.uint8), G["predict/X_sha256"])
+    sv, pts = np.ascontiguousarray(X[:nsv]), np.ascontiguousarray(X[nsv:])
+    alpha = np.random.default_rng(seed).standard_normal(nsv).astype(np.float32)
+    prm = Parameter(kernel_type="rbf")
+    info = {}
+    got, _ = backend.predict_values(prm, sv, alpha, 0.25, None, pts, info_out=info)
+    with backend.Predictor(prm, sv, alpha, 0.25) as pred:
+        info_r = {}
+        got_r = pred.predict(pts, info_out=info_r)
+    assert info_r["resident"] == 1 and np.array_equal(got, got_r)
+    idx, ref32, ref64 = G["predict/points"], G["predict/values"].astype(np.float64), G["predict/values64"]
+    sv64, p64 = sv.astype(np.float64), pts[idx].astype(np.float64)
+    sq_s, sq_p = np.einsum("ij,ij->i", sv64, sv64), np.einsum("ij,ij->i", p64, p64)
+    K = np.exp(-(1.0 / d) * np.maximum(sq_p[:, None] + sq_s[None, :] - 2.0 * (p64 @ sv64.T), 0.0))
+    scale = K @ np.abs(alpha.astype(np.float64)) + 0.25
+    e_gpu, e_ref = float(np.max(np.abs(got[idx] - ref64) / scale)), float(np.max(np.abs(ref32 - ref64) / scale))
+    print(f"\npredict at full size ({info['gram_mode']=}): sampled points vs the reference's float64 values {e_gpu / EPS32:.3f} eps of a point's summands [the reference's own fp32 values: {e_ref / EPS32:.2f} eps]")
+    assert e_gpu <= 1 * EPS32 and e_gpu <= e_ref
+
+
 # ------------------------------------------------------------------------------------------------------------ the Gram mode by data (VERDICT r05 item 4)
 @pytest.mark.parametrize("name", ["plus_minus_one", "small_integers", "sparse01"])
 @pytest.mark.parametrize("kernel", ["linear", "rbf"])
