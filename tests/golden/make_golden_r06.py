@@ -55,7 +55,7 @@ def main():
     ref = oracle_lib.ref()
     path = os.path.join(HERE, "full_size_rows.npz")
     out = dict(np.load(path)) if os.path.isfile(path) else {}
-    names = [] if ("--only-c5" in sys.argv or "--only-predict" in sys.argv) else ["c2", "c4"] + (["c3"] if "--with-c3" in sys.argv else [])
+    names = [] if ("--only-c5" in sys.argv or "--only-predict" in sys.argv or "--only-solve" in sys.argv) else ["c2", "c4"] + (["c3"] if "--with-c3" in sys.argv else [])
     for name in names:
         kernel, X, rhs, rows = inputs(name)
         N, d = X.shape
@@ -127,6 +127,24 @@ def main():
               f"fp32 against float64: {float(np.max(np.abs(v32 - v64))):.3e} (largest |value| {float(np.max(np.abs(v64))):.3e})", flush=True)
         out["predict/points"], out["predict/values"], out["predict/values64"] = idx, v32, v64
         out["predict/X_sha256"] = np.frombuffer(hashlib.sha256(X.tobytes()).digest(), dtype=np.uint8)
+        np.savez_compressed(path, **out)
+    if "--with-solve" in sys.argv:
+        # the SOLVE of BASELINE configs[1] (50 000 x 128 rbf fp32, the bench's data and labels) at the reference's default epsilon 1e-3 by the reference's kernels under the
+        # restated CG driver (oracle/ref_shim.cpp `solve`, csvm.cpp:71-183): alpha at 512 seeded indices + its last entry, rho, iterations -- in fp32 and in float64
+        kernel, N, d, dt = CASES["c2"]
+        X, y = make_blobs_pm1(N, d, seed=DATA_SEED, dtype=dt)
+        idx = np.sort(np.random.default_rng(ROWS_SEED).choice(N, size=NROWS, replace=False))
+        idx[0], idx[-1] = 0, N - 1
+        for rt, tag in ((np.float32, ""), (np.float64, "64")):
+            t0 = time.perf_counter()
+            a, rho, info = ref.solve(kernel, X.astype(rt), y.astype(rt), 1e-3, N, gamma=1.0 / d)
+            print(f"solve c2{tag}: {info['iterations']} iterations in {time.perf_counter() - t0:.1f} s, rho {float(rho):.9g}, max |alpha| {float(np.max(np.abs(a))):.6g}", flush=True)
+            out[f"solve_c2/alpha{tag}"], out[f"solve_c2/rho{tag}"], out[f"solve_c2/iterations{tag}"] = a[idx], np.asarray(rho), np.asarray(int(info["iterations"]))
+            out[f"solve_c2/alpha_absmax{tag}"] = np.asarray(np.max(np.abs(a)))
+        out["solve_c2/indices"] = idx
+        out["solve_c2/X_sha256"] = np.frombuffer(hashlib.sha256(X.tobytes()).digest(), dtype=np.uint8)
+        e = float(np.max(np.abs(out["solve_c2/alpha"].astype(np.float64) - out["solve_c2/alpha64"]))) / float(out["solve_c2/alpha_absmax64"])
+        print(f"solve c2: the reference's fp32 alpha against its float64 alpha at the sampled indices: {e:.3e} rel-inf", flush=True)
         np.savez_compressed(path, **out)
     print("full_size_rows.npz", os.path.getsize(path), "bytes")
 
