@@ -128,23 +128,27 @@ def main():
         out["predict/points"], out["predict/values"], out["predict/values64"] = idx, v32, v64
         out["predict/X_sha256"] = np.frombuffer(hashlib.sha256(X.tobytes()).digest(), dtype=np.uint8)
         np.savez_compressed(path, **out)
-    if "--with-solve" in sys.argv:
-        # the SOLVE of BASELINE configs[1] (50 000 x 128 rbf fp32, the bench's data and labels) at the reference's default epsilon 1e-3 by the reference's kernels under the
-        # restated CG driver (oracle/ref_shim.cpp `solve`, csvm.cpp:71-183): alpha at 512 seeded indices + its last entry, rho, iterations -- in fp32 and in float64
-        kernel, N, d, dt = CASES["c2"]
+    # SOLVES of BASELINE's configurations at full size (the bench's data and labels) at the reference's default epsilon 1e-3 by the reference's kernels under the restated CG
+    # driver (oracle/ref_shim.cpp `solve`, csvm.cpp:71-183): alpha at 512 seeded indices, rho, iterations.  --with-solve: configs[1] in fp32 and float64 (six minutes);
+    # --with-solve-c4: configs[3] in its own float64 (a quarter of an hour); --with-solve-c3: configs[2] in float64 only (its fp32 run would double two hours)
+    for flag, name, precisions in (("--with-solve", "c2", ((np.float32, ""), (np.float64, "64"))), ("--with-solve-c4", "c4", ((np.float64, "64"),)), ("--with-solve-c3", "c3", ((np.float64, "64"),))):
+        if flag not in sys.argv:
+            continue
+        kernel, N, d, dt = CASES[name]
         X, y = make_blobs_pm1(N, d, seed=DATA_SEED, dtype=dt)
         idx = np.sort(np.random.default_rng(ROWS_SEED).choice(N, size=NROWS, replace=False))
         idx[0], idx[-1] = 0, N - 1
-        for rt, tag in ((np.float32, ""), (np.float64, "64")):
+        for rt, tag in precisions:
             t0 = time.perf_counter()
-            a, rho, info = ref.solve(kernel, X.astype(rt), y.astype(rt), 1e-3, N, gamma=1.0 / d)
-            print(f"solve c2{tag}: {info['iterations']} iterations in {time.perf_counter() - t0:.1f} s, rho {float(rho):.9g}, max |alpha| {float(np.max(np.abs(a))):.6g}", flush=True)
-            out[f"solve_c2/alpha{tag}"], out[f"solve_c2/rho{tag}"], out[f"solve_c2/iterations{tag}"] = a[idx], np.asarray(rho), np.asarray(int(info["iterations"]))
-            out[f"solve_c2/alpha_absmax{tag}"] = np.asarray(np.max(np.abs(a)))
-        out["solve_c2/indices"] = idx
-        out["solve_c2/X_sha256"] = np.frombuffer(hashlib.sha256(X.tobytes()).digest(), dtype=np.uint8)
-        e = float(np.max(np.abs(out["solve_c2/alpha"].astype(np.float64) - out["solve_c2/alpha64"]))) / float(out["solve_c2/alpha_absmax64"])
-        print(f"solve c2: the reference's fp32 alpha against its float64 alpha at the sampled indices: {e:.3e} rel-inf", flush=True)
+            a, rho, info = ref.solve(kernel, X.astype(rt), y.astype(rt), 1e-3, N, degree=3, gamma=1.0 / d, coef0=0.0)
+            print(f"solve {name}{tag}: {info['iterations']} iterations in {time.perf_counter() - t0:.1f} s, rho {float(rho):.9g}, max |alpha| {float(np.max(np.abs(a))):.6g}", flush=True)
+            out[f"solve_{name}/alpha{tag}"], out[f"solve_{name}/rho{tag}"], out[f"solve_{name}/iterations{tag}"] = a[idx], np.asarray(rho), np.asarray(int(info["iterations"]))
+            out[f"solve_{name}/alpha_absmax{tag}"] = np.asarray(np.max(np.abs(a)))
+        out[f"solve_{name}/indices"] = idx
+        out[f"solve_{name}/X_sha256"] = np.frombuffer(hashlib.sha256(X.tobytes()).digest(), dtype=np.uint8)
+        if len(precisions) == 2:
+            e = float(np.max(np.abs(out[f"solve_{name}/alpha"].astype(np.float64) - out[f"solve_{name}/alpha64"]))) / float(out[f"solve_{name}/alpha_absmax64"])
+            print(f"solve {name}: the reference's fp32 alpha against its float64 alpha at the sampled indices: {e:.3e} rel-inf", flush=True)
         np.savez_compressed(path, **out)
     print("full_size_rows.npz", os.path.getsize(path), "bytes")
 

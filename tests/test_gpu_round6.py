@@ -400,6 +400,39 @@ def test_the_solve_of_baseline_config1_at_full_size_vs_the_references_solve():
     assert e_32 <= 1e-2
 
 
+@pytest.mark.parametrize("name, kernel, N, d", [("c4", "polynomial", 100_000, 64), ("c3", "linear", 200_000, 256)])
+def test_the_float64_solves_of_baseline_configs_2_and_3_at_full_size_vs_the_references_solve(name, kernel, N, d):
+    """BASELINE configs[3] (100 000 x 64 polynomial, fp64 -- its own precision) and configs[2] (200 000 x 256 linear; the float64 solve beside the configuration's fp32 one) SOLVED
+    at full size at the reference's default epsilon by the reference's kernels under the restated CG driver (make_golden_r06.py --with-solve-c4 / --with-solve-c3: a quarter
+    of an hour / two hours of CPU): the GPU's fp64 solve stops after the same iterations with alpha and rho within 1e-6 -- "alpha within 1e-4 rel-inf of OpenMP" as written,
+    with two digits to spare.  configs[2]'s own precision: the fp32 solve of the GPU is reported against that float64 solve (no fp32 run of the reference: two more hours)."""
+    global FULL_SIZE
+    if FULL_SIZE is None:
+        FULL_SIZE = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_rows.npz"))
+    G = FULL_SIZE
+    if f"solve_{name}/indices" not in G:
+        pytest.skip(f"tests/golden/full_size_rows.npz holds no solve of {name} (python tests/golden/make_golden_r06.py --only-solve --with-solve-{name})")
+    import hashlib
+
+    dt = np.float64 if name == "c4" else np.float32
+    X, y = make_blobs_pm1(N, d, seed=42, dtype=dt)
+    assert np.array_equal(np.frombuffer(hashlib.sha256(X.tobytes()).digest(), dtype=np.uint8), G[f"solve_{name}/X_sha256"])
+    idx, ref64, top = G[f"solve_{name}/indices"], G[f"solve_{name}/alpha64"], float(G[f"solve_{name}/alpha_absmax64"])
+    prm = Parameter(kernel_type=kernel, degree=3)
+    a64, rho64, info64 = backend.solve_system_of_linear_equations(prm, X.astype(np.float64), y.astype(np.float64), 1e-3, N)
+    e_64 = float(np.max(np.abs(a64[idx] - ref64))) / top
+    r_ref = float(G[f"solve_{name}/rho64"])
+    print(f"\n{name} solved at full size in fp64: {info64['iterations']} iterations (reference {int(G[f'solve_{name}/iterations64'])}), alpha {e_64:.2e} rel-inf from the reference's float64 solve, "
+          f"rho {float(rho64):.12g} (reference {r_ref:.12g})")
+    assert info64["converged"] == 1 and info64["iterations"] == int(G[f"solve_{name}/iterations64"])
+    assert e_64 <= 1e-6 and abs(float(rho64) - r_ref) <= 1e-6 * max(1.0, abs(r_ref))
+    if dt == np.float32:
+        a32, rho32, info32 = backend.solve_system_of_linear_equations(prm, X, y, 1e-3, N)
+        e_32 = float(np.max(np.abs(a32[idx].astype(np.float64) - ref64))) / top
+        print(f"{name} in its own fp32: {info32['iterations']} iterations, alpha {e_32:.2e} rel-inf from the reference's float64 solve, rho {float(rho32):.9g}")
+        assert info32["converged"] == 1 and np.all(np.isfinite(a32))
+
+
 def test_the_bench_predict_leg_at_full_size_vs_the_references_kernel_function():
     """bench.py's `other_workloads.predict` input (200 000 points x 50 000 support vectors x 128, rbf fp32, the leg's own data): tests/golden/full_size_rows.npz holds the decision
     values of 512 seeded points as sums of the reference's COMPILED kernel_function in the order of csvm.cpp:188-227 (oracle/ref_shim.cpp `predict`; fp32 and float64).  The
