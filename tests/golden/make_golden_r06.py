@@ -126,6 +126,11 @@ def main():
         print(f"predict: {NROWS} of {npts} points x {nsv} support vectors x {d}: the reference's kernel_function sums in fp32 and float64 in {time.perf_counter() - t0:.1f} s; "
               f"fp32 against float64: {float(np.max(np.abs(v32 - v64))):.3e} (largest |value| {float(np.max(np.abs(v64))):.3e})", flush=True)
         out["predict/points"], out["predict/values"], out["predict/values64"] = idx, v32, v64
+        # ... and the leg's linear kernel: w = sum_i alpha_i sv_i by the restated calculate_w (csvm.cpp:253-281), then w . x - rho (csvm.cpp:204-213)
+        l32, _ = ref.predict_values("linear", sv, alpha, np.float32(0.25), pts[idx])
+        l64, _ = ref.predict_values("linear", sv.astype(np.float64), alpha.astype(np.float64), 0.25, pts[idx].astype(np.float64))
+        print(f"predict, linear: fp32 against float64: {float(np.max(np.abs(l32 - l64))):.3e} (largest |value| {float(np.max(np.abs(l64))):.3e})", flush=True)
+        out["predict/linear_values"], out["predict/linear_values64"] = l32, l64
         out["predict/X_sha256"] = np.frombuffer(hashlib.sha256(X.tobytes()).digest(), dtype=np.uint8)
         np.savez_compressed(path, **out)
     # SOLVES of BASELINE's configurations at full size (the bench's data and labels) at the reference's default epsilon 1e-3 by the reference's kernels under the restated CG

@@ -466,6 +466,15 @@ def test_the_bench_predict_leg_at_full_size_vs_the_references_kernel_function():
     e_gpu, e_ref = float(np.max(np.abs(got[idx] - ref64) / scale)), float(np.max(np.abs(ref32 - ref64) / scale))
     print(f"\npredict at full size ({info['gram_mode']=}): sampled points vs the reference's float64 values {e_gpu / EPS32:.3f} eps of a point's summands [the reference's own fp32 values: {e_ref / EPS32:.2f} eps]")
     assert e_gpu <= 1 * EPS32 and e_gpu <= e_ref
+    if "predict/linear_values64" in G:
+        # the leg's linear kernel: w = sum_i alpha_i sv_i (calculate_w), then w . x - rho -- on the scale of |w| . |x| + |rho|, against the reference's float64 values
+        lin, w = backend.predict_values(Parameter(kernel_type="linear"), sv, alpha, 0.25, None, pts)
+        w64 = alpha.astype(np.float64) @ sv64
+        lscale = np.abs(p64) @ np.abs(w64) + 0.25
+        l_gpu = float(np.max(np.abs(lin[idx] - G["predict/linear_values64"]) / lscale))
+        l_ref = float(np.max(np.abs(G["predict/linear_values"].astype(np.float64) - G["predict/linear_values64"]) / lscale))
+        print(f"predict at full size, linear: {l_gpu / EPS32:.3f} eps of |w|.|x| from the reference's float64 values [the reference's own fp32 values: {l_ref / EPS32:.2f} eps]")
+        assert l_gpu <= 4 * EPS32
 
 
 # ------------------------------------------------------------------------------------------------------------ the Gram mode by data
